@@ -1,0 +1,69 @@
+"""Deterministic regeneration of the golden cases' inputs (numpy legacy RandomState is bit-stable).
+Mirrors make_inputs/make_state of tests/golden/make_student_golden.py, which produced the fixtures."""
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["bn_small", "nonorm_fullbatch", "arxiv_dims", "products_dims_narrow"]
+
+
+def make_inputs(seed, n, f, c, n_l):
+    rs = np.random.RandomState(seed)
+    feats = rs.standard_normal((n, f)).astype(np.float32)
+    labels = rs.randint(0, c, size=n).astype(np.int64)
+    t = rs.standard_normal((n, c)).astype(np.float32)
+    t = t - t.max(1, keepdims=True)
+    out_t = (t - np.log(np.exp(t.astype(np.float64)).sum(1, keepdims=True))).astype(np.float32)
+    idx_l = rs.permutation(n)[:n_l].astype(np.int64)
+    return feats, labels, out_t, idx_l
+
+
+def make_state(seed, dims, norm):
+    rs = np.random.RandomState(seed + 1000)
+    sd = {}
+    L = len(dims) - 1
+    for i in range(L):
+        bound = 1.0 / np.sqrt(dims[i])
+        sd[f"encoder.layers.{i}.weight"] = rs.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(np.float32)
+        sd[f"encoder.layers.{i}.bias"] = rs.uniform(-bound, bound, (dims[i + 1],)).astype(np.float32)
+    if norm == "batch":
+        for i in range(L - 1):
+            h = dims[i + 1]
+            sd[f"encoder.norms.{i}.weight"] = rs.uniform(0.5, 1.5, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.bias"] = rs.uniform(-0.2, 0.2, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.running_mean"] = rs.uniform(-0.1, 0.1, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.running_var"] = rs.uniform(0.8, 1.2, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.num_batches_tracked"] = np.int64(0)
+    return sd
+
+
+class Golden:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN_DIR, f"student_{name}.npz"))
+        z = self.z
+        self.dims = [int(d) for d in z["cfg.dims"]]
+        self.norm = str(z["cfg.norm"])
+        self.B, self.n, self.n_l = int(z["cfg.B"]), int(z["cfg.n"]), int(z["cfg.n_l"])
+        self.lamb, self.lr, self.wd = float(z["cfg.lamb"]), float(z["cfg.lr"]), float(z["cfg.wd"])
+        self.epochs, self.seed = int(z["cfg.epochs"]), int(z["cfg.seed"])
+        self.full = bool(int(z["cfg.full"]))
+        self.stride = int(z["cfg.sample_stride"])
+        self.feats, self.labels, self.out_t, self.idx_l = make_inputs(self.seed, self.n, self.dims[0], self.dims[-1], self.n_l)
+        self.sd0 = make_state(self.seed, self.dims, self.norm)
+        if self.full:   # the stored copies must equal the regenerated ones
+            assert np.array_equal(z["in.feats"], self.feats) and np.array_equal(z["in.idx_l"], self.idx_l)
+            for k, v in self.sd0.items():
+                assert np.array_equal(z[f"init.{k}"], v)
+        self.perms = [z[f"perm_{i}"].astype(np.int64) for i in range(int(z["num_perms"]))]
+        self.param_names = [f"encoder.layers.{i}.{s}" for i in range(len(self.dims) - 1) for s in ("weight", "bias")]
+        if self.norm == "batch":
+            self.param_names += [f"encoder.norms.{i}.{s}" for i in range(len(self.dims) - 2) for s in ("weight", "bias")]
+
+    def view(self, a):
+        """How an array is stored in this fixture (full, or strided sample)."""
+        a = np.asarray(a)
+        if self.full or a.ndim == 0:
+            return a
+        return a.astype(np.float32).ravel()[:: self.stride]

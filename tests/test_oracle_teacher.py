@@ -1,0 +1,132 @@
+"""Pins for the teacher CPU oracle (oracle/glnn_oracle.c via oracle/teacher_oracle.py).
+
+The reference holds no tests or vectors at the DGL boundary, so the restatement is pinned by
+  (1) hand-derived known answers on tiny graphs (path, star, isolated node, duplicate edge, self-loop,
+      block with n_dst < n_src),
+  (2) scipy.sparse CSR matmul and (3) torch.sparse_csr matmul as two independent implementations,
+  (4) identities: chunked == whole-graph, project-first == aggregate-first (1e-4)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from graphgen import csr_from_edges, random_graph
+from oracle import teacher_oracle as to
+
+
+def test_known_answer_sage_gcn_tiny():
+    # 5 nodes. edges u->v: 0->1, 2->1, 2->1 (duplicate), 3->3 (self-loop), 1->0 ; node 4 isolated, node 2 no in-edges
+    src = np.array([0, 2, 2, 3, 1]); dst = np.array([1, 1, 1, 3, 0])
+    indptr, indices = csr_from_edges(src, dst, 5)
+    x = np.array([[1, 10], [2, 20], [3, 30], [4, 40], [5, 50]], np.float32)
+    got = to.sage_gcn_agg(indptr, indices, x)
+    want = np.array([
+        [(2 + 1) / 2, (20 + 10) / 2],            # v0: in {1}
+        [(1 + 3 + 3 + 2) / 4, (10 + 30 + 30 + 20) / 4],   # v1: in {0,2,2} duplicate counts twice
+        [3, 30],                                  # v2: no in-edges -> self/1
+        [(4 + 4) / 2, (40 + 40) / 2],             # v3: self-loop counts as an edge AND self is added
+        [5, 50],                                  # v4: isolated
+    ], np.float32)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_known_answer_block_ndst_lt_nsrc():
+    # block: 2 dst nodes (= first 2 of 4 src nodes). edges: 2->0, 3->0, 1->0, 3->1
+    indptr = np.array([0, 3, 4], np.int64); indices = np.array([2, 3, 1, 3], np.int32)
+    x = np.array([[1.0], [2.0], [4.0], [8.0]], np.float32)
+    got = to.sage_gcn_agg(indptr, indices, x, n_dst=2)
+    np.testing.assert_array_equal(got, np.array([[(4 + 8 + 2 + 1) / 4], [(8 + 2) / 2]], np.float32))
+
+
+def test_known_answer_graphconv_star():
+    # star: leaves 1,2,3 <-> centre 0, both directions. out_deg = in_deg = [3,1,1,1]
+    src = np.array([1, 2, 3, 0, 0, 0]); dst = np.array([0, 0, 0, 1, 2, 3])
+    indptr, indices = csr_from_edges(src, dst, 4)
+    h = np.array([[3.0], [1.0], [2.0], [4.0]], np.float32)
+    w = np.array([[2.0]], np.float32); b = np.array([0.5], np.float32)
+    got = to.graph_conv_both(indptr, indices, h, w, b, relu=False)
+    s3 = 1 / np.sqrt(3.0)
+    want = np.array([[(1 + 2 + 4) * 1.0 * s3 * 2 + 0.5], [3 * s3 * 2 + 0.5], [3 * s3 * 2 + 0.5], [3 * s3 * 2 + 0.5]])
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+
+
+def test_known_answer_feature_prop_path():
+    # path 0-1-2 undirected; in_deg = [1,2,1]; one hop of D^-1/2 A D^-1/2
+    src = np.array([1, 0, 2, 1]); dst = np.array([0, 1, 1, 2])
+    indptr, indices = csr_from_edges(src, dst, 3)
+    x = np.array([[1.0], [2.0], [3.0]], np.float32)
+    r2 = 1 / np.sqrt(2.0)
+    want = np.array([[2 * r2], [(1 + 3) * r2], [2 * r2]])
+    np.testing.assert_allclose(to.feature_prop(indptr, indices, x, 1), want, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,deg,d", [(300, 6, 17), (2000, 15, 128), (1500, 40, 100)])
+def test_vs_scipy_and_torch_sparse(n, deg, d):
+    indptr, indices = random_graph(n, deg, seed=n, power=0.5, isolated=5, hub=700)
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((n, d)).astype(np.float32)
+    a_sp = sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(n, n))
+    a_t = torch.sparse_csr_tensor(torch.from_numpy(indptr), torch.from_numpy(indices.astype(np.int64)),
+                                  torch.ones(len(indices)), size=(n, n))
+    got = to.spmm_sum(indptr, indices, x)
+    ref64 = sp.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n)) @ x.astype(np.float64)
+    np.testing.assert_allclose(got, a_sp @ x, atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(got, (a_t @ torch.from_numpy(x)).numpy(), atol=1e-4, rtol=1e-5)
+    np.testing.assert_allclose(got, ref64, atol=1e-4, rtol=1e-5)
+    deg_in = np.diff(indptr).astype(np.float64)
+    want = (ref64 + x) / (deg_in[:, None] + 1)
+    np.testing.assert_allclose(to.sage_gcn_agg(indptr, indices, x), want, atol=1e-5, rtol=1e-5)
+    # multi-threaded == single-threaded, bit for bit (rows are independent)
+    np.testing.assert_array_equal(to.sage_gcn_agg(indptr, indices, x, threads=4), to.sage_gcn_agg(indptr, indices, x))
+
+
+def _sage_params(dims, seed, bn=True):
+    rs = np.random.RandomState(seed)
+    layers, norms = [], []
+    for i in range(len(dims) - 1):
+        layers.append(dict(weight=(rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32),
+                           bias=rs.standard_normal(dims[i + 1]).astype(np.float32) * 0.1))
+        if i < len(dims) - 2:
+            h = dims[i + 1]
+            norms.append(dict(weight=rs.uniform(0.5, 1.5, h).astype(np.float32), bias=rs.uniform(-.2, .2, h).astype(np.float32),
+                              running_mean=rs.uniform(-.3, .3, h).astype(np.float32),
+                              running_var=rs.uniform(0.5, 1.5, h).astype(np.float32)) if bn else None)
+    return layers, norms
+
+
+def test_sage_inference_chunked_equals_whole_graph():
+    n = 700
+    indptr, indices = random_graph(n, 9, seed=7, power=0.4, isolated=3, self_loops=False)
+    x = np.random.RandomState(1).standard_normal((n, 20)).astype(np.float32)
+    layers, norms = _sage_params([20, 32, 32, 6], 3)
+    whole = to.sage_inference(indptr, indices, x, layers, norms)
+    chunked = to.sage_inference(indptr, indices, x, layers, norms, batch_size=64)   # dataloader_eval sweep
+    np.testing.assert_array_equal(whole, chunked)
+
+
+def test_project_first_equals_aggregate_first():
+    n = 500
+    indptr, indices = random_graph(n, 12, seed=11, power=0.5)
+    x = np.random.RandomState(2).standard_normal((n, 64)).astype(np.float32)
+    layers, _ = _sage_params([64, 10], 5)
+    w, b = layers[0]["weight"], layers[0]["bias"]
+    agg_first = to.sage_conv_gcn(indptr, indices, x, w, b)
+    proj = to.linear(x, w, None)
+    proj_first = to.sage_gcn_agg(indptr, indices, proj) + b[None, :]
+    np.testing.assert_allclose(agg_first, proj_first, atol=1e-4, rtol=0)
+
+
+def test_gcn_forward_matches_dense_formula():
+    n = 200
+    indptr, indices = random_graph(n, 4, seed=5, symmetric=True, self_loops=True)
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((n, 50)).astype(np.float32)
+    w0 = (rs.standard_normal((50, 16)) / 7).astype(np.float32); b0 = rs.standard_normal(16).astype(np.float32) * .1
+    w1 = (rs.standard_normal((16, 7)) / 4).astype(np.float32); b1 = rs.standard_normal(7).astype(np.float32) * .1
+    got = to.gcn_forward(indptr, indices, x, [dict(weight=w0, bias=b0), dict(weight=w1, bias=b1)])
+    a = sp.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(n, n)).toarray()
+    din = np.maximum(a.sum(1), 1) ** -0.5; dout = np.maximum(a.sum(0), 1) ** -0.5
+    ahat = din[:, None] * a * dout[None, :]
+    h1 = np.maximum(ahat @ (x.astype(np.float64) @ w0) + b0, 0)
+    want = ahat @ (h1 @ w1) + b1
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
