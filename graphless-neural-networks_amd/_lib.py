@@ -1,0 +1,65 @@
+"""ctypes binding of libglnn_hip.so (the C ABI declared in include/glnn_hip.h).
+
+There is NO fallback: if the shared library is missing or does not export a symbol the import of
+this module's `lib()` raises, and every op in glnn_amd.ops raises on non-CUDA tensors.  The library is
+built in-tree by `python __graft_entry__.py` (hipcc --offload-arch=gfx950)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglnn_hip.so")
+
+c_i64, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/glnn_hip.h (pointers as void*)
+SIGNATURES = {
+    "glnn_abi_version": [],
+    "glnn_device_info": [c_vp, c_vp, c_vp, c_int],
+    "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                          c_int, c_vp, c_i64, c_vp],
+    "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
+                      c_vp, c_i64, c_vp],
+    "glnn_gemm_tn_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp,
+                         c_i64, c_vp],
+    "glnn_softmax_loss_f32": [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64,
+                              c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_log_softmax_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "glnn_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                          c_vp, c_vp, c_i64, c_vp],
+    "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                             c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
+    "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
+    "glnn_scatter_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
+}
+
+_lib = None
+
+
+class GlnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GlnnError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError => missing export: fail loudly
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        h.glnn_last_error.argtypes = []
+        h.glnn_last_error.restype = ctypes.c_char_p
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().glnn_last_error().decode(errors="replace")
+        raise GlnnError(f"{what} failed (status {rc}): {msg}")

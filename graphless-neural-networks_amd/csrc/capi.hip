@@ -1,0 +1,77 @@
+// Error state, device query and the K7 row gather / scatter of libglnn_hip.so.
+#include <cstring>
+
+#include "glnn_common.h"
+
+namespace glnn {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace glnn
+
+namespace {
+
+// out[i, :] = x[rows[i], :] (gather) or out[rows[i], :] = x[i, :] (scatter); one float4 per thread.
+template <bool SCATTER>
+__global__ void move_rows_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ rows,
+                                 int64_t n_rows, int dv, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = n_rows * dv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / dv;
+    const int c4 = (int)(i - r * dv) * 4;
+    const int64_t rr = rows[r];
+    const int64_t src = SCATTER ? r : rr, dst = SCATTER ? rr : r;
+    *reinterpret_cast<float4*>(out + dst * ldo + c4) = *reinterpret_cast<const float4*>(x + src * ldx + c4);
+  }
+}
+
+template <bool SCATTER>
+int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, int d, float* out, int64_t ldo,
+              void* stream, const char* name) {
+  GLNN_REQUIRE(x && rows && out, "%s: null pointer", name);
+  GLNN_REQUIRE(d >= 1 && n_rows >= 0, "%s: bad size", name);
+  const int dpad = (d + 3) & ~3;
+  GLNN_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= dpad && ldo >= dpad, "%s: leading dims must be multiples of 4 and >= %d", name, dpad);
+  GLNN_REQUIRE(glnn::aligned16(x) && glnn::aligned16(out), "%s: 16-byte alignment required", name);
+  if (n_rows == 0) return GLNN_OK;
+  const int dv = dpad / 4;
+  int64_t blocks = (n_rows * dv + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL((move_rows_kernel<SCATTER>), dim3((unsigned)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, ldx, rows, n_rows, dv, out, ldo);
+  return glnn::check_launch(name);
+}
+
+}  // namespace
+
+extern "C" int glnn_abi_version(void) { return 1; }
+
+extern "C" const char* glnn_last_error(void) { return glnn::g_err; }
+
+extern "C" int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int arch_buf_len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return glnn::fail(GLNN_ERR_NO_DEVICE, "glnn_device_info: no HIP device");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_device_info: hipGetDeviceProperties failed");
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (xcd_count) *xcd_count = 8;  // MI355X: 8 XCDs x 32 CUs
+  if (arch_buf && arch_buf_len > 0) {
+    strncpy(arch_buf, p.gcnArchName, (size_t)arch_buf_len - 1);
+    arch_buf[arch_buf_len - 1] = 0;
+  }
+  return GLNN_OK;
+}
+
+extern "C" int glnn_gather_rows_f32(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, int d,
+                                    float* out, int64_t ldo, void* stream) {
+  return move_rows<false>(x, ldx, rows, n_rows, d, out, ldo, stream, "glnn_gather_rows_f32");
+}
+
+extern "C" int glnn_scatter_rows_f32(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, int d,
+                                     float* out, int64_t ldo, void* stream) {
+  return move_rows<true>(x, ldx, rows, n_rows, d, out, ldo, stream, "glnn_scatter_rows_f32");
+}

@@ -1,0 +1,492 @@
+// K3: fp32 dense projections on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32
+// accumulate, bit-equal to an fmaf chain, 157 TF peak -- the 1e-4 parity bar rules out bf16).
+//
+// Replaces nn.Linear / dgl SAGEConv.fc_neigh / dgl GraphConv.weight matmuls of the reference
+// (models.py:45,112,138,193) and, in the TN form, the weight-gradient matmul autograd runs inside
+// loss.backward() (train_and_eval.py:84).
+//
+// Tiling: 128 x BN block tile (BN = 128 or 64), BK = 32, 256 threads = 4 waves as 2(M) x 2(N); each
+// wave owns 64 x BN/2 = 2 x (BN/64) MFMA 32x32 tiles (64 / 32 accumulator VGPRs).  Operand tiles go
+// global -> registers -> LDS (double-buffered, one barrier per k-tile, next tile's global loads issued
+// before the MFMAs of the current one).  The operand transform of the previous layer tail (row gather,
+// BatchNorm scale/shift, ReLU) is applied in registers on the way to LDS, so activations are never
+// re-materialised in HBM.
+//
+// k-order trick for the row-major-along-k operands: a lane reads 4 consecutive k with ONE ds_read_b128
+// (lane half kk takes k0+4kk..k0+4kk+3) and feeds MFMA t with element t, i.e. the 4 MFMAs of a group
+// consume k pairs (t, 4+t).  Both operands use the same pairing, and a dot product does not care about
+// the order of its terms.  LDS rows are padded to 36 floats: conflict-free for ds_read_b128's 16-lane
+// groups (slot = 9*i mod 16 is a bijection on each group).
+#include "glnn_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_K = BK + 4;  // padded row stride (floats) for [row][k] tiles
+
+struct GemmArgs {
+  const float* a; int64_t lda; const int64_t* a_rows; const float* a_scale; const float* a_shift;
+  int64_t m; int k;
+  const float* b; int64_t ldb; int n;
+  const float* row_scale; const float* ep_scale; const float* ep_shift; int relu;
+  float* c; int64_t ldc;
+  int a_vec; int b_vec;  // 1 = float4 loads are aligned and in-bounds
+};
+
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// 4 consecutive elements p[0..3] of a row, elements at index >= limit (relative to p) read as 0.
+__device__ __forceinline__ float4 load4_guard(const float* p, int limit, bool vec) {
+  if (limit <= 0) return zero4();
+  if (vec && limit >= 4) return *reinterpret_cast<const float4*>(p);
+  float4 r;
+  r.x = p[0];
+  r.y = limit > 1 ? p[1] : 0.f;
+  r.z = limit > 2 ? p[2] : 0.f;
+  r.w = limit > 3 ? p[3] : 0.f;
+  return r;
+}
+
+__device__ __forceinline__ float4 xform4(float4 v, const float* sc, const float* sh, int k, int klimit) {
+  // a' = max(a*scale + shift, 0) for k < klimit, else 0
+  float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (k + t < klimit) {
+      vv[t] = fmaxf(fmaf(vv[t], sc[k + t], sh[k + t]), 0.f);
+    } else {
+      vv[t] = 0.f;
+    }
+  }
+  return make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C[m,n] = epi( sum_k A'[m,k] * B[k,n] ),  B given as W[n,k] (B_KN = false) or W[k,n] (B_KN = true)
+// ---------------------------------------------------------------------------------------------
+template <int BN, bool B_KN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  constexpr int NT = BN / 64;            // MFMA tiles per wave along N
+  constexpr int LDS_N = BN + 4;          // row stride of the [k][n] B tile
+  constexpr int A_TILE = BM * LDS_K;
+  constexpr int B_TILE = B_KN ? BK * LDS_N : BN * LDS_K;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][A_TILE]
+  float* Bs = smem + 2 * A_TILE;         // [2][B_TILE]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kk = lane >> 5;
+
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- global->register staging assignment ----
+  // A tile: 128 rows x 8 float4; thread f = tid + 256*q -> row f/8, c4 = f%8
+  const float* a_ptr[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f = tid + 256 * q;
+    const int row = f >> 3;
+    const int64_t mrow = m0 + row;
+    a_ok[q] = mrow < g.m;
+    const int64_t src = a_ok[q] ? (g.a_rows ? g.a_rows[mrow] : mrow) : 0;
+    a_ptr[q] = g.a + src * g.lda + (f & 7) * 4;
+  }
+  constexpr int BQ = B_KN ? (BK * BN / 4) / 256 : (BN * 8) / 256;   // float4 per thread for B
+
+  float4 a_reg[4], b_reg[BQ];
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kc = k0 + ((tid + 256 * q) & 7) * 4;
+      float4 v = a_ok[q] ? load4_guard(a_ptr[q] + k0, g.k - kc, g.a_vec) : zero4();
+      if (g.a_scale) v = a_ok[q] ? xform4(v, g.a_scale, g.a_shift, kc, g.k) : zero4();
+      a_reg[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const int f = tid + 256 * q;
+      if (B_KN) {
+        const int krow = f / (BN / 4), c4 = (f % (BN / 4)) * 4;
+        const int kg = k0 + krow, ng = n0 + c4;
+        b_reg[q] = (kg < g.k) ? load4_guard(g.b + (int64_t)kg * g.ldb + ng, g.n - ng, g.b_vec) : zero4();
+      } else {
+        const int nrow = f >> 3, kc = k0 + (f & 7) * 4;
+        const int ng = n0 + nrow;
+        b_reg[q] = (ng < g.n) ? load4_guard(g.b + (int64_t)ng * g.ldb + kc, g.k - kc, g.b_vec) : zero4();
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * A_TILE;
+    float* bs = Bs + buf * B_TILE;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = tid + 256 * q;
+      *reinterpret_cast<float4*>(as + (f >> 3) * LDS_K + (f & 7) * 4) = a_reg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const int f = tid + 256 * q;
+      if (B_KN) {
+        *reinterpret_cast<float4*>(bs + (f / (BN / 4)) * LDS_N + (f % (BN / 4)) * 4) = b_reg[q];
+      } else {
+        *reinterpret_cast<float4*>(bs + (f >> 3) * LDS_K + (f & 7) * 4) = b_reg[q];
+      }
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (g.k + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tiles(kt + 1);
+    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+    const float* bs = B_KN ? Bs + cur * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
+                           : Bs + cur * B_TILE + (wn * (BN / 2) + li) * LDS_K + kk * 4;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[2][4], bf[NT][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (B_KN) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kg * 8 + t) * LDS_N + j * 32];
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
+          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + li;
+    const bool col_ok = col < g.n;
+    const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
+    const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (col_ok && row < g.m) {
+          float v = acc[i][j][r];
+          if (g.row_scale) v *= g.row_scale[row];
+          v = fmaf(v, es, eh);
+          if (g.relu) v = fmaxf(v, 0.f);
+          g.c[row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: C[i,j] = sum_m A'[m,i] * B[m,j]   (i < ka, j < nb), reduction over rows m, optional split over m.
+// Both operand tiles are [m][*] row-major in global and stay k(m)-major in LDS ([BK][128+4]); MFMA
+// fragments are ds_read_b32 with consecutive lanes on consecutive floats.
+// ---------------------------------------------------------------------------------------------
+struct GemmTnArgs {
+  const float* a; int64_t lda;
+  int64_t m; int ka;
+  const float* b; int64_t ldb; const int64_t* b_rows; const float* b_scale; const float* b_shift; int nb;
+  float* c; int64_t ldc;   // final C, or the split workspace [splits][ka][nb] when splits > 1
+  int splits; int64_t rows_per_split;
+  int a_vec; int b_vec;
+};
+
+template <int BNT>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
+  constexpr int NT = BNT / 64;
+  constexpr int LDA_S = BM + 4, LDB_S = BNT + 4;
+  constexpr int A_TILE = BK * LDA_S, B_TILE = BK * LDB_S;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
+  const int i0 = blockIdx.x * BM;      // along ka
+  const int j0 = blockIdx.y * BNT;     // along nb
+  const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
+  int64_t mend = mbeg + g.rows_per_split;
+  if (mend > g.m) mend = g.m;
+
+  constexpr int AQ = (BK * BM / 4) / 256;    // 4
+  constexpr int BQ = (BK * BNT / 4) / 256;   // 4 or 2
+  float4 a_reg[AQ], b_reg[BQ];
+
+  auto load_tiles = [&](int64_t mt) {
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) {
+      const int f = tid + 256 * q;
+      const int r = f / (BM / 4), c4 = (f % (BM / 4)) * 4;
+      const int64_t mrow = mt + r;
+      const int ig = i0 + c4;
+      a_reg[q] = (mrow < mend) ? load4_guard(g.a + mrow * g.lda + ig, g.ka - ig, g.a_vec) : zero4();
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const int f = tid + 256 * q;
+      const int r = f / (BNT / 4), c4 = (f % (BNT / 4)) * 4;
+      const int64_t mrow = mt + r;
+      const int jg = j0 + c4;
+      float4 v = zero4();
+      if (mrow < mend) {
+        const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
+        v = load4_guard(g.b + src * g.ldb + jg, g.nb - jg, g.b_vec);
+        if (g.b_scale) v = xform4(v, g.b_scale, g.b_shift, jg, g.nb);
+      }
+      b_reg[q] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) {
+      const int f = tid + 256 * q;
+      *reinterpret_cast<float4*>(As + buf * A_TILE + (f / (BM / 4)) * LDA_S + (f % (BM / 4)) * 4) = a_reg[q];
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      const int f = tid + 256 * q;
+      *reinterpret_cast<float4*>(Bs + buf * B_TILE + (f / (BNT / 4)) * LDB_S + (f % (BNT / 4)) * 4) = b_reg[q];
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t nkt = (mend - mbeg + BK - 1) / BK;
+  if (nkt > 0) {
+    load_tiles(mbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nkt) load_tiles(mbeg + (kt + 1) * BK);
+    const float* as = As + cur * A_TILE + kk * LDA_S + wm * 64 + li;
+    const float* bs = Bs + cur * B_TILE + kk * LDB_S + wn * (BNT / 2) + li;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float af[2], bf[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = as[(2 * s) * LDA_S + i * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = bs[(2 * s) * LDB_S + j * 32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = j0 + wn * (BNT / 2) + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
+      }
+  }
+}
+
+// sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
+__global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
+                                    int64_t ldc, int ka, int nb) {
+  const int64_t total = (int64_t)ka * nb;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
+    const int64_t r = i / nb, cc = i - r * nb;
+    c[r * ldc + cc] = s;
+  }
+}
+
+// column sums of B [m, nb]: stage 1 -> partial[blk][nb], stage 2 -> out[nb]  (deterministic)
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ b, int64_t ldb, int64_t m, int nb,
+                                                      int64_t rows_per_blk, float* __restrict__ partial) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rlane = threadIdx.x >> 6;  // 0..3
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk;
+  if (r1 > m) r1 = m;
+  float s = 0.f;
+  if (col < nb)
+    for (int64_t r = r0 + rlane; r < r1; r += 4) s += b[r * ldb + col];
+  __shared__ float sh[4][64];
+  sh[rlane][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rlane == 0 && col < nb) partial[(int64_t)blockIdx.y * nb + col] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void colsum_stage2(const float* __restrict__ partial, int nblk, int nb, float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= nb) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * nb + col];
+  out[col] = s;
+}
+
+template <typename K>
+int set_smem(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+      return glnn::fail(GLNN_ERR_HIP, "hipFuncSetAttribute(max dynamic LDS=%zu) failed", bytes);
+  }
+  return GLNN_OK;
+}
+
+template <int BN, bool B_KN>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  constexpr int A_TILE = BM * LDS_K;
+  constexpr int B_TILE = B_KN ? BK * (BN + 4) : BN * LDS_K;
+  constexpr size_t smem = sizeof(float) * 2 * (A_TILE + B_TILE);
+  static int configured = set_smem(gemm_kernel<BN, B_KN>, smem);
+  if (configured != GLNN_OK) return configured;
+  const int64_t gm = (g.m + BM - 1) / BM;
+  const int gn = (g.n + BN - 1) / BN;
+  if (gm > 0x7fffffffLL) return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_gemm_f32: m too large");
+  hipLaunchKernelGGL((gemm_kernel<BN, B_KN>), dim3((unsigned)gm, (unsigned)gn), dim3(256), smem, st, g);
+  return glnn::check_launch("glnn_gemm_f32");
+}
+
+}  // namespace
+
+extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
+                             const float* a_shift, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
+                             const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
+                             int64_t ldc, void* stream) {
+  GLNN_REQUIRE(a && b && c, "glnn_gemm_f32: null pointer");
+  GLNN_REQUIRE(m >= 0 && k >= 1 && n >= 1, "glnn_gemm_f32: bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
+  GLNN_REQUIRE(lda >= k && ldc >= n, "glnn_gemm_f32: lda/ldc too small");
+  GLNN_REQUIRE(b_layout == 0 || b_layout == 1, "glnn_gemm_f32: b_layout must be 0 ([n,k]) or 1 ([k,n])");
+  GLNN_REQUIRE(ldb >= (b_layout ? n : k), "glnn_gemm_f32: ldb too small");
+  GLNN_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "glnn_gemm_f32: a_scale and a_shift go together");
+  if (m == 0) return GLNN_OK;
+  GemmArgs g;
+  g.a = a; g.lda = lda; g.a_rows = a_rows; g.a_scale = a_scale; g.a_shift = a_shift; g.m = m; g.k = k;
+  g.b = b; g.ldb = ldb; g.n = n; g.row_scale = row_scale; g.ep_scale = ep_scale; g.ep_shift = ep_shift; g.relu = relu;
+  g.c = c; g.ldc = ldc;
+  // float4 loads are legal when every row start is 16-byte aligned; the tail (k or n not a multiple of 4)
+  // is handled per element inside load4_guard, which needs the padded part of the row to be readable:
+  // true for A when lda >= roundup4(k); for B only when ldb >= roundup4(extent).
+  g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
+  g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n > 64) return b_layout ? launch_gemm<128, true>(g, st) : launch_gemm<128, false>(g, st);
+  return b_layout ? launch_gemm<64, true>(g, st) : launch_gemm<64, false>(g, st);
+}
+
+extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
+                                const int64_t* b_rows, const float* b_scale, const float* b_shift, int nb, float* c,
+                                int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
+  GLNN_REQUIRE(a && b && c, "glnn_gemm_tn_f32: null pointer");
+  GLNN_REQUIRE(m >= 1 && ka >= 1 && nb >= 1, "glnn_gemm_tn_f32: bad sizes");
+  GLNN_REQUIRE(lda >= ka && ldb >= nb && ldc >= nb, "glnn_gemm_tn_f32: leading dimension too small");
+  GLNN_REQUIRE((b_scale == nullptr) == (b_shift == nullptr), "glnn_gemm_tn_f32: b_scale and b_shift go together");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GemmTnArgs g;
+  g.a = a; g.lda = lda; g.m = m; g.ka = ka;
+  g.b = b; g.ldb = ldb; g.b_rows = b_rows; g.b_scale = b_scale; g.b_shift = b_shift; g.nb = nb;
+  g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
+  g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
+  const int bnt = nb > 64 ? 128 : 64;
+  const int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;
+  // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
+  int splits = 1;
+  const int64_t slab = (int64_t)ka * nb;
+  const int64_t colsum_need = col_sum_a ? (int64_t)64 * ka : 0;
+  if (workspace && gi * gj < 192) {
+    splits = 256 / (gi * gj);
+    const int64_t max_by_rows = (m + 4 * BK - 1) / (4 * BK);      // at least 4 k-tiles per split
+    if (splits > max_by_rows) splits = (int)max_by_rows;
+    const int64_t avail = workspace_floats - colsum_need;
+    if ((int64_t)splits * slab > avail) splits = (int)(avail / slab);
+    if (splits < 1) splits = 1;
+  }
+  g.splits = splits;
+  int64_t rps = (m + splits - 1) / splits;
+  rps = (rps + BK - 1) / BK * BK;
+  g.rows_per_split = rps;
+  splits = (int)((m + rps - 1) / rps);
+  g.splits = splits;
+  float* ws_partial = workspace ? workspace + colsum_need : nullptr;
+  if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
+  if (bnt == 128) {
+    constexpr size_t smem = sizeof(float) * 2 * (BK * (BM + 4) + BK * (128 + 4));
+    static int configured = set_smem(gemm_tn_kernel<128>, smem);
+    if (configured != GLNN_OK) return configured;
+    hipLaunchKernelGGL((gemm_tn_kernel<128>), dim3(gi, gj, splits), dim3(256), smem, st, g);
+  } else {
+    constexpr size_t smem = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
+    hipLaunchKernelGGL((gemm_tn_kernel<64>), dim3(gi, gj, splits), dim3(256), smem, st, g);
+  }
+  int rc = glnn::check_launch("glnn_gemm_tn_f32");
+  if (rc != GLNN_OK) return rc;
+  if (splits > 1) {
+    int blocks = (int)((slab + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_partial, slab, splits, c, ldc, ka, nb);
+    rc = glnn::check_launch("glnn_gemm_tn_f32(reduce)");
+    if (rc != GLNN_OK) return rc;
+  }
+  if (col_sum_a) {
+    GLNN_REQUIRE(workspace && workspace_floats >= colsum_need, "glnn_gemm_tn_f32: col_sum_a needs workspace >= 64*ka floats");
+    int nblk = (int)((m + 255) / 256);
+    if (nblk > 64) nblk = 64;
+    const int64_t rpb = (m + nblk - 1) / nblk;
+    hipLaunchKernelGGL(colsum_stage1, dim3((ka + 63) / 64, nblk), dim3(256), 0, st, a, lda, m, ka, rpb, workspace);
+    hipLaunchKernelGGL(colsum_stage2, dim3((ka + 255) / 256), dim3(256), 0, st, workspace, nblk, ka, col_sum_a);
+    rc = glnn::check_launch("glnn_gemm_tn_f32(colsum)");
+  }
+  return rc;
+}

@@ -1,0 +1,287 @@
+// K1/K2: CSR neighbour aggregation for gfx950 (MI355X).  HBM-bound gather: the only goal is to keep
+// as many 16-byte-per-lane row loads in flight as the memory system will take.
+//
+// Replaces (see include/glnn_hip.h): dgl SAGEConv "gcn" aggregation (reference models.py:112,138),
+// dgl GraphConv norm="both" aggregation (models.py:193) and update_all(copy_u,sum) (utils.py:185).
+//
+// Mapping
+//   * one 64-lane wavefront per destination row (rows of degree <= LONG_ROW), 8 waves per workgroup;
+//   * a feature row of d floats is covered by LPR = 4..64 lanes moving float4 (LPR*16 B per row);
+//     the G = 64/LPR lane groups of the wave take different in-edges of the same row, U edges per
+//     group in flight, and are folded with two cross-lane adds at the end;
+//   * the row's column indices are read coalesced (one per lane, 64 at a time) and handed to the
+//     groups with ds_bpermute / v_readlane -- no per-edge dependent index load;
+//   * power-law tails: rows with degree > LONG_ROW are skipped by the row waves and taken by the
+//     first `n_long_blocks` workgroups of the SAME launch (dispatched first, so their long latency
+//     overlaps the bulk), 8 waves per row, LDS fold in fixed order => deterministic results;
+//   * epilogue fused: +self, /(deg+1) (SAGE "gcn") or *row_scale (GraphConv / feature_prop), then
+//     optional per-column scale/shift (+ReLU) for the project-first form.
+#include "glnn_common.h"
+
+namespace {
+
+constexpr int kBlock = 512;              // 8 waves
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kRowsPerWave = 8;
+constexpr int kLongRow = 512;            // degree above which a whole workgroup takes the row
+
+struct SpmmArgs {
+  const int64_t* indptr;
+  const int32_t* indices;
+  int64_t n_dst;
+  const float* x;
+  int64_t ldx;
+  int d;
+  const float* row_scale;
+  const float* col_scale;
+  const float* x_self;
+  int64_t ld_self;
+  const float* ep_scale;
+  const float* ep_shift;
+  int relu;
+  float* out;
+  int64_t ldo;
+  int n_long_blocks;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, float4 v, float4 a) {
+  return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
+}
+__device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
+  return make_float4(__shfl_xor(v.x, m), __shfl_xor(v.y, m), __shfl_xor(v.z, m), __shfl_xor(v.w, m));
+}
+
+// Sum of x[indices[e], col4..col4+3] over the edges e in [e0,e1) that belong to this wave:
+// 64-edge chunks  e0 + 64*(wave_id + k*n_waves).  Returns the total in every lane of group 0
+// (lanes < LPR); other lanes hold partial garbage.
+template <int LPR, int U, bool CS>
+__device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ indices, int64_t e0, int64_t e1,
+                                                  int wave_id, int n_waves, const float* __restrict__ x,
+                                                  int64_t ldx, int col4, bool col_ok,
+                                                  const float* __restrict__ col_scale, int lane) {
+  constexpr int G = 64 / LPR;
+  const int g = lane / LPR;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t base = e0 + (int64_t)wave_id * 64; base < e1; base += (int64_t)n_waves * 64) {
+    const int64_t rem = e1 - base;
+    const int cnt = rem < 64 ? (int)rem : 64;
+    const int my_idx = lane < cnt ? indices[base + lane] : 0;
+    float my_cs = 1.f;
+    if (CS) my_cs = lane < cnt ? col_scale[my_idx] : 0.f;
+    for (int j = 0; j < cnt; j += G * U) {
+      float4 v[U];
+      float s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ei = j + u * G + g;
+        int src;
+        if (G == 1) {
+          src = __builtin_amdgcn_readlane(my_idx, ei & 63);
+        } else {
+          src = __shfl(my_idx, ei & 63);
+        }
+        if (CS) s[u] = (G == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cs), ei & 63))
+                                : __shfl(my_cs, ei & 63);
+        const bool ok = (ei < cnt) && col_ok;
+        v[u] = ok ? ld4(x + (int64_t)src * ldx + col4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc = CS ? fma4(s[u], v[u], acc) : add4(acc, v[u]);
+    }
+  }
+  if (G >= 2) acc = add4(acc, shfl_xor4(acc, 32));
+  if (G >= 4) acc = add4(acc, shfl_xor4(acc, 16));
+  if (G >= 8) acc = add4(acc, shfl_xor4(acc, 8));
+  if (G >= 16) acc = add4(acc, shfl_xor4(acc, 4));
+  return acc;
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4) {
+  float4 y;
+  if (MODE == GLNN_AGG_SAGE_GCN) {
+    const float4 s = ld4(a.x_self + v * a.ld_self + col4);
+    const float dp1 = (float)deg + 1.0f;
+    y = make_float4((acc.x + s.x) / dp1, (acc.y + s.y) / dp1, (acc.z + s.z) / dp1, (acc.w + s.w) / dp1);
+  } else {
+    const float rs = a.row_scale ? a.row_scale[v] : 1.0f;
+    y = make_float4(acc.x * rs, acc.y * rs, acc.z * rs, acc.w * rs);
+  }
+  float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = col4 + t;
+    if (c < a.d) {
+      if (a.ep_scale) yy[t] *= a.ep_scale[c];
+      if (a.ep_shift) yy[t] += a.ep_shift[c];
+      if (a.relu) yy[t] = fmaxf(yy[t], 0.f);
+    } else {
+      yy[t] = 0.f;  // padding columns are written as zero
+    }
+  }
+  st4(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
+}
+
+template <int LPR, int U, int MODE, bool CS>
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane % LPR;
+  const int col4 = c * 4;
+  const bool col_ok = col4 < a.d;
+
+  if ((int)blockIdx.x < a.n_long_blocks) {
+    // ---- long-row role: scan a strided share of the rows, whole workgroup per long row ----
+    __shared__ int64_t s_rows[kBlock];
+    __shared__ int s_count;
+    __shared__ float4 s_part[kWavesPerBlock][64];
+    const int64_t n_chunks = (a.n_dst + kBlock - 1) / kBlock;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += a.n_long_blocks) {
+      if (threadIdx.x == 0) s_count = 0;
+      __syncthreads();
+      const int64_t r = chunk * kBlock + threadIdx.x;
+      if (r < a.n_dst && (a.indptr[r + 1] - a.indptr[r]) > kLongRow) {
+        const int slot = atomicAdd(&s_count, 1);
+        s_rows[slot] = r;
+      }
+      __syncthreads();
+      const int n_found = s_count;
+      for (int i = 0; i < n_found; ++i) {
+        const int64_t v = s_rows[i];
+        const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+        float4 acc = wave_gather_sum<LPR, U, CS>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok,
+                                                 a.col_scale, lane);
+        if (lane < LPR) s_part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && lane < LPR && col_ok) {
+          float4 t = s_part[0][lane];
+#pragma unroll
+          for (int w = 1; w < kWavesPerBlock; ++w) t = add4(t, s_part[w][lane]);
+          finish_row<MODE>(a, v, e1 - e0, t, col4);
+        }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+
+  // ---- row role: one wave per row, rows interleaved across the 8 waves of the workgroup ----
+  const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
+  const int64_t row_base = blk * (kWavesPerBlock * kRowsPerWave);
+#pragma unroll 1
+  for (int r = 0; r < kRowsPerWave; ++r) {
+    const int64_t v = row_base + (int64_t)r * kWavesPerBlock + wave;
+    if (v >= a.n_dst) break;
+    const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+    const int64_t deg = e1 - e0;
+    if (deg > kLongRow) continue;
+    float4 acc = wave_gather_sum<LPR, U, CS>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane);
+    if (lane < LPR && col_ok) finish_row<MODE>(a, v, deg, acc, col4);
+  }
+}
+
+template <int LPR, int U>
+int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid) {
+  const bool cs = a.col_scale != nullptr;
+  if (mode == GLNN_AGG_SAGE_GCN) {
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  } else if (cs) {
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, true>), dim3(grid), dim3(kBlock), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, false>), dim3(grid), dim3(kBlock), 0, st, a);
+  }
+  return glnn::check_launch("glnn_spmm_csr_f32");
+}
+
+__global__ void degrees_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_dst,
+                               int64_t nnz, float* in_deg, float* out_deg_as_int) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (in_deg)
+    for (int64_t v = i; v < n_dst; v += stride) in_deg[v] = (float)(indptr[v + 1] - indptr[v]);
+  if (out_deg_as_int) {
+    int* cnt = reinterpret_cast<int*>(out_deg_as_int);
+    for (int64_t e = i; e < nnz; e += stride) atomicAdd(&cnt[indices[e]], 1);
+  }
+}
+
+__global__ void int_to_float_kernel(float* p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (float)reinterpret_cast<int*>(p)[i];
+}
+
+}  // namespace
+
+extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                 const float* x, int64_t ldx, int d, int mode, const float* row_scale,
+                                 const float* col_scale, const float* x_self, int64_t ld_self,
+                                 const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
+                                 void* stream) {
+  GLNN_REQUIRE(indptr && indices && x && out, "glnn_spmm_csr_f32: null pointer");
+  GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
+  GLNN_REQUIRE(d >= 1 && d <= 1024, "glnn_spmm_csr_f32: d=%d outside [1,1024]", d);
+  GLNN_REQUIRE(mode == GLNN_AGG_SUM || mode == GLNN_AGG_SAGE_GCN, "glnn_spmm_csr_f32: unknown mode %d", mode);
+  const int dpad = (d + 3) & ~3;
+  GLNN_REQUIRE(ldx % 4 == 0 && ldx >= dpad, "glnn_spmm_csr_f32: ldx=%lld must be a multiple of 4 and >= %d", (long long)ldx, dpad);
+  GLNN_REQUIRE(ldo % 4 == 0 && ldo >= dpad, "glnn_spmm_csr_f32: ldo=%lld must be a multiple of 4 and >= %d", (long long)ldo, dpad);
+  GLNN_REQUIRE(glnn::aligned16(x) && glnn::aligned16(out), "glnn_spmm_csr_f32: x/out must be 16-byte aligned");
+  if (mode == GLNN_AGG_SAGE_GCN) {
+    GLNN_REQUIRE(x_self && ld_self % 4 == 0 && ld_self >= dpad && glnn::aligned16(x_self),
+                 "glnn_spmm_csr_f32: SAGE_GCN needs x_self with ld multiple of 4");
+    GLNN_REQUIRE(!row_scale && !col_scale, "glnn_spmm_csr_f32: scales are not used in SAGE_GCN mode");
+  }
+  if (n_dst == 0) return GLNN_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  // column tiles of <= 256 floats (64 lanes x float4); wider rows (raw cora features in feature_prop) loop.
+  for (int c0 = 0; c0 < d; c0 += 256) {
+    const int dt = (d - c0) < 256 ? (d - c0) : 256;
+    SpmmArgs a;
+    a.indptr = indptr; a.indices = indices; a.n_dst = n_dst;
+    a.x = x + c0; a.ldx = ldx; a.d = dt;
+    a.row_scale = row_scale; a.col_scale = col_scale;
+    a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self;
+    a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
+    a.relu = relu; a.out = out + c0; a.ldo = ldo;
+    int64_t n_long = n_dst / 4096;
+    if (n_long < 1) n_long = 1;
+    if (n_long > 512) n_long = 512;
+    a.n_long_blocks = (int)n_long;
+    const int64_t rows_per_block = kWavesPerBlock * kRowsPerWave;
+    const int64_t row_blocks = (n_dst + rows_per_block - 1) / rows_per_block;
+    GLNN_REQUIRE(row_blocks + n_long < ((int64_t)1 << 31), "glnn_spmm_csr_f32: n_dst too large for one launch");
+    const int grid = (int)(row_blocks + n_long);
+    const int dv = (dt + 3) / 4;
+    int rc;
+    if (dv <= 4) rc = launch_lpr<4, 4>(a, mode, st, grid);
+    else if (dv <= 8) rc = launch_lpr<8, 4>(a, mode, st, grid);
+    else if (dv <= 16) rc = launch_lpr<16, 4>(a, mode, st, grid);
+    else if (dv <= 32) rc = launch_lpr<32, 4>(a, mode, st, grid);
+    else rc = launch_lpr<64, 4>(a, mode, st, grid);
+    if (rc != GLNN_OK) return rc;
+  }
+  return GLNN_OK;
+}
+
+extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                int64_t nnz, float* in_deg, float* out_deg, void* stream) {
+  GLNN_REQUIRE(indptr, "glnn_degrees_f32: null indptr");
+  GLNN_REQUIRE(!out_deg || indices, "glnn_degrees_f32: out_deg needs indices");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GLNN_REQUIRE(nnz >= 0 && n_dst >= 0 && n_src >= 0, "glnn_degrees_f32: negative size");
+  if (out_deg) {
+    if (hipMemsetAsync(out_deg, 0, sizeof(float) * (size_t)n_src, st) != hipSuccess)
+      return glnn::fail(GLNN_ERR_HIP, "glnn_degrees_f32: memset failed");
+  }
+  const int64_t work = nnz > n_dst ? nnz : n_dst;
+  int grid = (int)((work + 255) / 256);
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(degrees_kernel, dim3(grid), dim3(256), 0, st, indptr, indices, n_dst, nnz, in_deg, out_deg);
+  if (out_deg && n_src > 0)
+    hipLaunchKernelGGL(int_to_float_kernel, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, st, out_deg, n_src);
+  return glnn::check_launch("glnn_degrees_f32");
+}

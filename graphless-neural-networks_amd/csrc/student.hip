@@ -1,0 +1,378 @@
+// K4-K6: the non-GEMM pieces of the MLP student distillation step (gfx950).
+//   K4  log_softmax + NLL / KL(log-target, batchmean) forward AND gradient wrt logits in one pass
+//       (reference train_and_eval.py:77-84 with the criteria of train_student.py:278-279)
+//   K5  BatchNorm1d training statistics / backward (reference models.py:28-31,48-49)
+//   K6  fused multi-tensor Adam, torch.optim.Adam semantics (reference train_student.py:275-277)
+// All reductions are tree/fixed-order (no float atomics): results are run-to-run deterministic.
+#include <cmath>
+
+#include "glnn_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: one wavefront per row (c <= 64: one class per lane; larger c loops), 4 rows per workgroup.
+// ------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float* z; int64_t ldz; int64_t rows; int c; int kind;
+  const int64_t* labels; const int64_t* label_rows;
+  const float* t; int64_t ldt; const int64_t* t_rows;
+  float scale;  // lamb / rows
+  float* dz; int64_t ldg; float* logp; int64_t ldl;
+  float* partial;  // [gridDim.x] per-block loss sums, or NULL (log_softmax only)
+};
+
+template <bool LOSS>
+__global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wave_loss = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+    const float* zr = a.z + row * a.ldz;
+    float mx = -INFINITY;
+    for (int j = lane; j < a.c; j += 64) mx = fmaxf(mx, zr[j]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int j = lane; j < a.c; j += 64) se += expf(zr[j] - mx);
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    if (!LOSS) {
+      for (int j = lane; j < a.c; j += 64) a.logp[row * a.ldl + j] = zr[j] - lse;
+      continue;
+    }
+    float row_loss = 0.f;
+    if (a.kind == GLNN_LOSS_NLL) {
+      const int64_t y = a.labels[a.label_rows ? a.label_rows[row] : row];
+      for (int j = lane; j < a.c; j += 64) {
+        const float lp = zr[j] - lse;
+        if (a.logp) a.logp[row * a.ldl + j] = lp;
+        const float sm = expf(lp);
+        a.dz[row * a.ldg + j] = (sm - (j == y ? 1.f : 0.f)) * a.scale;
+        if (j == y) row_loss = -lp;
+      }
+      row_loss = wave_sum(row_loss);
+    } else {
+      const float* tr = a.t + (a.t_rows ? a.t_rows[row] : row) * a.ldt;
+      float set = 0.f;
+      for (int j = lane; j < a.c; j += 64) {
+        const float tj = tr[j], et = expf(tj);
+        set += et;
+        row_loss += et * (tj - (zr[j] - lse));
+      }
+      set = wave_sum(set);
+      row_loss = wave_sum(row_loss);
+      for (int j = lane; j < a.c; j += 64) {
+        const float lp = zr[j] - lse;
+        if (a.logp) a.logp[row * a.ldl + j] = lp;
+        a.dz[row * a.ldg + j] = (expf(lp) * set - expf(tr[j])) * a.scale;
+      }
+    }
+    wave_loss += row_loss;
+  }
+  if (LOSS) {
+    __shared__ float s[4];
+    if (lane == 0) s[wave] = wave_loss;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int n, float inv_rows,
+                                                            float* loss_out, float* loss_accum) {
+  __shared__ float s[256];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float l = s[0] * inv_rows;
+    if (loss_out) loss_out[0] = l;
+    if (loss_accum) loss_accum[0] += l;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: BatchNorm statistics.  Stage 1: per (row-chunk, column) mean and M2 by a two-pass over the
+// chunk (second pass hits L1/L2); stage 2: Chan's pairwise combine in double, fixed order.
+// ------------------------------------------------------------------------------------------
+constexpr int kBnRows = 128;  // rows per chunk
+
+__global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
+                                                        float* __restrict__ ws_mean, float* __restrict__ ws_m2) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > rows) r1 = rows;
+  const int cnt = (int)(r1 - r0);
+  __shared__ float sh[4][64];
+  float s = 0.f;
+  if (col < h)
+    for (int64_t r = r0 + rl; r < r1; r += 4) s += z[r * ldz + col];
+  sh[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = ((sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63]) + (sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63])) / (float)cnt;
+  __syncthreads();
+  float q = 0.f;
+  if (col < h)
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float d = z[r * ldz + col] - mean;
+      q = fmaf(d, d, q);
+    }
+  sh[rl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rl == 0 && col < h) {
+    ws_mean[(int64_t)blockIdx.y * h + col] = mean;
+    ws_m2[(int64_t)blockIdx.y * h + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  }
+}
+
+struct BnFinArgs {
+  const float* ws_mean; const float* ws_m2; int nchunks; int64_t rows; int h;
+  const float* gamma; const float* beta; float eps; float momentum;
+  float* running_mean; float* running_var; int64_t* nbt;
+  float* mean_out; float* rstd_out; float* a_scale; float* a_shift;
+};
+
+__global__ void bn_stats_stage2(const BnFinArgs a) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col == 0 && a.nbt) a.nbt[0] += 1;
+  if (col >= a.h) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int k = 0; k < a.nchunks; ++k) {
+    int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
+    if (r1 > a.rows) r1 = a.rows;
+    const double nb = (double)(r1 - r0);
+    const double mb = a.ws_mean[(int64_t)k * a.h + col], qb = a.ws_m2[(int64_t)k * a.h + col];
+    const double delta = mb - mean, nn = n + nb;
+    mean += delta * nb / nn;
+    m2 += qb + delta * delta * n * nb / nn;
+    n = nn;
+  }
+  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
+  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
+  const float meanf = (float)mean;
+  const float rstd = 1.0f / sqrtf(var_b + a.eps);
+  if (a.mean_out) a.mean_out[col] = meanf;
+  if (a.rstd_out) a.rstd_out[col] = rstd;
+  const float g = a.gamma ? a.gamma[col] : 1.f, b = a.beta ? a.beta[col] : 0.f;
+  const float sc = g * rstd;
+  a.a_scale[col] = sc;
+  a.a_shift[col] = b - meanf * sc;
+  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
+  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
+}
+
+// backward stage 1: per (row-chunk, column) sums of dy and dy*xhat,  dy = da * [z*a_scale+a_shift > 0]
+__global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ da, int64_t ldda, const float* __restrict__ z,
+                                                      int64_t ldz, int64_t rows, int h, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ a_scale,
+                                                      const float* __restrict__ a_shift, float* __restrict__ ws1,
+                                                      float* __restrict__ ws2) {
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > rows) r1 = rows;
+  float s1 = 0.f, s2 = 0.f;
+  if (col < h) {
+    const float mu = mean[col], rs = rstd[col], sc = a_scale[col], sf = a_shift[col];
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float zz = z[r * ldz + col];
+      const float dy = fmaf(zz, sc, sf) > 0.f ? da[r * ldda + col] : 0.f;
+      s1 += dy;
+      s2 = fmaf(dy, (zz - mu) * rs, s2);
+    }
+  }
+  __shared__ float sh1[4][64], sh2[4][64];
+  sh1[rl][threadIdx.x & 63] = s1;
+  sh2[rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl == 0 && col < h) {
+    ws1[(int64_t)blockIdx.y * h + col] = (sh1[0][threadIdx.x] + sh1[1][threadIdx.x]) + (sh1[2][threadIdx.x] + sh1[3][threadIdx.x]);
+    ws2[(int64_t)blockIdx.y * h + col] = (sh2[0][threadIdx.x] + sh2[1][threadIdx.x]) + (sh2[2][threadIdx.x] + sh2[3][threadIdx.x]);
+  }
+}
+__global__ void bn_bwd_stage2(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks, int h,
+                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= h) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    s1 += ws1[(int64_t)k * h + col];
+    s2 += ws2[(int64_t)k * h + col];
+  }
+  dbeta[col] = s1;
+  dgamma[col] = s2;
+}
+// stage 3 (BN):  dz = gamma*rstd*(dy - s1/B - xhat*s2/B);   (no BN): dz = da*[z>0]
+template <bool BN>
+__global__ __launch_bounds__(256) void bn_bwd_stage3(const float* __restrict__ da, int64_t ldda, const float* __restrict__ z,
+                                                      int64_t ldz, int64_t rows, int h, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                      float* __restrict__ dz, int64_t lddz) {
+  const int64_t total = rows * h;
+  const float inv_b = 1.0f / (float)rows;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / h;
+    const int col = (int)(i - r * h);
+    const float zz = z[r * ldz + col];
+    if (BN) {
+      const float dy = fmaf(zz, a_scale[col], a_shift[col]) > 0.f ? da[r * ldda + col] : 0.f;
+      const float xhat = (zz - mean[col]) * rstd[col];
+      dz[r * lddz + col] = gamma[col] * rstd[col] * (dy - dbeta[col] * inv_b - xhat * dgamma[col] * inv_b);
+    } else {
+      dz[r * lddz + col] = zz > 0.f ? da[r * ldda + col] : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: multi-tensor Adam. grid = (chunks, tensors), float4 where the tensor allows it.
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* const* p; const float* const* g; float* const* m; float* const* v; const int64_t* sizes;
+  float beta1, beta2, eps, wd, step_size, bc2_sqrt;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
+  const int t = blockIdx.y;
+  const int64_t n = a.sizes[t];
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = fmaf(gi * gi, 1.f - a.beta2, v[i] * a.beta2);  // mul_(beta2).addcmul_(g,g,1-beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    p[i] = pi - a.step_size * (mi / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t rows, int c, int kind,
+                                     const int64_t* labels, const int64_t* label_rows, const float* target_logp,
+                                     int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
+                                     float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
+                                     float* workspace, int64_t workspace_floats, void* stream) {
+  GLNN_REQUIRE(logits && dlogits && workspace, "glnn_softmax_loss_f32: null pointer");
+  GLNN_REQUIRE(rows >= 1 && c >= 1 && ldz >= c && ldg >= c, "glnn_softmax_loss_f32: bad sizes");
+  GLNN_REQUIRE(kind == GLNN_LOSS_NLL || kind == GLNN_LOSS_KL, "glnn_softmax_loss_f32: unknown kind %d", kind);
+  if (kind == GLNN_LOSS_NLL) GLNN_REQUIRE(labels, "glnn_softmax_loss_f32: NLL needs labels");
+  if (kind == GLNN_LOSS_KL) GLNN_REQUIRE(target_logp && ldt >= c, "glnn_softmax_loss_f32: KL needs target_logp");
+  GLNN_REQUIRE(!logprob_out || ldl >= c, "glnn_softmax_loss_f32: ldl too small");
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  GLNN_REQUIRE(workspace_floats >= blocks, "glnn_softmax_loss_f32: workspace needs >= %lld floats", (long long)blocks);
+  LossArgs a;
+  a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.kind = kind; a.labels = labels; a.label_rows = label_rows;
+  a.t = target_logp; a.ldt = ldt; a.t_rows = target_rows; a.scale = lamb / (float)rows;
+  a.dz = dlogits; a.ldg = ldg; a.logp = logprob_out; a.ldl = ldl; a.partial = workspace;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum);
+  return glnn::check_launch("glnn_softmax_loss_f32");
+}
+
+extern "C" int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows, int c, float* out, int64_t ldo,
+                                    void* stream) {
+  GLNN_REQUIRE(logits && out, "glnn_log_softmax_f32: null pointer");
+  GLNN_REQUIRE(rows >= 0 && c >= 1 && ldz >= c && ldo >= c, "glnn_log_softmax_f32: bad sizes");
+  if (rows == 0) return GLNN_OK;
+  int64_t blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  LossArgs a = {};
+  a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.logp = out; a.ldl = ldo;
+  hipLaunchKernelGGL((softmax_loss_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  return glnn::check_launch("glnn_log_softmax_f32");
+}
+
+extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean_out, float* rstd_out, float* a_scale_out,
+                                 float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream) {
+  GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
+  GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
+  const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
+  GLNN_REQUIRE(workspace_floats >= 2ll * nchunks * h, "glnn_bn_stats_f32: workspace needs >= %lld floats", 2ll * nchunks * h);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* ws_mean = workspace;
+  float* ws_m2 = workspace + (int64_t)nchunks * h;
+  hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2);
+  BnFinArgs a;
+  a.ws_mean = ws_mean; a.ws_m2 = ws_m2; a.nchunks = nchunks; a.rows = rows; a.h = h; a.gamma = gamma; a.beta = beta;
+  a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
+  a.mean_out = mean_out; a.rstd_out = rstd_out; a.a_scale = a_scale_out; a.a_shift = a_shift_out;
+  hipLaunchKernelGGL(bn_stats_stage2, dim3((h + 127) / 128), dim3(128), 0, st, a);
+  return glnn::check_launch("glnn_bn_stats_f32");
+}
+
+extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
+                                    const float* gamma, const float* mean, const float* rstd, const float* a_scale,
+                                    const float* a_shift, float* dz, int64_t lddz, float* dgamma, float* dbeta,
+                                    float* workspace, int64_t workspace_floats, void* stream) {
+  GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
+  GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int64_t blocks = (rows * h + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (!gamma) {
+    hipLaunchKernelGGL((bn_bwd_stage3<false>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dz, lddz);
+    return glnn::check_launch("glnn_bn_relu_bwd_f32");
+  }
+  GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta && workspace, "glnn_bn_relu_bwd_f32: BN path needs stats, outputs and workspace");
+  const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
+  GLNN_REQUIRE(workspace_floats >= 2ll * nchunks * h, "glnn_bn_relu_bwd_f32: workspace needs >= %lld floats", 2ll * nchunks * h);
+  float* ws1 = workspace;
+  float* ws2 = workspace + (int64_t)nchunks * h;
+  hipLaunchKernelGGL(bn_bwd_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, mean, rstd,
+                     a_scale, a_shift, ws1, ws2);
+  hipLaunchKernelGGL(bn_bwd_stage2, dim3((h + 127) / 128), dim3(128), 0, st, ws1, ws2, nchunks, h, dgamma, dbeta);
+  hipLaunchKernelGGL((bn_bwd_stage3<true>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, gamma, mean,
+                     rstd, a_scale, a_shift, dgamma, dbeta, dz, lddz);
+  return glnn::check_launch("glnn_bn_relu_bwd_f32");
+}
+
+extern "C" int glnn_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const int64_t* sizes, int num_tensors, int64_t max_size,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                  void* stream) {
+  GLNN_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes, "glnn_adam_step_f32: null pointer");
+  GLNN_REQUIRE(num_tensors >= 1 && max_size >= 1 && step >= 1, "glnn_adam_step_f32: bad sizes/step");
+  AdamArgs a;
+  a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.sizes = sizes;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.bc2_sqrt = (float)std::sqrt(bc2);
+  int64_t chunks = (max_size + 1023) / 1024;
+  if (chunks > 1024) chunks = 1024;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks, (unsigned)num_tensors), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  return glnn::check_launch("glnn_adam_step_f32");
+}

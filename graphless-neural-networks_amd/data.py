@@ -1,0 +1,102 @@
+"""Synthetic stand-ins for the reference's datasets (reference dataloader.py:42-111 loads the real
+ones through dgl/ogb; neither the datasets nor a network exist here -- SURVEY.md section 8d).
+
+Shapes are the public statistics of the datasets BASELINE.json names; graphs are seeded random
+multigraphs with a power-law degree profile in RANDOM node order (worst case for locality), stored as
+CSR over destination rows (int64 indptr, int32 indices) -- the layout libglnn_hip.so consumes.
+Everything is built with torch so that the big ones are generated directly in HBM."""
+import math
+
+import torch
+
+from .graph import CSRGraph
+
+SHAPES = {
+    # name: nodes, feature dim, classes, (train, val, test)
+    "cora": dict(n=2485, f=1433, c=7, split=(140, 210, 2135)),
+    "ogbn-arxiv": dict(n=169343, f=128, c=40, split=(90941, 29799, 48603)),
+    "ogbn-products": dict(n=2449029, f=100, c=47, split=(196615, 39323, 2213091)),
+}
+
+
+def _powerlaw_endpoints(n, m, alpha, offset, gen, device):
+    """m node ids drawn with P(i) ~ (rank_i + offset)^-alpha, ranks randomly permuted over node ids."""
+    w = (torch.arange(n, device=device, dtype=torch.float64) + offset).pow(-alpha)
+    cdf = torch.cumsum(w, 0)
+    cdf /= cdf[-1].clone()
+    perm = torch.randperm(n, generator=gen, device=device)
+    out = torch.empty(m, dtype=torch.int64, device=device)
+    step = 1 << 24
+    for s in range(0, m, step):
+        u = torch.rand(min(step, m - s), generator=gen, device=device, dtype=torch.float64)
+        out[s:s + step] = perm[torch.searchsorted(cdf, u).clamp_(max=n - 1)]
+    return out
+
+
+def csr_from_edges(src, dst, n_dst, n_src=None):
+    """CSR over destinations; duplicates kept (multi-edges count multiply, like dgl)."""
+    n_src = n_dst if n_src is None else n_src
+    order = torch.argsort(dst, stable=True)
+    indices = src[order].to(torch.int32)
+    counts = torch.bincount(dst, minlength=n_dst)
+    indptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=dst.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    return CSRGraph(indptr, indices, n_dst, n_src)
+
+
+def make_graph(name, seed=0, device="cpu", scale=1.0):
+    """cora / ogbn-arxiv / ogbn-products shaped graph. `scale` < 1 shrinks node and edge counts (tests)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    if name == "cora":
+        # 5,069 undirected edges, symmetrised, + self-loops -> 12,623 nnz   (dataloader.py:103-105)
+        n = max(8, int(2485 * scale))
+        m = max(8, int(5069 * scale))
+        a = torch.randint(0, n, (m,), generator=gen, device=device)
+        b = torch.randint(0, n, (m,), generator=gen, device=device)
+        loops = torch.arange(n, device=device)
+        return csr_from_edges(torch.cat([a, b, loops]), torch.cat([b, a, loops]), n)
+    if name == "ogbn-arxiv":
+        # 1,166,243 directed edges, + reverse (no dedup) + self-loops -> 2,501,829 nnz (dataloader.py:74-77)
+        n = max(8, int(169343 * scale))
+        m = max(8, int(1166243 * scale))
+        src = torch.randint(0, n, (m,), generator=gen, device=device)
+        dst = _powerlaw_endpoints(n, m, 0.6, 10.0, gen, device)
+        loops = torch.arange(n, device=device)
+        return csr_from_edges(torch.cat([src, dst, loops]), torch.cat([dst, src, loops]), n)
+    if name == "ogbn-products":
+        # 61,859,140 undirected edges stored in both directions -> 123,718,280 nnz, no self-loops
+        n = max(8, int(2449029 * scale))
+        m = max(8, int(61859140 * scale))
+        # alpha 0.5, offset 4: expected max degree ~17.7k at full scale (real graph: 17,481), min ~25
+        a = _powerlaw_endpoints(n, m, 0.5, 4.0, gen, device)
+        b = _powerlaw_endpoints(n, m, 0.5, 4.0, gen, device)
+        return csr_from_edges(torch.cat([a, b]), torch.cat([b, a]), n)
+    raise ValueError(f"Unknown dataset shape: {name}")
+
+
+def make_uniform_graph(n, avg_deg, seed=0, device="cpu"):
+    """Uniform random directed multigraph (the synthetic-XL config's per-shard generator)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    m = int(n * avg_deg)
+    src = torch.randint(0, n, (m,), generator=gen, device=device)
+    dst = torch.randint(0, n, (m,), generator=gen, device=device)
+    return csr_from_edges(src, dst, n)
+
+
+def make_node_data(name, seed=0, device="cpu", scale=1.0, n=None):
+    """feats ~ N(0,1) fp32, labels uniform int64, teacher out_t = log_softmax(N(0,1)), index split."""
+    sh = SHAPES[name]
+    n = n if n is not None else max(8, int(sh["n"] * scale))
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed + 12345)
+    feats = torch.randn((n, sh["f"]), generator=gen, device=device, dtype=torch.float32)
+    labels = torch.randint(0, sh["c"], (n,), generator=gen, device=device, dtype=torch.int64)
+    out_t = torch.log_softmax(torch.randn((n, sh["c"]), generator=gen, device=device, dtype=torch.float32), dim=1)
+    perm = torch.randperm(n, generator=gen, device=device)
+    tr, va, te = sh["split"]
+    tot = tr + va + te
+    n_tr, n_va = max(1, math.floor(n * tr / tot)), max(1, math.floor(n * va / tot))
+    idx_train, idx_val, idx_test = perm[:n_tr], perm[n_tr:n_tr + n_va], perm[n_tr + n_va:]
+    return feats, labels, out_t, (idx_train, idx_val, idx_test)

@@ -1,0 +1,146 @@
+"""CSR graph / block container exposing the handful of DGLGraph methods the reference touches.
+
+The reference passes `dgl.DGLGraph` objects and 1-hop "blocks" around (reference models.py:109,134-137,
+train_and_eval.py:41,178-211, utils.py:162-163,176-185, dataloader.py:105).  This container keeps the
+same call surface -- num_nodes(), number_of_nodes(), number_of_edges(), num_dst_nodes(), in_degrees(),
+out_degrees(), ndata[...], int(), to(device), create_formats_(), subgraph(idx) -- over the ONE layout the
+HIP kernels read: CSR over destination rows, int64 indptr, int32 indices, resident in HBM."""
+import torch
+
+
+class CSRGraph:
+    def __init__(self, indptr, indices, n_dst, n_src=None):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
+        assert indptr.numel() == n_dst + 1
+        self.indptr = indptr.contiguous()
+        self.indices = indices.contiguous()
+        self.n_dst = int(n_dst)
+        self.n_src = int(n_dst if n_src is None else n_src)
+        self.ndata = {}
+        self._nnz = None
+        self._cache = {}
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def from_edges(cls, src, dst, num_nodes):
+        """dgl.graph((src, dst)) equivalent: edge u->v means v aggregates from u."""
+        src = torch.as_tensor(src, dtype=torch.int64)
+        dst = torch.as_tensor(dst, dtype=torch.int64)
+        order = torch.argsort(dst, stable=True)
+        counts = torch.bincount(dst, minlength=num_nodes)
+        indptr = torch.zeros(num_nodes + 1, dtype=torch.int64, device=dst.device)
+        torch.cumsum(counts, 0, out=indptr[1:])
+        return cls(indptr, src[order].to(torch.int32), num_nodes)
+
+    # ---- DGL-like surface -----------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.indptr.device
+
+    def num_nodes(self):
+        return self.n_src
+
+    number_of_nodes = num_nodes
+
+    def num_src_nodes(self):
+        return self.n_src
+
+    def num_dst_nodes(self):
+        return self.n_dst
+
+    def num_edges(self):
+        if self._nnz is None:
+            self._nnz = int(self.indptr[-1].item())
+        return self._nnz
+
+    number_of_edges = num_edges
+
+    def int(self):
+        return self            # indices already int32 (reference: block.int(), models.py:134)
+
+    def create_formats_(self):
+        return None            # CSR-by-destination is the only format used
+
+    def to(self, device):
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        if device == self.indptr.device:
+            return self
+        g = CSRGraph(self.indptr.to(device), self.indices.to(device), self.n_dst, self.n_src)
+        g._nnz = self._nnz
+        g.ndata = {k: v.to(device) for k, v in self.ndata.items()}
+        return g
+
+    def in_degrees(self):
+        return self.indptr[1:] - self.indptr[:-1]
+
+    def out_degrees(self):
+        return torch.bincount(self.indices.long(), minlength=self.n_src)
+
+    def degree_norms(self):
+        """(in_deg.clamp(1)^-1/2, out_deg.clamp(1)^-1/2) as fp32 device vectors, computed once by
+        glnn_degrees_f32 (GraphConv norm='both' / feature_prop, reference utils.py:178-179)."""
+        if "norms" not in self._cache:
+            if self.indptr.is_cuda:
+                from . import ops
+                in_deg, out_deg = ops.degrees(self.indptr, self.indices, self.n_dst, self.n_src, self.num_edges())
+            else:
+                in_deg, out_deg = self.in_degrees().float(), self.out_degrees().float()
+            self._cache["norms"] = (in_deg.clamp(min=1).pow(-0.5), out_deg.clamp(min=1).pow(-0.5))
+        return self._cache["norms"]
+
+    def row_range(self, start, stop):
+        """Destination rows [start, stop) with ALL source columns kept (node-range shard / eval chunk)."""
+        lo, hi = int(self.indptr[start].item()), int(self.indptr[stop].item())
+        g = CSRGraph((self.indptr[start:stop + 1] - lo).contiguous(), self.indices[lo:hi], stop - start, self.n_src)
+        g._nnz = hi - lo
+        return g
+
+    def subgraph(self, idx):
+        """g.subgraph(idx_obs) (reference train_and_eval.py:324): induced subgraph, nodes relabelled in
+        the order of idx."""
+        idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device)
+        remap = torch.full((self.n_src,), -1, dtype=torch.int64, device=self.device)
+        remap[idx] = torch.arange(idx.numel(), device=self.device)
+        deg = self.in_degrees()
+        dst_all = torch.repeat_interleave(torch.arange(self.n_dst, device=self.device), deg)
+        src_new, dst_new = remap[self.indices.long()], remap[dst_all]
+        keep = (src_new >= 0) & (dst_new >= 0)
+        g = CSRGraph.from_edges(src_new[keep], dst_new[keep], idx.numel())
+        g.ndata = {k: v[idx] for k, v in self.ndata.items()}
+        return g
+
+
+class FullNeighborLoader:
+    """The reference's `dataloader_eval` (train_and_eval.py:193-202): MultiLayerFullNeighborSampler(1)
+    over torch.arange(N), shuffle=False, drop_last=False.  Iterating yields
+    (input_nodes, output_nodes, [block]) per chunk of `batch_size` destination nodes in node-id order,
+    the chunk's dst nodes first among the block's sources.  `graph` exposes the whole CSR so that
+    SAGE.inference can take the unchunked fast path (identical arithmetic: every dst row is independent)."""
+
+    def __init__(self, graph, batch_size):
+        self.graph = graph
+        self.batch_size = int(batch_size)
+
+    def __len__(self):
+        return (self.graph.n_dst + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        g = self.graph
+        dev = g.device
+        n = g.n_dst
+        for s in range(0, n, self.batch_size):
+            e = min(n, s + self.batch_size)
+            lo, hi = int(g.indptr[s].item()), int(g.indptr[e].item())
+            src = g.indices[lo:hi].long()
+            output_nodes = torch.arange(s, e, device=dev)
+            is_out = torch.zeros(g.n_src, dtype=torch.bool, device=dev)
+            is_out[s:e] = True
+            uniq = torch.unique(src)
+            extra = uniq[~is_out[uniq]]
+            input_nodes = torch.cat([output_nodes, extra])
+            remap = torch.empty(g.n_src, dtype=torch.int64, device=dev)
+            remap[input_nodes] = torch.arange(input_nodes.numel(), device=dev)
+            block = CSRGraph((g.indptr[s:e + 1] - lo).contiguous(), remap[src].to(torch.int32), e - s,
+                             input_nodes.numel())
+            block._nnz = hi - lo
+            yield input_nodes, output_nodes, [block]

@@ -1,0 +1,260 @@
+"""Thin torch-tensor wrappers over the C ABI (include/glnn_hip.h).  torch is plumbing here: it owns
+device memory and the current HIP stream; all arithmetic is in libglnn_hip.so.  Every function
+raises on CPU tensors -- there is no fallback path."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+AGG_SUM, AGG_SAGE_GCN = 0, 1
+LOSS_NLL, LOSS_KL = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GlnnError("glnn_amd.ops: tensors must live on the GPU (HIP path only, no CPU fallback)")
+
+
+def _vec(t, n, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if t.dtype != dtype or t.dim() != 1 or t.numel() < n or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous {dtype} vector with >= {n} elements")
+    return t
+
+
+def _mat(t, name):
+    if t.dtype != torch.float32 or t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{name}: expected 2-D float32 row-major tensor")
+    return t
+
+
+def _ld(t):
+    return t.stride(0)
+
+
+def round4(d):
+    return (d + 3) // 4 * 4
+
+
+def feat_empty(n, d, device, zero=False):
+    """[n, d] fp32 view of an [n, round4(d)] buffer: rows 16-byte aligned as the float4 kernels need."""
+    ld = round4(d)
+    buf = (torch.zeros if zero else torch.empty)((n, ld), dtype=torch.float32, device=device)
+    return buf[:, :d]
+
+
+def as_feat(t):
+    """Return t itself if its layout suits the float4 kernels, else a padded copy."""
+    _mat(t, "as_feat")
+    if t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t
+    out = feat_empty(t.shape[0], t.shape[1], t.device, zero=True)
+    out.copy_(t)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None,
+         relu=False, out=None):
+    """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d]."""
+    _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out)
+    x = as_feat(x)
+    n_src, d = x.shape
+    if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
+        raise ValueError("spmm: indptr must be int64 and indices int32")
+    if out is None:
+        out = feat_empty(n_dst, d, x.device)
+    _mat(out, "spmm out")
+    rc = _lib.lib().glnn_spmm_csr_f32(
+        _p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
+        _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
+        _p(x) if mode == AGG_SAGE_GCN else None, _ld(x),
+        _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
+        _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_spmm_csr_f32")
+    return out
+
+
+def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
+    _need_cuda(indptr, indices)
+    in_deg = torch.empty(n_dst, dtype=torch.float32, device=indptr.device)
+    out_deg = torch.empty(n_src, dtype=torch.float32, device=indptr.device) if want_out else None
+    rc = _lib.lib().glnn_degrees_f32(_p(indptr), _p(indices), n_dst, n_src, nnz, _p(in_deg), _p(out_deg), _stream())
+    _lib.check(rc, "glnn_degrees_f32")
+    return in_deg, out_deg
+
+
+def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale=None, ep_scale=None,
+         ep_shift=None, relu=False, out=None, m=None):
+    """K3 glnn_gemm_f32: out = epi(A' @ W^T) (w [n,k], torch Linear layout) or epi(A' @ W) (w [k,n])."""
+    _need_cuda(a, w, a_rows, a_scale, a_shift, row_scale, ep_scale, ep_shift, out)
+    _mat(a, "gemm a")
+    _mat(w, "gemm w")
+    k = a.shape[1]
+    n = w.shape[1] if w_is_kn else w.shape[0]
+    if (w.shape[0] if w_is_kn else w.shape[1]) != k:
+        raise ValueError(f"gemm: inner dimensions differ: a {tuple(a.shape)} w {tuple(w.shape)} kn={w_is_kn}")
+    if m is None:
+        m = a_rows.numel() if a_rows is not None else a.shape[0]
+    if a_rows is not None and (a_rows.dtype != torch.int64 or not a_rows.is_contiguous()):
+        raise ValueError("gemm: a_rows must be contiguous int64")
+    if out is None:
+        out = feat_empty(m, n, a.device)
+    _mat(out, "gemm out")
+    rc = _lib.lib().glnn_gemm_f32(
+        _p(a), _ld(a), _p(a_rows), _p(_vec(a_scale, k, "a_scale")), _p(_vec(a_shift, k, "a_shift")), m, k,
+        _p(w), _ld(w), 1 if w_is_kn else 0, n, _p(_vec(row_scale, m, "row_scale")),
+        _p(_vec(ep_scale, n, "ep_scale")), _p(_vec(ep_shift, n, "ep_shift")), 1 if relu else 0,
+        _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_gemm_f32")
+    return out
+
+
+def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=None, workspace=None, m=None):
+    """glnn_gemm_tn_f32: out[i,j] = sum_m a[m,i] * b'[m,j]  (weight gradient dW = dZ^T @ A_prev)."""
+    _need_cuda(a, b, b_rows, b_scale, b_shift, out, col_sum_a, workspace)
+    _mat(a, "gemm_tn a")
+    _mat(b, "gemm_tn b")
+    if m is None:
+        m = a.shape[0]
+    ka, nb = a.shape[1], b.shape[1]
+    if out is None:
+        out = torch.empty((ka, nb), dtype=torch.float32, device=a.device)
+    if workspace is None:
+        workspace = torch.empty(64 * ka + 256 * 128 * 128, dtype=torch.float32, device=a.device)
+    rc = _lib.lib().glnn_gemm_tn_f32(
+        _p(a), _ld(a), m, ka, _p(b), _ld(b), _p(b_rows), _p(_vec(b_scale, nb, "b_scale")),
+        _p(_vec(b_shift, nb, "b_shift")), nb, _p(out), _ld(out), _p(col_sum_a), _p(workspace), workspace.numel(), _stream())
+    _lib.check(rc, "glnn_gemm_tn_f32")
+    return out
+
+
+def softmax_loss(logits, kind, lamb, labels=None, label_rows=None, target_logp=None, target_rows=None,
+                 dlogits=None, logprob_out=None, loss_out=None, loss_accum=None, workspace=None):
+    """K4 glnn_softmax_loss_f32.  Returns (loss_out [1] device tensor, dlogits)."""
+    _need_cuda(logits, labels, label_rows, target_logp, target_rows, dlogits, logprob_out, loss_out, loss_accum)
+    _mat(logits, "softmax_loss logits")
+    rows, c = logits.shape
+    if dlogits is None:
+        dlogits = torch.empty((rows, c), dtype=torch.float32, device=logits.device)
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    if workspace is None:
+        workspace = torch.empty(1024, dtype=torch.float32, device=logits.device)
+    if labels is not None and labels.dtype != torch.int64:
+        raise ValueError("softmax_loss: labels must be int64")
+    rc = _lib.lib().glnn_softmax_loss_f32(
+        _p(logits), _ld(logits), rows, c, kind, _p(labels), _p(label_rows),
+        _p(target_logp), _ld(target_logp) if target_logp is not None else 0, _p(target_rows), float(lamb),
+        _p(dlogits), _ld(dlogits), _p(logprob_out), _ld(logprob_out) if logprob_out is not None else 0,
+        _p(loss_out), _p(loss_accum), _p(workspace), workspace.numel(), _stream())
+    _lib.check(rc, "glnn_softmax_loss_f32")
+    return loss_out, dlogits
+
+
+def log_softmax(logits, out=None):
+    _need_cuda(logits, out)
+    _mat(logits, "log_softmax logits")
+    rows, c = logits.shape
+    if out is None:
+        out = torch.empty((rows, c), dtype=torch.float32, device=logits.device)
+    rc = _lib.lib().glnn_log_softmax_f32(_p(logits), _ld(logits), rows, c, _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_log_softmax_f32")
+    return out
+
+
+def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, outs=None, workspace=None):
+    """K5 glnn_bn_stats_f32.  Returns (mean, rstd, a_scale, a_shift)."""
+    _need_cuda(z, gamma, beta, running_mean, running_var, nbt, workspace)
+    _mat(z, "bn_stats z")
+    rows, h = z.shape
+    if outs is None:
+        outs = tuple(torch.empty(h, dtype=torch.float32, device=z.device) for _ in range(4))
+    mean, rstd, a_scale, a_shift = outs
+    need = 2 * ((rows + 127) // 128) * h
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.float32, device=z.device)
+    rc = _lib.lib().glnn_bn_stats_f32(_p(z), _ld(z), rows, h, _p(gamma), _p(beta), eps, momentum, _p(running_mean),
+                                      _p(running_var), _p(nbt), _p(mean), _p(rstd), _p(a_scale), _p(a_shift),
+                                      _p(workspace), workspace.numel(), _stream())
+    _lib.check(rc, "glnn_bn_stats_f32")
+    return mean, rstd, a_scale, a_shift
+
+
+def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=None, dz=None, dgamma=None,
+                dbeta=None, workspace=None):
+    """K5 glnn_bn_relu_bwd_f32.  Returns (dz, dgamma, dbeta); gamma=None => plain ReLU backward."""
+    _need_cuda(da, z, gamma, mean, rstd, a_scale, a_shift, dz, dgamma, dbeta, workspace)
+    _mat(da, "bn_relu_bwd da")
+    _mat(z, "bn_relu_bwd z")
+    rows, h = z.shape
+    if dz is None:
+        dz = torch.empty((rows, h), dtype=torch.float32, device=z.device)
+    if gamma is not None:
+        if dgamma is None:
+            dgamma = torch.empty(h, dtype=torch.float32, device=z.device)
+        if dbeta is None:
+            dbeta = torch.empty(h, dtype=torch.float32, device=z.device)
+        if workspace is None:
+            workspace = torch.empty(2 * ((rows + 127) // 128) * h, dtype=torch.float32, device=z.device)
+    rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
+                                         _p(a_scale), _p(a_shift), _p(dz), _ld(dz), _p(dgamma), _p(dbeta),
+                                         _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
+    _lib.check(rc, "glnn_bn_relu_bwd_f32")
+    return dz, dgamma, dbeta
+
+
+class TensorTable:
+    """Device-side pointer table for the multi-tensor Adam (built once per optimiser)."""
+
+    def __init__(self, params, grads, exp_avg, exp_avg_sq):
+        dev = params[0].device
+        for group in (params, grads, exp_avg, exp_avg_sq):
+            for t in group:
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise ValueError("TensorTable: contiguous float32 CUDA tensors required")
+        self.keep = (list(params), list(grads), list(exp_avg), list(exp_avg_sq))
+        mk = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev)
+        self.p, self.g, self.m, self.v = mk(params), mk(grads), mk(exp_avg), mk(exp_avg_sq)
+        self.sizes = torch.tensor([t.numel() for t in params], dtype=torch.int64, device=dev)
+        self.n = len(params)
+        self.max_size = max(t.numel() for t in params)
+
+
+def adam_step(table, lr, step, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    rc = _lib.lib().glnn_adam_step_f32(_p(table.p), _p(table.g), _p(table.m), _p(table.v), _p(table.sizes), table.n,
+                                       table.max_size, lr, beta1, beta2, eps, weight_decay, step, _stream())
+    _lib.check(rc, "glnn_adam_step_f32")
+
+
+def gather_rows(x, rows, out=None):
+    _need_cuda(x, rows, out)
+    x = as_feat(x)
+    d = x.shape[1]
+    if rows.dtype != torch.int64:
+        raise ValueError("gather_rows: rows must be int64")
+    if out is None:
+        out = feat_empty(rows.numel(), d, x.device)
+    rc = _lib.lib().glnn_gather_rows_f32(_p(x), _ld(x), _p(rows), rows.numel(), d, _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_gather_rows_f32")
+    return out
+
+
+def scatter_rows(x, rows, out):
+    _need_cuda(x, rows, out)
+    x = as_feat(x)
+    d = x.shape[1]
+    rc = _lib.lib().glnn_scatter_rows_f32(_p(x), _ld(x), _p(rows), rows.numel(), d, _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_scatter_rows_f32")
+    return out

@@ -1,0 +1,186 @@
+/*
+ * glnn_hip.h -- C ABI of libglnn_hip.so, the MI355X (gfx950) implementation of the GLNN hot path:
+ * teacher neighbour aggregation + dense projections, and the MLP student distillation step.
+ *
+ * The reference (snap-research/graphless-neural-networks) has NO native/FFI layer: it is pure
+ * Python whose graph arithmetic is delegated to dgl==0.6.1 and whose dense arithmetic is
+ * torch==1.7.0.  Each entry point below therefore cites the reference *call site* (file:line under
+ * /root/reference) whose arithmetic it replaces; INTEGRATION.md shows the ctypes binding a
+ * maintainer would add at that call site.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + explicit sizes and leading dimensions (in ELEMENTS), no torch types;
+ *   - every data pointer is a DEVICE pointer (HBM) unless the parameter says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only ENQUEUE
+ *     work, never synchronise, never allocate or free caller memory;
+ *   - return value: 0 = GLNN_OK, negative = glnn_status; glnn_last_error() gives a thread-local
+ *     message for the last failing call on this thread;
+ *   - fp32 values, int32 column indices, int64 row pointers; row-major matrices;
+ *   - feature matrices must have a leading dimension that is a multiple of 4 floats and a
+ *     16-byte aligned base (the kernels move float4); columns [d, ld) are padding: read but
+ *     never trusted, and written as 0 by kernels that own an output.
+ */
+#ifndef GLNN_HIP_H
+#define GLNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLNN_API __attribute__((visibility("default")))
+
+typedef enum {
+  GLNN_OK = 0,
+  GLNN_ERR_INVALID_ARG = -1,   /* null pointer, bad size, bad alignment / leading dimension */
+  GLNN_ERR_UNSUPPORTED = -2,   /* shape or mode outside what the kernels implement */
+  GLNN_ERR_HIP = -3,           /* a HIP runtime call or launch failed */
+  GLNN_ERR_NO_DEVICE = -4      /* no gfx950 device visible */
+} glnn_status;
+
+GLNN_API int glnn_abi_version(void);               /* bumped on any signature change */
+GLNN_API const char* glnn_last_error(void);        /* thread-local, never NULL */
+GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int arch_buf_len);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2  CSR neighbour aggregation (SpMM with an implicit all-ones adjacency, multi-edges kept).
+ * CSR is over DESTINATION rows: row v lists the sources u of its in-edges u->v.
+ *
+ * mode GLNN_AGG_SUM       out[v,:] = row_scale[v] * sum_{u->v} col_scale[u] * x[u,:]
+ *        replaces g.update_all(fn.copy_u("h","m"), fn.sum("m","h")), reference utils.py:185
+ *        (feature_prop) and the aggregation inside dgl GraphConv(norm="both"), reference
+ *        models.py:193 (ctor :170-187): col_scale = out_deg.clamp(1)^-1/2,
+ *        row_scale = in_deg.clamp(1)^-1/2.  Either scale may be NULL (= 1).
+ * mode GLNN_AGG_SAGE_GCN  out[v,:] = (sum_{u->v} x[u,:] + x_self[v,:]) / (in_deg(v) + 1)
+ *        replaces the "gcn" aggregator of dgl SAGEConv, reference models.py:112,138
+ *        (ctor :84-99); x_self is h_dst = the first n_dst rows of the block's source features
+ *        (models.py:109,137), normally x_self == x.
+ * Epilogue (both modes), per output element, in this order, each optional:
+ *        y = y * ep_scale[j] + ep_shift[j] ;  y = max(y, 0) if relu
+ *   (bias, eval-mode BatchNorm and ReLU of models.py:139-143 when the dense projection was
+ *    applied BEFORE aggregation; NULL/0 otherwise).
+ * n_src bounds the column indices (only used for argument checking).  d <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+#define GLNN_AGG_SUM 0
+#define GLNN_AGG_SAGE_GCN 1
+
+GLNN_API int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                               int64_t n_src, const float* x, int64_t ldx, int d, int mode,
+                               const float* row_scale, const float* col_scale,
+                               const float* x_self, int64_t ld_self, const float* ep_scale,
+                               const float* ep_shift, int relu, float* out, int64_t ldo,
+                               void* stream);
+
+/* in_deg[v] = indptr[v+1]-indptr[v] (as float); out_deg[u] = #edges with source u.
+ * replaces g.in_degrees()/g.out_degrees() used by GraphConv and utils.py:178.  Either may be NULL.
+ * nnz = indptr[n_dst] (host value).  out_deg need not be zeroed by the caller. */
+GLNN_API int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                              int64_t n_src, int64_t nnz, float* in_deg, float* out_deg,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3  Dense projection on the fp32 MFMA path (v_mfma_f32_32x32x2_f32, exact fp32).
+ *   C[m,n] = epilogue( sum_k A'[m,k] * B[k,n] )
+ *   A' = A, or rows gathered through a_rows (A'[m,:] = A[a_rows[m],:], replaces feats[idx]
+ *        at reference train_and_eval.py:76 / models.py:136), optionally passed through the
+ *        "previous layer tail"  A'[m,k] = max(A[m,k]*a_scale[k] + a_shift[k], 0)  (BatchNorm + ReLU
+ *        of reference models.py:48-51 folded into the operand load; NULL = identity, no ReLU).
+ *   B  = W^T with W [n,k] row-major (torch.nn.Linear / dgl SAGEConv.fc_neigh, b_layout 0)
+ *        or W [k,n] row-major (dgl GraphConv.weight, b_layout 1).
+ *   epilogue, in order, each optional: * row_scale[m] ; * ep_scale[n] ; + ep_shift[n] ; ReLU.
+ * replaces fc_neigh / GraphConv weight / nn.Linear: reference models.py:45,112,138,193.
+ * ------------------------------------------------------------------------------------------ */
+GLNN_API int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
+                           const float* a_scale, const float* a_shift, int64_t m, int k,
+                           const float* b, int64_t ldb, int b_layout, int n,
+                           const float* row_scale, const float* ep_scale, const float* ep_shift,
+                           int relu, float* c, int64_t ldc, void* stream);
+
+/* TN form, the weight-gradient shape:  C[i,j] = sum_m A[m,i] * B'[m,j]   (i < ka, j < nb)
+ *   dW[out,in] = dZ^T @ A_prev with A = dZ [m,out] and B = the previous layer's PRE-activation
+ *   (or the gathered input features), B' = B passed through the same operand transform as
+ *   glnn_gemm_f32 (row gather b_rows, then max(B*b_scale+b_shift,0)), so the activation is
+ *   recomputed instead of stored.  Replaces the nn.Linear weight/bias gradient autograd computes
+ *   inside loss.backward(), reference train_and_eval.py:84.
+ *   col_sum_a != NULL also writes col_sum_a[i] = sum_m A[m,i] (the bias gradient).
+ *   workspace (floats) is used for a deterministic split of the m-reduction when the output is
+ *   small, and for the column sums (needs >= 64*ka floats for those). */
+GLNN_API int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b,
+                              int64_t ldb, const int64_t* b_rows, const float* b_scale,
+                              const float* b_shift, int nb, float* c, int64_t ldc,
+                              float* col_sum_a, float* workspace, int64_t workspace_floats,
+                              void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  Losses on raw logits, forward + gradient wrt logits in one pass.
+ *   kind GLNN_LOSS_NLL: NLLLoss()(log_softmax(z), y)                 train_student.py:278
+ *   kind GLNN_LOSS_KL : KLDivLoss("batchmean", log_target=True)(log_softmax(z), t)  :279
+ *   loss_out[0]   = unscaled mean loss of the batch (what .item() reports, train_and_eval.py:80)
+ *   loss_accum[0]+= the same (optional, NULL to skip) so a whole pass reads back ONE scalar
+ *   dlogits       = d(lamb * loss)/dz   (train_and_eval.py:82 scales the loss by lamb)
+ *   logprob_out   = log_softmax(z) (optional)
+ *   workspace     >= min(ceil(rows/4), 1024) floats (per-workgroup partial sums; fixed-order reduce)
+ *   labels / target_logp may be indexed through label_rows / target_rows (the batch's node ids) so
+ *   that labels[idx] / out_t[idx] (train_and_eval.py:79) are never materialised; NULL = identity.
+ * ------------------------------------------------------------------------------------------ */
+#define GLNN_LOSS_NLL 0
+#define GLNN_LOSS_KL 1
+GLNN_API int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t rows, int c, int kind,
+                                   const int64_t* labels, const int64_t* label_rows,
+                                   const float* target_logp, int64_t ldt, const int64_t* target_rows,
+                                   float lamb, float* dlogits, int64_t ldg, float* logprob_out,
+                                   int64_t ldl, float* loss_out, float* loss_accum,
+                                   float* workspace, int64_t workspace_floats, void* stream);
+
+/* row-wise log_softmax only (evaluate paths, train_and_eval.py:98,124). in place allowed. */
+GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows, int c, float* out,
+                                  int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5  BatchNorm1d training statistics + backward pieces (reference models.py:28-31,48-49:
+ *     eps 1e-5, momentum 0.1, biased batch variance for normalisation, unbiased for running_var).
+ *   glnn_bn_stats_f32: from z [rows,h] computes a_scale = gamma*rstd, a_shift = beta - mean*a_scale
+ *     (the operand transform the next glnn_gemm_f32 consumes), saves mean/rstd, and updates
+ *     running_mean / running_var / num_batches_tracked in place.
+ *   glnn_bn_relu_bwd_f32: given da (grad wrt the post-ReLU activation) and z, computes
+ *     dy = da * [z*a_scale+a_shift > 0], dgamma = sum dy*xhat, dbeta = sum dy and
+ *     dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); in place on da allowed.
+ *     With gamma == NULL (norm_type "none") it is the plain ReLU backward dz = da*[z>0].
+ * ------------------------------------------------------------------------------------------ */
+GLNN_API int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, float* mean_out,
+                               float* rstd_out, float* a_scale_out, float* a_shift_out,
+                               float* workspace, int64_t workspace_floats, void* stream);
+
+GLNN_API int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz,
+                                  int64_t rows, int h, const float* gamma, const float* mean,
+                                  const float* rstd, const float* a_scale, const float* a_shift,
+                                  float* dz, int64_t lddz, float* dgamma, float* dbeta,
+                                  float* workspace, int64_t workspace_floats, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  Fused multi-tensor Adam, torch.optim.Adam semantics (L2 weight decay folded into the
+ *     gradient, bias correction, eps outside the sqrt): reference train_student.py:275-277,
+ *     train_teacher.py:234-236, stepped at train_and_eval.py:85.
+ *   The tensor table is 4 device arrays of `num_tensors` pointers + one of sizes (elements).
+ *   `step` is the 1-based step count AFTER this update.
+ * ------------------------------------------------------------------------------------------ */
+GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
+                                float* const* exp_avg, float* const* exp_avg_sq,
+                                const int64_t* sizes, int num_tensors, int64_t max_size,
+                                float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int64_t step, void* stream);
+
+/* K7  row gather: out[i,:] = x[rows[i],:]  (feats[idx], reference train_and_eval.py:42,76,
+ *     models.py:136) and scatter y[rows[i],:] = x[i,:] (models.py:145). */
+GLNN_API int glnn_gather_rows_f32(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows,
+                                  int d, float* out, int64_t ldo, void* stream);
+GLNN_API int glnn_scatter_rows_f32(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows,
+                                   int d, float* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLNN_HIP_H */

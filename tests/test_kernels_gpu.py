@@ -1,0 +1,293 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle (bar: 1e-4 abs fp32, north star).
+All calls go through glnn_amd.ops -> ctypes -> libglnn_hip.so."""
+import numpy as np
+import pytest
+import torch
+
+from graphgen import csr_from_edges, random_graph
+from oracle import student_oracle as so
+from oracle import teacher_oracle as to
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def g2d(indptr, indices):
+    return dev(indptr), dev(indices)
+
+
+# ------------------------------------------------------------------------------------------- K1/K2
+@pytest.mark.parametrize("d", [1, 7, 16, 40, 47, 64, 100, 128, 256, 300])
+def test_spmm_sage_gcn_vs_oracle(d):
+    from glnn_amd import ops
+    n = 3000
+    indptr, indices = random_graph(n, 12, seed=d, power=0.6, isolated=7, hub=2500)   # hub > 512 -> long-row role
+    x = np.random.RandomState(d).standard_normal((n, d)).astype(np.float32)
+    want = to.sage_gcn_agg(indptr, indices, x)
+    ip, ix = g2d(indptr, indices)
+    got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN)
+    assert got.shape == (n, d)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+    # padding columns of the output buffer are written as zero
+    if got.stride(0) > d:
+        base = torch.as_strided(got, (n, got.stride(0)), (got.stride(0), 1))
+        assert float(base[:, d:].abs().max()) == 0.0
+
+
+def test_spmm_known_answers_on_gpu():
+    from glnn_amd import ops
+    src = np.array([0, 2, 2, 3, 1]); dst = np.array([1, 1, 1, 3, 0])
+    indptr, indices = csr_from_edges(src, dst, 5)
+    x = np.array([[1, 10], [2, 20], [3, 30], [4, 40], [5, 50]], np.float32)
+    got = ops.spmm(dev(indptr), dev(indices), dev(x), 5, ops.AGG_SAGE_GCN).cpu().numpy()
+    want = np.array([[1.5, 15], [2.25, 22.5], [3, 30], [4, 40], [5, 50]], np.float32)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_spmm_block_ndst_lt_nsrc():
+    from glnn_amd import ops
+    indptr = np.array([0, 3, 4], np.int64); indices = np.array([2, 3, 1, 3], np.int32)
+    x = np.array([[1.0], [2.0], [4.0], [8.0]], np.float32)
+    got = ops.spmm(dev(indptr), dev(indices), dev(x), 2, ops.AGG_SAGE_GCN).cpu().numpy()
+    np.testing.assert_array_equal(got, np.array([[15 / 4], [5.0]], np.float32))
+
+
+@pytest.mark.parametrize("d,use_rs,use_cs", [(64, True, True), (7, True, False), (128, False, True), (33, False, False)])
+def test_spmm_sum_scaled_vs_oracle(d, use_rs, use_cs):
+    from glnn_amd import ops
+    n = 2500
+    indptr, indices = random_graph(n, 9, seed=100 + d, power=0.5, symmetric=True, self_loops=True, hub=900)
+    rs_ = np.random.RandomState(5)
+    x = rs_.standard_normal((n, d)).astype(np.float32)
+    rs = rs_.uniform(0.1, 1, n).astype(np.float32) if use_rs else None
+    cs = rs_.uniform(0.1, 1, n).astype(np.float32) if use_cs else None
+    want = to.spmm_sum(indptr, indices, x, rs, cs)
+    got = ops.spmm(dev(indptr), dev(indices), dev(x), n, ops.AGG_SUM,
+                   row_scale=None if rs is None else dev(rs), col_scale=None if cs is None else dev(cs))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+
+
+def test_spmm_epilogue_scale_shift_relu():
+    from glnn_amd import ops
+    n, d = 1200, 47
+    indptr, indices = random_graph(n, 20, seed=3, power=0.5)
+    r = np.random.RandomState(1)
+    x = r.standard_normal((n, d)).astype(np.float32)
+    sc, sh = r.uniform(0.5, 1.5, d).astype(np.float32), r.standard_normal(d).astype(np.float32)
+    want = np.maximum(to.sage_gcn_agg(indptr, indices, x) * sc + sh, 0)
+    got = ops.spmm(dev(indptr), dev(indices), dev(x), n, ops.AGG_SAGE_GCN, ep_scale=dev(sc), ep_shift=dev(sh), relu=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+
+
+def test_spmm_empty_rows_and_wide_features():
+    from glnn_amd import ops
+    n, d = 300, 1433          # raw cora feature width: 6 column tiles
+    indptr, indices = random_graph(n, 3, seed=9, isolated=100)
+    x = np.random.RandomState(2).standard_normal((n, d)).astype(np.float32)
+    got = ops.spmm(dev(indptr), dev(indices), dev(x), n, ops.AGG_SUM)
+    np.testing.assert_allclose(got.cpu().numpy(), to.spmm_sum(indptr, indices, x), atol=TOL, rtol=0)
+
+
+def test_degrees():
+    from glnn_amd import ops
+    n = 1000
+    indptr, indices = random_graph(n, 6, seed=4, power=0.7, isolated=11)
+    i_want, o_want = to.degrees(indptr, indices)
+    i_got, o_got = ops.degrees(dev(indptr), dev(indices), n, n, int(indptr[-1]))
+    np.testing.assert_array_equal(i_got.cpu().numpy(), i_want)
+    np.testing.assert_array_equal(o_got.cpu().numpy(), o_want)
+
+
+# ------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("m,k,n,kn", [(1000, 100, 256, False), (517, 256, 47, False), (130, 1433, 64, True),
+                                      (64, 7, 7, True), (2048, 128, 256, False), (300, 33, 130, False),
+                                      (4096, 2048, 47, False), (1, 5, 3, False)])
+def test_gemm_vs_oracle(m, k, n, kn):
+    from glnn_amd import ops
+    r = np.random.RandomState(m + k + n)
+    a = r.standard_normal((m, k)).astype(np.float32)
+    w = (r.standard_normal((k, n) if kn else (n, k)) / np.sqrt(k)).astype(np.float32)
+    want = to.linear(a, w, None, w_is_in_by_out=kn)
+    got = ops.gemm(ops.as_feat(dev(a)), dev(w), w_is_kn=kn)
+    assert got.shape == (m, n)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+
+
+def test_gemm_transpose_detecting():
+    # A = I (padded) against an ASYMMETRIC B catches swapped C layouts
+    from glnn_amd import ops
+    k = n = 96
+    a = np.eye(k, dtype=np.float32)
+    w = np.arange(n * k, dtype=np.float32).reshape(n, k) / 100.0
+    got = ops.gemm(dev(a), dev(w)).cpu().numpy()
+    np.testing.assert_allclose(got, w.T, atol=1e-6, rtol=0)
+
+
+def test_gemm_full_epilogue_and_operand_transform():
+    from glnn_amd import ops
+    r = np.random.RandomState(11)
+    nrows, m, k, n = 5000, 1500, 100, 200
+    x = r.standard_normal((nrows, k)).astype(np.float32)
+    rows = r.randint(0, nrows, m).astype(np.int64)
+    a_sc, a_sh = r.uniform(0.5, 1.5, k).astype(np.float32), r.standard_normal(k).astype(np.float32) * 0.3
+    w = (r.standard_normal((n, k)) / 10).astype(np.float32)
+    rs = r.uniform(0.5, 2, m).astype(np.float32)
+    e_sc, e_sh = r.uniform(0.5, 1.5, n).astype(np.float32), r.standard_normal(n).astype(np.float32)
+    ap = np.maximum(x[rows] * a_sc + a_sh, 0)
+    want = np.maximum((to.linear(ap, w) * rs[:, None]) * e_sc + e_sh, 0)
+    got = ops.gemm(dev(x), dev(w), a_rows=dev(rows), a_scale=dev(a_sc), a_shift=dev(a_sh), row_scale=dev(rs),
+                   ep_scale=dev(e_sc), ep_shift=dev(e_sh), relu=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("m,ka,nb", [(512, 40, 256), (4096, 47, 300), (700, 256, 128), (333, 130, 100), (4096, 256, 256)])
+def test_gemm_tn_vs_numpy(m, ka, nb):
+    from glnn_amd import ops
+    r = np.random.RandomState(m + ka)
+    a = (r.standard_normal((m, ka)) / 8).astype(np.float32)
+    b = r.standard_normal((m, nb)).astype(np.float32)
+    want = (a.astype(np.float64).T @ b.astype(np.float64))
+    colsum = torch.empty(ka, device=DEV)
+    got = ops.gemm_tn(ops.as_feat(dev(a)), ops.as_feat(dev(b)), col_sum_a=colsum)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+    np.testing.assert_allclose(colsum.cpu().numpy(), a.astype(np.float64).sum(0), atol=TOL, rtol=1e-5)
+
+
+def test_gemm_tn_gather_and_transform():
+    from glnn_amd import ops
+    r = np.random.RandomState(8)
+    nrows, m, ka, nb = 3000, 1024, 64, 100
+    dz = (r.standard_normal((m, ka)) / 8).astype(np.float32)
+    x = r.standard_normal((nrows, nb)).astype(np.float32)
+    rows = r.randint(0, nrows, m).astype(np.int64)
+    sc, sh = r.uniform(0.5, 1.5, nb).astype(np.float32), r.standard_normal(nb).astype(np.float32) * .2
+    want = dz.astype(np.float64).T @ np.maximum(x[rows] * sc + sh, 0).astype(np.float64)
+    got = ops.gemm_tn(dev(dz), dev(x), b_rows=dev(rows), b_scale=dev(sc), b_shift=dev(sh), m=m)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("rows,c", [(512, 40), (4096, 47), (140, 7), (37, 100)])
+@pytest.mark.parametrize("kind", ["nll", "kl"])
+def test_softmax_loss_vs_oracle(rows, c, kind):
+    from glnn_amd import ops
+    r = np.random.RandomState(rows + c)
+    z = (r.standard_normal((rows, c)) * 2).astype(np.float32)
+    lamb = 0.37
+    if kind == "nll":
+        y = r.randint(0, c, rows).astype(np.int64)
+        loss_w, dz_w = so.loss_and_dlogits(z, y, "nll", lamb)
+        loss, dz = ops.softmax_loss(dev(z), ops.LOSS_NLL, lamb, labels=dev(y))
+    else:
+        t = so.log_softmax(r.standard_normal((rows, c)).astype(np.float32))
+        loss_w, dz_w = so.loss_and_dlogits(z, t, "kl", lamb)
+        loss, dz = ops.softmax_loss(dev(z), ops.LOSS_KL, lamb, target_logp=dev(t))
+    assert abs(float(loss.item()) - float(loss_w)) < TOL
+    np.testing.assert_allclose(dz.cpu().numpy(), dz_w, atol=1e-6, rtol=1e-4)
+
+
+def test_softmax_loss_indexed_targets_and_accum():
+    from glnn_amd import ops
+    r = np.random.RandomState(0)
+    n, rows, c = 900, 256, 40
+    z = r.standard_normal((rows, c)).astype(np.float32)
+    labels_all = r.randint(0, c, n).astype(np.int64)
+    t_all = so.log_softmax(r.standard_normal((n, c)).astype(np.float32))
+    idx = r.permutation(n)[:rows].astype(np.int64)
+    acc = torch.zeros(1, device=DEV)
+    l1, d1 = ops.softmax_loss(dev(z), ops.LOSS_NLL, 1.0, labels=dev(labels_all), label_rows=dev(idx), loss_accum=acc)
+    l2, d2 = ops.softmax_loss(dev(z), ops.LOSS_KL, 0.5, target_logp=dev(t_all), target_rows=dev(idx), loss_accum=acc)
+    w1, g1 = so.loss_and_dlogits(z, labels_all[idx], "nll", 1.0)
+    w2, g2 = so.loss_and_dlogits(z, t_all[idx], "kl", 0.5)
+    assert abs(l1.item() - w1) < TOL and abs(l2.item() - w2) < TOL and abs(acc.item() - (w1 + w2)) < TOL
+    np.testing.assert_allclose(d1.cpu().numpy(), g1, atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(d2.cpu().numpy(), g2, atol=1e-6, rtol=1e-4)
+
+
+def test_log_softmax():
+    from glnn_amd import ops
+    z = (np.random.RandomState(1).standard_normal((1000, 47)) * 3).astype(np.float32)
+    np.testing.assert_allclose(ops.log_softmax(dev(z)).cpu().numpy(), so.log_softmax(z), atol=1e-5, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------- K5
+@pytest.mark.parametrize("rows,h", [(512, 256), (4096, 300), (100, 64), (129, 70)])
+def test_bn_stats_and_backward_vs_oracle(rows, h):
+    from glnn_amd import ops
+    r = np.random.RandomState(rows)
+    z = (r.standard_normal((rows, h)) * 1.7 + r.standard_normal(h) * 3).astype(np.float32)   # offset mean: var stability
+    gamma, beta = r.uniform(.5, 1.5, h).astype(np.float32), r.standard_normal(h).astype(np.float32) * .2
+    rm, rv = r.standard_normal(h).astype(np.float32) * .1, r.uniform(.5, 1.5, h).astype(np.float32)
+    sd = {"encoder.layers.0.weight": np.eye(h, dtype=np.float32), "encoder.layers.0.bias": np.zeros(h, np.float32),
+          "encoder.layers.1.weight": np.zeros((1, h), np.float32), "encoder.layers.1.bias": np.zeros(1, np.float32),
+          "encoder.norms.0.weight": gamma, "encoder.norms.0.bias": beta, "encoder.norms.0.running_mean": rm,
+          "encoder.norms.0.running_var": rv, "encoder.norms.0.num_batches_tracked": np.int64(3)}
+    st = so.MLPState(sd, 2, "batch")
+    _, cache = so.mlp_forward(st, z, training=True)          # layer 0 is the identity: z is the BN input
+    t_rm, t_rv, t_nbt = dev(rm.copy()), dev(rv.copy()), torch.tensor([3], device=DEV)
+    mean, rstd, a_sc, a_sh = ops.bn_stats(dev(z), dev(gamma), dev(beta), t_rm, t_rv, t_nbt)
+    np.testing.assert_allclose(rstd.cpu().numpy(), cache["rstd"][0], rtol=1e-5)
+    y = z * a_sc.cpu().numpy() + a_sh.cpu().numpy()
+    np.testing.assert_allclose(y, cache["bn_out"][0], atol=TOL, rtol=0)
+    np.testing.assert_allclose(t_rm.cpu().numpy(), st.rm[0], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(t_rv.cpu().numpy(), st.rv[0], atol=1e-5, rtol=1e-5)
+    assert int(t_nbt.item()) == 4 == st.nbt[0]
+    # backward: dlogits = ones through W1 = 0 would be zero, so drive mlp_backward pieces directly
+    da = r.standard_normal((rows, h)).astype(np.float32)
+    dy = da * (cache["bn_out"][0] > 0)
+    xhat = cache["xhat"][0]
+    s1, s2 = dy.sum(0, dtype=np.float64), (dy.astype(np.float64) * xhat).sum(0)
+    dz_w = gamma * cache["rstd"][0] * (dy - s1 / rows - xhat * (s2 / rows))
+    dz, dg, db = ops.bn_relu_bwd(dev(da), dev(z), dev(gamma), mean, rstd, a_sc, a_sh)
+    np.testing.assert_allclose(dg.cpu().numpy(), s2, atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), s1, atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(dz.cpu().numpy(), dz_w, atol=TOL, rtol=0)
+    dz2, _, _ = ops.bn_relu_bwd(dev(da), dev(z))
+    np.testing.assert_array_equal(dz2.cpu().numpy(), da * (z > 0))
+
+
+# ------------------------------------------------------------------------------------------- K6
+@pytest.mark.parametrize("wd", [0.0, 5e-4])
+def test_adam_vs_oracle(wd):
+    from glnn_amd import ops
+    r = np.random.RandomState(3)
+    shapes = [(256, 100), (256,), (47, 256), (47,), (1,), (1000, 33)]
+    ps = [r.standard_normal(s).astype(np.float32) for s in shapes]
+
+    class St:       # minimal state the oracle's adam_step needs
+        pass
+    st = St(); st.t = 0
+    st.params = lambda: st._p
+    st._p = [p.copy() for p in ps]; st.m = [np.zeros_like(p) for p in ps]; st.v = [np.zeros_like(p) for p in ps]
+    tp = [dev(p) for p in ps]; tg = [torch.zeros_like(p) for p in tp]
+    tm = [torch.zeros_like(p) for p in tp]; tv = [torch.zeros_like(p) for p in tp]
+    table = ops.TensorTable(tp, tg, tm, tv)
+    for step in range(1, 6):
+        gs = [(r.standard_normal(s) * (10.0 ** r.randint(-4, 1))).astype(np.float32) for s in shapes]
+        so.adam_step(st, gs, lr=0.01, weight_decay=wd)
+        for t, g in zip(tg, gs):
+            t.copy_(dev(g))
+        ops.adam_step(table, 0.01, step, weight_decay=wd)
+        for a, b in zip(tp, st._p):
+            np.testing.assert_allclose(a.cpu().numpy(), b, atol=2e-6, rtol=1e-5)
+    for a, b in zip(tm, st.m):
+        np.testing.assert_allclose(a.cpu().numpy(), b, atol=1e-7, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- K7
+def test_gather_scatter_rows():
+    from glnn_amd import ops
+    r = np.random.RandomState(0)
+    x = r.standard_normal((1000, 100)).astype(np.float32)
+    rows = r.permutation(1000)[:300].astype(np.int64)
+    got = ops.gather_rows(dev(x), dev(rows))
+    np.testing.assert_array_equal(got.cpu().numpy(), x[rows])
+    y = ops.feat_empty(1000, 100, DEV, zero=True)
+    ops.scatter_rows(got, dev(rows), y)
+    want = np.zeros_like(x); want[rows] = x[rows]
+    np.testing.assert_array_equal(y.cpu().numpy(), want)
