@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglnn_hip.so")
 
-c_i64, c_int, c_f32, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+c_i64, c_int, c_f32, c_vp, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32
 
 # name -> argtypes, exactly the prototypes of include/glnn_hip.h (pointers as void*)
 SIGNATURES = {
@@ -18,18 +18,19 @@ SIGNATURES = {
     "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
                           c_int, c_vp, c_i64, c_vp],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
-    "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
+    "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp],
-    "glnn_gemm_tn_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_vp, c_vp,
+    "glnn_gemm_tn_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_int, c_vp, c_i64, c_vp, c_vp,
                          c_i64, c_vp],
     "glnn_softmax_loss_f32": [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_log_softmax_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
     "glnn_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                           c_vp, c_vp, c_i64, c_vp],
-    "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+    "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64,
                              c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
+    "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
     "glnn_scatter_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
 }

@@ -34,6 +34,7 @@ struct GemmArgs {
   const float* row_scale; const float* ep_scale; const float* ep_shift; int relu;
   float* c; int64_t ldc;
   int a_vec; int b_vec;  // 1 = float4 loads are aligned and in-bounds
+  uint32_t drop_thr; uint32_t drop_seed; float drop_scale;   // drop_thr == 0: no dropout
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -50,13 +51,18 @@ __device__ __forceinline__ float4 load4_guard(const float* p, int limit, bool ve
   return r;
 }
 
-__device__ __forceinline__ float4 xform4(float4 v, const float* sc, const float* sh, int k, int klimit) {
-  // a' = max(a*scale + shift, 0) for k < klimit, else 0
+struct DropCfg { uint32_t thr, seed; float scale; };
+
+__device__ __forceinline__ float4 xform4(float4 v, const float* sc, const float* sh, int k, int klimit, int64_t row,
+                                         const DropCfg dc) {
+  // a' = drop(max(a*scale + shift, 0)) for k < klimit, else 0
   float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     if (k + t < klimit) {
-      vv[t] = fmaxf(fmaf(vv[t], sc[k + t], sh[k + t]), 0.f);
+      float y = fmaxf(fmaf(vv[t], sc[k + t], sh[k + t]), 0.f);
+      if (dc.thr) y = glnn::drop_keep(dc.seed, dc.thr, (uint32_t)row, (uint32_t)(k + t)) ? y * dc.scale : 0.f;
+      vv[t] = y;
     } else {
       vv[t] = 0.f;
     }
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  const DropCfg dc = {g.drop_thr, g.drop_seed, g.drop_scale};
 
   // ---- global->register staging assignment ----
   // A tile: 128 rows x 8 float4; thread f = tid + 256*q -> row f/8, c4 = f%8
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     for (int q = 0; q < 4; ++q) {
       const int kc = k0 + ((tid + 256 * q) & 7) * 4;
       float4 v = a_ok[q] ? load4_guard(a_ptr[q] + k0, g.k - kc, g.a_vec) : zero4();
-      if (g.a_scale) v = a_ok[q] ? xform4(v, g.a_scale, g.a_shift, kc, g.k) : zero4();
+      if (g.a_scale) v = a_ok[q] ? xform4(v, g.a_scale, g.a_shift, kc, g.k, m0 + ((tid + 256 * q) >> 3), dc) : zero4();
       a_reg[q] = v;
     }
 #pragma unroll
@@ -230,6 +237,7 @@ struct GemmTnArgs {
   float* c; int64_t ldc;   // final C, or the split workspace [splits][ka][nb] when splits > 1
   int splits; int64_t rows_per_split;
   int a_vec; int b_vec;
+  uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
 };
 
 template <int BNT>
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
+  const DropCfg dc = {g.drop_thr, g.drop_seed, g.drop_scale};
   const int i0 = blockIdx.x * BM;      // along ka
   const int j0 = blockIdx.y * BNT;     // along nb
   const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
       if (mrow < mend) {
         const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
         v = load4_guard(g.b + src * g.ldb + jg, g.nb - jg, g.b_vec);
-        if (g.b_scale) v = xform4(v, g.b_scale, g.b_shift, jg, g.nb);
+        if (g.b_scale) v = xform4(v, g.b_scale, g.b_shift, jg, g.nb, mrow, dc);
       }
       b_reg[q] = v;
     }
@@ -402,7 +411,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 }  // namespace
 
 extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
-                             const float* a_shift, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
+                             const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
                              const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
                              int64_t ldc, void* stream) {
   GLNN_REQUIRE(a && b && c, "glnn_gemm_f32: null pointer");
@@ -411,8 +420,10 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   GLNN_REQUIRE(b_layout == 0 || b_layout == 1, "glnn_gemm_f32: b_layout must be 0 ([n,k]) or 1 ([k,n])");
   GLNN_REQUIRE(ldb >= (b_layout ? n : k), "glnn_gemm_f32: ldb too small");
   GLNN_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "glnn_gemm_f32: a_scale and a_shift go together");
+  GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || a_scale), "glnn_gemm_f32: drop_p in [0,1) and needs a_scale/a_shift");
   if (m == 0) return GLNN_OK;
   GemmArgs g;
+  g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
   g.a = a; g.lda = lda; g.a_rows = a_rows; g.a_scale = a_scale; g.a_shift = a_shift; g.m = m; g.k = k;
   g.b = b; g.ldb = ldb; g.n = n; g.row_scale = row_scale; g.ep_scale = ep_scale; g.ep_shift = ep_shift; g.relu = relu;
   g.c = c; g.ldc = ldc;
@@ -427,14 +438,16 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
 }
 
 extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
-                                const int64_t* b_rows, const float* b_scale, const float* b_shift, int nb, float* c,
-                                int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
+                                const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
+                                uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
   GLNN_REQUIRE(a && b && c, "glnn_gemm_tn_f32: null pointer");
   GLNN_REQUIRE(m >= 1 && ka >= 1 && nb >= 1, "glnn_gemm_tn_f32: bad sizes");
   GLNN_REQUIRE(lda >= ka && ldb >= nb && ldc >= nb, "glnn_gemm_tn_f32: leading dimension too small");
   GLNN_REQUIRE((b_scale == nullptr) == (b_shift == nullptr), "glnn_gemm_tn_f32: b_scale and b_shift go together");
+  GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || b_scale), "glnn_gemm_tn_f32: drop_p in [0,1) and needs b_scale/b_shift");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GemmTnArgs g;
+  g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
   g.a = a; g.lda = lda; g.m = m; g.ka = ka;
   g.b = b; g.ldb = ldb; g.b_rows = b_rows; g.b_scale = b_scale; g.b_shift = b_shift; g.nb = nb;
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);

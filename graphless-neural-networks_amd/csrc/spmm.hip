@@ -222,7 +222,7 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
                                  void* stream) {
   GLNN_REQUIRE(indptr && indices && x && out, "glnn_spmm_csr_f32: null pointer");
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
-  GLNN_REQUIRE(d >= 1 && d <= 1024, "glnn_spmm_csr_f32: d=%d outside [1,1024]", d);
+  GLNN_REQUIRE(d >= 1, "glnn_spmm_csr_f32: d=%d must be >= 1", d);
   GLNN_REQUIRE(mode == GLNN_AGG_SUM || mode == GLNN_AGG_SAGE_GCN, "glnn_spmm_csr_f32: unknown mode %d", mode);
   const int dpad = (d + 3) & ~3;
   GLNN_REQUIRE(ldx % 4 == 0 && ldx >= dpad, "glnn_spmm_csr_f32: ldx=%lld must be a multiple of 4 and >= %d", (long long)ldx, dpad);

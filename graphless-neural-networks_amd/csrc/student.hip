@@ -181,8 +181,8 @@ __global__ void bn_stats_stage2(const BnFinArgs a) {
 __global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ da, int64_t ldda, const float* __restrict__ z,
                                                       int64_t ldz, int64_t rows, int h, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ a_scale,
-                                                      const float* __restrict__ a_shift, float* __restrict__ ws1,
-                                                      float* __restrict__ ws2) {
+                                                      const float* __restrict__ a_shift, uint32_t dthr, uint32_t dseed,
+                                                      float dscale, float* __restrict__ ws1, float* __restrict__ ws2) {
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ d
     const float mu = mean[col], rs = rstd[col], sc = a_scale[col], sf = a_shift[col];
     for (int64_t r = r0 + rl; r < r1; r += 4) {
       const float zz = z[r * ldz + col];
-      const float dy = fmaf(zz, sc, sf) > 0.f ? da[r * ldda + col] : 0.f;
+      float dy = fmaf(zz, sc, sf) > 0.f ? da[r * ldda + col] : 0.f;
+      if (dthr) dy = glnn::drop_keep(dseed, dthr, (uint32_t)r, (uint32_t)col) ? dy * dscale : 0.f;
       s1 += dy;
       s2 = fmaf(dy, (zz - mu) * rs, s2);
     }
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stage3(const float* __restrict__ d
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                      uint32_t dthr, uint32_t dseed, float dscale,
                                                       float* __restrict__ dz, int64_t lddz) {
   const int64_t total = rows * h;
   const float inv_b = 1.0f / (float)rows;
@@ -233,12 +235,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stage3(const float* __restrict__ d
     const int64_t r = i / h;
     const int col = (int)(i - r * h);
     const float zz = z[r * ldz + col];
+    float dav = da[r * ldda + col];
+    if (dthr) dav = glnn::drop_keep(dseed, dthr, (uint32_t)r, (uint32_t)col) ? dav * dscale : 0.f;
     if (BN) {
-      const float dy = fmaf(zz, a_scale[col], a_shift[col]) > 0.f ? da[r * ldda + col] : 0.f;
+      const float dy = fmaf(zz, a_scale[col], a_shift[col]) > 0.f ? dav : 0.f;
       const float xhat = (zz - mean[col]) * rstd[col];
       dz[r * lddz + col] = gamma[col] * rstd[col] * (dy - dbeta[col] * inv_b - xhat * dgamma[col] * inv_b);
     } else {
-      dz[r * lddz + col] = zz > 0.f ? da[r * ldda + col] : 0.f;
+      dz[r * lddz + col] = zz > 0.f ? dav : 0.f;
     }
   }
 }
@@ -332,16 +336,20 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
 
 extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
                                     const float* gamma, const float* mean, const float* rstd, const float* a_scale,
-                                    const float* a_shift, float* dz, int64_t lddz, float* dgamma, float* dbeta,
-                                    float* workspace, int64_t workspace_floats, void* stream) {
+                                    const float* a_shift, float drop_p, uint32_t drop_seed, float* dz, int64_t lddz,
+                                    float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
+                                    void* stream) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
+  GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
+  const uint32_t dthr = glnn::drop_threshold(drop_p);
+  const float dscale = 1.0f / (1.0f - drop_p);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int64_t blocks = (rows * h + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (!gamma) {
     hipLaunchKernelGGL((bn_bwd_stage3<false>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dz, lddz);
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dthr, drop_seed, dscale, dz, lddz);
     return glnn::check_launch("glnn_bn_relu_bwd_f32");
   }
   GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta && workspace, "glnn_bn_relu_bwd_f32: BN path needs stats, outputs and workspace");
@@ -350,11 +358,28 @@ extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* 
   float* ws1 = workspace;
   float* ws2 = workspace + (int64_t)nchunks * h;
   hipLaunchKernelGGL(bn_bwd_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, mean, rstd,
-                     a_scale, a_shift, ws1, ws2);
+                     a_scale, a_shift, dthr, drop_seed, dscale, ws1, ws2);
   hipLaunchKernelGGL(bn_bwd_stage2, dim3((h + 127) / 128), dim3(128), 0, st, ws1, ws2, nchunks, h, dgamma, dbeta);
   hipLaunchKernelGGL((bn_bwd_stage3<true>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, gamma, mean,
-                     rstd, a_scale, a_shift, dgamma, dbeta, dz, lddz);
+                     rstd, a_scale, a_shift, dgamma, dbeta, dthr, drop_seed, dscale, dz, lddz);
   return glnn::check_launch("glnn_bn_relu_bwd_f32");
+}
+
+__global__ void dropout_mask_kernel(int64_t rows, int h, uint32_t thr, uint32_t seed, uint8_t* mask) {
+  const int64_t total = rows * h;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / h;
+    mask[i] = (thr == 0 || glnn::drop_keep(seed, thr, (uint32_t)r, (uint32_t)(i - r * h))) ? 1 : 0;
+  }
+}
+
+extern "C" int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t drop_seed, uint8_t* mask, void* stream) {
+  GLNN_REQUIRE(mask && rows >= 1 && h >= 1 && drop_p >= 0.f && drop_p < 1.f, "glnn_dropout_mask_u8: bad arguments");
+  int64_t blocks = (rows * h + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, h,
+                     glnn::drop_threshold(drop_p), drop_seed, mask);
+  return glnn::check_launch("glnn_dropout_mask_u8");
 }
 
 extern "C" int glnn_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,

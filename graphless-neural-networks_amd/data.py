@@ -68,9 +68,9 @@ def make_graph(name, seed=0, device="cpu", scale=1.0):
         # 61,859,140 undirected edges stored in both directions -> 123,718,280 nnz, no self-loops
         n = max(8, int(2449029 * scale))
         m = max(8, int(61859140 * scale))
-        # alpha 0.5, offset 4: expected max degree ~17.7k at full scale (real graph: 17,481), min ~25
-        a = _powerlaw_endpoints(n, m, 0.5, 4.0, gen, device)
-        b = _powerlaw_endpoints(n, m, 0.5, 4.0, gen, device)
+        # alpha 0.5, offset 5: expected max degree ~17.7k at full scale (real graph: 17,481), min ~10
+        ab = _powerlaw_endpoints(n, 2 * m, 0.5, 5.0, gen, device)     # ONE rank->node permutation for both ends
+        a, b = ab[:m], ab[m:]
         return csr_from_edges(torch.cat([a, b]), torch.cat([b, a]), n)
     raise ValueError(f"Unknown dataset shape: {name}")
 

@@ -88,6 +88,18 @@ class CSRGraph:
             self._cache["norms"] = (in_deg.clamp(min=1).pow(-0.5), out_deg.clamp(min=1).pow(-0.5))
         return self._cache["norms"]
 
+    def reverse(self):
+        """Transposed graph (CSR over the original SOURCE nodes), cached: used by the aggregation backward."""
+        if "rev" not in self._cache:
+            dst_all = torch.repeat_interleave(torch.arange(self.n_dst, device=self.device), self.in_degrees())
+            src = self.indices.long()
+            order = torch.argsort(src, stable=True)
+            counts = torch.bincount(src, minlength=self.n_src)
+            indptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(counts, 0, out=indptr[1:])
+            self._cache["rev"] = CSRGraph(indptr, dst_all[order].to(torch.int32), self.n_src, self.n_dst)
+        return self._cache["rev"]
+
     def row_range(self, start, stop):
         """Destination rows [start, stop) with ALL source columns kept (node-range shard / eval chunk)."""
         lo, hi = int(self.indptr[start].item()), int(self.indptr[stop].item())

@@ -1,0 +1,250 @@
+"""The reference's model zoo surface (reference models.py) on the HIP hot path.
+
+Kept byte-for-byte: class names, constructor arguments, `forward` return conventions ((h_list, h)),
+`Model(conf)` substring dispatch ("MLP" tested first, models.py:355,409), `Model.forward /
+forward_fitnet / inference`, and state_dict key names (encoder.layers.{i}.weight|bias |
+.fc_neigh.weight|bias, encoder.norms.{i}.*).  What changed is where the arithmetic runs: every
+Linear / SAGEConv / GraphConv / BatchNorm(eval) / ReLU goes through libglnn_hip.so.
+
+GAT / APPNP (ablation-only teachers) are out of scope and raise."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .autograd import linear_fn
+from .nn import GraphConv, SAGEConv
+
+
+def _bn_eval_fold(bn, bias):
+    """Per-column (scale, shift) of  BN_eval(x + bias):  y = x*s + ((bias - rm)*s + beta), s = gamma/sqrt(rv+eps)."""
+    s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    b = bias.detach() if bias is not None else 0.0
+    return s.contiguous(), ((b - bn.running_mean) * s + bn.bias.detach()).contiguous()
+
+
+def _hip_eval_ok(module, x):
+    return x.is_cuda and not module.training and not torch.is_grad_enabled()
+
+
+class MLP(nn.Module):
+    """reference models.py:7-53"""
+
+    def __init__(self, num_layers, input_dim, hidden_dim, output_dim, dropout_ratio, norm_type="none"):
+        super().__init__()
+        self.num_layers = num_layers
+        self.norm_type = norm_type
+        self.dropout = nn.Dropout(dropout_ratio)
+        self.layers = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        if num_layers == 1:
+            self.layers.append(nn.Linear(input_dim, output_dim))
+        else:
+            self.layers.append(nn.Linear(input_dim, hidden_dim))
+            self._add_norm(hidden_dim)
+            for _ in range(num_layers - 2):
+                self.layers.append(nn.Linear(hidden_dim, hidden_dim))
+                self._add_norm(hidden_dim)
+            self.layers.append(nn.Linear(hidden_dim, output_dim))
+
+    def _add_norm(self, hidden_dim):
+        if self.norm_type == "batch":
+            self.norms.append(nn.BatchNorm1d(hidden_dim))
+        elif self.norm_type == "layer":
+            self.norms.append(nn.LayerNorm(hidden_dim))
+
+    def forward(self, feats):
+        if _hip_eval_ok(self, feats) and self.norm_type in ("none", "batch"):
+            return self._forward_hip_eval(feats)
+        h = feats
+        h_list = []
+        for l, layer in enumerate(self.layers):
+            h = linear_fn(h, layer.weight, layer.bias) if h.is_cuda else layer(h)
+            if l != self.num_layers - 1:
+                h_list.append(h)
+                if self.norm_type != "none":
+                    h = self.norms[l](h)
+                h = F.relu(h)
+                h = self.dropout(h)
+        return h_list, h
+
+    def _forward_hip_eval(self, feats):
+        """Eval-mode chain: each Linear is one glnn_gemm_f32; BN(eval)+ReLU of layer l are folded into the
+        operand load of layer l+1 (dropout is the identity in eval mode), so h_list holds the raw Linear outputs
+        exactly as the reference returns them."""
+        h = ops.as_feat(feats)
+        h_list = []
+        a_scale = a_shift = None
+        for l, layer in enumerate(self.layers):
+            z = ops.gemm(h, layer.weight, a_scale=a_scale, a_shift=a_shift, ep_shift=layer.bias)
+            if l != self.num_layers - 1:
+                h_list.append(z)
+                if self.norm_type == "batch":
+                    a_scale, a_shift = _bn_eval_fold(self.norms[l], None)
+                else:
+                    a_scale = torch.ones(z.shape[1], device=z.device)
+                    a_shift = torch.zeros(z.shape[1], device=z.device)
+            h = z
+        return h_list, h
+
+
+class SAGE(nn.Module):
+    """reference models.py:62-148"""
+
+    def __init__(self, num_layers, input_dim, hidden_dim, output_dim, dropout_ratio, activation, norm_type="none"):
+        super().__init__()
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.norm_type = norm_type
+        self.activation = activation
+        self.dropout = nn.Dropout(dropout_ratio)
+        self.layers = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        if num_layers == 1:
+            self.layers.append(SAGEConv(input_dim, output_dim, "gcn"))
+        else:
+            self.layers.append(SAGEConv(input_dim, hidden_dim, "gcn"))
+            self._add_norm(hidden_dim)
+            for _ in range(num_layers - 2):
+                self.layers.append(SAGEConv(hidden_dim, hidden_dim, "gcn"))
+                self._add_norm(hidden_dim)
+            self.layers.append(SAGEConv(hidden_dim, output_dim, "gcn"))
+
+    def _add_norm(self, hidden_dim):
+        if self.norm_type == "batch":
+            self.norms.append(nn.BatchNorm1d(hidden_dim))
+        elif self.norm_type == "layer":
+            self.norms.append(nn.LayerNorm(hidden_dim))
+
+    def forward(self, blocks, feats):
+        """Sampled-block forward (reference models.py:101-119)."""
+        h = feats
+        h_list = []
+        for l, (layer, block) in enumerate(zip(self.layers, blocks)):
+            h_dst = h[: block.num_dst_nodes()]
+            h = layer(block, (h, h_dst))
+            if l != self.num_layers - 1:
+                h_list.append(h)
+                if self.norm_type != "none":
+                    h = self.norms[l](h)
+                h = self.activation(h)
+                h = self.dropout(h)
+        return h_list, h
+
+    def _tail(self, l):
+        """Fused eval tail of layer l: (ep_scale, ep_shift, relu) = BN(eval) o (+bias) o ReLU; dropout is a no-op."""
+        bias = self.layers[l].fc_neigh.bias
+        if l == self.num_layers - 1:
+            return None, bias, False
+        if self.activation is not F.relu and getattr(self.activation, "__name__", "") != "relu":
+            raise NotImplementedError("SAGE.inference: the reference always passes activation=F.relu (models.py:371)")
+        if self.norm_type == "batch":
+            s, sh = _bn_eval_fold(self.norms[l], bias)
+            return s, sh, True
+        if self.norm_type == "none":
+            return None, bias, True
+        raise NotImplementedError("SAGE.inference fast path: norm_type 'layer' is not used by the hot-path configs")
+
+    def inference(self, dataloader, feats, whole_graph=True):
+        """Layer-wise full-neighbour inference (reference models.py:121-148).
+
+        `dataloader` is a glnn_amd.graph.FullNeighborLoader.  whole_graph=True aggregates every destination row
+        of a layer in ONE launch over the resident CSR (each dst row is independent, so the result is identical
+        to the chunked sweep); whole_graph=False walks the chunks exactly like the reference does
+        (gather input rows -> block conv -> fused BN/ReLU -> scatter)."""
+        if not feats.is_cuda:
+            raise RuntimeError("SAGE.inference runs on the HIP path only (feats must be on the GPU)")
+        with torch.no_grad():
+            x = ops.as_feat(feats)
+            for l, layer in enumerate(self.layers):
+                ep_scale, ep_shift, relu = self._tail(l)
+                if whole_graph:
+                    g = dataloader.graph
+                    y = layer(g, (x, x[: g.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                else:
+                    d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
+                    y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132
+                    for input_nodes, output_nodes, blocks in dataloader:
+                        block = blocks[0].int().to(x.device)
+                        h = ops.gather_rows(x, input_nodes)                              # feats[input_nodes]
+                        h = layer(block, (h, h[: block.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                        ops.scatter_rows(h, output_nodes, y)                             # y[output_nodes] = h
+                x = y
+            return x
+
+
+class GCN(nn.Module):
+    """reference models.py:151-199"""
+
+    def __init__(self, num_layers, input_dim, hidden_dim, output_dim, dropout_ratio, activation, norm_type="none"):
+        super().__init__()
+        self.num_layers = num_layers
+        self.norm_type = norm_type
+        self.dropout = nn.Dropout(dropout_ratio)
+        self.layers = nn.ModuleList()
+        self.norms = nn.ModuleList()
+        if num_layers == 1:
+            self.layers.append(GraphConv(input_dim, output_dim, activation=activation))
+        else:
+            self.layers.append(GraphConv(input_dim, hidden_dim, activation=activation))
+            self._add_norm(hidden_dim)
+            for _ in range(num_layers - 2):
+                self.layers.append(GraphConv(hidden_dim, hidden_dim, activation=activation))
+                self._add_norm(hidden_dim)
+            self.layers.append(GraphConv(hidden_dim, output_dim))
+
+    def _add_norm(self, hidden_dim):
+        if self.norm_type == "batch":
+            self.norms.append(nn.BatchNorm1d(hidden_dim))
+        elif self.norm_type == "layer":
+            self.norms.append(nn.LayerNorm(hidden_dim))
+
+    def forward(self, g, feats):
+        h = feats
+        h_list = []
+        for l, layer in enumerate(self.layers):
+            h = layer(g, h)
+            if l != self.num_layers - 1:
+                h_list.append(h)
+                if self.norm_type != "none":
+                    h = self.norms[l](h)
+                h = self.dropout(h)
+        return h_list, h
+
+
+class Model(nn.Module):
+    """Wrapper of different models (reference models.py:347-429)."""
+
+    def __init__(self, conf):
+        super().__init__()
+        self.model_name = conf["model_name"]
+        common = dict(num_layers=conf["num_layers"], input_dim=conf["feat_dim"], hidden_dim=conf["hidden_dim"],
+                      output_dim=conf["label_dim"], dropout_ratio=conf["dropout_ratio"])
+        if "MLP" in conf["model_name"]:
+            self.encoder = MLP(norm_type=conf["norm_type"], **common).to(conf["device"])
+        elif "SAGE" in conf["model_name"]:
+            self.encoder = SAGE(activation=F.relu, norm_type=conf["norm_type"], **common).to(conf["device"])
+        elif "GCN" in conf["model_name"]:
+            self.encoder = GCN(activation=F.relu, norm_type=conf["norm_type"], **common).to(conf["device"])
+        elif "GAT" in conf["model_name"] or "APPNP" in conf["model_name"]:
+            raise NotImplementedError(f"{conf['model_name']}: ablation-only teacher (reference models.py:202-344), "
+                                      "outside the MI355X hot-path scope (SURVEY.md section 2 row 5)")
+        else:
+            raise ValueError(f"Unknown model_name {conf['model_name']}")
+
+    def forward(self, data, feats):
+        """data: a graph `g`, a list of blocks, or None for MLPs."""
+        if "MLP" in self.model_name:
+            return self.encoder(feats)[1]
+        return self.encoder(data, feats)[1]
+
+    def forward_fitnet(self, data, feats):
+        if "MLP" in self.model_name:
+            return self.encoder(feats)
+        return self.encoder(data, feats)
+
+    def inference(self, data, feats):
+        if "SAGE" in self.model_name:
+            return self.encoder.inference(data, feats)
+        return self.forward(data, feats)

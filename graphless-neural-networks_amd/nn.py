@@ -1,0 +1,94 @@
+"""Drop-in modules for the two dgl layers the reference's hot path uses, computing on libglnn_hip.so.
+
+  SAGEConv(in, out, "gcn")(block, (h, h_dst))   <- dgl.nn.SAGEConv, reference models.py:84-99,112,138
+  GraphConv(in, out, activation=)(g, h)          <- dgl.nn.GraphConv, reference models.py:170-187,193
+
+Parameter names follow dgl 0.6.1 so that a reference `model.pth` loads: SAGEConv.fc_neigh.{weight,bias}
+(weight [out,in], xavier_uniform gain=relu; no fc_self for "gcn"), GraphConv.{weight [in,out] xavier_uniform,
+bias zeros}.  Only what the reference constructs is implemented; anything else raises."""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .autograd import SpmmFn, linear_fn
+
+
+class SAGEConv(nn.Module):
+    def __init__(self, in_feats, out_feats, aggregator_type, bias=True):
+        super().__init__()
+        if aggregator_type != "gcn":
+            raise NotImplementedError("the reference only builds SAGEConv(..., 'gcn') (models.py:84-99)")
+        self._in_feats, self._out_feats = in_feats, out_feats
+        self.fc_neigh = nn.Linear(in_feats, out_feats, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=nn.init.calculate_gain("relu"))
+
+    def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False):
+        """out = fc_neigh((sum_{u->v} h[u] + h_dst[v]) / (deg(v)+1)).  ep_* / relu: optional fused tail
+        (eval-mode BatchNorm + ReLU of the caller) used by SAGE.inference; bias is folded by the caller then."""
+        h_src, h_dst = feat if isinstance(feat, tuple) else (feat, feat)
+        n_dst = graph.num_dst_nodes()
+        if h_dst.shape[0] != n_dst:
+            raise ValueError("SAGEConv: h_dst must hold the block's destination rows")
+        w, b = self.fc_neigh.weight, self.fc_neigh.bias
+        needs_grad = torch.is_grad_enabled() and (h_src.requires_grad or w.requires_grad)
+        if needs_grad:
+            agg = SpmmFn.apply(graph, h_src, ops.AGG_SAGE_GCN)
+            return linear_fn(agg, w, b)
+        fused_tail = ep_scale is not None or ep_shift is not None or relu
+        shift = ep_shift if fused_tail else b
+        if self._in_feats > self._out_feats:
+            # project first (linear commutes with the mean): aggregate at the narrower width
+            hw = ops.gemm(ops.as_feat(h_src), w)
+            return ops.spmm(graph.indptr, graph.indices, hw, n_dst, ops.AGG_SAGE_GCN, ep_scale=ep_scale,
+                            ep_shift=shift, relu=relu)
+        agg = ops.spmm(graph.indptr, graph.indices, h_src, n_dst, ops.AGG_SAGE_GCN)
+        return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu)
+
+
+class GraphConv(nn.Module):
+    def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None,
+                 allow_zero_in_degree=False):
+        super().__init__()
+        if norm != "both" or not weight:
+            raise NotImplementedError("the reference only builds GraphConv(in, out, activation=...) (models.py:170-187)")
+        self._in_feats, self._out_feats = in_feats, out_feats
+        self._activation = activation
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.empty(out_feats)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, graph, feat):
+        if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+            raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid "
+                               "(dgl GraphConv semantics; add self-loops or set allow_zero_in_degree).")
+        rs, cs = graph.degree_norms()          # in_deg.clamp(1)^-1/2 (dst), out_deg.clamp(1)^-1/2 (src)
+        act = self._activation
+        relu = act is not None and getattr(act, "__name__", "") == "relu"
+        if act is not None and not relu:
+            raise NotImplementedError("GraphConv: only activation=F.relu or None is used by the reference")
+        n = graph.num_dst_nodes()
+        needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
+        if needs_grad:
+            h = feat * cs.unsqueeze(1)
+            if self._in_feats > self._out_feats:
+                rst = SpmmFn.apply(graph, linear_fn(h, self.weight.t(), None), ops.AGG_SUM)
+            else:
+                rst = linear_fn(SpmmFn.apply(graph, h, ops.AGG_SUM), self.weight.t(), None)
+            rst = rst * rs.unsqueeze(1)
+            if self.bias is not None:
+                rst = rst + self.bias
+            return torch.relu(rst) if relu else rst
+        if self._in_feats > self._out_feats:
+            hw = ops.gemm(ops.as_feat(feat), self.weight, w_is_kn=True, row_scale=cs)
+            return ops.spmm(graph.indptr, graph.indices, hw, n, ops.AGG_SUM, row_scale=rs, ep_shift=self.bias, relu=relu)
+        agg = ops.spmm(graph.indptr, graph.indices, feat, n, ops.AGG_SUM, col_scale=cs)
+        return ops.gemm(agg, self.weight, w_is_kn=True, row_scale=rs, ep_shift=self.bias, relu=relu)

@@ -96,7 +96,7 @@ def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
 
 
 def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale=None, ep_scale=None,
-         ep_shift=None, relu=False, out=None, m=None):
+         ep_shift=None, relu=False, out=None, m=None, drop_p=0.0, drop_seed=0):
     """K3 glnn_gemm_f32: out = epi(A' @ W^T) (w [n,k], torch Linear layout) or epi(A' @ W) (w [k,n])."""
     _need_cuda(a, w, a_rows, a_scale, a_shift, row_scale, ep_scale, ep_shift, out)
     _mat(a, "gemm a")
@@ -113,7 +113,8 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
     rc = _lib.lib().glnn_gemm_f32(
-        _p(a), _ld(a), _p(a_rows), _p(_vec(a_scale, k, "a_scale")), _p(_vec(a_shift, k, "a_shift")), m, k,
+        _p(a), _ld(a), _p(a_rows), _p(_vec(a_scale, k, "a_scale")), _p(_vec(a_shift, k, "a_shift")),
+        float(drop_p), int(drop_seed) & 0xFFFFFFFF, m, k,
         _p(w), _ld(w), 1 if w_is_kn else 0, n, _p(_vec(row_scale, m, "row_scale")),
         _p(_vec(ep_scale, n, "ep_scale")), _p(_vec(ep_shift, n, "ep_shift")), 1 if relu else 0,
         _p(out), _ld(out), _stream())
@@ -121,7 +122,8 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     return out
 
 
-def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=None, workspace=None, m=None):
+def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=None, workspace=None, m=None,
+            drop_p=0.0, drop_seed=0):
     """glnn_gemm_tn_f32: out[i,j] = sum_m a[m,i] * b'[m,j]  (weight gradient dW = dZ^T @ A_prev)."""
     _need_cuda(a, b, b_rows, b_scale, b_shift, out, col_sum_a, workspace)
     _mat(a, "gemm_tn a")
@@ -135,7 +137,7 @@ def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=N
         workspace = torch.empty(64 * ka + 256 * 128 * 128, dtype=torch.float32, device=a.device)
     rc = _lib.lib().glnn_gemm_tn_f32(
         _p(a), _ld(a), m, ka, _p(b), _ld(b), _p(b_rows), _p(_vec(b_scale, nb, "b_scale")),
-        _p(_vec(b_shift, nb, "b_shift")), nb, _p(out), _ld(out), _p(col_sum_a), _p(workspace), workspace.numel(), _stream())
+        _p(_vec(b_shift, nb, "b_shift")), float(drop_p), int(drop_seed) & 0xFFFFFFFF, nb, _p(out), _ld(out), _p(col_sum_a), _p(workspace), workspace.numel(), _stream())
     _lib.check(rc, "glnn_gemm_tn_f32")
     return out
 
@@ -193,7 +195,7 @@ def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=
 
 
 def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=None, dz=None, dgamma=None,
-                dbeta=None, workspace=None):
+                dbeta=None, workspace=None, drop_p=0.0, drop_seed=0):
     """K5 glnn_bn_relu_bwd_f32.  Returns (dz, dgamma, dbeta); gamma=None => plain ReLU backward."""
     _need_cuda(da, z, gamma, mean, rstd, a_scale, a_shift, dz, dgamma, dbeta, workspace)
     _mat(da, "bn_relu_bwd da")
@@ -209,7 +211,8 @@ def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=N
         if workspace is None:
             workspace = torch.empty(2 * ((rows + 127) // 128) * h, dtype=torch.float32, device=z.device)
     rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
-                                         _p(a_scale), _p(a_shift), _p(dz), _ld(dz), _p(dgamma), _p(dbeta),
+                                         _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
+                                         _p(dz), _ld(dz), _p(dgamma), _p(dbeta),
                                          _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
     _lib.check(rc, "glnn_bn_relu_bwd_f32")
     return dz, dgamma, dbeta
@@ -236,6 +239,13 @@ def adam_step(table, lr, step, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-
     rc = _lib.lib().glnn_adam_step_f32(_p(table.p), _p(table.g), _p(table.m), _p(table.v), _p(table.sizes), table.n,
                                        table.max_size, lr, beta1, beta2, eps, weight_decay, step, _stream())
     _lib.check(rc, "glnn_adam_step_f32")
+
+
+def dropout_mask(rows, h, drop_p, drop_seed, device):
+    mask = torch.empty((rows, h), dtype=torch.uint8, device=device)
+    rc = _lib.lib().glnn_dropout_mask_u8(rows, h, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(mask), _stream())
+    _lib.check(rc, "glnn_dropout_mask_u8")
+    return mask
 
 
 def gather_rows(x, rows, out=None):

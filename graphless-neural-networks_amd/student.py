@@ -1,0 +1,196 @@
+"""Fused MLP student training step on libglnn_hip.so.
+
+One `StudentEngine.step()` is the loop body of the reference's `train_mini_batch`
+(reference train_and_eval.py:74-85):
+
+    logits = model(None, feats[idx]); out = logits.log_softmax(1); loss = criterion(out, target[idx])
+    total_loss += loss.item(); loss *= lamb; optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+executed as a fixed sequence of C-ABI kernel launches with NO autograd graph, NO intermediate
+activation tensors beyond the pre-activation outputs z_l, and NO host synchronisation:
+
+  forward   z_0 = gemm(feats[idx] gathered in the operand load) ; per hidden layer: bn_stats(z_l) ->
+            (scale, shift) ; z_{l+1} = gemm(drop(relu(z_l*scale+shift)) formed in the operand load)
+  loss      log_softmax + NLL | KL(log-target) -> loss (accumulated on device) and dlogits (x lamb/B)
+  backward  dW_l = gemm_tn(dz_l, recomputed activation) (+ bias grad) ; da = gemm(dz_l, W_l) ;
+            dz_{l-1} = BN/ReLU/dropout backward
+  update    one fused multi-tensor Adam launch over all parameters (torch.optim.Adam semantics)
+
+The engine works IN PLACE on the `Model`'s own parameters/buffers and on the torch optimizer's own state
+tensors (exp_avg / exp_avg_sq / step), so `state_dict()`, early-stopping snapshots
+(train_and_eval.py:588,596) and `optimizer.state_dict()` behave exactly as with the reference."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def _mix32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+class StudentEngine:
+    def __init__(self, model, optimizer, max_batch):
+        enc = model.encoder
+        if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch"):
+            raise NotImplementedError("StudentEngine: MLP students with norm_type none|batch (the hot-path configs)")
+        if type(optimizer) is not torch.optim.Adam:
+            raise NotImplementedError("StudentEngine: the reference uses torch.optim.Adam (train_student.py:275)")
+        grp = optimizer.param_groups
+        if len(grp) != 1 or grp[0].get("amsgrad") or grp[0].get("maximize"):
+            raise NotImplementedError("StudentEngine: single param group, no amsgrad/maximize")
+        self.model, self.enc, self.opt = model, enc, optimizer
+        self.L = enc.num_layers
+        self.bn = enc.norm_type == "batch"
+        self.p = float(enc.dropout.p)
+        self.W = [l.weight for l in enc.layers]
+        self.b = [l.bias for l in enc.layers]
+        dev = self.W[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("StudentEngine needs the model on the GPU (HIP path only)")
+        self.dev = dev
+        self.dims = [self.W[0].shape[1]] + [w.shape[0] for w in self.W]
+        self.B = int(max_batch)
+        f32 = dict(dtype=torch.float32, device=dev)
+        B = self.B
+        # pre-activation outputs z_l (l < L-1), logits, gradient buffers
+        self.z = [ops.feat_empty(B, self.dims[l + 1], dev) for l in range(self.L - 1)]
+        self.logits = ops.feat_empty(B, self.dims[-1], dev)
+        self.dlogits = ops.feat_empty(B, self.dims[-1], dev)
+        hmax = max(self.dims[1:-1]) if self.L > 1 else 4
+        self.da = ops.feat_empty(B, hmax, dev)
+        self.dz = ops.feat_empty(B, hmax, dev)
+        self.stats = []      # per hidden layer: (mean, rstd, a_scale, a_shift)
+        for l in range(self.L - 1):
+            h = self.dims[l + 1]
+            if self.bn:
+                self.stats.append(tuple(torch.empty(h, **f32) for _ in range(4)))
+            else:
+                self.stats.append((None, None, torch.ones(h, **f32), torch.zeros(h, **f32)))
+        # parameters in torch order (model.parameters()): layers.{i}.weight, .bias ..., norms.{i}.weight, .bias ...
+        params = list(model.parameters())
+        self.params = params
+        self.grads = [torch.zeros_like(p) for p in params]
+        for p, g in zip(params, self.grads):
+            p.grad = g                               # optimizer.zero_grad() semantics: overwritten every step
+        self._gW = {id(p): g for p, g in zip(params, self.grads)}
+        # share the torch optimizer's state tensors
+        exp_avg, exp_avg_sq = [], []
+        for p in params:
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            exp_avg.append(st["exp_avg"])
+            exp_avg_sq.append(st["exp_avg_sq"])
+        self.step_count = int(optimizer.state[params[0]]["step"])
+        self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
+        # workspaces
+        hk = max(self.dims)
+        n_chunks = (B + 127) // 128
+        self.ws_bn = torch.empty(max(2 * n_chunks * hmax, 1024), **f32)
+        self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + hk * hk, **f32)
+        self.ws_loss = torch.empty(1024, **f32)
+        self.loss_out = torch.zeros(1, **f32)
+        self.loss_accum = torch.zeros(1, **f32)
+        self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
+
+    # ------------------------------------------------------------------------------------------
+    def _grad(self, p):
+        return self._gW[id(p)]
+
+    def _seed(self, layer):
+        return _mix32(self.base_seed ^ _mix32(self.step_count * 131 + layer + 1))
+
+    def step(self, feats, idx, kind, target, lamb, target_rows=None):
+        """One optimisation step on rows `idx` (int64 device vector, or None = rows 0..m-1 of feats)."""
+        enc, L, p = self.enc, self.L, self.p
+        m = idx.numel() if idx is not None else feats.shape[0]
+        if m > self.B:
+            raise ValueError(f"batch of {m} rows exceeds the engine's buffers ({self.B})")
+        lr = self.opt.param_groups[0]["lr"]
+        wd = self.opt.param_groups[0]["weight_decay"]
+        beta1, beta2 = self.opt.param_groups[0]["betas"]
+        eps = self.opt.param_groups[0]["eps"]
+        self.step_count += 1
+        z = [t[:m] for t in self.z]
+        logits, dlogits = self.logits[:m], self.dlogits[:m]
+        seeds = [self._seed(l) for l in range(L - 1)] if p > 0 else [0] * (L - 1)
+
+        # ---- forward -------------------------------------------------------------------------
+        a_scale = a_shift = None
+        src, rows = feats, idx
+        for l in range(L):
+            out = logits if l == L - 1 else z[l]
+            ops.gemm(src, self.W[l], a_rows=rows, a_scale=a_scale, a_shift=a_shift, ep_shift=self.b[l], out=out, m=m,
+                     drop_p=p if l > 0 else 0.0, drop_seed=seeds[l - 1] if l > 0 else 0)
+            if l < L - 1:
+                mean, rstd, a_scale, a_shift = self.stats[l]
+                if self.bn:
+                    bn = enc.norms[l]
+                    ops.bn_stats(out, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 eps=bn.eps, momentum=bn.momentum, outs=self.stats[l], workspace=self.ws_bn)
+                src, rows = out, None
+
+        # ---- loss + dlogits ---------------------------------------------------------------------
+        if kind == ops.LOSS_NLL:
+            ops.softmax_loss(logits, kind, lamb, labels=target, label_rows=idx if target_rows is None else target_rows,
+                             dlogits=dlogits, loss_out=self.loss_out, loss_accum=self.loss_accum, workspace=self.ws_loss)
+        else:
+            ops.softmax_loss(logits, kind, lamb, target_logp=target, target_rows=idx if target_rows is None else target_rows,
+                             dlogits=dlogits, loss_out=self.loss_out, loss_accum=self.loss_accum, workspace=self.ws_loss)
+
+        # ---- backward --------------------------------------------------------------------------
+        dz = dlogits
+        for l in range(L - 1, -1, -1):
+            gW, gb = self._grad(self.W[l]), self._grad(self.b[l])
+            if l == 0:
+                ops.gemm_tn(dz, feats, b_rows=idx, out=gW, col_sum_a=gb, workspace=self.ws_tn, m=m)
+                break
+            mean, rstd, sc, sh = self.stats[l - 1]
+            ops.gemm_tn(dz, z[l - 1], b_scale=sc, b_shift=sh, out=gW, col_sum_a=gb, workspace=self.ws_tn, m=m,
+                        drop_p=p, drop_seed=seeds[l - 1])
+            h = self.dims[l]
+            da = self.da[:m, :h]
+            ops.gemm(dz, self.W[l], w_is_kn=True, out=da, m=m)                      # dz [m,out] @ W [out,in]
+            dz_prev = self.dz[:m, :h]
+            if self.bn:
+                bn = enc.norms[l - 1]
+                ops.bn_relu_bwd(da, z[l - 1], bn.weight, mean, rstd, sc, sh, dz=dz_prev, dgamma=self._grad(bn.weight),
+                                dbeta=self._grad(bn.bias), workspace=self.ws_bn, drop_p=p, drop_seed=seeds[l - 1])
+            else:
+                ops.bn_relu_bwd(da, z[l - 1], dz=dz_prev, drop_p=p, drop_seed=seeds[l - 1])
+            dz = dz_prev
+
+        # ---- Adam ------------------------------------------------------------------------------
+        ops.adam_step(self.table, lr, self.step_count, weight_decay=wd, beta1=beta1, beta2=beta2, eps=eps)
+
+    def sync_optimizer_state(self):
+        """Write the step counter back into the torch optimizer's state (host-side scalars)."""
+        for p in self.params:
+            self.opt.state[p]["step"] = torch.tensor(float(self.step_count))
+
+
+def get_engine(model, optimizer, batch):
+    eng = getattr(model, "_glnn_engine", None)
+    if eng is None or eng.opt is not optimizer or eng.B < batch or any(a is not b for a, b in zip(eng.params, model.parameters())):
+        eng = StudentEngine(model, optimizer, batch)
+        object.__setattr__(model, "_glnn_engine", eng)
+    return eng
+
+
+def criterion_kind(criterion):
+    """Map the reference's criterion objects (train_student.py:278-279) onto the fused loss kernel."""
+    if isinstance(criterion, nn.NLLLoss) and criterion.reduction == "mean" and criterion.weight is None \
+            and criterion.ignore_index == -100:
+        return ops.LOSS_NLL
+    if isinstance(criterion, nn.KLDivLoss) and criterion.reduction == "batchmean" and criterion.log_target:
+        return ops.LOSS_KL
+    return None

@@ -1,0 +1,252 @@
+"""The reference's train / eval / distill loops (reference train_and_eval.py) with the same function
+names, arguments and return values, re-pointed at the HIP hot path.
+
+  * train_mini_batch / evaluate_mini_batch (the student's loops, :59-86 / :108-136) run on the fused
+    StudentEngine when the (model, criterion, optimizer) triple is what train_student.py:274-279 builds;
+    anything else takes the generic autograd loop (still HIP kernels through glnn_amd.autograd).
+  * evaluate (:89-105) calls Model.inference -> SAGE.inference on the aggregation kernel.
+  * The per-step `loss.item()` host sync of the reference (:80) is replaced by a device-side running sum
+    read ONCE per pass; the returned mean of per-batch losses is the same number.
+  * Sampling-based teacher TRAINING (`train_sage` with MultiLayerNeighborSampler) needs the on-device
+    block sampler, a 'next' row of SURVEY.md section 8f; `train` (full-graph GCN) works through autograd."""
+import copy
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import FullNeighborLoader
+from .student import criterion_kind, get_engine
+from .utils import set_seed
+
+
+def train(model, data, feats, labels, criterion, optimizer, idx_train, lamb=1):
+    """GNN full-batch training step (reference train_and_eval.py:12-29)."""
+    model.train()
+    logits = model(data, feats)
+    out = logits.log_softmax(dim=1)
+    loss = criterion(out[idx_train], labels[idx_train])
+    loss_val = loss.item()
+    loss *= lamb
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss_val
+
+
+def train_sage(model, dataloader, feats, labels, criterion, optimizer, lamb=1):
+    """Sampled-block SAGE training (reference train_and_eval.py:32-56); `dataloader` yields
+    (input_nodes, output_nodes, blocks) with glnn_amd CSR blocks."""
+    device = feats.device
+    model.train()
+    total_loss = 0
+    for step, (input_nodes, output_nodes, blocks) in enumerate(dataloader):
+        blocks = [blk.int().to(device) for blk in blocks]
+        batch_feats = feats[input_nodes]
+        batch_labels = labels[output_nodes]
+        logits = model(blocks, batch_feats)
+        out = logits.log_softmax(dim=1)
+        loss = criterion(out, batch_labels)
+        total_loss += loss.item()
+        loss *= lamb
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+    return total_loss / len(dataloader)
+
+
+def _batch_indices(n, batch_size):
+    """reference train_and_eval.py:65-71: CPU randperm, remainder dropped, [nb, B] view."""
+    num_batches = max(1, n // batch_size)
+    idx_batch = torch.randperm(n)[: num_batches * batch_size]
+    idx_batch = idx_batch.view(1, -1) if num_batches == 1 else idx_batch.view(num_batches, batch_size)
+    return num_batches, idx_batch
+
+
+def train_mini_batch(model, feats, labels, batch_size, criterion, optimizer, lamb=1):
+    """One pass of the MLP over `feats` in random mini-batches (reference train_and_eval.py:59-86).
+    `labels` is int64 [N] with NLLLoss or fp32 teacher log-probs [N, C] with KLDivLoss(log_target)."""
+    model.train()
+    num_batches, idx_batch = _batch_indices(feats.shape[0], batch_size)
+    kind = criterion_kind(criterion)
+    fused = kind is not None and feats.is_cuda and "MLP" in model.model_name and type(optimizer) is torch.optim.Adam \
+        and model.encoder.norm_type in ("none", "batch")
+    if not fused:
+        total_loss = 0
+        for i in range(num_batches):
+            idx = idx_batch[i].to(feats.device)
+            logits = model(None, feats[idx])
+            out = logits.log_softmax(dim=1)
+            loss = criterion(out, labels[idx])
+            total_loss += loss.item()
+            loss *= lamb
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        return total_loss / num_batches
+    eng = get_engine(model, optimizer, idx_batch.shape[1])
+    x = ops.as_feat(feats)
+    target = labels if kind == ops.LOSS_NLL else ops.as_feat(labels)
+    idx_dev = idx_batch.to(feats.device)           # one H2D copy per pass
+    eng.loss_accum.zero_()
+    for i in range(num_batches):
+        eng.step(x, idx_dev[i], kind, target, float(lamb))
+    eng.sync_optimizer_state()
+    return eng.loss_accum.item() / num_batches      # the only host sync of the pass
+
+
+def evaluate(model, data, feats, labels, criterion, evaluator, idx_eval=None):
+    """reference train_and_eval.py:89-105"""
+    model.eval()
+    with torch.no_grad():
+        logits = model.inference(data, feats)
+        out = ops.log_softmax(logits) if logits.is_cuda else logits.log_softmax(dim=1)
+        if idx_eval is None:
+            loss = criterion(out, labels)
+            score = evaluator(out, labels)
+        else:
+            loss = criterion(out[idx_eval], labels[idx_eval])
+            score = evaluator(out[idx_eval], labels[idx_eval])
+    return out, loss.item(), score
+
+
+def evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, idx_eval=None):
+    """reference train_and_eval.py:108-136.  Eval-mode rows are independent, so on the GPU the whole
+    matrix goes through ONE chain of GEMMs instead of ceil(N/B) chunks; the output is the same [N, C]."""
+    model.eval()
+    with torch.no_grad():
+        if feats.is_cuda:
+            out_all = ops.log_softmax(model.inference(None, feats))
+        else:
+            num_batches = int(np.ceil(len(feats) / batch_size))
+            out_all = torch.cat([model.inference(None, feats[batch_size * i: batch_size * (i + 1)]).log_softmax(dim=1)
+                                 for i in range(num_batches)])
+        if idx_eval is None:
+            loss = criterion(out_all, labels)
+            score = evaluator(out_all, labels)
+        else:
+            loss = criterion(out_all[idx_eval], labels[idx_eval])
+            score = evaluator(out_all[idx_eval], labels[idx_eval])
+    return out_all, loss.item(), score
+
+
+def _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch):
+    """Shared epoch loop of the reference's run_* / distill_run_* drivers: evaluate every
+    `eval_interval`, keep the best-validation state_dict in RAM, stop after `patience` bad evals
+    (reference train_and_eval.py:215-271, :558-594)."""
+    best_epoch, best_score_val, count = 0, 0, 0
+    state = copy.deepcopy(model.state_dict())
+    for epoch in range(1, conf["max_epoch"] + 1):
+        loss = train_epoch()
+        if epoch % conf["eval_interval"] == 0:
+            row, score_train, score_val, score_test = eval_epoch()
+            logger.debug(f"Ep {epoch:3d} | loss: {loss:.4f} | s_train: {score_train:.4f} | s_val: {score_val:.4f} | s_test: {score_test:.4f}")
+            loss_and_score += [[epoch] + row]
+            if score_val >= best_score_val:
+                best_epoch, best_score_val = epoch, score_val
+                state = copy.deepcopy(model.state_dict())
+                count = 0
+            else:
+                count += 1
+        if count == conf["patience"] or epoch == conf["max_epoch"]:
+            break
+    model.load_state_dict(state)
+    return best_epoch
+
+
+def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluator, optimizer, logger, loss_and_score):
+    """Teacher (or plain-MLP) training + eval, transductive (reference train_and_eval.py:144-287).
+    SAGE: evaluation = layer-wise full-neighbour inference on the aggregation kernel; training needs the
+    neighbour sampler (next row) and is done here with FULL-neighbour blocks over the training nodes."""
+    set_seed(conf["seed"])
+    device = conf["device"]
+    batch_size = conf["batch_size"]
+    idx_train, idx_val, idx_test = indices
+    feats, labels = feats.to(device), labels.to(device)
+    idx_train, idx_val, idx_test = idx_train.to(device), idx_val.to(device), idx_test.to(device)
+    is_mlp, is_sage = "MLP" in model.model_name, "SAGE" in model.model_name
+    if is_sage:
+        g = g.to(device)
+        data_eval = FullNeighborLoader(g, batch_size)
+        data = g
+    elif is_mlp:
+        feats_train, labels_train = feats[idx_train], labels[idx_train]
+        feats_val, labels_val = feats[idx_val], labels[idx_val]
+        feats_test, labels_test = feats[idx_test], labels[idx_test]
+    else:
+        g = g.to(device)
+        data = data_eval = g
+
+    def train_epoch():
+        if is_sage:
+            return _train_sage_full_graph(model, data, feats, labels, criterion, optimizer, idx_train)
+        if is_mlp:
+            return train_mini_batch(model, feats_train, labels_train, batch_size, criterion, optimizer)
+        return train(model, data, feats, labels, criterion, optimizer, idx_train)
+
+    def eval_epoch():
+        if is_mlp:
+            _, l_tr, s_tr = evaluate_mini_batch(model, feats_train, labels_train, criterion, batch_size, evaluator)
+            _, l_va, s_va = evaluate_mini_batch(model, feats_val, labels_val, criterion, batch_size, evaluator)
+            _, l_te, s_te = evaluate_mini_batch(model, feats_test, labels_test, criterion, batch_size, evaluator)
+        else:
+            out, l_tr, s_tr = evaluate(model, data_eval, feats, labels, criterion, evaluator, idx_train)
+            l_va, s_va = criterion(out[idx_val], labels[idx_val]).item(), evaluator(out[idx_val], labels[idx_val])
+            l_te, s_te = criterion(out[idx_test], labels[idx_test]).item(), evaluator(out[idx_test], labels[idx_test])
+        return [l_tr, l_va, l_te, s_tr, s_va, s_te], s_tr, s_va, s_te
+
+    best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
+    if is_mlp:
+        out, _, score_val = evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, idx_val)
+    else:
+        out, _, score_val = evaluate(model, data_eval, feats, labels, criterion, evaluator, idx_val)
+    score_test = evaluator(out[idx_test], labels[idx_test])
+    logger.info(f"Best valid model at epoch: {best_epoch: 3d}, score_val: {score_val :.4f}, score_test: {score_test :.4f}")
+    return out, score_val, score_test
+
+
+def _train_sage_full_graph(model, g, feats, labels, criterion, optimizer, idx_train):
+    """SAGE training step with full-neighbour aggregation over the whole graph (every layer's block is the
+    graph itself) -- stands in for the fan-out sampled `train_sage` until the on-device sampler exists."""
+    model.train()
+    logits = model([g] * model.encoder.num_layers, feats)
+    out = logits.log_softmax(dim=1)
+    loss = criterion(out[idx_train], labels[idx_train])
+    loss_val = loss.item()
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss_val
+
+
+def distill_run_transductive(conf, model, feats, labels, out_t_all, distill_indices, criterion_l, criterion_t,
+                             evaluator, optimizer, logger, loss_and_score):
+    """Distillation, transductive (reference train_and_eval.py:520-606): per epoch a hard-label pass
+    weighted lamb, then a soft-label pass weighted 1-lamb, each with its own randperm and optimiser steps."""
+    set_seed(conf["seed"])
+    device = conf["device"]
+    batch_size = conf["batch_size"]
+    lamb = conf["lamb"]
+    idx_l, idx_t, idx_val, idx_test = [i.to(device) for i in distill_indices]
+    feats, labels, out_t_all = feats.to(device), labels.to(device), out_t_all.to(device)
+    feats_l, labels_l = feats[idx_l], labels[idx_l]
+    feats_t, out_t = feats[idx_t], out_t_all[idx_t]
+    feats_val, labels_val = feats[idx_val], labels[idx_val]
+    feats_test, labels_test = feats[idx_test], labels[idx_test]
+
+    def train_epoch():
+        loss_l = train_mini_batch(model, feats_l, labels_l, batch_size, criterion_l, optimizer, lamb)
+        loss_t = train_mini_batch(model, feats_t, out_t, batch_size, criterion_t, optimizer, 1 - lamb)
+        return loss_l + loss_t
+
+    def eval_epoch():
+        _, l_l, s_l = evaluate_mini_batch(model, feats_l, labels_l, criterion_l, batch_size, evaluator)
+        _, l_va, s_va = evaluate_mini_batch(model, feats_val, labels_val, criterion_l, batch_size, evaluator)
+        _, l_te, s_te = evaluate_mini_batch(model, feats_test, labels_test, criterion_l, batch_size, evaluator)
+        return [l_l, l_va, l_te, s_l, s_va, s_te], s_l, s_va, s_te
+
+    best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
+    out, _, score_val = evaluate_mini_batch(model, feats, labels, criterion_l, batch_size, evaluator, idx_val)
+    score_test = evaluator(out[idx_test], labels_test)
+    logger.info(f"Best valid model at epoch: {best_epoch: 3d}, score_val: {score_val :.4f}, score_test: {score_test :.4f}")
+    return out, score_val, score_test

@@ -60,7 +60,8 @@ GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int
  *        y = y * ep_scale[j] + ep_shift[j] ;  y = max(y, 0) if relu
  *   (bias, eval-mode BatchNorm and ReLU of models.py:139-143 when the dense projection was
  *    applied BEFORE aggregation; NULL/0 otherwise).
- * n_src bounds the column indices (only used for argument checking).  d <= 1024.
+ * n_src bounds the column indices (only used for argument checking).  Rows wider than 256 floats
+ * are processed in column tiles of 256 (one launch per tile).
  * ------------------------------------------------------------------------------------------ */
 #define GLNN_AGG_SUM 0
 #define GLNN_AGG_SAGE_GCN 1
@@ -84,15 +85,18 @@ GLNN_API int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int
  *   C[m,n] = epilogue( sum_k A'[m,k] * B[k,n] )
  *   A' = A, or rows gathered through a_rows (A'[m,:] = A[a_rows[m],:], replaces feats[idx]
  *        at reference train_and_eval.py:76 / models.py:136), optionally passed through the
- *        "previous layer tail"  A'[m,k] = max(A[m,k]*a_scale[k] + a_shift[k], 0)  (BatchNorm + ReLU
- *        of reference models.py:48-51 folded into the operand load; NULL = identity, no ReLU).
+ *        "previous layer tail"  A'[m,k] = drop(max(A[m,k]*a_scale[k] + a_shift[k], 0))  (BatchNorm,
+ *        ReLU and training-mode Dropout of reference models.py:48-52 folded into the operand load;
+ *        a_scale NULL = identity, no ReLU, no dropout).  drop(v) = keep(m,k) ? v/(1-drop_p) : 0 with
+ *        keep() the counter-based mask of glnn_dropout_mask_u8 (drop_p = 0 disables it).
  *   B  = W^T with W [n,k] row-major (torch.nn.Linear / dgl SAGEConv.fc_neigh, b_layout 0)
  *        or W [k,n] row-major (dgl GraphConv.weight, b_layout 1).
  *   epilogue, in order, each optional: * row_scale[m] ; * ep_scale[n] ; + ep_shift[n] ; ReLU.
  * replaces fc_neigh / GraphConv weight / nn.Linear: reference models.py:45,112,138,193.
  * ------------------------------------------------------------------------------------------ */
 GLNN_API int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
-                           const float* a_scale, const float* a_shift, int64_t m, int k,
+                           const float* a_scale, const float* a_shift, float drop_p,
+                           uint32_t drop_seed, int64_t m, int k,
                            const float* b, int64_t ldb, int b_layout, int n,
                            const float* row_scale, const float* ep_scale, const float* ep_shift,
                            int relu, float* c, int64_t ldc, void* stream);
@@ -108,7 +112,8 @@ GLNN_API int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
  *   small, and for the column sums (needs >= 64*ka floats for those). */
 GLNN_API int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b,
                               int64_t ldb, const int64_t* b_rows, const float* b_scale,
-                              const float* b_shift, int nb, float* c, int64_t ldc,
+                              const float* b_shift, float drop_p, uint32_t drop_seed, int nb,
+                              float* c, int64_t ldc,
                               float* col_sum_a, float* workspace, int64_t workspace_floats,
                               void* stream);
 
@@ -147,6 +152,8 @@ GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows
  *     dy = da * [z*a_scale+a_shift > 0], dgamma = sum dy*xhat, dbeta = sum dy and
  *     dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); in place on da allowed.
  *     With gamma == NULL (norm_type "none") it is the plain ReLU backward dz = da*[z>0].
+ *     drop_p > 0 first applies the Dropout backward da *= keep(row,col)/(1-drop_p) with the same
+ *     (drop_seed) mask the forward operand transform used.
  * ------------------------------------------------------------------------------------------ */
 GLNN_API int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                                const float* beta, float eps, float momentum, float* running_mean,
@@ -157,6 +164,7 @@ GLNN_API int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h,
 GLNN_API int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz,
                                   int64_t rows, int h, const float* gamma, const float* mean,
                                   const float* rstd, const float* a_scale, const float* a_shift,
+                                  float drop_p, uint32_t drop_seed,
                                   float* dz, int64_t lddz, float* dgamma, float* dbeta,
                                   float* workspace, int64_t workspace_floats, void* stream);
 
@@ -172,6 +180,12 @@ GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
                                 const int64_t* sizes, int num_tensors, int64_t max_size,
                                 float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int64_t step, void* stream);
+
+/* The dropout keep-mask the kernels above evaluate on the fly (nn.Dropout, reference models.py:52):
+ * mask[r*h + c] = 1 if element (r,c) is kept under (drop_p, drop_seed).  torch's Philox stream cannot
+ * be reproduced by a custom kernel, so parity tests run the oracle with THIS mask as an input. */
+GLNN_API int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t drop_seed,
+                                  uint8_t* mask, void* stream);
 
 /* K7  row gather: out[i,:] = x[rows[i],:]  (feats[idx], reference train_and_eval.py:42,76,
  *     models.py:136) and scatter y[rows[i],:] = x[i,:] (models.py:145). */

@@ -46,7 +46,7 @@ def main():
             med, best = timeit(lambda: ops.spmm(g.indptr, g.indices, x, n, ops.AGG_SAGE_GCN, out=out))
             balg = nnz * (4 * d + 4) + n * (8 * d + 8)
             print(f"spmm sage_gcn d={d:4d} ld={ld:4d}: {med:8.3f} ms (best {best:.3f})  {nnz / med / 1e6:7.2f} Gedges/s  "
-                  f"alg {balg / med / 1e9:7.1f} GB/s = {balg / med / 1e9 / 8000 * 100:5.1f}% of 8 TB/s", flush=True)
+                  f"alg {balg / med / 1e6:7.1f} GB/s = {balg / med / 1e6 / 8000 * 100:5.1f}% of 8 TB/s", flush=True)
             del buf, x, out
     if "gemm" in what:
         for m, k, n in [(2449029, 100, 256), (2449029, 256, 256), (2449029, 256, 47), (4096, 100, 2048), (4096, 2048, 2048),
@@ -59,7 +59,7 @@ def main():
             fl = 2.0 * m * n * k
             medt, _ = timeit(lambda: torch.matmul(x, w.t()))
             print(f"gemm m={m} k={k} n={n}: {med:8.3f} ms  {fl / med / 1e9:8.1f} TF/s (torch/rocBLAS {medt:8.3f} ms {fl / medt / 1e9:8.1f} TF/s)  "
-                  f"bytes {(m * k + m * n) * 4 / med / 1e9:7.1f} GB/s", flush=True)
+                  f"bytes {(m * k + m * n) * 4 / med / 1e6:7.1f} GB/s", flush=True)
         for m, ka, nb in [(4096, 2048, 2048), (4096, 2048, 100), (4096, 47, 2048)]:
             dz = torch.randn((m, ka), device=dev)
             act = torch.randn((m, nb), device=dev)

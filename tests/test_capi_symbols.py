@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     lib_path = ge.build()
     h = ctypes.CDLL(lib_path)
     fns = header_functions()
-    assert len(fns) >= 14
+    assert len(fns) >= 15
     for name in fns:
         assert hasattr(h, name), f"{name} declared in include/glnn_hip.h but not exported"
     h.glnn_abi_version.restype = ctypes.c_int
@@ -51,7 +51,7 @@ def test_invalid_arguments_are_reported_not_crashed():
     h = _lib.lib()
     rc = h.glnn_spmm_csr_f32(None, None, 4, 4, None, 4, 4, 0, None, None, None, 0, None, None, 0, None, 4, None)
     assert rc == -1 and b"null pointer" in h.glnn_last_error()
-    rc = h.glnn_gemm_f32(None, 4, None, None, None, 4, 4, None, 4, 0, 4, None, None, None, 0, None, 4, None)
+    rc = h.glnn_gemm_f32(None, 4, None, None, None, 0.0, 0, 4, 4, None, 4, 0, 4, None, None, None, 0, None, 4, None)
     assert rc == -1
 
 

@@ -1,0 +1,296 @@
+"""GPU parity of the preserved Python surface (Model / train_mini_batch / evaluate_mini_batch /
+SAGE.inference / GCN.forward / feature_prop) against the golden vectors produced by the reference
+and against the CPU oracle.  Bar: 1e-4 abs fp32 (tests/parity_rules.py explains the Adam gauge cases)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import CASES, Golden
+from graphgen import random_graph
+from oracle import student_oracle as so
+from oracle import teacher_oracle as to
+from parity_rules import check_final_state, eval_tol, has_gauge
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _student(g, dropout=0.0):
+    from glnn_amd.models import Model
+    L = len(g.dims) - 1
+    conf = dict(model_name="MLP", num_layers=L, feat_dim=g.dims[0], hidden_dim=g.dims[1], label_dim=g.dims[-1],
+                dropout_ratio=dropout, norm_type=g.norm, device=DEV)
+    model = Model(conf)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in g.sd0.items()})
+    opt = torch.optim.Adam(model.parameters(), lr=g.lr, weight_decay=g.wd)      # train_student.py:275-277
+    return model, opt
+
+
+def test_model_state_dict_keys_match_reference():
+    from glnn_amd.models import Model
+    g = Golden("bn_small")
+    model, _ = _student(g)
+    assert list(model.state_dict().keys()) == list(g.sd0.keys())
+    sage = Model(dict(model_name="SAGE", num_layers=3, feat_dim=8, hidden_dim=16, label_dim=4, dropout_ratio=0.0,
+                      norm_type="batch", device=DEV))
+    keys = list(sage.state_dict().keys())
+    assert "encoder.layers.0.fc_neigh.weight" in keys and "encoder.layers.2.fc_neigh.bias" in keys
+    assert tuple(sage.state_dict()["encoder.layers.0.fc_neigh.weight"].shape) == (16, 8)
+    gcn = Model(dict(model_name="GCN", num_layers=2, feat_dim=8, hidden_dim=16, label_dim=4, dropout_ratio=0.0,
+                     norm_type="none", device=DEV))
+    assert tuple(gcn.state_dict()["encoder.layers.0.weight"].shape) == (8, 16)     # dgl GraphConv: [in, out]
+    with pytest.raises(NotImplementedError):
+        Model(dict(model_name="GAT", num_layers=2, feat_dim=8, hidden_dim=16, label_dim=4, dropout_ratio=0.0,
+                   norm_type="none", device=DEV, attn_dropout_ratio=0.1))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_single_step_gradients_vs_reference_golden(name):
+    from glnn_amd import ops
+    from glnn_amd.student import StudentEngine
+    g = Golden(name)
+    feats_l, labels_l = g.feats[g.idx_l], g.labels[g.idx_l]
+    for kind, x, y in (("nll", feats_l, labels_l), ("kl", g.feats, g.out_t)):
+        model, opt = _student(g)
+        model.train()
+        bsz = min(g.B, x.shape[0])
+        eng = StudentEngine(model, opt, bsz)
+        lam = float(g.z[f"step_{kind}_lamb"])
+        xd = ops.as_feat(torch.from_numpy(x).to(DEV))
+        yd = torch.from_numpy(y).to(DEV)
+        idx = torch.arange(bsz, device=DEV)
+        eng.step(xd, idx, ops.LOSS_NLL if kind == "nll" else ops.LOSS_KL, yd if kind == "nll" else ops.as_feat(yd), lam)
+        assert abs(eng.loss_out.item() - float(g.z[f"step_{kind}_loss"])) < TOL
+        np.testing.assert_allclose(g.view(eng.logits[:bsz].cpu().numpy()), g.z[f"step_{kind}_logits"], atol=TOL, rtol=0)
+        np.testing.assert_allclose(g.view(eng.dlogits[:bsz].cpu().numpy()), g.z[f"step_{kind}_dlogits"], atol=1e-6, rtol=1e-4)
+        for pname, p in model.named_parameters():
+            np.testing.assert_allclose(g.view(p.grad.cpu().numpy()), g.z[f"step_{kind}_grad.{pname}"], atol=TOL, rtol=1e-4,
+                                       err_msg=f"{kind} {pname}")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_distill_passes_vs_reference_golden(name, monkeypatch):
+    """The reference's epoch body (train_and_eval.py:559-566) through glnn_amd.train_and_eval with the
+    reference's own criterion / optimizer objects; permutations replayed from the golden run."""
+    from glnn_amd import train_and_eval as te
+    g = Golden(name)
+    model, opt = _student(g)
+    criterion_l = torch.nn.NLLLoss()
+    criterion_t = torch.nn.KLDivLoss(reduction="batchmean", log_target=True)
+    perms = iter(g.perms)
+    monkeypatch.setattr(torch, "randperm", lambda n, *a, **k: torch.from_numpy(next(perms)))
+    feats, labels, out_t = (torch.from_numpy(a).to(DEV) for a in (g.feats, g.labels, g.out_t))
+    idx_l = torch.from_numpy(g.idx_l).to(DEV)
+    feats_l, labels_l = feats[idx_l], labels[idx_l]
+    means = []
+    for _ in range(g.epochs):
+        means.append(te.train_mini_batch(model, feats_l, labels_l, g.B, criterion_l, opt, g.lamb))
+        means.append(te.train_mini_batch(model, feats, out_t, g.B, criterion_t, opt, 1 - g.lamb))
+    np.testing.assert_allclose(means, g.z["pass_means"], atol=TOL, rtol=0)
+    assert int(opt.state[next(model.parameters())]["step"]) == int(g.z["adam.step"])
+    check_final_state(g, {k: v.cpu().numpy() for k, v in model.state_dict().items()})
+    evaluator = lambda o, y: o.argmax(1).eq(y).float().mean().item()
+    out, loss_e, score_e = te.evaluate_mini_batch(model, feats, labels, criterion_l, g.B, evaluator)
+    np.testing.assert_allclose(g.view(out.cpu().numpy()), g.z["eval_out"], atol=eval_tol(g), rtol=0)
+    assert abs(loss_e - float(g.z["eval_loss"])) < eval_tol(g)
+    assert abs(score_e - float(g.z["eval_score"])) < (1e-6 if not has_gauge(g) else 5e-3)
+
+
+def test_eval_forward_at_identical_state_vs_oracle():
+    """Eval-mode forward (BN running stats) at a FIXED state: 1e-4 even for the gauge configs."""
+    from glnn_amd import train_and_eval as te
+    g = Golden("arxiv_dims")
+    model, _ = _student(g, dropout=0.5)           # dropout must be a no-op in eval mode
+    st = so.MLPState(g.sd0, len(g.dims) - 1, g.norm)
+    want = so.evaluate_mini_batch(st, g.feats, g.B)
+    out, _, _ = te.evaluate_mini_batch(model, torch.from_numpy(g.feats).to(DEV), torch.from_numpy(g.labels).to(DEV),
+                                       torch.nn.NLLLoss(), g.B, lambda o, y: 0.0)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL, rtol=0)
+    model.eval()
+    with torch.no_grad():
+        h_list, h = model.forward_fitnet(None, torch.from_numpy(g.feats).to(DEV))     # (h_list, logits), models.py:414-423
+    _, cache = so.mlp_forward(st, g.feats, training=False)
+    assert len(h_list) == len(g.dims) - 2
+    for got_z, want_z in zip(h_list, cache["z"]):
+        np.testing.assert_allclose(got_z.cpu().numpy(), want_z, atol=TOL, rtol=0)
+
+
+def test_training_step_with_dropout_matches_oracle_given_the_mask():
+    from glnn_amd import ops
+    from glnn_amd.student import StudentEngine
+    g = Golden("bn_small")
+    p = 0.4
+    model, opt = _student(g, dropout=p)
+    model.train()
+    L = len(g.dims) - 1
+    bsz = 64
+    eng = StudentEngine(model, opt, bsz)
+    x = ops.as_feat(torch.from_numpy(g.feats).to(DEV))
+    idx = torch.arange(100, 100 + bsz, device=DEV)
+    # the engine derives its dropout seeds from (base_seed, step_count); recompute those of step 1
+    eng.step_count = 1
+    seeds = [eng._seed(l) for l in range(L - 1)]
+    eng.step_count = 0
+    eng.step(x, idx, ops.LOSS_KL, ops.as_feat(torch.from_numpy(g.out_t).to(DEV)), 0.7)
+    masks = [ops.dropout_mask(bsz, g.dims[l + 1], p, seeds[l], DEV).cpu().numpy().astype(np.float32) for l in range(L - 1)]
+    for mk in masks:
+        assert abs(mk.mean() - (1 - p)) < 0.05
+    st = so.MLPState(g.sd0, L, g.norm, dropout_ratio=p)
+    rows = idx.cpu().numpy()
+    logits, cache = so.mlp_forward(st, g.feats[rows], training=True, masks=masks)
+    loss, dlogits = so.loss_and_dlogits(logits, g.out_t[rows], "kl", 0.7)
+    grads = so.mlp_backward(st, cache, dlogits)
+    assert abs(eng.loss_out.item() - float(loss)) < TOL
+    np.testing.assert_allclose(eng.logits[:bsz].cpu().numpy(), logits, atol=TOL, rtol=0)
+    for (pname, prm), gr in zip(model.named_parameters(), grads):
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=TOL, rtol=1e-4, err_msg=pname)
+
+
+# ------------------------------------------------------------------------------------------- teacher
+def _sage_model(dims, norm, seed):
+    from glnn_amd.models import Model
+    L = len(dims) - 1
+    torch.manual_seed(seed)
+    model = Model(dict(model_name="SAGE", num_layers=L, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                       dropout_ratio=0.5, norm_type=norm, device=DEV))
+    rs = np.random.RandomState(seed)
+    with torch.no_grad():
+        for i, bn in enumerate(model.encoder.norms):
+            h = bn.weight.shape[0]
+            bn.weight.copy_(torch.from_numpy(rs.uniform(.5, 1.5, h).astype(np.float32)))
+            bn.bias.copy_(torch.from_numpy(rs.uniform(-.2, .2, h).astype(np.float32)))
+            bn.running_mean.copy_(torch.from_numpy(rs.uniform(-.3, .3, h).astype(np.float32)))
+            bn.running_var.copy_(torch.from_numpy(rs.uniform(.5, 1.5, h).astype(np.float32)))
+        for lay in model.encoder.layers:
+            lay.fc_neigh.bias.copy_(torch.from_numpy((rs.standard_normal(lay.fc_neigh.bias.shape[0]) * .1).astype(np.float32)))
+    model.eval()
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    layers = [dict(weight=sd[f"encoder.layers.{i}.fc_neigh.weight"], bias=sd[f"encoder.layers.{i}.fc_neigh.bias"]) for i in range(L)]
+    norms = [dict(weight=sd[f"encoder.norms.{i}.weight"], bias=sd[f"encoder.norms.{i}.bias"],
+                  running_mean=sd[f"encoder.norms.{i}.running_mean"], running_var=sd[f"encoder.norms.{i}.running_var"])
+             for i in range(L - 1)] if norm == "batch" else None
+    return model, layers, norms
+
+
+@pytest.mark.parametrize("dims,norm", [([128, 256, 256, 40], "batch"), ([100, 256, 256, 47], "batch"), ([20, 32, 6], "none")])
+def test_sage_inference_vs_oracle(dims, norm):
+    """SAGE.inference (reference models.py:121-148) through Model.inference: whole-graph fast path AND the
+    reference's chunked sweep, both against the CPU oracle."""
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    n = 4000
+    indptr, indices = random_graph(n, 14, seed=dims[0], power=0.6, isolated=9, hub=1500)
+    x = np.random.RandomState(0).standard_normal((n, dims[0])).astype(np.float32)
+    model, layers, norms = _sage_model(dims, norm, seed=1)
+    want = to.sage_inference(indptr, indices, x, layers, norms)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    loader = FullNeighborLoader(g, 512)
+    got = model.inference(loader, torch.from_numpy(x).to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+    got_chunked = model.encoder.inference(loader, torch.from_numpy(x).to(DEV), whole_graph=False)
+    np.testing.assert_allclose(got_chunked.cpu().numpy(), want, atol=TOL, rtol=0)
+
+
+def test_evaluate_sage_log_probs_and_score():
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    n, dims = 1500, [16, 32, 5]
+    indptr, indices = random_graph(n, 8, seed=4, power=0.5)
+    x = np.random.RandomState(3).standard_normal((n, dims[0])).astype(np.float32)
+    y = np.random.RandomState(4).randint(0, 5, n).astype(np.int64)
+    model, layers, norms = _sage_model(dims, "batch", seed=2)
+    want = to.log_softmax_(to.sage_inference(indptr, indices, x, layers, norms))
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    out, loss, score = te.evaluate(model, FullNeighborLoader(g, 256), torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV),
+                                   torch.nn.NLLLoss(), lambda o, l: o.argmax(1).eq(l).float().mean().item())
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL, rtol=0)
+    assert abs(loss - so.nll_loss(want, y)) < TOL and abs(score - so.accuracy(want, y)) < 1e-6
+
+
+def test_gcn_forward_cora_shape_vs_oracle():
+    """config 0: cora-shaped GCN teacher (1433 -> 64 -> 7, reference train.conf.yaml:12-15)."""
+    from glnn_amd import data
+    from glnn_amd.models import Model
+    g = data.make_graph("cora", seed=0, device="cpu")
+    n = g.n_dst
+    x = np.random.RandomState(0).standard_normal((n, 1433)).astype(np.float32) * 0.1
+    torch.manual_seed(0)
+    model = Model(dict(model_name="GCN", num_layers=2, feat_dim=1433, hidden_dim=64, label_dim=7, dropout_ratio=0.8,
+                       norm_type="none", device=DEV))
+    with torch.no_grad():
+        for lay in model.encoder.layers:
+            lay.bias.copy_(torch.randn_like(lay.bias) * 0.1)
+    model.eval()
+    sd = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+    layers = [dict(weight=sd[f"encoder.layers.{i}.weight"], bias=sd[f"encoder.layers.{i}.bias"]) for i in range(2)]
+    want = to.gcn_forward(g.indptr.numpy(), g.indices.numpy(), x, layers)
+    with torch.no_grad():
+        got = model.inference(g.to(DEV), torch.from_numpy(x).to(DEV))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+
+
+def test_feature_prop_vs_oracle():
+    from glnn_amd import utils
+    from glnn_amd.graph import CSRGraph
+    n = 2000
+    indptr, indices = random_graph(n, 7, seed=12, power=0.5, symmetric=True, self_loops=True)
+    x = np.random.RandomState(5).standard_normal((n, 128)).astype(np.float32)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    got = utils.feature_prop(torch.from_numpy(x).to(DEV), g, 2)
+    np.testing.assert_allclose(got.cpu().numpy(), to.feature_prop(indptr, indices, x, 2), atol=TOL, rtol=0)
+
+
+def test_teacher_autograd_matches_torch_dense():
+    """Aggregation + projection backward (the teacher-training direction) vs dense torch autograd."""
+    from glnn_amd import ops
+    from glnn_amd.autograd import SpmmFn, linear_fn
+    from glnn_amd.graph import CSRGraph
+    n, d, o = 300, 24, 10
+    indptr, indices = random_graph(n, 5, seed=2, power=0.5, isolated=4)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    a = torch.zeros(n, n, dtype=torch.float64)
+    for v in range(n):
+        for e in range(indptr[v], indptr[v + 1]):
+            a[v, indices[e]] += 1
+    deg = a.sum(1, keepdim=True)
+    x0 = torch.randn(n, d, dtype=torch.float64)
+    w0 = torch.randn(o, d, dtype=torch.float64) / 5
+    b0 = torch.randn(o, dtype=torch.float64)
+    xr, wr, br = x0.clone().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+    yr = ((a @ xr + xr) / (deg + 1)) @ wr.t() + br
+    (yr.pow(2).sum()).backward()
+    x = x0.float().to(DEV).requires_grad_(); w = w0.float().to(DEV).requires_grad_(); b = b0.float().to(DEV).requires_grad_()
+    y = linear_fn(SpmmFn.apply(g, x, ops.AGG_SAGE_GCN), w, b)
+    (y.pow(2).sum()).backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), atol=TOL, rtol=1e-4)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), atol=1e-3, rtol=1e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), wr.grad.numpy(), atol=1e-2, rtol=1e-4)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), br.grad.numpy(), atol=1e-2, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- full size
+def test_full_size_products_properties():
+    """ogbn-products-shaped aggregation at FULL size through size-independent properties:
+    (1) conservation: sum_v (deg_v+1) * out[v] == sum_u (outdeg_u+1) * x[u]  (fp64 check);
+    (2) row-range sharding: out[a:b] from the row shard == the unsharded rows, bit for bit;
+    (3) linearity: agg(2x + y) == 2 agg(x) + agg(y) to rounding."""
+    from glnn_amd import data, ops
+    g = data.make_graph("ogbn-products", seed=0, device=DEV)
+    n, d = g.n_dst, 100
+    assert n == 2449029 and g.num_edges() == 123718280
+    x = torch.randn(n, d, device=DEV)
+    out = ops.spmm(g.indptr, g.indices, x, n, ops.AGG_SAGE_GCN)
+    deg = g.in_degrees().double()
+    outdeg = g.out_degrees().double()
+    lhs = ((deg + 1).unsqueeze(1) * out.double()).sum(0)
+    rhs = ((outdeg + 1).unsqueeze(1) * x.double()).sum(0)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1)) < 1e-4
+    lo, hi = n // 3, n // 3 + 300000
+    shard = g.row_range(lo, hi)
+    part = ops.spmm(shard.indptr, shard.indices, x, hi - lo, ops.AGG_SUM)
+    full_sum = ops.spmm(g.indptr, g.indices, x, n, ops.AGG_SUM)
+    assert torch.equal(part, full_sum[lo:hi])
+    y = torch.randn(n, d, device=DEV)
+    lin = ops.spmm(g.indptr, g.indices, ops.as_feat(2 * x + y), n, ops.AGG_SAGE_GCN)
+    outy = ops.spmm(g.indptr, g.indices, y, n, ops.AGG_SAGE_GCN)
+    assert float((lin - (2 * out + outy)).abs().max()) < 1e-4
