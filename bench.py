@@ -1,0 +1,289 @@
+#!/usr/bin/env python
+"""Contract benchmark: BASELINE.json's metric -- aggregated edges/sec of the GLNN teacher forward
+(SAGE layer-wise full-neighbour inference, reference models.py:121-148) plus student distillation
+steps/sec (loop body of reference train_and_eval.py:74-85) -- on ogbn-products-SHAPED synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE full teacher forward over the products-shaped graph (3 layers, every edge aggregated once
+per layer = 371,154,840 edge aggregations); `value` = aggregated edges / s over the whole job, inputs
+resident in HBM.  N > 1: strong scaling, the graph's destination rows are range-sharded over the ranks and
+one all-gather per layer exchanges activations (glnn_amd/dist.py).  The student leg times the fused
+distillation step of the products student MLP3w8 (100-2048-2048-47, B=4096, KL soft-label pass) under the
+same protocol and is reported in the "student" object.
+
+Extra objects on the JSON line (rank 0, N = 1): "roofline" for the dominant kernel (the aggregation), from
+per-launch HIP events recorded inside the timed region on the launch stream, and "cpu_baseline": the CPU
+oracle ("port": this repo's restatement -- the reference's own dgl CPU path cannot run here, dgl is not
+installed) timed on a bounded sample with all host cores."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
+SAGE_DIMS = [100, 256, 256, 47]  # reference train.conf.yaml:196-204 (ogbn-products SAGE, hidden 256, BN)
+STUDENT = dict(name="MLP3w8", dims=[100, 2048, 2048, 47], batch=4096, dropout=0.2, lr=0.01, wd=0.0)   # :187-194
+
+
+def agg_width(d_in, d_out):
+    return d_out if d_in > d_out else d_in      # project-first when the layer narrows
+
+
+def lanes_per_row(d):
+    dv = (d + 3) // 4
+    return 4 if dv <= 4 else 8 if dv <= 8 else 16 if dv <= 16 else 32 if dv <= 32 else 64
+
+
+def alg_bytes(nnz, n_dst, d):
+    """per edge one gathered fp32 source row + one int32 index; per dst row one self-row read,
+    one output-row write, one int64 indptr entry."""
+    return nnz * (4 * d + 4) + n_dst * (8 * d + 8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; 1.0 = the metric's config)")
+    ap.add_argument("--student-steps-per-step", type=int, default=10, help="student steps timed per --steps unit")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+    from glnn_amd import data, ops
+    from glnn_amd.dist import RowShards, ShardedTeacher, make_grad_sync
+    from glnn_amd.graph import FullNeighborLoader
+    from glnn_amd.models import Model
+    from glnn_amd.student import StudentEngine
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- synthetic ogbn-products-shaped inputs, generated in HBM (seed 0, identical on every rank) --------
+    torch.manual_seed(0)
+    g = data.make_graph("ogbn-products", seed=0, device=dev, scale=args.scale)
+    n, nnz = g.n_dst, g.num_edges()
+    feats, labels, out_t, _ = data.make_node_data("ogbn-products", seed=0, device=dev, n=n)
+    feats = ops.as_feat(feats)
+
+    teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1],
+                         label_dim=SAGE_DIMS[-1], dropout_ratio=0.5, norm_type="batch", device=dev))
+    teacher.eval()
+    shards = RowShards(n, world, rank)
+    if world > 1:
+        shard_graph = g.row_range(shards.lo, shards.hi)
+        sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops)
+        del g
+        torch.cuda.empty_cache()
+
+        def teacher_forward():
+            with torch.no_grad():
+                return sharded.forward(feats)
+    else:
+        loader = FullNeighborLoader(g, 4096)
+
+        def teacher_forward():
+            return teacher.inference(loader, feats)
+
+    edges_per_forward = 3 * nnz
+
+    # ---- teacher: W warm-up forwards, then exactly K timed forwards ---------------------------------------
+    for _ in range(args.warmup):
+        teacher_forward()
+    timing = []
+    barrier()
+    if rank == 0 and world == 1:
+        ops.set_timing(timing)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        teacher_forward()
+    barrier()
+    t_teacher = time.perf_counter() - t0
+    ops.set_timing(None)
+    if world > 1:
+        tt = torch.tensor([t_teacher], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_teacher = float(tt.item())
+    edges_per_s = edges_per_forward * args.steps / t_teacher
+
+    # ---- student: fused distillation steps (soft-label pass: KL against teacher log-probs) ----------------
+    sd = STUDENT
+    student = Model(dict(model_name=sd["name"], num_layers=3, feat_dim=sd["dims"][0], hidden_dim=sd["dims"][1],
+                         label_dim=sd["dims"][-1], dropout_ratio=sd["dropout"], norm_type="batch", device=dev))
+    student.train()
+    opt = torch.optim.Adam(student.parameters(), lr=sd["lr"], weight_decay=sd["wd"])
+    eng = StudentEngine(student, opt, sd["batch"])
+    if world > 1:   # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
+        eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
+    out_t = ops.as_feat(out_t)
+    k_student = args.steps * args.student_steps_per_step
+    w_student = max(args.warmup, 3)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(1234 + rank)
+    nb = max(1, n // sd["batch"])
+    perm = torch.randperm(n, generator=gen)[: nb * sd["batch"]].view(nb, -1).to(dev)     # train_and_eval.py:65-71
+    for i in range(w_student):
+        eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(k_student):
+        eng.step(feats, perm[(w_student + i) % nb], ops.LOSS_KL, out_t, 1.0)
+    barrier()
+    t_student = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t_student], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_student = float(tt.item())
+    student_steps_per_s = world * k_student / t_student      # B-row batches processed per second, whole job
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    result = {
+        "metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products",
+        "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * t_teacher / args.steps, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ogbn-products-shaped SAGE teacher forward (3 layers 100-256-256-47, BN, layer-wise "
+                               "full-neighbour inference, reference models.py:121-148) + MLP3w8 student KL distillation step",
+                   "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
+                   "graph": "seeded power-law multigraph, random node order", "scale": args.scale,
+                   "parallelism": "1 GPU" if world == 1 else f"node-range row shards x{world}, all-gather per layer; student dp{world}"},
+        "student": {"metric": "student distill steps/s (MLP3w8 100-2048-2048-47, B=4096 per rank, dropout 0.2, BN, "
+                              "KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
+                    "value": student_steps_per_s, "unit": "steps/s", "steps": k_student, "warmup": w_student,
+                    "ms_per_step": 1e3 * t_student / k_student, "global_batch": world * sd["batch"],
+                    "scaling": "weak", "gflop_per_step": 3 * 2 * sd["batch"] * (100 * 2048 + 2048 * 2048 + 2048 * 47) / 1e9},
+    }
+    result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3
+
+    # ---- roofline of the dominant kernel (N = 1): per-launch HIP events from the timed region -------------
+    if world == 1 and timing:
+        torch.cuda.synchronize()
+        per = {}
+        for name, info, s, e in timing:
+            key = (name, info.get("d", info.get("n")), info.get("k"))
+            per.setdefault(key, []).append(s.elapsed_time(e))
+        layers, tot_b, tot_ms = [], 0.0, 0.0
+        for (name, d, _), ms in per.items():
+            if name != "spmm":
+                continue
+            b = alg_bytes(nnz, n, d)
+            avg = float(np.mean(ms))
+            layers.append({"d": d, "avg_ms": avg, "alg_GB": b / 1e9, "GBps": b / avg / 1e6, "launches": len(ms),
+                           "Gedges_per_s": nnz / avg / 1e6})
+            tot_b += b
+            tot_ms += avg
+        gemm_ms = sum(float(np.mean(ms)) for (name, _, _), ms in per.items() if name == "gemm")
+        dom = max(layers, key=lambda r: r["avg_ms"])
+        result["roofline"] = {
+            "bound": "hbm", "kernel": f"spmm_csr_kernel<LPR={lanes_per_row(dom['d'])},U=4,SAGE_GCN> (D={dom['d']})",
+            "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": dom["alg_GB"] * 1e9, "avg_launch_ms": dom["avg_ms"],
+            "all_aggregation_launches": sorted(layers, key=lambda r: r["d"]),
+            "aggregation_total": {"alg_GB": tot_b / 1e9, "ms": tot_ms, "GBps": tot_b / tot_ms / 1e6, "frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS},
+            "dense_projection_ms_per_forward": gemm_ms,
+            "note": "achieved = SURVEY 8(d) algorithmic bytes nnz*(4D+4)+n*(8D+8) / mean HIP-event launch time over the timed region",
+        }
+
+    # ---- CPU baseline on the host cores (oracle = 'port'; bounded sample) ---------------------------------
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd)
+
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sd):
+    """The CPU oracle timed on the host: (i) the same 3-layer SAGE forward on a 1/20-scale products-shaped
+    graph (same generator, same degree profile), all cores, OpenMP C; (ii) numpy student steps, MLP3w8 dims."""
+    from oracle import student_oracle as so
+    from oracle import teacher_oracle as to
+    from glnn_amd import data
+    threads = to.max_threads()
+    scale = 0.05
+    g = data.make_graph("ogbn-products", seed=0, device="cpu", scale=scale)
+    n, nnz = g.n_dst, g.num_edges()
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((n, SAGE_DIMS[0])).astype(np.float32)
+    layers, norms = [], []
+    for i in range(3):
+        layers.append(dict(weight=(rs.standard_normal((SAGE_DIMS[i + 1], SAGE_DIMS[i])) / np.sqrt(SAGE_DIMS[i])).astype(np.float32),
+                           bias=np.zeros(SAGE_DIMS[i + 1], np.float32)))
+        if i < 2:
+            h = SAGE_DIMS[i + 1]
+            norms.append(dict(weight=np.ones(h, np.float32), bias=np.zeros(h, np.float32),
+                              running_mean=np.zeros(h, np.float32), running_var=np.ones(h, np.float32)))
+    ip, ix = g.indptr.numpy(), g.indices.numpy()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 8.0:
+        to.sage_inference(ip, ix, x, layers, norms, threads=threads)
+        reps += 1
+    t_teacher = (time.perf_counter() - t0) / reps
+    # aggregation alone (layer 1, D=100), the memory-bound part
+    t1 = time.perf_counter()
+    areps = 0
+    while areps < 2 or time.perf_counter() - t1 < 3.0:
+        to.sage_gcn_agg(ip, ix, x, threads=threads)
+        areps += 1
+    t_agg = (time.perf_counter() - t1) / areps
+    # student: numpy (BLAS) train step at the MLP3w8 shape
+    dims, B = sd["dims"], sd["batch"]
+    sd0 = {}
+    for i in range(3):
+        sd0[f"encoder.layers.{i}.weight"] = (rs.standard_normal((dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)
+        sd0[f"encoder.layers.{i}.bias"] = np.zeros(dims[i + 1], np.float32)
+    for i in range(2):
+        h = dims[i + 1]
+        sd0[f"encoder.norms.{i}.weight"] = np.ones(h, np.float32); sd0[f"encoder.norms.{i}.bias"] = np.zeros(h, np.float32)
+        sd0[f"encoder.norms.{i}.running_mean"] = np.zeros(h, np.float32); sd0[f"encoder.norms.{i}.running_var"] = np.ones(h, np.float32)
+        sd0[f"encoder.norms.{i}.num_batches_tracked"] = np.int64(0)
+    st = so.MLPState(sd0, 3, "batch", dropout_ratio=0.0)
+    xb = rs.standard_normal((2 * B, dims[0])).astype(np.float32)
+    tb = so.log_softmax(rs.standard_normal((2 * B, dims[-1])).astype(np.float32))
+    so.train_mini_batch(st, xb[:B], tb[:B], B, "kl", 1.0, np.arange(B), sd["lr"], sd["wd"])
+    t2 = time.perf_counter()
+    sreps = 0
+    while sreps < 2 or time.perf_counter() - t2 < 6.0:
+        so.train_mini_batch(st, xb, tb, B, "kl", 1.0, np.arange(2 * B), sd["lr"], sd["wd"])
+        sreps += 2
+    t_step = (time.perf_counter() - t2) / sreps
+    return {"value": 3 * nnz / t_teacher, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": f"3-layer SAGE forward (100-256-256-47, BN eval) on a 1/20-scale products-shaped graph "
+                      f"(n={n}, nnz={nnz}), oracle/glnn_oracle.c with OpenMP on {threads} threads, {reps} reps; "
+                      "the reference's own dgl CPU path cannot be timed (dgl not installed)",
+            "aggregation_only_edges_per_s": nnz / t_agg,
+            "student_steps_per_s": 1.0 / t_step,
+            "student_sample": f"numpy/BLAS oracle train step, MLP3w8 dims, B={B}, {sreps} steps, numpy threads = BLAS default"}
+
+
+if __name__ == "__main__":
+    main()

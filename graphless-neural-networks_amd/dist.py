@@ -1,0 +1,102 @@
+"""Node-range sharding of the hot path over the GPUs of one node (one process per GPU, RCCL over xGMI
+through torch.distributed; backend "nccl" IS RCCL on ROCm).  The reference has no distributed code at all
+(SURVEY.md section 2), so everything here is new: SURVEY.md section 8e is the design brief.
+
+Teacher (layer-wise full-neighbour inference, reference models.py:121-148)
+  * rank r owns the contiguous destination rows [r*rpr, (r+1)*rpr) of every layer: their CSR rows, their
+    output rows.  Every dst row is independent, so a layer needs no collective while it runs.
+  * one exchange per layer: the own slab of the layer's output is written straight into the rank's slot of
+    a full-size activation buffer and an in-place all-gather completes it for the next layer's gathers.
+    Layer-1 input features are static -> replicated once, outside the timed loop.
+  * layers with in > out project FIRST (dense, row-parallel, weights replicated) and all-gather the narrow
+    projected rows, then aggregate: the last products layer moves 47 floats per node, not 256.
+Student (reference train_and_eval.py:59-86): data parallel, gradients summed with ONE all-reduce over a flat
+  gradient buffer before the fused Adam launch (glnn_amd.student.StudentEngine(grad_sync=...)).
+
+The compute backend is a parameter (`be`): production passes glnn_amd.ops (HIP); the world_size-2 gloo tests
+pass a CPU stand-in with the same signatures so the sharding / exchange logic is exercised without a GPU."""
+import torch
+import torch.distributed as dist
+
+
+class RowShards:
+    """Equal contiguous row ranges; the last ranks may be short (buffers are padded to world*rpr rows)."""
+
+    def __init__(self, n, world, rank):
+        self.n, self.world, self.rank = int(n), int(world), int(rank)
+        self.rpr = (self.n + self.world - 1) // self.world
+        self.lo = min(self.n, self.rank * self.rpr)
+        self.hi = min(self.n, self.lo + self.rpr)
+        self.rows = self.hi - self.lo
+        self.n_pad = self.rpr * self.world
+
+
+def all_gather_rows(buf, shards, group=None):
+    """In-place all-gather of [n_pad, ld] `buf` whose slot [rank*rpr, (rank+1)*rpr) this rank has filled."""
+    if shards.world == 1:
+        return buf
+    mine = buf[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
+    try:
+        dist.all_gather_into_tensor(buf, mine, group=group)
+    except (RuntimeError, NotImplementedError):
+        parts = [buf[r * shards.rpr:(r + 1) * shards.rpr] for r in range(shards.world)]
+        tmp = [torch.empty_like(mine) for _ in range(shards.world)]
+        dist.all_gather(tmp, mine.contiguous(), group=group)
+        for p, t in zip(parts, tmp):
+            p.copy_(t)
+    return buf
+
+
+class ShardedTeacher:
+    """SAGE layer-wise inference over a row-sharded graph.  `graph_shard` = full graph's rows [lo,hi)
+    (glnn_amd.graph.CSRGraph.row_range), column indices global."""
+
+    def __init__(self, encoder, graph_shard, shards, be, group=None):
+        self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
+        self._bufs = {}
+
+    def _full_buffer(self, key, d, device):
+        k = (key, d)
+        if k not in self._bufs:
+            self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
+        return self._bufs[k]
+
+    def forward(self, x_full):
+        """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
+        enc, sh, be, g = self.enc, self.sh, self.be, self.g
+        x = be.as_feat(x_full)
+        L = enc.num_layers
+        y_own = None
+        for l, layer in enumerate(enc.layers):
+            w = layer.fc_neigh.weight
+            ep_scale, ep_shift, relu = enc._tail(l)
+            d_in, d_out = w.shape[1], w.shape[0]
+            last = l == L - 1
+            if d_in > d_out:
+                # project own rows, exchange the narrow rows, aggregate own rows
+                hw = self._full_buffer(("hw", l), d_out, x.device)
+                be.gemm(x[sh.lo:sh.hi], w, out=hw[sh.lo:sh.hi])
+                all_gather_rows(hw, sh, self.group)
+                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
+                be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
+                        out=out, x_self=hw[sh.lo:sh.hi])
+            else:
+                agg = be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, x_self=x[sh.lo:sh.hi])
+                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
+                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+            y_own = out
+            if not last:
+                x = all_gather_rows(self._full_buffer(("y", l), d_out, x.device), sh, self.group)
+        return y_own
+
+
+def make_grad_sync(flat_grads, world, group=None, average=False):
+    """Gradient exchange for the data-parallel student: one all-reduce over the engine's flat grad buffer."""
+    if world == 1:
+        return None
+
+    def sync():
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat_grads.mul_(1.0 / world)
+    return sync

@@ -10,6 +10,34 @@ from . import _lib
 AGG_SUM, AGG_SAGE_GCN = 0, 1
 LOSS_NLL, LOSS_KL = 0, 1
 
+# Optional per-launch timing (bench.py's roofline leg): a list that receives
+# (kernel_name, info_dict, start_event, end_event) for every aggregation / GEMM launch, recorded on the
+# stream the kernel is launched on.  None = no events (the default).
+_TIMING = None
+
+
+def set_timing(collector):
+    global _TIMING
+    _TIMING = collector
+
+
+class _Timed:
+    __slots__ = ("name", "info", "s")
+
+    def __init__(self, name, **info):
+        self.name, self.info, self.s = name, info, None
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            _TIMING.append((self.name, self.info, self.s, e))
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -66,24 +94,35 @@ def as_feat(t):
 
 # ---------------------------------------------------------------------------------------------
 def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None,
-         relu=False, out=None):
-    """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d]."""
-    _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out)
+         relu=False, out=None, x_self=None):
+    """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d].
+    x_self (SAGE_GCN only): the destination rows' own features, default x[:n_dst] (a row shard passes its slice)."""
+    _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out, x_self)
     x = as_feat(x)
+    if x_self is None:
+        x_self = x
+    elif x_self.shape[0] < n_dst or x_self.shape[1] != x.shape[1]:
+        raise ValueError("spmm: x_self must hold n_dst rows of the same width as x")
     n_src, d = x.shape
     if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
         raise ValueError("spmm: indptr must be int64 and indices int32")
     if out is None:
         out = feat_empty(n_dst, d, x.device)
     _mat(out, "spmm out")
-    rc = _lib.lib().glnn_spmm_csr_f32(
-        _p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
-        _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
-        _p(x) if mode == AGG_SAGE_GCN else None, _ld(x),
-        _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
-        _p(out), _ld(out), _stream())
+    with _Timed("spmm", d=d, n_dst=n_dst, mode=mode):
+        rc = _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out,
+                        as_feat(x_self))
     _lib.check(rc, "glnn_spmm_csr_f32")
     return out
+
+
+def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self):
+    return _lib.lib().glnn_spmm_csr_f32(
+        _p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
+        _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
+        _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self),
+        _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
+        _p(out), _ld(out), _stream())
 
 
 def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
@@ -112,14 +151,19 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     if out is None:
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
-    rc = _lib.lib().glnn_gemm_f32(
+    with _Timed("gemm", m=m, k=k, n=n):
+        rc = _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out)
+    _lib.check(rc, "glnn_gemm_f32")
+    return out
+
+
+def _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out):
+    return _lib.lib().glnn_gemm_f32(
         _p(a), _ld(a), _p(a_rows), _p(_vec(a_scale, k, "a_scale")), _p(_vec(a_shift, k, "a_shift")),
         float(drop_p), int(drop_seed) & 0xFFFFFFFF, m, k,
         _p(w), _ld(w), 1 if w_is_kn else 0, n, _p(_vec(row_scale, m, "row_scale")),
         _p(_vec(ep_scale, n, "ep_scale")), _p(_vec(ep_shift, n, "ep_shift")), 1 if relu else 0,
         _p(out), _ld(out), _stream())
-    _lib.check(rc, "glnn_gemm_f32")
-    return out
 
 
 def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=None, workspace=None, m=None,

@@ -36,7 +36,10 @@ def _mix32(x):
 
 
 class StudentEngine:
-    def __init__(self, model, optimizer, max_batch):
+    def __init__(self, model, optimizer, max_batch, grad_sync=None, loss_scale_rows=None):
+        """grad_sync: optional callable run between backward and Adam (data-parallel all-reduce over
+        `self.flat_grads`, see glnn_amd.dist.make_grad_sync).  loss_scale_rows: the GLOBAL batch size when
+        the batch is split over ranks (the loss mean and dlogits are taken over it)."""
         enc = model.encoder
         if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch"):
             raise NotImplementedError("StudentEngine: MLP students with norm_type none|batch (the hot-path configs)")
@@ -76,7 +79,13 @@ class StudentEngine:
         # parameters in torch order (model.parameters()): layers.{i}.weight, .bias ..., norms.{i}.weight, .bias ...
         params = list(model.parameters())
         self.params = params
-        self.grads = [torch.zeros_like(p) for p in params]
+        self.grad_sync, self.loss_scale_rows = grad_sync, loss_scale_rows
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]          # keep every view 16-byte aligned
+        self.flat_grads = torch.zeros(sum(sizes), **f32)
+        self.grads, off = [], 0
+        for p, sz in zip(params, sizes):
+            self.grads.append(self.flat_grads[off:off + p.numel()].view_as(p))
+            off += sz
         for p, g in zip(params, self.grads):
             p.grad = g                               # optimizer.zero_grad() semantics: overwritten every step
         self._gW = {id(p): g for p, g in zip(params, self.grads)}
@@ -140,6 +149,8 @@ class StudentEngine:
                 src, rows = out, None
 
         # ---- loss + dlogits ---------------------------------------------------------------------
+        if self.loss_scale_rows is not None:
+            lamb = lamb * m / float(self.loss_scale_rows)       # dlogits scale becomes lamb / global_rows
         if kind == ops.LOSS_NLL:
             ops.softmax_loss(logits, kind, lamb, labels=target, label_rows=idx if target_rows is None else target_rows,
                              dlogits=dlogits, loss_out=self.loss_out, loss_accum=self.loss_accum, workspace=self.ws_loss)
@@ -169,7 +180,9 @@ class StudentEngine:
                 ops.bn_relu_bwd(da, z[l - 1], dz=dz_prev, drop_p=p, drop_seed=seeds[l - 1])
             dz = dz_prev
 
-        # ---- Adam ------------------------------------------------------------------------------
+        # ---- (data-parallel) gradient exchange, then Adam ---------------------------------------
+        if self.grad_sync is not None:
+            self.grad_sync()
         ops.adam_step(self.table, lr, self.step_count, weight_decay=wd, beta1=beta1, beta2=beta2, eps=eps)
 
     def sync_optimizer_state(self):
