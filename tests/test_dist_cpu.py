@@ -1,0 +1,141 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes run glnn_amd.dist.ShardedTeacher with an ORACLE-backed
+compute stand-in (same signatures as glnn_amd.ops), and the DP gradient all-reduce.  What is verified is the
+sharding / slot / all-gather orchestration: the gathered result must equal the unsharded oracle forward."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """CPU stand-in for glnn_amd.ops built on the oracle (tests only)."""
+    AGG_SUM, AGG_SAGE_GCN = 0, 1
+
+    def __init__(self):
+        from oracle import teacher_oracle as to
+        self.to = to
+
+    @staticmethod
+    def feat_empty(n, d, device, zero=False):
+        return torch.zeros((n, d), dtype=torch.float32)
+
+    @staticmethod
+    def as_feat(t):
+        return t.contiguous()
+
+    def gemm(self, a, w, ep_scale=None, ep_shift=None, relu=False, out=None, **kw):
+        y = torch.from_numpy(self.to.linear(a.contiguous().numpy(), w.detach().numpy(), None))
+        if ep_scale is not None:
+            y = y * ep_scale
+        if ep_shift is not None:
+            y = y + ep_shift.detach()
+        if relu:
+            y = y.clamp(min=0)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+    def spmm(self, indptr, indices, x, n_dst, mode, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, **kw):
+        assert mode == self.AGG_SAGE_GCN
+        xs = x if x_self is None else x_self
+        s = self.to.spmm_sum(indptr.numpy(), indices.numpy(), x.contiguous().numpy(), n_dst=n_dst)
+        deg = (indptr[1:] - indptr[:-1]).float().unsqueeze(1)
+        y = (torch.from_numpy(s) + xs[:n_dst]) / (deg + 1)
+        if ep_scale is not None:
+            y = y * ep_scale
+        if ep_shift is not None:
+            y = y + ep_shift.detach()
+        if relu:
+            y = y.clamp(min=0)
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, dims, seed, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glnn_amd.dist import RowShards, ShardedTeacher, make_grad_sync
+        from glnn_amd.graph import CSRGraph
+        from glnn_amd.models import SAGE
+        from graphgen import random_graph
+        import torch.nn.functional as F
+        indptr, indices = random_graph(n, 9, seed=seed, power=0.5, isolated=3, hub=200)
+        g = CSRGraph(torch.from_numpy(indptr), torch.from_numpy(indices), n)
+        torch.manual_seed(seed)
+        enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+        with torch.no_grad():
+            for bn in enc.norms:
+                bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+        enc.eval()
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
+        sh = RowShards(n, world, rank)
+        be = OracleBackend()
+        with torch.no_grad():
+            y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be).forward(x)
+        # DP gradient exchange
+        flat = torch.full((10,), float(rank + 1))
+        make_grad_sync(flat, world, average=True)()
+        q.put((rank, sh.lo, sh.hi, y_own.numpy().copy(), flat.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,dims", [(1001, [12, 16, 16, 5]), (640, [8, 24, 6])])
+def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims):
+    sys.path.insert(0, ROOT)
+    from oracle import teacher_oracle as to
+    from graphgen import random_graph
+    import torch.nn.functional as F
+    from glnn_amd.models import SAGE
+    world, seed = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # unsharded reference on the same seeded inputs
+    indptr, indices = random_graph(n, 9, seed=seed, power=0.5, isolated=3, hub=200)
+    torch.manual_seed(seed)
+    enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+    with torch.no_grad():
+        for bn in enc.norms:
+            bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+    sd = {k: v.numpy() for k, v in enc.state_dict().items()}
+    L = len(dims) - 1
+    layers = [dict(weight=sd[f"layers.{i}.fc_neigh.weight"], bias=sd[f"layers.{i}.fc_neigh.bias"]) for i in range(L)]
+    norms = [dict(weight=sd[f"norms.{i}.weight"], bias=sd[f"norms.{i}.bias"], running_mean=sd[f"norms.{i}.running_mean"],
+                  running_var=sd[f"norms.{i}.running_var"]) for i in range(L - 1)]
+    x = np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32)
+    want = to.sage_inference(indptr, indices, x, layers, norms)
+    covered = np.zeros(n, bool)
+    for rank, lo, hi, y, flat in res:
+        np.testing.assert_allclose(y, want[lo:hi], atol=1e-4, rtol=0)
+        covered[lo:hi] = True
+        np.testing.assert_allclose(flat, np.full(10, 1.5))      # mean of 1 and 2
+    assert covered.all()
