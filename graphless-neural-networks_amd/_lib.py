@@ -19,7 +19,7 @@ SIGNATURES = {
                           c_int, c_vp, c_i64, c_vp],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
-                      c_vp, c_i64, c_vp],
+                      c_vp, c_i64, c_vp, c_i64, c_vp],
     "glnn_gemm_tn_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_int, c_vp, c_i64, c_vp, c_vp,
                          c_i64, c_vp],
     "glnn_softmax_loss_f32": [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64,

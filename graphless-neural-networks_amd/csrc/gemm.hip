@@ -35,6 +35,7 @@ struct GemmArgs {
   float* c; int64_t ldc;
   int a_vec; int b_vec;  // 1 = float4 loads are aligned and in-bounds
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;   // drop_thr == 0: no dropout
+  int ksplits; int ktiles_per_split; float* ws;               // split-K (fast kernel): raw partials -> ws[z][m][n]
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -71,10 +72,12 @@ __device__ __forceinline__ float4 xform4(float4 v, const float* sc, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// GENERIC variant (any alignment / any K, N): per-element guarded loads.  Only odd shapes take it
+// (e.g. the 1433-wide cora weight); everything on the benchmark path uses gemm_kernel_fast below.
 // C[m,n] = epi( sum_k A'[m,k] * B[k,n] ),  B given as W[n,k] (B_KN = false) or W[k,n] (B_KN = true)
 // ---------------------------------------------------------------------------------------------
 template <int BN, bool B_KN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm_kernel_generic(const GemmArgs g) {
   constexpr int NT = BN / 64;            // MFMA tiles per wave along N
   constexpr int LDS_N = BN + 4;          // row stride of the [k][n] B tile
   constexpr int A_TILE = BM * LDS_K;
@@ -226,6 +229,250 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// FAST variant: every row start 16-byte aligned and every row readable up to round4(extent) (true whenever
+// the leading dimension is a multiple of 4).  All global loads are UNCONDITIONAL float4 loads from clamped
+// (always valid) addresses, issued back to back before the MFMA block; tails are handled arithmetically:
+//   * rows / columns past M / N: the clamped row is re-read (or padding columns are read); their products
+//     land in output rows/cols that the epilogue never stores (an output element depends only on its own
+//     A row and B row);
+//   * k past K: replaced by zeros, per element, on the way to LDS.
+// XF: 0 = plain operand, 1 = max(a*scale+shift, 0), 2 = the same + counter-based dropout.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 mask4(float4 v, int left) {   // keep elements t < left
+  v.x = left > 0 ? v.x : 0.f;
+  v.y = left > 1 ? v.y : 0.f;
+  v.z = left > 2 ? v.z : 0.f;
+  v.w = left > 3 ? v.w : 0.f;
+  return v;
+}
+
+template <int BN, bool B_KN, int XF>
+__global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
+  constexpr int NT = BN / 64;
+  constexpr int LDS_N = BN + 4;
+  constexpr int A_TILE = BM * LDS_K;
+  constexpr int B_TILE = B_KN ? BK * LDS_N : BN * LDS_K;
+  constexpr int BQ = B_KN ? (BK * BN / 4) / 256 : (BN * 8) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * A_TILE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kk = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int c4 = (tid & 7) * 4;          // k offset of this thread's float4 inside a [row][k] tile
+  const int r0 = tid >> 3;               // its first row; rows r0 + 32 q
+
+  const float* a_base[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int64_t mrow = m0 + r0 + 32 * q;
+    if (mrow > g.m - 1) mrow = g.m - 1;
+    const int64_t src = g.a_rows ? g.a_rows[mrow] : mrow;
+    a_base[q] = g.a + src * g.lda;
+  }
+  const float* b_base[BQ];
+  if (!B_KN) {
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      int ng = n0 + r0 + 32 * q;
+      if (ng > g.n - 1) ng = g.n - 1;
+      b_base[q] = g.b + (int64_t)ng * g.ldb;
+    }
+  } else {
+    int ng = n0 + (tid % (BN / 4)) * 4;
+    const int npad = (g.n + 3) & ~3;
+    if (ng > npad - 4) ng = npad - 4;
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) b_base[q] = g.b + ng;
+  }
+
+  float4 a_reg[4], b_reg[BQ], sc4, sh4;
+  int kc_cur = 0;
+  const int kpad = (g.k + 3) & ~3;
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    kc_cur = k0 + c4;
+    int kcc = kc_cur;
+    if (kcc > kpad - 4) kcc = kpad - 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_reg[q] = ld4g(a_base[q] + kcc);
+    if (XF) {
+      sc4 = ld4g(g.a_scale + kcc);
+      sh4 = ld4g(g.a_shift + kcc);
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      if (B_KN) {
+        int kg = k0 + (tid + 256 * q) / (BN / 4);
+        if (kg > g.k - 1) kg = g.k - 1;
+        b_reg[q] = ld4g(b_base[q] + (int64_t)kg * g.ldb);
+      } else {
+        b_reg[q] = ld4g(b_base[q] + kcc);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf, int kt) {
+    float* as = As + buf * A_TILE;
+    float* bs = Bs + buf * B_TILE;
+    const int kleft = g.k - kc_cur;            // elements t < kleft of this float4 are inside K
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = a_reg[q];
+      if (XF) {
+        v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+        if (XF == 2) {
+          const uint32_t row = (uint32_t)(m0 + r0 + 32 * q);
+          v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 0) ? v.x * g.drop_scale : 0.f;
+          v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 1) ? v.y * g.drop_scale : 0.f;
+          v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 2) ? v.z * g.drop_scale : 0.f;
+          v.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 3) ? v.w * g.drop_scale : 0.f;
+        }
+      }
+      v = mask4(v, kleft);
+      *reinterpret_cast<float4*>(as + (r0 + 32 * q) * LDS_K + c4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+      float4 v = b_reg[q];
+      if (B_KN) {
+        const int f = tid + 256 * q;
+        const int krow = f / (BN / 4);
+        if (kt * BK + krow >= g.k) v = zero4();
+        *reinterpret_cast<float4*>(bs + krow * LDS_N + (f % (BN / 4)) * 4) = v;
+      } else {
+        v = mask4(v, kleft);
+        *reinterpret_cast<float4*>(bs + (r0 + 32 * q) * LDS_K + c4) = v;
+      }
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk_all = (g.k + BK - 1) / BK;
+  const int kt_beg = blockIdx.z * g.ktiles_per_split;
+  int kt_end = kt_beg + g.ktiles_per_split;
+  if (kt_end > nk_all) kt_end = nk_all;
+  load_tiles(kt_beg);
+  store_tiles(0, kt_beg);
+  __syncthreads();
+
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_beg) & 1;
+    if (kt + 1 < kt_end) load_tiles(kt + 1);
+    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+    const float* bs = B_KN ? Bs + cur * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
+                           : Bs + cur * B_TILE + (wn * (BN / 2) + li) * LDS_K + kk * 4;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[2][4], bf[NT][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (B_KN) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kg * 8 + t) * LDS_N + j * 32];
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
+          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt_end) store_tiles(cur ^ 1, kt + 1);
+    __syncthreads();
+  }
+
+  if (g.ksplits > 1) {
+    // split-K: raw partial sums to the workspace slab of this k-range; the reduce kernel applies the epilogue
+    float* wsz = g.ws + (int64_t)blockIdx.z * g.m * g.n;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * (BN / 2) + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * kk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
+          if (col < g.n && row < g.m) wsz[row * g.n + col] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const bool full_tile = (m0 + BM <= g.m) && (n0 + BN <= g.n);     // workgroup-uniform
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + li;
+    const bool col_ok = col < g.n;
+    const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
+    const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * kk;
+      float* cp = g.c + rbase * g.ldc + col;
+      float rs[16];
+      if (g.row_scale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int64_t rr = rbase + (r & 3) + 8 * (r >> 2);
+          if (rr > g.m - 1) rr = g.m - 1;
+          rs[r] = g.row_scale[rr];
+        }
+      }
+      if (full_tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          if (g.row_scale) v *= rs[r];
+          v = fmaf(v, es, eh);
+          if (g.relu) v = fmaxf(v, 0.f);
+          cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r];
+          if (g.row_scale) v *= rs[r];
+          v = fmaf(v, es, eh);
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (col_ok && rbase + ro < g.m) cp[(int64_t)ro * g.ldc] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN: C[i,j] = sum_m A'[m,i] * B[m,j]   (i < ka, j < nb), reduction over rows m, optional split over m.
 // Both operand tiles are [m][*] row-major in global and stay k(m)-major in LDS ([BK][128+4]); MFMA
 // fragments are ds_read_b32 with consecutive lanes on consecutive floats.
@@ -240,7 +487,7 @@ struct GemmTnArgs {
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
 };
 
-template <int BNT>
+template <int BNT, bool FAST, int XF>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
   constexpr int NT = BNT / 64;
   constexpr int LDA_S = BM + 4, LDB_S = BNT + 4;
@@ -262,7 +509,42 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
   constexpr int BQ = (BK * BNT / 4) / 256;   // 4 or 2
   float4 a_reg[AQ], b_reg[BQ];
 
+  // FAST: unconditional float4 loads from clamped addresses; rows past the split's end are zeroed on the way
+  // to LDS (they are reduction terms), column tails only feed output rows/cols that are never stored.
+  const int a_c4 = (tid % (BM / 4)) * 4, a_r0 = tid / (BM / 4);      // A tile: BK rows x BM cols
+  const int b_c4 = (tid % (BNT / 4)) * 4, b_r0 = tid / (BNT / 4);    // B tile: BK rows x BNT cols
+  constexpr int A_RSTEP = 256 / (BM / 4), B_RSTEP = 256 / (BNT / 4);
+  int a_col = i0 + a_c4, b_col = j0 + b_c4;
+  if (FAST) {
+    const int kap = (g.ka + 3) & ~3, nbp = (g.nb + 3) & ~3;
+    if (a_col > kap - 4) a_col = kap - 4;
+    if (b_col > nbp - 4) b_col = nbp - 4;
+  }
+  float4 sc4 = zero4(), sh4 = zero4();
+  if (FAST && XF) {
+    sc4 = ld4g(g.b_scale + b_col);
+    sh4 = ld4g(g.b_shift + b_col);
+  }
+  int64_t mt_cur = 0;
+
   auto load_tiles = [&](int64_t mt) {
+    mt_cur = mt;
+    if (FAST) {
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) {
+        int64_t mrow = mt + a_r0 + A_RSTEP * q;
+        if (mrow > g.m - 1) mrow = g.m - 1;
+        a_reg[q] = ld4g(g.a + mrow * g.lda + a_col);
+      }
+#pragma unroll
+      for (int q = 0; q < BQ; ++q) {
+        int64_t mrow = mt + b_r0 + B_RSTEP * q;
+        if (mrow > g.m - 1) mrow = g.m - 1;
+        const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
+        b_reg[q] = ld4g(g.b + src * g.ldb + b_col);
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
       const int f = tid + 256 * q;
@@ -287,6 +569,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
     }
   };
   auto store_tiles = [&](int buf) {
+    if (FAST) {
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) {
+        const int r = a_r0 + A_RSTEP * q;
+        float4 v = (mt_cur + r < mend) ? a_reg[q] : zero4();
+        *reinterpret_cast<float4*>(As + buf * A_TILE + r * LDA_S + a_c4) = v;
+      }
+#pragma unroll
+      for (int q = 0; q < BQ; ++q) {
+        const int r = b_r0 + B_RSTEP * q;
+        float4 v = b_reg[q];
+        if (XF) {
+          v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
+          v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+          v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
+          v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+          if (XF == 2) {
+            const uint32_t row = (uint32_t)(mt_cur + r);
+            const uint32_t c = (uint32_t)(j0 + b_c4);    // true column (dropout only runs with nb % 4 == 0)
+            v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 0) ? v.x * g.drop_scale : 0.f;
+            v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 1) ? v.y * g.drop_scale : 0.f;
+            v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 2) ? v.z * g.drop_scale : 0.f;
+            v.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 3) ? v.w * g.drop_scale : 0.f;
+          }
+        }
+        if (!(mt_cur + r < mend)) v = zero4();
+        *reinterpret_cast<float4*>(Bs + buf * B_TILE + r * LDB_S + b_c4) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
       const int f = tid + 256 * q;
@@ -349,6 +661,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
   }
 }
 
+// split-K finish: c[m,n] = epi( sum_z ws[z][m][n] ), fixed order => deterministic
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) {
+  const int64_t total = g.m * g.n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / g.n;
+    const int col = (int)(i - row * g.n);
+    float v = 0.f;
+    for (int z = 0; z < g.ksplits; ++z) v += g.ws[(int64_t)z * total + i];
+    if (g.row_scale) v *= g.row_scale[row];
+    v = fmaf(v, g.ep_scale ? g.ep_scale[col] : 1.f, g.ep_shift ? g.ep_shift[col] : 0.f);
+    if (g.relu) v = fmaxf(v, 0.f);
+    g.c[row * g.ldc + col] = v;
+  }
+}
+
 // sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
 __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
                                     int64_t ldc, int ka, int nb) {
@@ -394,18 +721,34 @@ int set_smem(K kernel, size_t bytes) {
   return GLNN_OK;
 }
 
+template <typename K>
+int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g, int bn, hipStream_t st) {
+  if (configured > 0) configured = set_smem(kernel, smem);
+  if (configured != GLNN_OK) return configured;
+  const int64_t gm = (g.m + BM - 1) / BM;
+  const int gn = (g.n + bn - 1) / bn;
+  if (gm > 0x7fffffffLL) return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_gemm_f32: m too large");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)gm, (unsigned)gn, (unsigned)g.ksplits), dim3(256), smem, st, g);
+  int rc = glnn::check_launch("glnn_gemm_f32");
+  if (rc == GLNN_OK && g.ksplits > 1) {
+    int64_t blocks = (g.m * g.n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
+    rc = glnn::check_launch("glnn_gemm_f32(split-k epilogue)");
+  }
+  return rc;
+}
+
 template <int BN, bool B_KN>
-int launch_gemm(const GemmArgs& g, hipStream_t st) {
+int launch_gemm(const GemmArgs& g, bool fast, hipStream_t st) {
   constexpr int A_TILE = BM * LDS_K;
   constexpr int B_TILE = B_KN ? BK * (BN + 4) : BN * LDS_K;
   constexpr size_t smem = sizeof(float) * 2 * (A_TILE + B_TILE);
-  static int configured = set_smem(gemm_kernel<BN, B_KN>, smem);
-  if (configured != GLNN_OK) return configured;
-  const int64_t gm = (g.m + BM - 1) / BM;
-  const int gn = (g.n + BN - 1) / BN;
-  if (gm > 0x7fffffffLL) return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_gemm_f32: m too large");
-  hipLaunchKernelGGL((gemm_kernel<BN, B_KN>), dim3((unsigned)gm, (unsigned)gn), dim3(256), smem, st, g);
-  return glnn::check_launch("glnn_gemm_f32");
+  static int cfg[4] = {1, 1, 1, 1};   // >0 = not configured yet
+  if (!fast) return launch_gemm_kernel(gemm_kernel_generic<BN, B_KN>, cfg[3], smem, g, BN, st);
+  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 0>, cfg[0], smem, g, BN, st);
+  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 1>, cfg[1], smem, g, BN, st);
+  return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 2>, cfg[2], smem, g, BN, st);
 }
 
 }  // namespace
@@ -413,7 +756,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
                              const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
                              const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
-                             int64_t ldc, void* stream) {
+                             int64_t ldc, float* workspace, int64_t workspace_floats, void* stream) {
   GLNN_REQUIRE(a && b && c, "glnn_gemm_f32: null pointer");
   GLNN_REQUIRE(m >= 0 && k >= 1 && n >= 1, "glnn_gemm_f32: bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
   GLNN_REQUIRE(lda >= k && ldc >= n, "glnn_gemm_f32: lda/ldc too small");
@@ -432,9 +775,29 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   // true for A when lda >= roundup4(k); for B only when ldb >= roundup4(extent).
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
+  g.ksplits = 1; g.ktiles_per_split = (k + BK - 1) / BK; g.ws = nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (n > 64) return b_layout ? launch_gemm<128, true>(g, st) : launch_gemm<128, false>(g, st);
-  return b_layout ? launch_gemm<64, true>(g, st) : launch_gemm<64, false>(g, st);
+  // fast path: all float4 loads legal and all-or-nothing at the k (and, for [k,n], n) boundary
+  const bool fast = g.a_vec && g.b_vec && lda >= ((k + 3) & ~3) && ldb >= (((b_layout ? n : k) + 3) & ~3) &&
+                    (!a_scale || (k % 4 == 0 && glnn::aligned16(a_scale) && glnn::aligned16(a_shift)));
+  // split-K when the output has too few tiles to fill 256 CUs twice over and K is deep enough
+  if (fast && workspace) {
+    const int bn = n > 64 ? 128 : 64;
+    const int64_t tiles = ((m + BM - 1) / BM) * ((n + bn - 1) / bn);
+    const int nk = (k + BK - 1) / BK;
+    if (tiles < 256 && nk >= 8) {
+      int64_t sp = (512 + tiles - 1) / tiles;
+      if (sp > nk / 4) sp = nk / 4;                                   // >= 4 k-tiles per split
+      if (sp * m * n > workspace_floats) sp = workspace_floats / (m * n);
+      if (sp > 1) {
+        g.ktiles_per_split = (nk + (int)sp - 1) / (int)sp;
+        g.ksplits = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+        g.ws = workspace;
+      }
+    }
+  }
+  if (n > 64) return b_layout ? launch_gemm<128, true>(g, fast, st) : launch_gemm<128, false>(g, fast, st);
+  return b_layout ? launch_gemm<64, true>(g, fast, st) : launch_gemm<64, false>(g, fast, st);
 }
 
 extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
@@ -458,8 +821,8 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   int splits = 1;
   const int64_t slab = (int64_t)ka * nb;
   const int64_t colsum_need = col_sum_a ? (int64_t)64 * ka : 0;
-  if (workspace && gi * gj < 192) {
-    splits = 256 / (gi * gj);
+  if (workspace && gi * gj < 512) {
+    splits = (512 + gi * gj - 1) / (gi * gj);
     const int64_t max_by_rows = (m + 4 * BK - 1) / (4 * BK);      // at least 4 k-tiles per split
     if (splits > max_by_rows) splits = (int)max_by_rows;
     const int64_t avail = workspace_floats - colsum_need;
@@ -474,14 +837,32 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   g.splits = splits;
   float* ws_partial = workspace ? workspace + colsum_need : nullptr;
   if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
-  if (bnt == 128) {
-    constexpr size_t smem = sizeof(float) * 2 * (BK * (BM + 4) + BK * (128 + 4));
-    static int configured = set_smem(gemm_tn_kernel<128>, smem);
-    if (configured != GLNN_OK) return configured;
-    hipLaunchKernelGGL((gemm_tn_kernel<128>), dim3(gi, gj, splits), dim3(256), smem, st, g);
-  } else {
-    constexpr size_t smem = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
-    hipLaunchKernelGGL((gemm_tn_kernel<64>), dim3(gi, gj, splits), dim3(256), smem, st, g);
+  const bool fast = g.a_vec && g.b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
+                    (!b_scale || (nb % 4 == 0 && glnn::aligned16(b_scale) && glnn::aligned16(b_shift)));
+  const int xf = !b_scale ? 0 : (g.drop_thr ? 2 : 1);
+  {
+    constexpr size_t smem128 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (128 + 4));
+    constexpr size_t smem64 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
+    static int cfg[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    const dim3 grid(gi, gj, splits);
+#define GLNN_TN_LAUNCH(BNT_, FAST_, XF_, SLOT_, SMEM_)                                                        \
+  do {                                                                                                         \
+    if (cfg[SLOT_] > 0) cfg[SLOT_] = set_smem(gemm_tn_kernel<BNT_, FAST_, XF_>, SMEM_);                        \
+    if (cfg[SLOT_] != GLNN_OK) return cfg[SLOT_];                                                              \
+    hipLaunchKernelGGL((gemm_tn_kernel<BNT_, FAST_, XF_>), grid, dim3(256), SMEM_, st, g);                     \
+  } while (0)
+    if (bnt == 128) {
+      if (!fast) GLNN_TN_LAUNCH(128, false, 0, 0, smem128);
+      else if (xf == 0) GLNN_TN_LAUNCH(128, true, 0, 1, smem128);
+      else if (xf == 1) GLNN_TN_LAUNCH(128, true, 1, 2, smem128);
+      else GLNN_TN_LAUNCH(128, true, 2, 3, smem128);
+    } else {
+      if (!fast) GLNN_TN_LAUNCH(64, false, 0, 4, smem64);
+      else if (xf == 0) GLNN_TN_LAUNCH(64, true, 0, 5, smem64);
+      else if (xf == 1) GLNN_TN_LAUNCH(64, true, 1, 6, smem64);
+      else GLNN_TN_LAUNCH(64, true, 2, 7, smem64);
+    }
+#undef GLNN_TN_LAUNCH
   }
   int rc = glnn::check_launch("glnn_gemm_tn_f32");
   if (rc != GLNN_OK) return rc;

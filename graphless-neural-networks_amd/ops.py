@@ -135,7 +135,7 @@ def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
 
 
 def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale=None, ep_scale=None,
-         ep_shift=None, relu=False, out=None, m=None, drop_p=0.0, drop_seed=0):
+         ep_shift=None, relu=False, out=None, m=None, drop_p=0.0, drop_seed=0, workspace=None):
     """K3 glnn_gemm_f32: out = epi(A' @ W^T) (w [n,k], torch Linear layout) or epi(A' @ W) (w [k,n])."""
     _need_cuda(a, w, a_rows, a_scale, a_shift, row_scale, ep_scale, ep_shift, out)
     _mat(a, "gemm a")
@@ -152,18 +152,20 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
     with _Timed("gemm", m=m, k=k, n=n):
-        rc = _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out)
+        rc = _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out,
+                        workspace)
     _lib.check(rc, "glnn_gemm_f32")
     return out
 
 
-def _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out):
+def _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out,
+               workspace):
     return _lib.lib().glnn_gemm_f32(
         _p(a), _ld(a), _p(a_rows), _p(_vec(a_scale, k, "a_scale")), _p(_vec(a_shift, k, "a_shift")),
         float(drop_p), int(drop_seed) & 0xFFFFFFFF, m, k,
         _p(w), _ld(w), 1 if w_is_kn else 0, n, _p(_vec(row_scale, m, "row_scale")),
         _p(_vec(ep_scale, n, "ep_scale")), _p(_vec(ep_shift, n, "ep_shift")), 1 if relu else 0,
-        _p(out), _ld(out), _stream())
+        _p(out), _ld(out), _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
 
 
 def gemm_tn(a, b, b_rows=None, b_scale=None, b_shift=None, out=None, col_sum_a=None, workspace=None, m=None,

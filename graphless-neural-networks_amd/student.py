@@ -105,7 +105,8 @@ class StudentEngine:
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
         self.ws_bn = torch.empty(max(2 * n_chunks * hmax, 1024), **f32)
-        self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + hk * hk, **f32)
+        self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
+        self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
         self.ws_loss = torch.empty(1024, **f32)
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
@@ -139,7 +140,7 @@ class StudentEngine:
         for l in range(L):
             out = logits if l == L - 1 else z[l]
             ops.gemm(src, self.W[l], a_rows=rows, a_scale=a_scale, a_shift=a_shift, ep_shift=self.b[l], out=out, m=m,
-                     drop_p=p if l > 0 else 0.0, drop_seed=seeds[l - 1] if l > 0 else 0)
+                     drop_p=p if l > 0 else 0.0, drop_seed=seeds[l - 1] if l > 0 else 0, workspace=self.ws_gemm)
             if l < L - 1:
                 mean, rstd, a_scale, a_shift = self.stats[l]
                 if self.bn:

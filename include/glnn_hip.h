@@ -92,6 +92,8 @@ GLNN_API int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int
  *   B  = W^T with W [n,k] row-major (torch.nn.Linear / dgl SAGEConv.fc_neigh, b_layout 0)
  *        or W [k,n] row-major (dgl GraphConv.weight, b_layout 1).
  *   epilogue, in order, each optional: * row_scale[m] ; * ep_scale[n] ; + ep_shift[n] ; ReLU.
+ *   workspace (optional, floats): lets skinny outputs (few 128x128 tiles, deep K) split the K
+ *   reduction over more workgroups; partials are summed in fixed order (deterministic).  NULL = never.
  * replaces fc_neigh / GraphConv weight / nn.Linear: reference models.py:45,112,138,193.
  * ------------------------------------------------------------------------------------------ */
 GLNN_API int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
@@ -99,7 +101,8 @@ GLNN_API int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
                            uint32_t drop_seed, int64_t m, int k,
                            const float* b, int64_t ldb, int b_layout, int n,
                            const float* row_scale, const float* ep_scale, const float* ep_shift,
-                           int relu, float* c, int64_t ldc, void* stream);
+                           int relu, float* c, int64_t ldc, float* workspace,
+                           int64_t workspace_floats, void* stream);
 
 /* TN form, the weight-gradient shape:  C[i,j] = sum_m A[m,i] * B'[m,j]   (i < ka, j < nb)
  *   dW[out,in] = dZ^T @ A_prev with A = dZ [m,out] and B = the previous layer's PRE-activation

@@ -55,7 +55,8 @@ def main():
             x = torch.randn((m, k), device=dev)
             w = torch.randn((n, k), device=dev) / k ** 0.5
             out = ops.feat_empty(m, n, dev)
-            med, best = timeit(lambda: ops.gemm(x, w, out=out))
+            wsg = torch.empty(1 << 24, device=dev)
+            med, best = timeit(lambda: ops.gemm(x, w, out=out, workspace=wsg))
             fl = 2.0 * m * n * k
             medt, _ = timeit(lambda: torch.matmul(x, w.t()))
             print(f"gemm m={m} k={k} n={n}: {med:8.3f} ms  {fl / med / 1e9:8.1f} TF/s (torch/rocBLAS {medt:8.3f} ms {fl / medt / 1e9:8.1f} TF/s)  "
@@ -64,7 +65,7 @@ def main():
             dz = torch.randn((m, ka), device=dev)
             act = torch.randn((m, nb), device=dev)
             outw = torch.empty((ka, nb), device=dev)
-            ws = torch.empty(64 * ka + 64 * ka * nb, device=dev)
+            ws = torch.empty(64 * ka + max(64 * ka * nb, 2 * ka * nb + (1 << 22)), device=dev)
             med, _ = timeit(lambda: ops.gemm_tn(dz, act, out=outw, workspace=ws))
             medt, _ = timeit(lambda: torch.matmul(dz.t(), act))
             fl = 2.0 * m * ka * nb
