@@ -139,8 +139,8 @@ def _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoc
     for epoch in range(1, conf["max_epoch"] + 1):
         loss = train_epoch()
         if epoch % conf["eval_interval"] == 0:
-            row, score_train, score_val, score_test = eval_epoch()
-            logger.debug(f"Ep {epoch:3d} | loss: {loss:.4f} | s_train: {score_train:.4f} | s_val: {score_val:.4f} | s_test: {score_test:.4f}")
+            row, score_val, msg = eval_epoch()
+            logger.debug(f"Ep {epoch:3d} | loss: {loss:.4f} | {msg}")
             loss_and_score += [[epoch] + row]
             if score_val >= best_score_val:
                 best_epoch, best_score_val = epoch, score_val
@@ -193,7 +193,7 @@ def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluato
             out, l_tr, s_tr = evaluate(model, data_eval, feats, labels, criterion, evaluator, idx_train)
             l_va, s_va = criterion(out[idx_val], labels[idx_val]).item(), evaluator(out[idx_val], labels[idx_val])
             l_te, s_te = criterion(out[idx_test], labels[idx_test]).item(), evaluator(out[idx_test], labels[idx_test])
-        return [l_tr, l_va, l_te, s_tr, s_va, s_te], s_tr, s_va, s_te
+        return [l_tr, l_va, l_te, s_tr, s_va, s_te], s_va, f"s_train: {s_tr:.4f} | s_val: {s_va:.4f} | s_test: {s_te:.4f}"
 
     best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
     if is_mlp:
@@ -243,10 +243,106 @@ def distill_run_transductive(conf, model, feats, labels, out_t_all, distill_indi
         _, l_l, s_l = evaluate_mini_batch(model, feats_l, labels_l, criterion_l, batch_size, evaluator)
         _, l_va, s_va = evaluate_mini_batch(model, feats_val, labels_val, criterion_l, batch_size, evaluator)
         _, l_te, s_te = evaluate_mini_batch(model, feats_test, labels_test, criterion_l, batch_size, evaluator)
-        return [l_l, l_va, l_te, s_l, s_va, s_te], s_l, s_va, s_te
+        return [l_l, l_va, l_te, s_l, s_va, s_te], s_va, f"s_l: {s_l:.4f} | s_val: {s_va:.4f} | s_test: {s_te:.4f}"
 
     best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
     out, _, score_val = evaluate_mini_batch(model, feats, labels, criterion_l, batch_size, evaluator, idx_val)
     score_test = evaluator(out[idx_test], labels_test)
     logger.info(f"Best valid model at epoch: {best_epoch: 3d}, score_val: {score_val :.4f}, score_test: {score_test :.4f}")
     return out, score_val, score_test
+
+
+def run_inductive(conf, model, g, feats, labels, indices, criterion, evaluator, optimizer, logger, loss_and_score):
+    """Teacher / plain-MLP training under the inductive ("production") setting (reference
+    train_and_eval.py:290-512): train on the observed subgraph `obs_g = g.subgraph(idx_obs)`, evaluate on the
+    observed test nodes AND, with the full graph, on the held-out inductive test nodes."""
+    set_seed(conf["seed"])
+    device = conf["device"]
+    batch_size = conf["batch_size"]
+    obs_idx_train, obs_idx_val, obs_idx_test, idx_obs, idx_test_ind = [i.to(device) for i in indices]
+    feats, labels = feats.to(device), labels.to(device)
+    obs_feats, obs_labels = feats[idx_obs], labels[idx_obs]
+    is_mlp, is_sage = "MLP" in model.model_name, "SAGE" in model.model_name
+    if is_mlp:
+        feats_train, labels_train = obs_feats[obs_idx_train], obs_labels[obs_idx_train]
+        feats_val, labels_val = obs_feats[obs_idx_val], obs_labels[obs_idx_val]
+        feats_tt, labels_tt = obs_feats[obs_idx_test], obs_labels[obs_idx_test]
+        feats_ti, labels_ti = feats[idx_test_ind], labels[idx_test_ind]
+    else:
+        g = g.to(device)
+        obs_g = g.subgraph(idx_obs)
+        obs_data = obs_g
+        obs_data_eval = FullNeighborLoader(obs_g, batch_size) if is_sage else obs_g
+        data_eval = FullNeighborLoader(g, batch_size) if is_sage else g
+
+    def train_epoch():
+        if is_sage:
+            return _train_sage_full_graph(model, obs_data, obs_feats, obs_labels, criterion, optimizer, obs_idx_train)
+        if is_mlp:
+            return train_mini_batch(model, feats_train, labels_train, batch_size, criterion, optimizer)
+        return train(model, obs_data, obs_feats, obs_labels, criterion, optimizer, obs_idx_train)
+
+    def eval_epoch():
+        if is_mlp:
+            _, l_tr, s_tr = evaluate_mini_batch(model, feats_train, labels_train, criterion, batch_size, evaluator)
+            _, l_va, s_va = evaluate_mini_batch(model, feats_val, labels_val, criterion, batch_size, evaluator)
+            _, l_tt, s_tt = evaluate_mini_batch(model, feats_tt, labels_tt, criterion, batch_size, evaluator)
+            _, l_ti, s_ti = evaluate_mini_batch(model, feats_ti, labels_ti, criterion, batch_size, evaluator)
+        else:
+            obs_out, l_tr, s_tr = evaluate(model, obs_data_eval, obs_feats, obs_labels, criterion, evaluator, obs_idx_train)
+            l_va, s_va = criterion(obs_out[obs_idx_val], obs_labels[obs_idx_val]).item(), evaluator(obs_out[obs_idx_val], obs_labels[obs_idx_val])
+            l_tt, s_tt = criterion(obs_out[obs_idx_test], obs_labels[obs_idx_test]).item(), evaluator(obs_out[obs_idx_test], obs_labels[obs_idx_test])
+            _, l_ti, s_ti = evaluate(model, data_eval, feats, labels, criterion, evaluator, idx_test_ind)
+        return ([l_tr, l_va, l_tt, l_ti, s_tr, s_va, s_tt, s_ti], s_va,
+                f"s_train: {s_tr:.4f} | s_val: {s_va:.4f} | s_tt: {s_tt:.4f} | s_ti: {s_ti:.4f}")
+
+    best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
+    if is_mlp:
+        obs_out, _, score_val = evaluate_mini_batch(model, obs_feats, obs_labels, criterion, batch_size, evaluator, obs_idx_val)
+        out, _, score_test_ind = evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, idx_test_ind)
+    else:
+        obs_out, _, score_val = evaluate(model, obs_data_eval, obs_feats, obs_labels, criterion, evaluator, obs_idx_val)
+        out, _, score_test_ind = evaluate(model, data_eval, feats, labels, criterion, evaluator, idx_test_ind)
+    score_test_tran = evaluator(obs_out[obs_idx_test], obs_labels[obs_idx_test])
+    out[idx_obs] = obs_out
+    logger.info(f"Best valid model at epoch: {best_epoch :3d}, score_val: {score_val :.4f}, score_test_tran: {score_test_tran :.4f}, score_test_ind: {score_test_ind :.4f}")
+    return out, score_val, score_test_tran, score_test_ind
+
+
+def distill_run_inductive(conf, model, feats, labels, out_t_all, distill_indices, criterion_l, criterion_t, evaluator,
+                          optimizer, logger, loss_and_score):
+    """Distillation under the inductive setting (reference train_and_eval.py:609-742): the student only sees
+    the observed nodes' features and soft labels; it is scored on observed-test and inductive-test nodes."""
+    set_seed(conf["seed"])
+    device = conf["device"]
+    batch_size = conf["batch_size"]
+    lamb = conf["lamb"]
+    obs_idx_l, obs_idx_t, obs_idx_val, obs_idx_test, idx_obs, idx_test_ind = [i.to(device) for i in distill_indices]
+    feats, labels, out_t_all = feats.to(device), labels.to(device), out_t_all.to(device)
+    obs_feats, obs_labels, obs_out_t = feats[idx_obs], labels[idx_obs], out_t_all[idx_obs]
+    feats_l, labels_l = obs_feats[obs_idx_l], obs_labels[obs_idx_l]
+    feats_t, out_t = obs_feats[obs_idx_t], obs_out_t[obs_idx_t]
+    feats_val, labels_val = obs_feats[obs_idx_val], obs_labels[obs_idx_val]
+    feats_tt, labels_tt = obs_feats[obs_idx_test], obs_labels[obs_idx_test]
+    feats_ti, labels_ti = feats[idx_test_ind], labels[idx_test_ind]
+
+    def train_epoch():
+        loss_l = train_mini_batch(model, feats_l, labels_l, batch_size, criterion_l, optimizer, lamb)
+        loss_t = train_mini_batch(model, feats_t, out_t, batch_size, criterion_t, optimizer, 1 - lamb)
+        return loss_l + loss_t
+
+    def eval_epoch():
+        _, l_l, s_l = evaluate_mini_batch(model, feats_l, labels_l, criterion_l, batch_size, evaluator)
+        _, l_va, s_va = evaluate_mini_batch(model, feats_val, labels_val, criterion_l, batch_size, evaluator)
+        _, l_tt, s_tt = evaluate_mini_batch(model, feats_tt, labels_tt, criterion_l, batch_size, evaluator)
+        _, l_ti, s_ti = evaluate_mini_batch(model, feats_ti, labels_ti, criterion_l, batch_size, evaluator)
+        return ([l_l, l_va, l_tt, l_ti, s_l, s_va, s_tt, s_ti], s_va,
+                f"s_l: {s_l:.4f} | s_val: {s_va:.4f} | s_tt: {s_tt:.4f} | s_ti: {s_ti:.4f}")
+
+    best_epoch = _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoch)
+    obs_out, _, score_val = evaluate_mini_batch(model, obs_feats, obs_labels, criterion_l, batch_size, evaluator, obs_idx_val)
+    out, _, score_test_ind = evaluate_mini_batch(model, feats, labels, criterion_l, batch_size, evaluator, idx_test_ind)
+    score_test_tran = evaluator(obs_out[obs_idx_test], labels_tt)
+    out[idx_obs] = obs_out
+    logger.info(f"Best valid model at epoch: {best_epoch: 3d} score_val: {score_val :.4f}, score_test_tran: {score_test_tran :.4f}, score_test_ind: {score_test_ind :.4f}")
+    return out, score_val, score_test_tran, score_test_ind

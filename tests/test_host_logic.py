@@ -1,0 +1,129 @@
+"""CPU tests of the host-side logic that surrounds the hot path: config merge, index splits, the CSR graph
+container and its DGL-like surface, the full-neighbour chunk loader, the CPF .npz ingestion, CLI flags."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_training_config_merge_yaml_overrides_cli():
+    from glnn_amd import cli, utils
+    conf = utils.get_training_config(os.path.join(ROOT, "train.conf.yaml"), "MLP3w8", "ogbn-products")
+    assert conf == dict(num_layers=3, hidden_dim=2048, dropout_ratio=0.2, learning_rate=0.01, weight_decay=0,
+                        norm_type="batch", batch_size=4096, model_name="MLP3w8")
+    conf = utils.get_training_config(os.path.join(ROOT, "train.conf.yaml"), "GCN", "cora")
+    assert conf["hidden_dim"] == 64 and conf["num_layers"] == 2            # dataset section over `global`
+    args = cli.get_student_args(["--num_layers", "5", "--hidden_dim", "77", "--dataset", "ogbn-arxiv", "--student", "MLP3w4"])
+    merged = dict(args.__dict__, **utils.get_training_config(args.model_config_path, args.student, args.dataset))
+    assert merged["num_layers"] == 3 and merged["hidden_dim"] == 1024      # YAML beats the CLI flags (train_student.py:264-270)
+    assert merged["lamb"] == 0 and merged["batch_size"] == 512
+
+
+def test_cli_flags_match_reference_surface():
+    from glnn_amd import cli
+    t = cli.get_teacher_args([])
+    s = cli.get_student_args([])
+    for name, default in dict(device=-1, seed=0, log_level=20, output_path="outputs", num_exp=1, exp_setting="tran",
+                              eval_interval=1, dataset="cora", data_path="./data", labelrate_train=20, labelrate_val=30,
+                              split_idx=0, teacher="SAGE", num_layers=2, hidden_dim=128, dropout_ratio=0, norm_type="none",
+                              batch_size=512, fan_out="5,5", num_workers=0, learning_rate=0.01, weight_decay=0.0005,
+                              max_epoch=500, patience=50, feature_noise=0, split_rate=0.2, feature_aug_k=0).items():
+        assert getattr(t, name) == default and getattr(s, name) == default, name
+    assert s.student == "MLP" and s.lamb == 0 and s.out_t_path == "outputs"
+    assert not hasattr(t, "student") and t.console_log is False and t.save_results is False and t.compute_min_cut is False
+
+
+def test_graph_split_index_algebra():
+    from glnn_amd import utils
+    idx_train, idx_val, idx_test = torch.arange(0, 10), torch.arange(10, 15), torch.arange(15, 115)
+    o_tr, o_va, o_te, idx_obs, idx_ind = utils.graph_split(idx_train, idx_val, idx_test, 0.2, seed=3)
+    assert len(idx_ind) == 20 and len(idx_obs) == 10 + 5 + 80
+    assert torch.equal(idx_obs[o_tr], idx_train) and torch.equal(idx_obs[o_va], idx_val)
+    assert set(idx_obs[o_te].tolist()) | set(idx_ind.tolist()) == set(idx_test.tolist())
+    assert not (set(idx_obs.tolist()) & set(idx_ind.tolist()))
+    again = utils.graph_split(idx_train, idx_val, idx_test, 0.2, seed=3)
+    assert torch.equal(again[4], idx_ind)                                  # seeded: reproducible
+
+
+def test_csr_graph_surface_and_loader():
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    src = torch.tensor([0, 2, 2, 3, 1, 4, 4]); dst = torch.tensor([1, 1, 1, 3, 0, 2, 0])
+    g = CSRGraph.from_edges(src, dst, 5)
+    assert g.num_nodes() == g.number_of_nodes() == 5 and g.number_of_edges() == 7 and g.num_dst_nodes() == 5
+    assert g.in_degrees().tolist() == [2, 3, 1, 1, 0] and g.out_degrees().tolist() == [1, 1, 2, 1, 2]
+    assert g.int() is g and g.to("cpu") is g and g.create_formats_() is None
+    rev = g.reverse()
+    assert rev.in_degrees().tolist() == g.out_degrees().tolist()
+    seen = 0
+    for input_nodes, output_nodes, blocks in FullNeighborLoader(g, 2):
+        b = blocks[0]
+        assert torch.equal(input_nodes[: len(output_nodes)], output_nodes) and b.num_dst_nodes() == len(output_nodes)
+        for i, v in enumerate(output_nodes.tolist()):                       # block edges map back to the graph's edges
+            got = sorted(input_nodes[b.indices[b.indptr[i]:b.indptr[i + 1]].long()].tolist())
+            want = sorted(g.indices[g.indptr[v]:g.indptr[v + 1]].tolist())
+            assert got == want
+        seen += len(output_nodes)
+    assert seen == 5 and len(FullNeighborLoader(g, 2)) == 3
+    sub = g.subgraph(torch.tensor([1, 2, 0]))                               # relabel: 1->0, 2->1, 0->2
+    dense = torch.zeros(3, 3)
+    for v in range(3):
+        for u in sub.indices[sub.indptr[v]:sub.indptr[v + 1]].tolist():
+            dense[v, u] += 1
+    assert dense.tolist() == [[0, 2, 1], [0, 0, 0], [1, 0, 0]]
+    shard = g.row_range(1, 4)
+    assert shard.n_dst == 3 and shard.n_src == 5 and shard.num_edges() == 5
+
+
+def test_synthetic_shapes_are_the_public_statistics():
+    from glnn_amd import data
+    g = data.make_graph("cora", seed=0)
+    assert g.n_dst == 2485 and g.num_edges() == 12623
+    g = data.make_graph("ogbn-arxiv", seed=0)
+    assert g.n_dst == 169343 and g.num_edges() == 2501829
+    g2 = data.make_graph("ogbn-arxiv", seed=0)
+    assert torch.equal(g.indices, g2.indices)                               # seeded
+    small = data.make_graph("ogbn-products", seed=0, scale=0.002)
+    assert small.num_edges() == 2 * int(61859140 * 0.002)
+    feats, labels, out_t, (tr, va, te) = data.make_node_data("ogbn-arxiv", n=1000)
+    assert feats.shape == (1000, 128) and out_t.shape == (1000, 40) and len(tr) + len(va) + len(te) == 1000
+    assert torch.allclose(out_t.exp().sum(1), torch.ones(1000), atol=1e-5)
+
+
+def test_cpf_npz_ingestion(tmp_path, monkeypatch):
+    """A tiny CPF-format file through load_data: LCC, self-loop removal, symmetrisation, A+I pattern, split."""
+    from glnn_amd.dataloader import load_data
+    rs = np.random.RandomState(0)
+    n = 60
+    a = sp.random(n, n, density=0.08, random_state=rs, format="csr")
+    a = a + sp.eye(n, format="csr")                                         # self-loops must be dropped
+    a[50:, :] = 0; a[:, 50:] = 0                                            # nodes 50.. isolated -> outside the LCC
+    a = sp.csr_matrix(a); a.eliminate_zeros()
+    x = sp.random(n, 12, density=0.3, random_state=rs, format="csr")
+    y = rs.randint(0, 3, n)
+    os.makedirs(tmp_path / "data")
+    np.savez(tmp_path / "data" / "cora.npz", adj_data=a.data, adj_indices=a.indices, adj_indptr=a.indptr, adj_shape=a.shape,
+             attr_data=x.data, attr_indices=x.indices, attr_indptr=x.indptr, attr_shape=x.shape, labels=y)
+    monkeypatch.chdir(tmp_path)
+    g, labels, tr, va, te = load_data("cora", "./data", seed=1, labelrate_train=3, labelrate_val=2, split_idx=0)
+    n_lcc = g.num_nodes()
+    assert n_lcc <= 50 and g.ndata["feat"].shape == (n_lcc, 12) and len(labels) == n_lcc
+    dense = torch.zeros(n_lcc, n_lcc)
+    for v in range(n_lcc):
+        for u in g.indices[g.indptr[v]:g.indptr[v + 1]].tolist():
+            dense[v, u] += 1
+    assert torch.equal(dense, dense.t()) and float(dense.diag().min()) == 1 and float(dense.max()) == 1
+    assert len(tr) == 9 and len(va) == 6 and len(set(tr.tolist()) & set(va.tolist())) == 0
+    assert len(tr) + len(va) + len(te) == n_lcc
+    with pytest.raises(ValueError):
+        load_data("pokec", "./data", seed=0, labelrate_train=1, labelrate_val=1)
+
+
+def test_evaluator_is_plain_argmax_accuracy():
+    from glnn_amd import utils
+    ev = utils.get_evaluator("ogbn-arxiv")
+    out = torch.tensor([[0.1, 0.9], [0.8, 0.2], [0.3, 0.7]])
+    assert abs(ev(out, torch.tensor([1, 0, 0])) - 2 / 3) < 1e-7
