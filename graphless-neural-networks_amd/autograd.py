@@ -8,31 +8,38 @@ from . import ops
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x @ w.T (+ b), w [out,in] (nn.Linear / fc_neigh layout)."""
+    """y = x @ w.T (+ b) with w [out,in] (nn.Linear / fc_neigh layout), or y = x @ w (+ b) with w [in,out]
+    (dgl GraphConv layout) when w_is_kn."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, w_is_kn):
         x = ops.as_feat(x.detach())
         ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return ops.gemm(x, w.detach(), ep_shift=None if b is None else b.detach())
+        ctx.has_bias, ctx.kn = b is not None, w_is_kn
+        return ops.gemm(x, w.detach(), w_is_kn=w_is_kn, ep_shift=None if b is None else b.detach())
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = ops.as_feat(dy.contiguous())
         dx = dw = db = None
+        n_out = w.shape[1] if ctx.kn else w.shape[0]
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy, w.detach(), w_is_kn=True)          # dy [m,out] @ w [out,in]
+            dx = ops.gemm(dy, w.detach(), w_is_kn=not ctx.kn)       # dy @ W ([out,in])  |  dy @ W^T ([in,out])
         if ctx.needs_input_grad[1] or ctx.has_bias:
-            db_buf = torch.empty(w.shape[0], dtype=torch.float32, device=w.device) if ctx.has_bias else None
-            dw = ops.gemm_tn(dy, x, col_sum_a=db_buf)            # dy^T @ x -> [out,in]
+            db_buf = torch.empty(n_out, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            if ctx.kn:
+                dw = ops.gemm_tn(x, dy)                             # x^T @ dy -> [in,out]
+                if ctx.has_bias:
+                    db_buf = dy.sum(0)
+            else:
+                dw = ops.gemm_tn(dy, x, col_sum_a=db_buf)           # dy^T @ x -> [out,in]
             db = db_buf
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def linear_fn(x, w, b):
-    return _LinearFn.apply(x, w, b)
+def linear_fn(x, w, b, w_is_kn=False):
+    return _LinearFn.apply(x, w, b, w_is_kn)
 
 
 class SpmmFn(torch.autograd.Function):

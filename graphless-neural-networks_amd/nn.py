@@ -80,9 +80,9 @@ class GraphConv(nn.Module):
         if needs_grad:
             h = feat * cs.unsqueeze(1)
             if self._in_feats > self._out_feats:
-                rst = SpmmFn.apply(graph, linear_fn(h, self.weight.t(), None), ops.AGG_SUM)
+                rst = SpmmFn.apply(graph, linear_fn(h, self.weight, None, w_is_kn=True), ops.AGG_SUM)
             else:
-                rst = linear_fn(SpmmFn.apply(graph, h, ops.AGG_SUM), self.weight.t(), None)
+                rst = linear_fn(SpmmFn.apply(graph, h, ops.AGG_SUM), self.weight, None, w_is_kn=True)
             rst = rst * rs.unsqueeze(1)
             if self.bias is not None:
                 rst = rst + self.bias
