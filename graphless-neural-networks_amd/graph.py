@@ -156,3 +156,81 @@ class FullNeighborLoader:
                              input_nodes.numel())
             block._nnz = hi - lo
             yield input_nodes, output_nodes, [block]
+
+
+class MultiLayerNeighborSampler:
+    """dgl.dataloading.MultiLayerNeighborSampler(fanouts) (reference train_and_eval.py:179-181): per layer, at most
+    fanout[l] uniformly sampled in-neighbours per destination node, without replacement."""
+
+    def __init__(self, fanouts):
+        self.fanouts = [int(f) for f in fanouts]
+
+
+class MultiLayerFullNeighborSampler:
+    """dgl.dataloading.MultiLayerFullNeighborSampler(n_layers) (reference train_and_eval.py:193)."""
+
+    def __init__(self, n_layers):
+        self.n_layers = int(n_layers)
+
+
+class NodeDataLoader:
+    """dgl.dataloading.NodeDataLoader(g, nids, sampler, batch_size, shuffle, drop_last) (reference
+    train_and_eval.py:182-202) over the resident CSR.  Yields (input_nodes, output_nodes, blocks) with
+    blocks[0] the outermost (first-layer) block; every block lists its destination nodes first among its sources.
+    Sampling runs on the GPU (glnn_sample_neighbors); shuffling uses torch's CPU generator like a torch DataLoader."""
+
+    def __init__(self, g, nids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0, seed=None):
+        self.g, self.nids, self.sampler = g, torch.as_tensor(nids, dtype=torch.int64), sampler
+        self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
+        self._epoch = 0
+        self._seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFF
+        if isinstance(sampler, MultiLayerFullNeighborSampler) and sampler.n_layers == 1:
+            self.graph = g        # lets SAGE.inference take the whole-graph path when nids covers every node
+
+    def __len__(self):
+        n = self.nids.numel()
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _block(self, seeds, fanout, rng_seed):
+        from . import ops
+        g, dev = self.g, self.g.device
+        if fanout is None:                                   # full neighbourhood
+            deg = (g.indptr[seeds + 1] - g.indptr[seeds])
+            starts = g.indptr[seeds]
+            indptr = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(deg, 0, out=indptr[1:])
+            pos = torch.arange(int(indptr[-1].item()), device=dev) - torch.repeat_interleave(indptr[:-1] - starts, deg)
+            src = g.indices[pos].long()
+        else:
+            smp, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, fanout, rng_seed)
+            indptr = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(cnt.long(), 0, out=indptr[1:])
+            valid = torch.arange(fanout, device=dev).unsqueeze(0) < cnt.unsqueeze(1)
+            src = smp[valid].long()                          # row-major: edges stay grouped by destination
+        is_seed = torch.zeros(g.n_src, dtype=torch.bool, device=dev)
+        is_seed[seeds] = True
+        uniq = torch.unique(src)
+        input_nodes = torch.cat([seeds, uniq[~is_seed[uniq]]])
+        remap = torch.empty(g.n_src, dtype=torch.int64, device=dev)
+        remap[input_nodes] = torch.arange(input_nodes.numel(), device=dev)
+        block = CSRGraph(indptr, remap[src].to(torch.int32), seeds.numel(), input_nodes.numel())
+        block._nnz = int(src.numel())
+        return input_nodes, block
+
+    def __iter__(self):
+        self._epoch += 1
+        n = self.nids.numel()
+        order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        dev = self.g.device
+        fanouts = self.sampler.fanouts if isinstance(self.sampler, MultiLayerNeighborSampler) else [None] * self.sampler.n_layers
+        for b, s in enumerate(range(0, n, self.batch_size)):
+            idx = order[s:s + self.batch_size]
+            if self.drop_last and idx.numel() < self.batch_size:
+                break
+            output_nodes = self.nids[idx].to(dev)
+            seeds, blocks = output_nodes, []
+            for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
+                rng = (self._seed * 1000003 + self._epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
+                seeds, blk = self._block(seeds, fanouts[l], rng)
+                blocks.insert(0, blk)
+            yield seeds, output_nodes, blocks

@@ -294,6 +294,18 @@ def dropout_mask(rows, h, drop_p, drop_seed, device):
     return mask
 
 
+def sample_neighbors(indptr, indices, seeds, fanout, rng_seed):
+    """glnn_sample_neighbors: returns (src [n_seeds, fanout] int32, cnt [n_seeds] int32)."""
+    _need_cuda(indptr, indices, seeds)
+    n = seeds.numel()
+    src = torch.empty((n, fanout), dtype=torch.int32, device=seeds.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=seeds.device)
+    rc = _lib.lib().glnn_sample_neighbors(_p(indptr), _p(indices), _p(seeds.contiguous()), n, int(fanout), int(rng_seed) & 0xFFFFFFFF,
+                                          _p(src), _p(cnt), _stream())
+    _lib.check(rc, "glnn_sample_neighbors")
+    return src, cnt
+
+
 def gather_rows(x, rows, out=None):
     _need_cuda(x, rows, out)
     x = as_feat(x)

@@ -7,15 +7,15 @@ names, arguments and return values, re-pointed at the HIP hot path.
   * evaluate (:89-105) calls Model.inference -> SAGE.inference on the aggregation kernel.
   * The per-step `loss.item()` host sync of the reference (:80) is replaced by a device-side running sum
     read ONCE per pass; the returned mean of per-batch losses is the same number.
-  * Sampling-based teacher TRAINING (`train_sage` with MultiLayerNeighborSampler) needs the on-device
-    block sampler, a 'next' row of SURVEY.md section 8f; `train` (full-graph GCN) works through autograd."""
+  * Teacher TRAINING (`train_sage` on fan-out-sampled blocks from glnn_amd.graph.NodeDataLoader, `train` for
+    full-graph GCN) goes through the autograd shims: aggregation and projections run on HIP in both directions."""
 import copy
 
 import numpy as np
 import torch
 
 from . import ops
-from .graph import FullNeighborLoader
+from .graph import FullNeighborLoader, MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
 from .student import criterion_kind, get_engine
 from .utils import set_seed
 
@@ -156,8 +156,7 @@ def _early_stop_loop(conf, model, logger, loss_and_score, train_epoch, eval_epoc
 
 def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluator, optimizer, logger, loss_and_score):
     """Teacher (or plain-MLP) training + eval, transductive (reference train_and_eval.py:144-287).
-    SAGE: evaluation = layer-wise full-neighbour inference on the aggregation kernel; training needs the
-    neighbour sampler (next row) and is done here with FULL-neighbour blocks over the training nodes."""
+    SAGE: training on fan-out-sampled blocks (GPU sampler), evaluation = layer-wise full-neighbour inference."""
     set_seed(conf["seed"])
     device = conf["device"]
     batch_size = conf["batch_size"]
@@ -166,9 +165,12 @@ def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluato
     idx_train, idx_val, idx_test = idx_train.to(device), idx_val.to(device), idx_test.to(device)
     is_mlp, is_sage = "MLP" in model.model_name, "SAGE" in model.model_name
     if is_sage:
+        # the reference's two loaders (train_and_eval.py:176-205), sampling on the GPU-resident CSR
         g = g.to(device)
-        data_eval = FullNeighborLoader(g, batch_size)
-        data = g
+        sampler = MultiLayerNeighborSampler([int(fanout) for fanout in str(conf["fan_out"]).split(",")])
+        data = NodeDataLoader(g, idx_train, sampler, batch_size=batch_size, shuffle=True, drop_last=False)
+        data_eval = NodeDataLoader(g, torch.arange(g.num_nodes()), MultiLayerFullNeighborSampler(1), batch_size=batch_size,
+                                   shuffle=False, drop_last=False)
     elif is_mlp:
         feats_train, labels_train = feats[idx_train], labels[idx_train]
         feats_val, labels_val = feats[idx_val], labels[idx_val]
@@ -179,7 +181,7 @@ def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluato
 
     def train_epoch():
         if is_sage:
-            return _train_sage_full_graph(model, data, feats, labels, criterion, optimizer, idx_train)
+            return train_sage(model, data, feats, labels, criterion, optimizer)
         if is_mlp:
             return train_mini_batch(model, feats_train, labels_train, batch_size, criterion, optimizer)
         return train(model, data, feats, labels, criterion, optimizer, idx_train)
@@ -203,20 +205,6 @@ def run_transductive(conf, model, g, feats, labels, indices, criterion, evaluato
     score_test = evaluator(out[idx_test], labels[idx_test])
     logger.info(f"Best valid model at epoch: {best_epoch: 3d}, score_val: {score_val :.4f}, score_test: {score_test :.4f}")
     return out, score_val, score_test
-
-
-def _train_sage_full_graph(model, g, feats, labels, criterion, optimizer, idx_train):
-    """SAGE training step with full-neighbour aggregation over the whole graph (every layer's block is the
-    graph itself) -- stands in for the fan-out sampled `train_sage` until the on-device sampler exists."""
-    model.train()
-    logits = model([g] * model.encoder.num_layers, feats)
-    out = logits.log_softmax(dim=1)
-    loss = criterion(out[idx_train], labels[idx_train])
-    loss_val = loss.item()
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
-    return loss_val
 
 
 def distill_run_transductive(conf, model, feats, labels, out_t_all, distill_indices, criterion_l, criterion_t,
@@ -271,13 +259,19 @@ def run_inductive(conf, model, g, feats, labels, indices, criterion, evaluator, 
     else:
         g = g.to(device)
         obs_g = g.subgraph(idx_obs)
-        obs_data = obs_g
-        obs_data_eval = FullNeighborLoader(obs_g, batch_size) if is_sage else obs_g
-        data_eval = FullNeighborLoader(g, batch_size) if is_sage else g
+        if is_sage:
+            sampler = MultiLayerNeighborSampler([int(fanout) for fanout in str(conf["fan_out"]).split(",")])
+            obs_data = NodeDataLoader(obs_g, obs_idx_train, sampler, batch_size=batch_size, shuffle=True, drop_last=False)
+            full = MultiLayerFullNeighborSampler(1)
+            obs_data_eval = NodeDataLoader(obs_g, torch.arange(obs_g.num_nodes()), full, batch_size=batch_size)
+            data_eval = NodeDataLoader(g, torch.arange(g.num_nodes()), full, batch_size=batch_size)
+        else:
+            obs_data = obs_data_eval = obs_g
+            data_eval = g
 
     def train_epoch():
         if is_sage:
-            return _train_sage_full_graph(model, obs_data, obs_feats, obs_labels, criterion, optimizer, obs_idx_train)
+            return train_sage(model, obs_data, obs_feats, obs_labels, criterion, optimizer)
         if is_mlp:
             return train_mini_batch(model, feats_train, labels_train, batch_size, criterion, optimizer)
         return train(model, obs_data, obs_feats, obs_labels, criterion, optimizer, obs_idx_train)

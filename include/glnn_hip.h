@@ -190,6 +190,14 @@ GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
 GLNN_API int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t drop_seed,
                                   uint8_t* mask, void* stream);
 
+/* Uniform in-neighbour sampling WITHOUT replacement for a list of seed (destination) rows: at most `fanout`
+ * sources per seed, all of them when in_deg <= fanout (dgl semantics).  Replaces the CPU-side
+ * dgl.dataloading.MultiLayerNeighborSampler of reference train_and_eval.py:179-190 (one call per layer).
+ * out_src [n_seeds, fanout] int32 global source ids (first out_cnt[i] entries of row i valid). */
+GLNN_API int glnn_sample_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* seeds,
+                                   int64_t n_seeds, int fanout, uint32_t rng_seed, int32_t* out_src,
+                                   int32_t* out_cnt, void* stream);
+
 /* K7  row gather: out[i,:] = x[rows[i],:]  (feats[idx], reference train_and_eval.py:42,76,
  *     models.py:136) and scatter y[rows[i],:] = x[i,:] (models.py:145). */
 GLNN_API int glnn_gather_rows_f32(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows,

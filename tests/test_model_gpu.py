@@ -294,3 +294,56 @@ def test_full_size_products_properties():
     lin = ops.spmm(g.indptr, g.indices, ops.as_feat(2 * x + y), n, ops.AGG_SAGE_GCN)
     outy = ops.spmm(g.indptr, g.indices, y, n, ops.AGG_SAGE_GCN)
     assert float((lin - (2 * out + outy)).abs().max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- sampler
+def test_neighbor_sampler_and_blocks():
+    from glnn_amd import ops
+    from glnn_amd.graph import CSRGraph, MultiLayerNeighborSampler, NodeDataLoader
+    n = 3000
+    indptr, indices = random_graph(n, 20, seed=3, power=0.7, isolated=10, hub=400)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    seeds = torch.arange(0, n, 3, device=DEV)
+    src, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, 7, 1234)
+    deg = (g.indptr[seeds + 1] - g.indptr[seeds]).cpu().numpy()
+    np.testing.assert_array_equal(cnt.cpu().numpy(), np.minimum(deg, 7))
+    srcn, cntn = src.cpu().numpy(), cnt.cpu().numpy()
+    for i, v in enumerate(seeds.cpu().numpy()):
+        nb = indices[indptr[v]:indptr[v + 1]]
+        got = srcn[i, :cntn[i]]
+        # a sample without replacement of edge POSITIONS: multiplicities never exceed the row's
+        u, c = np.unique(got, return_counts=True)
+        un, cn = np.unique(nb, return_counts=True)
+        mult = dict(zip(un, cn))
+        assert all(mult.get(a, 0) >= b for a, b in zip(u, c))
+    src2, _ = ops.sample_neighbors(g.indptr, g.indices, seeds, 7, 99)
+    assert not torch.equal(src, src2)                                    # different rng seed -> different sample
+    loader = NodeDataLoader(g, torch.arange(100, 900), MultiLayerNeighborSampler([5, 10]), batch_size=256, shuffle=True)
+    assert len(loader) == 4
+    seen = []
+    for input_nodes, output_nodes, blocks in loader:
+        assert len(blocks) == 2 and blocks[1].num_dst_nodes() == len(output_nodes)
+        assert blocks[0].num_dst_nodes() == blocks[1].num_src_nodes() and blocks[0].num_src_nodes() == len(input_nodes)
+        assert torch.equal(input_nodes[: len(output_nodes)], output_nodes)
+        assert int(blocks[1].in_degrees().max()) <= 10 and int(blocks[0].in_degrees().max()) <= 5
+        seen.append(output_nodes)
+    assert sorted(torch.cat(seen).cpu().tolist()) == list(range(100, 900))
+
+
+def test_train_sage_on_sampled_blocks_learns():
+    """reference train_sage (train_and_eval.py:32-56) on GPU-sampled blocks: the loss must go down."""
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.graph import CSRGraph, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    torch.manual_seed(0)
+    n, f, c = 2000, 32, 4
+    indptr, indices = random_graph(n, 10, seed=8, power=0.5, symmetric=True, self_loops=True)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    x = torch.randn(n, f, device=DEV)
+    y = (x @ torch.randn(f, c, device=DEV)).argmax(1)
+    model = Model(dict(model_name="SAGE", num_layers=2, feat_dim=f, hidden_dim=64, label_dim=c, dropout_ratio=0.0,
+                       norm_type="batch", device=DEV))
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    loader = NodeDataLoader(g, torch.arange(n), MultiLayerNeighborSampler([5, 5]), batch_size=500, shuffle=True)
+    losses = [te.train_sage(model, loader, x, y, torch.nn.NLLLoss(), opt) for _ in range(8)]
+    assert losses[-1] < 0.7 * losses[0], losses
