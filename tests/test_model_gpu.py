@@ -339,11 +339,13 @@ def test_train_sage_on_sampled_blocks_learns():
     n, f, c = 2000, 32, 4
     indptr, indices = random_graph(n, 10, seed=8, power=0.5, symmetric=True, self_loops=True)
     g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    from glnn_amd import ops
     x = torch.randn(n, f, device=DEV)
-    y = (x @ torch.randn(f, c, device=DEV)).argmax(1)
+    agg = ops.spmm(g.indptr, g.indices, x, n, ops.AGG_SAGE_GCN)          # labels depend on the NEIGHBOURHOOD mean
+    y = (agg @ torch.randn(f, c, device=DEV)).argmax(1)
     model = Model(dict(model_name="SAGE", num_layers=2, feat_dim=f, hidden_dim=64, label_dim=c, dropout_ratio=0.0,
                        norm_type="batch", device=DEV))
     opt = torch.optim.Adam(model.parameters(), lr=0.01)
     loader = NodeDataLoader(g, torch.arange(n), MultiLayerNeighborSampler([5, 5]), batch_size=500, shuffle=True)
-    losses = [te.train_sage(model, loader, x, y, torch.nn.NLLLoss(), opt) for _ in range(8)]
-    assert losses[-1] < 0.7 * losses[0], losses
+    losses = [te.train_sage(model, loader, x, y, torch.nn.NLLLoss(), opt) for _ in range(12)]
+    assert losses[-1] < 0.85 * losses[0] and losses[-1] < min(losses[:3]), losses   # 5-of-~21 neighbour sampling is noisy
