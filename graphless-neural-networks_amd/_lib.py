@@ -30,11 +30,30 @@ SIGNATURES = {
     "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64,
                              c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
+    "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
     "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
     "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
     "glnn_scatter_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
 }
+
+MLP_MAX_LAYERS = 8
+_F = ctypes.c_void_p * MLP_MAX_LAYERS
+
+
+class MlpStepDesc(ctypes.Structure):
+    """glnn_mlp_step_desc of include/glnn_hip.h (field for field)."""
+    _fields_ = ([("num_layers", ctypes.c_int32), ("batchnorm", ctypes.c_int32), ("dims", ctypes.c_int32 * (MLP_MAX_LAYERS + 1)),
+                 ("dropout_p", c_f32), ("bn_eps", c_f32), ("bn_momentum", c_f32), ("max_batch", c_i64)] +
+                [(n, _F) for n in ("w", "b", "gw", "gb", "gamma", "beta", "ggamma", "gbeta", "running_mean", "running_var", "nbt",
+                                   "mean", "rstd", "a_scale", "a_shift", "z")] +
+                [("ldz", c_i64 * MLP_MAX_LAYERS),
+                 ("logits", c_vp), ("ld_logits", c_i64), ("dlogits", c_vp), ("ld_dlogits", c_i64),
+                 ("da", c_vp), ("ld_da", c_i64), ("dz", c_vp), ("ld_dz", c_i64),
+                 ("ws_bn", c_vp), ("ws_bn_floats", c_i64), ("ws_tn", c_vp), ("ws_tn_floats", c_i64),
+                 ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64), ("ws_loss", c_vp), ("ws_loss_floats", c_i64),
+                 ("loss_out", c_vp), ("loss_accum", c_vp)])
+
 
 _lib = None
 

@@ -1,0 +1,78 @@
+// One C call = forward + loss + backward of the MLP student step (reference train_and_eval.py:74-84): the
+// same kernel sequence glnn_amd/student.py documents, issued from C++ so that small configurations are not
+// bound by ~30 Python->ctypes round trips per step.  The gradient exchange (data parallel) and the fused Adam
+// (glnn_adam_step_f32) stay separate calls so that an all-reduce can sit between them.
+#include "glnn_common.h"
+
+#define GLNN_TRY(expr)          \
+  do {                          \
+    const int rc_ = (expr);     \
+    if (rc_ != GLNN_OK) return rc_; \
+  } while (0)
+
+extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* feats, int64_t ldx, const int64_t* idx,
+                                    int64_t m, int kind, const int64_t* labels, const float* target_logp, int64_t ldt,
+                                    const int64_t* target_rows, float lamb, const uint32_t* drop_seeds, void* stream) {
+  GLNN_REQUIRE(d && feats, "glnn_mlp_fwd_bwd_f32: null pointer");
+  const int L = d->num_layers;
+  GLNN_REQUIRE(L >= 1 && L <= GLNN_MLP_MAX_LAYERS, "glnn_mlp_fwd_bwd_f32: num_layers=%d outside [1,%d]", L, GLNN_MLP_MAX_LAYERS);
+  GLNN_REQUIRE(m >= 1 && m <= d->max_batch, "glnn_mlp_fwd_bwd_f32: batch %lld exceeds the buffers (%lld)", (long long)m, (long long)d->max_batch);
+  const float p = d->dropout_p;
+  GLNN_REQUIRE(p == 0.f || drop_seeds, "glnn_mlp_fwd_bwd_f32: dropout needs per-layer seeds");
+
+  // ---- forward ----
+  const float* src = feats;
+  int64_t ld_src = ldx;
+  const int64_t* rows = idx;
+  const float* a_scale = nullptr;
+  const float* a_shift = nullptr;
+  for (int l = 0; l < L; ++l) {
+    const bool last = (l == L - 1);
+    float* out = last ? d->logits : d->z[l];
+    const int64_t ldo = last ? d->ld_logits : d->ldz[l];
+    GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, l > 0 ? p : 0.f, (l > 0 && p > 0.f) ? drop_seeds[l - 1] : 0u, m,
+                           d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
+                           d->ws_gemm, d->ws_gemm_floats, stream));
+    if (!last) {
+      if (d->batchnorm)
+        GLNN_TRY(glnn_bn_stats_f32(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
+                                   d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
+                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream));
+      a_scale = d->a_scale[l];
+      a_shift = d->a_shift[l];
+      src = out;
+      ld_src = ldo;
+      rows = nullptr;
+    }
+  }
+  // ---- loss + dlogits ----
+  GLNN_TRY(glnn_softmax_loss_f32(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
+                                 target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
+                                 nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream));
+  // ---- backward ----
+  const float* dz = d->dlogits;
+  int64_t ld_dz = d->ld_dlogits;
+  for (int l = L - 1; l >= 0; --l) {
+    if (l == 0) {
+      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], feats, ldx, idx, nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
+                                d->dims[0], d->gb[0], d->ws_tn, d->ws_tn_floats, stream));
+      break;
+    }
+    const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
+    GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
+                              p, seed, d->dims[l], d->gw[l], d->dims[l], d->gb[l], d->ws_tn, d->ws_tn_floats, stream));
+    GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
+                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
+    if (d->batchnorm) {
+      GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
+                                    d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
+                                    d->gbeta[l - 1], d->ws_bn, d->ws_bn_floats, stream));
+    } else {
+      GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, nullptr, 0, stream));
+    }
+    dz = d->dz;
+    ld_dz = d->ld_dz;
+  }
+  return GLNN_OK;
+}

@@ -19,10 +19,12 @@ activation tensors beyond the pre-activation outputs z_l, and NO host synchronis
 The engine works IN PLACE on the `Model`'s own parameters/buffers and on the torch optimizer's own state
 tensors (exp_avg / exp_avg_sq / step), so `state_dict()`, early-stopping snapshots
 (train_and_eval.py:588,596) and `optimizer.state_dict()` behave exactly as with the reference."""
+import ctypes
+
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 
 
 def _mix32(x):
@@ -111,6 +113,45 @@ class StudentEngine:
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
+        self._seed_arr = (ctypes.c_uint32 * _lib.MLP_MAX_LAYERS)()
+        self.desc = self._build_desc()
+
+    def _build_desc(self):
+        d = _lib.MlpStepDesc()
+        L = self.L
+        if L > _lib.MLP_MAX_LAYERS:
+            raise NotImplementedError(f"StudentEngine: at most {_lib.MLP_MAX_LAYERS} layers")
+        d.num_layers, d.batchnorm, d.dropout_p, d.max_batch = L, 1 if self.bn else 0, self.p, self.B
+        for i, v in enumerate(self.dims):
+            d.dims[i] = v
+        ptr = lambda t: None if t is None else t.data_ptr()
+        for l in range(L):
+            if not (self.W[l].is_contiguous() and self.b[l].is_contiguous()):
+                raise ValueError("StudentEngine: contiguous parameters required")
+            d.w[l], d.b[l] = ptr(self.W[l]), ptr(self.b[l])
+            d.gw[l], d.gb[l] = ptr(self._grad(self.W[l])), ptr(self._grad(self.b[l]))
+        d.bn_eps, d.bn_momentum = 1e-5, 0.1
+        for l in range(L - 1):
+            mean, rstd, sc, sh = self.stats[l]
+            d.mean[l], d.rstd[l], d.a_scale[l], d.a_shift[l] = ptr(mean), ptr(rstd), ptr(sc), ptr(sh)
+            d.z[l], d.ldz[l] = ptr(self.z[l]), self.z[l].stride(0)
+            if self.bn:
+                bn = self.enc.norms[l]
+                if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+                    raise NotImplementedError("StudentEngine: BatchNorm1d with the reference's defaults")
+                d.bn_eps, d.bn_momentum = bn.eps, bn.momentum
+                d.gamma[l], d.beta[l] = ptr(bn.weight), ptr(bn.bias)
+                d.ggamma[l], d.gbeta[l] = ptr(self._grad(bn.weight)), ptr(self._grad(bn.bias))
+                d.running_mean[l], d.running_var[l], d.nbt[l] = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
+        d.logits, d.ld_logits = ptr(self.logits), self.logits.stride(0)
+        d.dlogits, d.ld_dlogits = ptr(self.dlogits), self.dlogits.stride(0)
+        d.da, d.ld_da, d.dz, d.ld_dz = ptr(self.da), self.da.stride(0), ptr(self.dz), self.dz.stride(0)
+        d.ws_bn, d.ws_bn_floats = ptr(self.ws_bn), self.ws_bn.numel()
+        d.ws_tn, d.ws_tn_floats = ptr(self.ws_tn), self.ws_tn.numel()
+        d.ws_gemm, d.ws_gemm_floats = ptr(self.ws_gemm), self.ws_gemm.numel()
+        d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
+        d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+        return d
 
     # ------------------------------------------------------------------------------------------
     def _grad(self, p):
@@ -125,61 +166,35 @@ class StudentEngine:
         m = idx.numel() if idx is not None else feats.shape[0]
         if m > self.B:
             raise ValueError(f"batch of {m} rows exceeds the engine's buffers ({self.B})")
+        ops._need_cuda(feats, idx, target, target_rows)
+        if feats.dtype != torch.float32 or feats.dim() != 2 or feats.stride(1) != 1 or feats.shape[1] != self.dims[0]:
+            raise ValueError("StudentEngine.step: feats must be a row-major float32 [N, feat_dim] tensor")
+        if idx is not None and (idx.dtype != torch.int64 or not idx.is_contiguous()):
+            raise ValueError("StudentEngine.step: idx must be a contiguous int64 vector")
+        if kind == ops.LOSS_NLL and target.dtype != torch.int64:
+            raise ValueError("StudentEngine.step: NLL targets are int64 labels")
+        if kind == ops.LOSS_KL and (target.dtype != torch.float32 or target.dim() != 2 or target.stride(1) != 1
+                                    or target.shape[1] != self.dims[-1]):
+            raise ValueError("StudentEngine.step: KL targets are float32 [N, C] teacher log-probabilities")
         lr = self.opt.param_groups[0]["lr"]
         wd = self.opt.param_groups[0]["weight_decay"]
         beta1, beta2 = self.opt.param_groups[0]["betas"]
         eps = self.opt.param_groups[0]["eps"]
         self.step_count += 1
-        z = [t[:m] for t in self.z]
-        logits, dlogits = self.logits[:m], self.dlogits[:m]
         seeds = [self._seed(l) for l in range(L - 1)] if p > 0 else [0] * (L - 1)
 
-        # ---- forward -------------------------------------------------------------------------
-        a_scale = a_shift = None
-        src, rows = feats, idx
-        for l in range(L):
-            out = logits if l == L - 1 else z[l]
-            ops.gemm(src, self.W[l], a_rows=rows, a_scale=a_scale, a_shift=a_shift, ep_shift=self.b[l], out=out, m=m,
-                     drop_p=p if l > 0 else 0.0, drop_seed=seeds[l - 1] if l > 0 else 0, workspace=self.ws_gemm)
-            if l < L - 1:
-                mean, rstd, a_scale, a_shift = self.stats[l]
-                if self.bn:
-                    bn = enc.norms[l]
-                    ops.bn_stats(out, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                 eps=bn.eps, momentum=bn.momentum, outs=self.stats[l], workspace=self.ws_bn)
-                src, rows = out, None
-
-        # ---- loss + dlogits ---------------------------------------------------------------------
+        # ---- forward + loss + backward: ONE C call issuing the whole kernel sequence (csrc/mlp_step.hip) ----
         if self.loss_scale_rows is not None:
             lamb = lamb * m / float(self.loss_scale_rows)       # dlogits scale becomes lamb / global_rows
-        if kind == ops.LOSS_NLL:
-            ops.softmax_loss(logits, kind, lamb, labels=target, label_rows=idx if target_rows is None else target_rows,
-                             dlogits=dlogits, loss_out=self.loss_out, loss_accum=self.loss_accum, workspace=self.ws_loss)
-        else:
-            ops.softmax_loss(logits, kind, lamb, target_logp=target, target_rows=idx if target_rows is None else target_rows,
-                             dlogits=dlogits, loss_out=self.loss_out, loss_accum=self.loss_accum, workspace=self.ws_loss)
-
-        # ---- backward --------------------------------------------------------------------------
-        dz = dlogits
-        for l in range(L - 1, -1, -1):
-            gW, gb = self._grad(self.W[l]), self._grad(self.b[l])
-            if l == 0:
-                ops.gemm_tn(dz, feats, b_rows=idx, out=gW, col_sum_a=gb, workspace=self.ws_tn, m=m)
-                break
-            mean, rstd, sc, sh = self.stats[l - 1]
-            ops.gemm_tn(dz, z[l - 1], b_scale=sc, b_shift=sh, out=gW, col_sum_a=gb, workspace=self.ws_tn, m=m,
-                        drop_p=p, drop_seed=seeds[l - 1])
-            h = self.dims[l]
-            da = self.da[:m, :h]
-            ops.gemm(dz, self.W[l], w_is_kn=True, out=da, m=m)                      # dz [m,out] @ W [out,in]
-            dz_prev = self.dz[:m, :h]
-            if self.bn:
-                bn = enc.norms[l - 1]
-                ops.bn_relu_bwd(da, z[l - 1], bn.weight, mean, rstd, sc, sh, dz=dz_prev, dgamma=self._grad(bn.weight),
-                                dbeta=self._grad(bn.bias), workspace=self.ws_bn, drop_p=p, drop_seed=seeds[l - 1])
-            else:
-                ops.bn_relu_bwd(da, z[l - 1], dz=dz_prev, drop_p=p, drop_seed=seeds[l - 1])
-            dz = dz_prev
+        for i, sd in enumerate(seeds):
+            self._seed_arr[i] = sd
+        trow = idx if target_rows is None else target_rows
+        rc = _lib.lib().glnn_mlp_fwd_bwd_f32(
+            ctypes.byref(self.desc), ops._p(feats), feats.stride(0), ops._p(idx), m, kind,
+            ops._p(target) if kind == ops.LOSS_NLL else None,
+            ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
+            ops._p(trow), float(lamb), self._seed_arr, ops._stream())
+        _lib.check(rc, "glnn_mlp_fwd_bwd_f32")
 
         # ---- (data-parallel) gradient exchange, then Adam ---------------------------------------
         if self.grad_sync is not None:

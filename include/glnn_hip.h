@@ -184,6 +184,72 @@ GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
                                 float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int64_t step, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The whole forward + loss + backward of one student step in ONE call (reference train_and_eval.py:74-84:
+ * model(None, feats[idx]) -> log_softmax -> criterion -> (loss*lamb).backward()), issuing the K3-K5
+ * launches above in a fixed order.  Every buffer is caller-owned; the descriptor only carries pointers:
+ *   w/b/gw/gb[l]      Linear l weight [dims[l+1], dims[l]] / bias and their gradients (contiguous)
+ *   gamma..nbt[l]     BatchNorm1d after hidden layer l (l < L-1) when batchnorm != 0
+ *   mean/rstd/a_scale/a_shift[l]  per-hidden-layer vectors; with batchnorm == 0 a_scale/a_shift must be
+ *                     pre-filled with ones/zeros (the operand transform is then the plain ReLU)
+ *   z[l] (ldz[l])     pre-activation output of hidden layer l, [max_batch, dims[l+1]]
+ *   da/dz             scratch [max_batch, max hidden]; ws_*: workspaces of the individual kernels
+ *   loss_out/accum    as in glnn_softmax_loss_f32
+ * idx: the batch's row ids into feats (and into labels / target_logp through target_rows), NULL = rows 0..m-1.
+ * drop_seeds: host array of L-1 uint32 (one per hidden layer) when dropout_p > 0.
+ * The optimiser step is NOT included: call glnn_adam_step_f32 next (a gradient all-reduce may sit between).
+ * ------------------------------------------------------------------------------------------ */
+#define GLNN_MLP_MAX_LAYERS 8
+typedef struct glnn_mlp_step_desc {
+  int32_t num_layers;
+  int32_t batchnorm;
+  int32_t dims[GLNN_MLP_MAX_LAYERS + 1];
+  float dropout_p;
+  float bn_eps;
+  float bn_momentum;
+  int64_t max_batch;
+  float* w[GLNN_MLP_MAX_LAYERS];
+  float* b[GLNN_MLP_MAX_LAYERS];
+  float* gw[GLNN_MLP_MAX_LAYERS];
+  float* gb[GLNN_MLP_MAX_LAYERS];
+  float* gamma[GLNN_MLP_MAX_LAYERS];
+  float* beta[GLNN_MLP_MAX_LAYERS];
+  float* ggamma[GLNN_MLP_MAX_LAYERS];
+  float* gbeta[GLNN_MLP_MAX_LAYERS];
+  float* running_mean[GLNN_MLP_MAX_LAYERS];
+  float* running_var[GLNN_MLP_MAX_LAYERS];
+  int64_t* nbt[GLNN_MLP_MAX_LAYERS];
+  float* mean[GLNN_MLP_MAX_LAYERS];
+  float* rstd[GLNN_MLP_MAX_LAYERS];
+  float* a_scale[GLNN_MLP_MAX_LAYERS];
+  float* a_shift[GLNN_MLP_MAX_LAYERS];
+  float* z[GLNN_MLP_MAX_LAYERS];
+  int64_t ldz[GLNN_MLP_MAX_LAYERS];
+  float* logits;
+  int64_t ld_logits;
+  float* dlogits;
+  int64_t ld_dlogits;
+  float* da;
+  int64_t ld_da;
+  float* dz;
+  int64_t ld_dz;
+  float* ws_bn;
+  int64_t ws_bn_floats;
+  float* ws_tn;
+  int64_t ws_tn_floats;
+  float* ws_gemm;
+  int64_t ws_gemm_floats;
+  float* ws_loss;
+  int64_t ws_loss_floats;
+  float* loss_out;
+  float* loss_accum;
+} glnn_mlp_step_desc;
+
+GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,
+                                  const int64_t* idx, int64_t m, int kind, const int64_t* labels,
+                                  const float* target_logp, int64_t ldt, const int64_t* target_rows,
+                                  float lamb, const uint32_t* drop_seeds, void* stream);
+
 /* The dropout keep-mask the kernels above evaluate on the fly (nn.Dropout, reference models.py:52):
  * mask[r*h + c] = 1 if element (r,c) is kept under (drop_p, drop_seed).  torch's Philox stream cannot
  * be reproduced by a custom kernel, so parity tests run the oracle with THIS mask as an input. */
