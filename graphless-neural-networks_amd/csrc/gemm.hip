@@ -691,18 +691,29 @@ __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
 // column sums of B [m, nb]: stage 1 -> partial[blk][nb], stage 2 -> out[nb]  (deterministic)
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ b, int64_t ldb, int64_t m, int nb,
                                                       int64_t rows_per_blk, float* __restrict__ partial) {
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lc = threadIdx.x & 63;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < nb ? col : nb - 1;
   const int rlane = threadIdx.x >> 6;  // 0..3
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk;
   if (r1 > m) r1 = m;
   float s = 0.f;
-  if (col < nb)
-    for (int64_t r = r0 + rlane; r < r1; r += 4) s += b[r * ldb + col];
+  // 8 independent (clamped, always valid) loads in flight per step instead of one dependent load per iteration
+  for (int64_t rb = r0 + rlane; rb < r1; rb += 32) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t r = rb + 4 * u;
+      v[u] = b[(r < r1 ? r : r0) * ldb + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (rb + 4 * u < r1) ? v[u] : 0.f;
+  }
   __shared__ float sh[4][64];
-  sh[rlane][threadIdx.x & 63] = s;
+  sh[rlane][lc] = s;
   __syncthreads();
-  if (rlane == 0 && col < nb) partial[(int64_t)blockIdx.y * nb + col] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (rlane == 0 && col < nb && r0 < m) partial[(int64_t)blockIdx.y * nb + col] = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
 }
 __global__ void colsum_stage2(const float* __restrict__ partial, int nblk, int nb, float* __restrict__ out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;

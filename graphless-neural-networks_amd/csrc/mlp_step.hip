@@ -55,21 +55,23 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   for (int l = L - 1; l >= 0; --l) {
     if (l == 0) {
       GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], feats, ldx, idx, nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
-                                d->dims[0], d->gb[0], d->ws_tn, d->ws_tn_floats, stream));
+                                d->dims[0], L == 1 ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
     GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                              p, seed, d->dims[l], d->gw[l], d->dims[l], d->gb[l], d->ws_tn, d->ws_tn_floats, stream));
+                              p, seed, d->dims[l], d->gw[l], d->dims[l], l == L - 1 ? d->gb[l] : nullptr, d->ws_tn, d->ws_tn_floats,
+                              stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
     if (d->batchnorm) {
       GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                     d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
-                                    d->gbeta[l - 1], d->ws_bn, d->ws_bn_floats, stream));
+                                    d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream));
     } else {
       GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
-                                    nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, nullptr, 0, stream));
+                                    nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
+                                    stream));
     }
     dz = d->dz;
     ld_dz = d->ld_dz;

@@ -111,33 +111,52 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 constexpr int kBnRows = 128;  // rows per chunk
 
+// Column kernels below share one mapping: a workgroup owns 64 columns x one chunk of kBnRows rows; thread =
+// (column = tid & 63, row lane = tid >> 6); a row lane walks rows r0 + lane + 4*i.  Loads are issued 8 rows at a
+// time from clamped (always valid) addresses so that they pipeline instead of serialising on a loop-carried
+// dependence; rows past the chunk end are masked arithmetically.
+constexpr int kRowLanes = 4;
+constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
+constexpr int kUnroll = 8;
+
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
                                                         float* __restrict__ ws_mean, float* __restrict__ ws_m2) {
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lc = threadIdx.x & 63;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < h ? col : h - 1;
   const int rl = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
   int64_t r1 = r0 + kBnRows;
   if (r1 > rows) r1 = rows;
   const int cnt = (int)(r1 - r0);
-  __shared__ float sh[4][64];
+  __shared__ float sh[kRowLanes][64];
+  float v[kRowsPerLane];
   float s = 0.f;
-  if (col < h)
-    for (int64_t r = r0 + rl; r < r1; r += 4) s += z[r * ldz + col];
-  sh[rl][threadIdx.x & 63] = s;
+#pragma unroll
+  for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      v[i0 + u] = z[(r < r1 ? r : r0) * ldz + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) s += (r0 + rl + 4 * (i0 + u) < r1) ? v[i0 + u] : 0.f;
+  }
+  sh[rl][lc] = s;
   __syncthreads();
-  const float mean = ((sh[0][threadIdx.x & 63] + sh[1][threadIdx.x & 63]) + (sh[2][threadIdx.x & 63] + sh[3][threadIdx.x & 63])) / (float)cnt;
+  const float mean = ((sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc])) / (float)cnt;
   __syncthreads();
   float q = 0.f;
-  if (col < h)
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
-      const float d = z[r * ldz + col] - mean;
-      q = fmaf(d, d, q);
-    }
-  sh[rl][threadIdx.x & 63] = q;
+#pragma unroll
+  for (int i = 0; i < kRowsPerLane; ++i) {
+    const float d = v[i] - mean;
+    q = (r0 + rl + 4 * i < r1) ? fmaf(d, d, q) : q;
+  }
+  sh[rl][lc] = q;
   __syncthreads();
   if (rl == 0 && col < h) {
     ws_mean[(int64_t)blockIdx.y * h + col] = mean;
-    ws_m2[(int64_t)blockIdx.y * h + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    ws_m2[(int64_t)blockIdx.y * h + col] = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
   }
 }
 
@@ -177,74 +196,124 @@ __global__ void bn_stats_stage2(const BnFinArgs a) {
   if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
 }
 
-// backward stage 1: per (row-chunk, column) sums of dy and dy*xhat,  dy = da * [z*a_scale+a_shift > 0]
-__global__ __launch_bounds__(256) void bn_bwd_stage1(const float* __restrict__ da, int64_t ldda, const float* __restrict__ z,
-                                                      int64_t ldz, int64_t rows, int h, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, const float* __restrict__ a_scale,
-                                                      const float* __restrict__ a_shift, uint32_t dthr, uint32_t dseed,
-                                                      float dscale, float* __restrict__ ws1, float* __restrict__ ws2) {
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
+// BN / ReLU / dropout backward in three launches (was five + two for the bias gradient):
+//   partial : per (row-chunk, column)  s1 = sum dy,  s2 = sum dy*xhat,   dy = drop'(da) * [z*a_scale+a_shift > 0]
+//   apply   : every workgroup re-reduces the nchunks partials of its 64 columns (fixed order), writes
+//             dz = gamma*rstd*(dy - S1/B - xhat*S2/B)  and the per-chunk column sums of dz (the bias gradient of
+//             the Linear in front of the BatchNorm); chunk 0 also stores dgamma = S2, dbeta = S1
+//   finalize: dbias[col] = sum over chunks (fixed order)
+struct BnBwdArgs {
+  const float* da; int64_t ldda; const float* z; int64_t ldz; int64_t rows; int h;
+  const float* gamma; const float* mean; const float* rstd; const float* a_scale; const float* a_shift;
+  uint32_t dthr; uint32_t dseed; float dscale;
+  float* dz; int64_t lddz; float* dgamma; float* dbeta;
+  float* ws1; float* ws2; float* ws3;   // [nchunks][h] each; ws3 may be NULL (no bias gradient wanted)
+  int nchunks;
+};
+
+template <bool BN>
+__device__ __forceinline__ float bn_dy(const BnBwdArgs& a, float zz, float dav, int64_t r, int col, float sc, float sf) {
+  if (a.dthr) dav = glnn::drop_keep(a.dseed, a.dthr, (uint32_t)r, (uint32_t)col) ? dav * a.dscale : 0.f;
+  return (BN ? fmaf(zz, sc, sf) : zz) > 0.f ? dav : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_partial(const BnBwdArgs a) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < a.h ? col : a.h - 1;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
   int64_t r1 = r0 + kBnRows;
-  if (r1 > rows) r1 = rows;
+  if (r1 > a.rows) r1 = a.rows;
+  const float mu = a.mean[colc], rs = a.rstd[colc], sc = a.a_scale[colc], sf = a.a_shift[colc];
   float s1 = 0.f, s2 = 0.f;
-  if (col < h) {
-    const float mu = mean[col], rs = rstd[col], sc = a_scale[col], sf = a_shift[col];
-    for (int64_t r = r0 + rl; r < r1; r += 4) {
-      const float zz = z[r * ldz + col];
-      float dy = fmaf(zz, sc, sf) > 0.f ? da[r * ldda + col] : 0.f;
-      if (dthr) dy = glnn::drop_keep(dseed, dthr, (uint32_t)r, (uint32_t)col) ? dy * dscale : 0.f;
+#pragma unroll
+  for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {
+    float zz[kUnroll], dd[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const int64_t rc = r < r1 ? r : r0;
+      zz[u] = a.z[rc * a.ldz + colc];
+      dd[u] = a.da[rc * a.ldda + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const float dy = r < r1 ? bn_dy<true>(a, zz[u], dd[u], r, colc, sc, sf) : 0.f;
       s1 += dy;
-      s2 = fmaf(dy, (zz - mu) * rs, s2);
+      s2 = fmaf(dy, (zz[u] - mu) * rs, s2);
     }
   }
-  __shared__ float sh1[4][64], sh2[4][64];
-  sh1[rl][threadIdx.x & 63] = s1;
-  sh2[rl][threadIdx.x & 63] = s2;
+  __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
+  sh1[rl][lc] = s1;
+  sh2[rl][lc] = s2;
   __syncthreads();
-  if (rl == 0 && col < h) {
-    ws1[(int64_t)blockIdx.y * h + col] = (sh1[0][threadIdx.x] + sh1[1][threadIdx.x]) + (sh1[2][threadIdx.x] + sh1[3][threadIdx.x]);
-    ws2[(int64_t)blockIdx.y * h + col] = (sh2[0][threadIdx.x] + sh2[1][threadIdx.x]) + (sh2[2][threadIdx.x] + sh2[3][threadIdx.x]);
+  if (rl == 0 && col < a.h) {
+    a.ws1[(int64_t)blockIdx.y * a.h + col] = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]);
+    a.ws2[(int64_t)blockIdx.y * a.h + col] = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
   }
 }
-__global__ void bn_bwd_stage2(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks, int h,
-                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+
+template <bool BN>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < a.h ? col : a.h - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > a.rows) r1 = a.rows;
+  __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
+  float S1 = 0.f, S2 = 0.f, mu = 0.f, rs = 1.f, sc = 1.f, sf = 0.f, g = 1.f;
+  if (BN) {
+    // every row lane sums the same partials in the same order -> identical S1/S2 in all four lanes, no LDS hop
+    for (int k = 0; k < a.nchunks; ++k) {
+      S1 += a.ws1[(int64_t)k * a.h + colc];
+      S2 += a.ws2[(int64_t)k * a.h + colc];
+    }
+    mu = a.mean[colc]; rs = a.rstd[colc]; sc = a.a_scale[colc]; sf = a.a_shift[colc]; g = a.gamma[colc];
+    if (blockIdx.y == 0 && rl == 0 && col < a.h) {
+      a.dbeta[col] = S1;
+      a.dgamma[col] = S2;
+    }
+  }
+  const float inv_b = 1.0f / (float)a.rows;
+  const float c1 = S1 * inv_b, c2 = S2 * inv_b, grs = g * rs;
+  float sdz = 0.f;
+#pragma unroll
+  for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {
+    float zz[kUnroll], dd[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const int64_t rc = r < r1 ? r : r0;
+      zz[u] = a.z[rc * a.ldz + colc];
+      dd[u] = a.da[rc * a.ldda + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      if (r < r1) {
+        const float dy = bn_dy<BN>(a, zz[u], dd[u], r, colc, sc, sf);
+        const float out = BN ? grs * (dy - c1 - (zz[u] - mu) * rs * c2) : dy;
+        if (col < a.h) a.dz[r * a.lddz + col] = out;
+        sdz += out;
+      }
+    }
+  }
+  if (a.ws3) {
+    sh1[rl][lc] = sdz;
+    __syncthreads();
+    if (rl == 0 && col < a.h) a.ws3[(int64_t)blockIdx.y * a.h + col] = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]);
+  }
+  (void)sh2;
+}
+
+__global__ void chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int h, float* __restrict__ out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= h) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    s1 += ws1[(int64_t)k * h + col];
-    s2 += ws2[(int64_t)k * h + col];
-  }
-  dbeta[col] = s1;
-  dgamma[col] = s2;
-}
-// stage 3 (BN):  dz = gamma*rstd*(dy - s1/B - xhat*s2/B);   (no BN): dz = da*[z>0]
-template <bool BN>
-__global__ __launch_bounds__(256) void bn_bwd_stage3(const float* __restrict__ da, int64_t ldda, const float* __restrict__ z,
-                                                      int64_t ldz, int64_t rows, int h, const float* __restrict__ gamma,
-                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ a_scale, const float* __restrict__ a_shift,
-                                                      const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                      uint32_t dthr, uint32_t dseed, float dscale,
-                                                      float* __restrict__ dz, int64_t lddz) {
-  const int64_t total = rows * h;
-  const float inv_b = 1.0f / (float)rows;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / h;
-    const int col = (int)(i - r * h);
-    const float zz = z[r * ldz + col];
-    float dav = da[r * ldda + col];
-    if (dthr) dav = glnn::drop_keep(dseed, dthr, (uint32_t)r, (uint32_t)col) ? dav * dscale : 0.f;
-    if (BN) {
-      const float dy = fmaf(zz, a_scale[col], a_shift[col]) > 0.f ? dav : 0.f;
-      const float xhat = (zz - mean[col]) * rstd[col];
-      dz[r * lddz + col] = gamma[col] * rstd[col] * (dy - dbeta[col] * inv_b - xhat * dgamma[col] * inv_b);
-    } else {
-      dz[r * lddz + col] = zz > 0.f ? dav : 0.f;
-    }
-  }
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += ws[(int64_t)k * h + col];
+  out[col] = s;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -337,31 +406,32 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
 extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
                                     const float* gamma, const float* mean, const float* rstd, const float* a_scale,
                                     const float* a_shift, float drop_p, uint32_t drop_seed, float* dz, int64_t lddz,
-                                    float* dgamma, float* dbeta, float* workspace, int64_t workspace_floats,
-                                    void* stream) {
+                                    float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                                    int64_t workspace_floats, void* stream) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
-  const uint32_t dthr = glnn::drop_threshold(drop_p);
-  const float dscale = 1.0f / (1.0f - drop_p);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  int64_t blocks = (rows * h + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (!gamma) {
-    hipLaunchKernelGGL((bn_bwd_stage3<false>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dthr, drop_seed, dscale, dz, lddz);
-    return glnn::check_launch("glnn_bn_relu_bwd_f32");
-  }
-  GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta && workspace, "glnn_bn_relu_bwd_f32: BN path needs stats, outputs and workspace");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
-  GLNN_REQUIRE(workspace_floats >= 2ll * nchunks * h, "glnn_bn_relu_bwd_f32: workspace needs >= %lld floats", 2ll * nchunks * h);
-  float* ws1 = workspace;
-  float* ws2 = workspace + (int64_t)nchunks * h;
-  hipLaunchKernelGGL(bn_bwd_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, mean, rstd,
-                     a_scale, a_shift, dthr, drop_seed, dscale, ws1, ws2);
-  hipLaunchKernelGGL(bn_bwd_stage2, dim3((h + 127) / 128), dim3(128), 0, st, ws1, ws2, nchunks, h, dgamma, dbeta);
-  hipLaunchKernelGGL((bn_bwd_stage3<true>), dim3((unsigned)blocks), dim3(256), 0, st, da, ldda, z, ldz, rows, h, gamma, mean,
-                     rstd, a_scale, a_shift, dgamma, dbeta, dthr, drop_seed, dscale, dz, lddz);
+  const int64_t need = (int64_t)nchunks * h * ((gamma ? 2 : 0) + (dz_col_sum ? 1 : 0));
+  GLNN_REQUIRE(need == 0 || (workspace && workspace_floats >= need), "glnn_bn_relu_bwd_f32: workspace needs >= %lld floats", (long long)need);
+  BnBwdArgs a;
+  a.da = da; a.ldda = ldda; a.z = z; a.ldz = ldz; a.rows = rows; a.h = h; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
+  a.a_scale = a_scale; a.a_shift = a_shift; a.dthr = glnn::drop_threshold(drop_p); a.dseed = drop_seed;
+  a.dscale = 1.0f / (1.0f - drop_p); a.dz = dz; a.lddz = lddz; a.dgamma = dgamma; a.dbeta = dbeta; a.nchunks = nchunks;
+  float* w = workspace;
+  a.ws1 = a.ws2 = a.ws3 = nullptr;
+  if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
+  if (dz_col_sum) a.ws3 = w;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((h + 63) / 64, nchunks);
+  if (gamma) {
+    GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
+    hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
+  }
+  if (dz_col_sum) hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws3, nchunks, h, dz_col_sum);
   return glnn::check_launch("glnn_bn_relu_bwd_f32");
 }
 

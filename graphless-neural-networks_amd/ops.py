@@ -241,8 +241,9 @@ def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=
 
 
 def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=None, dz=None, dgamma=None,
-                dbeta=None, workspace=None, drop_p=0.0, drop_seed=0):
-    """K5 glnn_bn_relu_bwd_f32.  Returns (dz, dgamma, dbeta); gamma=None => plain ReLU backward."""
+                dbeta=None, workspace=None, drop_p=0.0, drop_seed=0, dz_col_sum=None):
+    """K5 glnn_bn_relu_bwd_f32.  Returns (dz, dgamma, dbeta); gamma=None => plain ReLU backward.
+    dz_col_sum: optional [h] output = column sums of dz (the bias gradient of the Linear in front)."""
     _need_cuda(da, z, gamma, mean, rstd, a_scale, a_shift, dz, dgamma, dbeta, workspace)
     _mat(da, "bn_relu_bwd da")
     _mat(z, "bn_relu_bwd z")
@@ -254,11 +255,11 @@ def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=N
             dgamma = torch.empty(h, dtype=torch.float32, device=z.device)
         if dbeta is None:
             dbeta = torch.empty(h, dtype=torch.float32, device=z.device)
-        if workspace is None:
-            workspace = torch.empty(2 * ((rows + 127) // 128) * h, dtype=torch.float32, device=z.device)
+    if workspace is None and (gamma is not None or dz_col_sum is not None):
+        workspace = torch.empty(3 * ((rows + 127) // 128) * h, dtype=torch.float32, device=z.device)
     rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
                                          _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
-                                         _p(dz), _ld(dz), _p(dgamma), _p(dbeta),
+                                         _p(dz), _ld(dz), _p(dgamma), _p(dbeta), _p(dz_col_sum),
                                          _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
     _lib.check(rc, "glnn_bn_relu_bwd_f32")
     return dz, dgamma, dbeta

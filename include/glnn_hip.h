@@ -155,6 +155,8 @@ GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows
  *     dy = da * [z*a_scale+a_shift > 0], dgamma = sum dy*xhat, dbeta = sum dy and
  *     dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); in place on da allowed.
  *     With gamma == NULL (norm_type "none") it is the plain ReLU backward dz = da*[z>0].
+ *     dz_col_sum (optional) receives sum over rows of dz = the bias gradient of the Linear in front.
+ *     workspace: >= ceil(rows/128)*h*(2 if gamma else 0 + 1 if dz_col_sum else 0) floats.
  *     drop_p > 0 first applies the Dropout backward da *= keep(row,col)/(1-drop_p) with the same
  *     (drop_seed) mask the forward operand transform used.
  * ------------------------------------------------------------------------------------------ */
@@ -169,6 +171,7 @@ GLNN_API int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z,
                                   const float* rstd, const float* a_scale, const float* a_shift,
                                   float drop_p, uint32_t drop_seed,
                                   float* dz, int64_t lddz, float* dgamma, float* dbeta,
+                                  float* dz_col_sum,
                                   float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
