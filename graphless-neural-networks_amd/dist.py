@@ -31,19 +31,28 @@ class RowShards:
         self.n_pad = self.rpr * self.world
 
 
+def _storage_rows(buf):
+    """The contiguous [rows, ld] tensor behind a feature view [rows, d] (ld = row stride >= d)."""
+    if buf.is_contiguous():
+        return buf
+    return torch.as_strided(buf, (buf.shape[0], buf.stride(0)), (buf.stride(0), 1))
+
+
 def all_gather_rows(buf, shards, group=None):
-    """In-place all-gather of [n_pad, ld] `buf` whose slot [rank*rpr, (rank+1)*rpr) this rank has filled."""
+    """In-place all-gather of the [n_pad, d] feature buffer `buf` (row stride ld) whose slot
+    [rank*rpr, (rank+1)*rpr) this rank has filled.  The collective runs on the contiguous padded storage, whole
+    rows including the [d, ld) padding columns, so that every rank's slab is ONE contiguous block."""
     if shards.world == 1:
         return buf
-    mine = buf[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
-    try:
-        dist.all_gather_into_tensor(buf, mine, group=group)
-    except (RuntimeError, NotImplementedError):
-        parts = [buf[r * shards.rpr:(r + 1) * shards.rpr] for r in range(shards.world)]
+    base = _storage_rows(buf)
+    mine = base[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(base, mine, group=group)
+    else:   # gloo (CPU tests): list form
         tmp = [torch.empty_like(mine) for _ in range(shards.world)]
         dist.all_gather(tmp, mine.contiguous(), group=group)
-        for p, t in zip(parts, tmp):
-            p.copy_(t)
+        for r, t in enumerate(tmp):
+            base[r * shards.rpr:(r + 1) * shards.rpr].copy_(t)
     return buf
 
 

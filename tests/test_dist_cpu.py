@@ -24,14 +24,15 @@ class OracleBackend:
 
     @staticmethod
     def feat_empty(n, d, device, zero=False):
-        return torch.zeros((n, d), dtype=torch.float32)
+        # same layout contract as glnn_amd.ops.feat_empty: [n, d] view of a [n, round4(d)] buffer
+        return torch.full((n, (d + 3) // 4 * 4), float("nan"))[:, :d]
 
     @staticmethod
     def as_feat(t):
-        return t.contiguous()
+        return t
 
     def gemm(self, a, w, ep_scale=None, ep_shift=None, relu=False, out=None, **kw):
-        y = torch.from_numpy(self.to.linear(a.contiguous().numpy(), w.detach().numpy(), None))
+        y = torch.from_numpy(self.to.linear(a.contiguous().numpy(), w.detach().contiguous().numpy(), None))
         if ep_scale is not None:
             y = y * ep_scale
         if ep_shift is not None:
