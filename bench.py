@@ -43,10 +43,21 @@ def lanes_per_row(d):
     return 4 if dv <= 4 else 8 if dv <= 8 else 16 if dv <= 16 else 32 if dv <= 32 else 64
 
 
-def alg_bytes(nnz, n_dst, d):
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the named kernel instantiation, from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["per_launch_bytes"][kernel]["total"]
+    except Exception:
+        return None
+
+
+def alg_bytes(nnz, n_dst, d, d_out=None):
     """per edge one gathered fp32 source row + one int32 index; per dst row one self-row read,
-    one output-row write, one int64 indptr entry."""
-    return nnz * (4 * d + 4) + n_dst * (8 * d + 8)
+    one output-row write (d_out wide for the fused aggregate+project kernel), one int64 indptr entry."""
+    d_out = d if d_out is None else d_out
+    return nnz * (4 * d + 4) + n_dst * (4 * d + 4 * d_out + 8)
 
 
 def main():
@@ -187,24 +198,27 @@ def main():
         torch.cuda.synchronize()
         per = {}
         for name, info, s, e in timing:
-            key = (name, info.get("d", info.get("n")), info.get("k"))
+            key = (name, info.get("d", info.get("n")), info.get("d_out", info.get("k")))
             per.setdefault(key, []).append(s.elapsed_time(e))
         layers, tot_b, tot_ms = [], 0.0, 0.0
-        for (name, d, _), ms in per.items():
-            if name != "spmm":
+        for (name, d, d_out), ms in per.items():
+            if name not in ("spmm", "sage_fused"):
                 continue
-            b = alg_bytes(nnz, n, d)
+            fused = name == "sage_fused"
+            b = alg_bytes(nnz, n, d, d_out if fused else None)
             avg = float(np.mean(ms))
-            layers.append({"d": d, "avg_ms": avg, "alg_GB": b / 1e9, "GBps": b / avg / 1e6, "launches": len(ms),
+            layers.append({"kernel": (f"sage_fused_kernel<LPR={lanes_per_row(((d + 7) // 8) * 8)},U=8> (aggregate {d} wide + project to {d_out} on MFMA)"
+                                      if fused else f"spmm_csr_kernel<LPR={lanes_per_row(d)},U=4,SAGE_GCN>"),
+                           "d": d, "avg_ms": avg, "alg_GB": b / 1e9, "GBps": b / avg / 1e6, "launches": len(ms),
                            "Gedges_per_s": nnz / avg / 1e6})
             tot_b += b
             tot_ms += avg
         gemm_ms = sum(float(np.mean(ms)) for (name, _, _), ms in per.items() if name == "gemm")
         dom = max(layers, key=lambda r: r["avg_ms"])
         result["roofline"] = {
-            "bound": "hbm", "kernel": f"spmm_csr_kernel<LPR={lanes_per_row(dom['d'])},U=4,SAGE_GCN> (D={dom['d']})",
+            "bound": "hbm", "kernel": f"{dom['kernel']} (D={dom['d']})",
             "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(dom["kernel"].split(">")[0] + ">"),
             "algorithmic_bytes_per_launch": dom["alg_GB"] * 1e9, "avg_launch_ms": dom["avg_ms"],
             "all_aggregation_launches": sorted(layers, key=lambda r: r["d"]),
             "aggregation_total": {"alg_GB": tot_b / 1e9, "ms": tot_ms, "GBps": tot_b / tot_ms / 1e6, "frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS},

@@ -17,6 +17,10 @@ SIGNATURES = {
     "glnn_device_info": [c_vp, c_vp, c_vp, c_int],
     "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
                           c_int, c_vp, c_i64, c_vp],
+    "glnn_packed_weight_floats": [c_int, c_int],
+    "glnn_pack_weight_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp],
+    "glnn_sage_fused_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
+                            c_i64, c_vp],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp, c_i64, c_vp],
@@ -74,6 +78,7 @@ def lib():
             fn = getattr(h, name)          # AttributeError => missing export: fail loudly
             fn.argtypes = argtypes
             fn.restype = c_int
+        h.glnn_packed_weight_floats.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
         _lib = h

@@ -183,6 +183,167 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1F: fused SAGE-"gcn" layer  out = epi( ((sum_{u->v} x[u] + x_self[v]) / (deg+1)) @ W^T )
+// for aggregate-first layers (d_in <= 256, d_out <= 256): the aggregated rows never go to HBM.
+//   phase A  the 8 waves of a workgroup aggregate a tile of 32 destination rows (4 rows each, the same
+//            wave_gather_sum as the stand-alone kernel) and park the normalised rows in LDS;
+//            rows of degree > 512 in the tile are then taken by all 8 waves together;
+//   phase B  wave w multiplies the LDS tile [32 x K] with the w-th 32-column panel of W on the fp32 MFMA
+//            (v_mfma_f32_32x32x2_f32).  W arrives PRE-PACKED in MFMA B-fragment order (glnn_pack_weight_f32),
+//            so each k-group is one coalesced 1 KiB load per wave straight from L2 -- no LDS staging and no
+//            barrier inside the GEMM; the A fragments are ds_read_b128 from the padded (conflict-free) tile;
+//   epilogue per-column scale/shift (+bias, eval BatchNorm) and ReLU, stored from the MFMA accumulators.
+// Workgroups on the same CU run out of phase, so the short MFMA phase of one hides under the HBM-bound
+// aggregation of the others.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kFusedRows = 32;                     // destination rows per workgroup tile (64 rows / 16 waves measured 1.5x slower)
+constexpr int kFusedWaves = 8 * (kFusedRows / 32);  // one wave per (32-row tile, 32-column panel of W)
+constexpr int kFusedBlock = 64 * kFusedWaves;
+
+struct FusedArgs {
+  const int64_t* indptr; const int32_t* indices; int64_t n_dst;
+  const float* x; int64_t ldx; int d_in;
+  const float* x_self; int64_t ld_self;
+  const float* w_packed; int d_out; int kgroups;      // kgroups = ceil(d_in / 8)
+  const float* ep_scale; const float* ep_shift; int relu;
+  float* out; int64_t ldo;
+};
+
+template <int LPR, int U>
+__global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds_a[];      // [kFusedRows][kpad + 4]
+  __shared__ float4 s_part[kFusedWaves][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col4 = (lane % LPR) * 4;
+  const bool col_ok = col4 < a.d_in;
+  const int kpad = a.kgroups * 8;
+  const int lda = kpad + 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kFusedRows;
+
+  // ---- phase A: the 8 waves pull rows of the tile from an LDS ticket (degrees vary by 100x: a static
+  //      4-rows-per-wave split leaves most waves idle at the barrier behind the heaviest one) ---------
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = 0;
+  __syncthreads();
+#pragma unroll 1
+  while (true) {
+    int lr = 0;
+    if (lane == 0) lr = atomicAdd(&s_next, 1);
+    lr = __builtin_amdgcn_readfirstlane(lr);
+    if (lr >= kFusedRows) break;
+    const int64_t v = row0 + lr;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool deferred = false;
+    if (v < a.n_dst) {
+      const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+      const int64_t deg = e1 - e0;
+      deferred = deg > kLongRow;
+      if (!deferred) {
+        const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, nullptr, lane);
+        if (lane < LPR && col_ok) {
+          const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
+          const float dp1 = (float)deg + 1.0f;
+          y = make_float4((acc.x + sf.x) / dp1, (acc.y + sf.y) / dp1, (acc.z + sf.z) / dp1, (acc.w + sf.w) / dp1);
+          if (col4 + 1 >= a.d_in) y.y = 0.f;
+          if (col4 + 2 >= a.d_in) y.z = 0.f;
+          if (col4 + 3 >= a.d_in) y.w = 0.f;
+        }
+      }
+    }
+    if (!deferred && lane < LPR && col4 < kpad) st4(lds_a + lr * lda + col4, y);
+  }
+  __syncthreads();
+  // long rows of this tile: all 8 waves on one row at a time (uniform loop: every wave sees the same degrees)
+#pragma unroll 1
+  for (int lr = 0; lr < kFusedRows; ++lr) {
+    const int64_t v = row0 + lr;
+    if (v >= a.n_dst) break;
+    const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+    if (e1 - e0 <= kLongRow) continue;
+    const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane);
+    if (lane < LPR) s_part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && lane < LPR && col4 < kpad) {
+      float4 t = s_part[0][lane];
+#pragma unroll
+      for (int w = 1; w < kFusedWaves; ++w) t = add4(t, s_part[w][lane]);
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_ok) {
+        const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
+        const float dp1 = (float)(e1 - e0) + 1.0f;
+        y = make_float4((t.x + sf.x) / dp1, (t.y + sf.y) / dp1, (t.z + sf.z) / dp1, (t.w + sf.w) / dp1);
+        if (col4 + 1 >= a.d_in) y.y = 0.f;
+        if (col4 + 2 >= a.d_in) y.z = 0.f;
+        if (col4 + 3 >= a.d_in) y.w = 0.f;
+      }
+      st4(lds_a + lr * lda + col4, y);
+    }
+    __syncthreads();
+  }
+
+  // ---- phase B: [32 x K] (LDS) x W panel `wave` (packed, L2) on the MFMA ----------------------------
+  const int n_tiles = (a.d_out + 31) / 32;
+  const int nt = wave & 7, rt = wave >> 3;            // column panel of W, 32-row sub-tile
+  if (nt >= n_tiles) return;
+  const int li = lane & 31, kk = lane >> 5;
+  const float4* wp = reinterpret_cast<const float4*>(a.w_packed) + ((int64_t)nt * a.kgroups) * 64 + lane;
+  const float* ap = lds_a + (rt * 32 + li) * lda + kk * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int PF = 4;                      // B fragments in flight
+  float4 bq[PF];
+#pragma unroll
+  for (int q = 0; q < PF; ++q) bq[q] = (q < a.kgroups) ? wp[(int64_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kg0 = 0; kg0 < a.kgroups; kg0 += PF) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int kg = kg0 + q;
+      if (kg < a.kgroups) {
+        const float4 bv = bq[q];
+        const int nxt = kg + PF;
+        if (nxt < a.kgroups) bq[q] = wp[(int64_t)nxt * 64];
+        const float4 av = *reinterpret_cast<const float4*>(ap + kg * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----
+  const int col = nt * 32 + li;
+  if (col < a.d_out) {
+    const float es = a.ep_scale ? a.ep_scale[col] : 1.f;
+    const float eh = a.ep_shift ? a.ep_shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (row < a.n_dst) {
+        float v = fmaf(acc[r], es, eh);
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.out[row * a.ldo + col] = v;
+      }
+    }
+  }
+}
+
+// W [d_out, d_in] (ldw) -> MFMA B-fragment order: wp[nt][kg][lane][t] = W[nt*32 + (lane&31)][kg*8 + (lane>>5)*4 + t]
+__global__ void pack_weight_kernel(const float* __restrict__ w, int64_t ldw, int d_out, int d_in, int kgroups,
+                                   float* __restrict__ wp) {
+  const int64_t total = (int64_t)((d_out + 31) / 32) * kgroups * 256;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const int64_t g = i >> 8;
+    const int kg = (int)(g % kgroups), nt = (int)(g / kgroups);
+    const int n = nt * 32 + (lane & 31), k = kg * 8 + (lane >> 5) * 4 + t;
+    wp[i] = (n < d_out && k < d_in) ? w[(int64_t)n * ldw + k] : 0.f;
+  }
+}
+
 template <int LPR, int U>
 int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid) {
   const bool cs = a.col_scale != nullptr;
@@ -284,4 +445,52 @@ extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, i
   if (out_deg && n_src > 0)
     hipLaunchKernelGGL(int_to_float_kernel, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, st, out_deg, n_src);
   return glnn::check_launch("glnn_degrees_f32");
+}
+
+extern "C" int64_t glnn_packed_weight_floats(int d_out, int d_in) {
+  return (int64_t)((d_out + 31) / 32) * ((d_in + 7) / 8) * 256;
+}
+
+extern "C" int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int d_in, float* w_packed, void* stream) {
+  GLNN_REQUIRE(w && w_packed && d_out >= 1 && d_in >= 1 && ldw >= d_in, "glnn_pack_weight_f32: bad arguments");
+  GLNN_REQUIRE(glnn::aligned16(w_packed), "glnn_pack_weight_f32: w_packed must be 16-byte aligned");
+  const int kgroups = (d_in + 7) / 8;
+  const int64_t total = glnn_packed_weight_floats(d_out, d_in);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, ldw, d_out,
+                     d_in, kgroups, w_packed);
+  return glnn::check_launch("glnn_pack_weight_f32");
+}
+
+extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
+                                   int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
+                                   int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                   int64_t ldo, void* stream) {
+  GLNN_REQUIRE(indptr && indices && x && x_self && w_packed && out, "glnn_sage_fused_f32: null pointer");
+  GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_sage_fused_f32: bad n_dst/n_src");
+  GLNN_REQUIRE(d_in >= 1 && d_in <= 256 && d_out >= 1 && d_out <= 256, "glnn_sage_fused_f32: d_in and d_out must be in [1,256]");
+  const int dpad = (d_in + 3) & ~3;
+  GLNN_REQUIRE(ldx % 4 == 0 && ldx >= dpad && ld_self % 4 == 0 && ld_self >= dpad && ldo >= d_out,
+               "glnn_sage_fused_f32: leading dimensions (ldx, ld_self multiples of 4 and >= %d; ldo >= d_out)", dpad);
+  GLNN_REQUIRE(glnn::aligned16(x) && glnn::aligned16(x_self) && glnn::aligned16(w_packed), "glnn_sage_fused_f32: 16-byte alignment required");
+  if (n_dst == 0) return GLNN_OK;
+  FusedArgs a;
+  a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.d_in = d_in; a.x_self = x_self;
+  a.ld_self = ld_self; a.w_packed = w_packed; a.d_out = d_out; a.kgroups = (d_in + 7) / 8; a.ep_scale = ep_scale;
+  a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
+  const int64_t blocks = (n_dst + kFusedRows - 1) / kFusedRows;
+  GLNN_REQUIRE(blocks < ((int64_t)1 << 31), "glnn_sage_fused_f32: n_dst too large for one launch");
+  const size_t smem = sizeof(float) * kFusedRows * (a.kgroups * 8 + 4);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int dv = dpad / 4;
+  // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)
+  const int kv = a.kgroups * 2;      // float4 per padded row
+  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, 8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 0 : -1;
+  if (configured != 0) return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fused_f32: cannot raise the dynamic LDS limit");
+  if (kv <= 16 && dv <= 16) hipLaunchKernelGGL((sage_fused_kernel<16, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
+  else if (kv <= 32) hipLaunchKernelGGL((sage_fused_kernel<32, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
+  else hipLaunchKernelGGL((sage_fused_kernel<64, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
+  return glnn::check_launch("glnn_sage_fused_f32");
 }

@@ -13,6 +13,11 @@ from . import ops
 from .autograd import SpmmFn, linear_fn
 
 
+FUSED_SAGE_MAX_IN = 256   # aggregate-first layers with d_in, d_out <= 256 take the single-launch K1F kernel.  Interleaved
+                          # A/B on one MI355X, products shape (scripts/ab_fused.py): 100->256 10.6 vs 12.5 ms,
+                          # 128->256 11.4 vs 12.2 ms, 256->256 23.6 vs 25.1 ms (fused vs aggregation + GEMM)
+
+
 class SAGEConv(nn.Module):
     def __init__(self, in_feats, out_feats, aggregator_type, bias=True):
         super().__init__()
@@ -44,6 +49,10 @@ class SAGEConv(nn.Module):
             hw = ops.gemm(ops.as_feat(h_src), w)
             return ops.spmm(graph.indptr, graph.indices, hw, n_dst, ops.AGG_SAGE_GCN, ep_scale=ep_scale,
                             ep_shift=shift, relu=relu)
+        if self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256:
+            # aggregation + projection + epilogue in one launch: the aggregated rows never reach HBM
+            return ops.sage_fused(graph.indptr, graph.indices, h_src, n_dst, w, ep_scale=ep_scale, ep_shift=shift, relu=relu,
+                                  x_self=h_dst)
         agg = ops.spmm(graph.indptr, graph.indices, h_src, n_dst, ops.AGG_SAGE_GCN)
         return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu)
 

@@ -125,6 +125,38 @@ def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, 
         _p(out), _ld(out), _stream())
 
 
+def pack_weight(w):
+    """glnn_pack_weight_f32: W [d_out, d_in] -> MFMA B-fragment order for sage_fused."""
+    _need_cuda(w)
+    _mat(w, "pack_weight w")
+    d_out, d_in = w.shape
+    wp = torch.empty(_lib.lib().glnn_packed_weight_floats(d_out, d_in), dtype=torch.float32, device=w.device)
+    rc = _lib.lib().glnn_pack_weight_f32(_p(w), _ld(w), d_out, d_in, _p(wp), _stream())
+    _lib.check(rc, "glnn_pack_weight_f32")
+    return wp
+
+
+def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None):
+    """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256)."""
+    _need_cuda(indptr, indices, x, w, ep_scale, ep_shift, out, x_self)
+    x = as_feat(x)
+    x_self = x if x_self is None else as_feat(x_self)
+    n_src, d_in = x.shape
+    d_out = w.shape[0]
+    if w.shape[1] != d_in:
+        raise ValueError("sage_fused: weight must be [d_out, d_in]")
+    if w_packed is None:
+        w_packed = pack_weight(w)
+    if out is None:
+        out = feat_empty(n_dst, d_out, x.device)
+    with _Timed("sage_fused", d=d_in, n_dst=n_dst, d_out=d_out):
+        rc = _lib.lib().glnn_sage_fused_f32(_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d_in, _p(x_self), _ld(x_self),
+                                            _p(w_packed), d_out, _p(_vec(ep_scale, d_out, "ep_scale")),
+                                            _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_sage_fused_f32")
+    return out
+
+
 def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
     _need_cuda(indptr, indices)
     in_deg = torch.empty(n_dst, dtype=torch.float32, device=indptr.device)

@@ -73,6 +73,20 @@ GLNN_API int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, in
                                const float* ep_shift, int relu, float* out, int64_t ldo,
                                void* stream);
 
+/* K1F  Fused SAGE-"gcn" layer for aggregate-first layers (d_in, d_out <= 256):
+ *   out[v,:] = epi( ((sum_{u->v} x[u,:] + x_self[v,:]) / (in_deg(v)+1)) @ W^T ),  epi = *ep_scale +ep_shift, ReLU
+ * = SAGEConv(in,out,"gcn") + bias + eval BatchNorm + ReLU of reference models.py:138-143 in ONE launch; the
+ * aggregated rows stay in LDS and feed the fp32 MFMA directly.  W must be pre-packed into MFMA fragment
+ * order with glnn_pack_weight_f32 (glnn_packed_weight_floats(d_out, d_in) floats, 16-byte aligned). */
+GLNN_API int64_t glnn_packed_weight_floats(int d_out, int d_in);
+GLNN_API int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int d_in, float* w_packed,
+                                  void* stream);
+GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                                 int64_t n_src, const float* x, int64_t ldx, int d_in,
+                                 const float* x_self, int64_t ld_self, const float* w_packed,
+                                 int d_out, const float* ep_scale, const float* ep_shift, int relu,
+                                 float* out, int64_t ldo, void* stream);
+
 /* in_deg[v] = indptr[v+1]-indptr[v] (as float); out_deg[u] = #edges with source u.
  * replaces g.in_degrees()/g.out_degrees() used by GraphConv and utils.py:178.  Either may be NULL.
  * nnz = indptr[n_dst] (host value).  out_deg need not be zeroed by the caller. */

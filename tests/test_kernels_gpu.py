@@ -93,6 +93,23 @@ def test_spmm_empty_rows_and_wide_features():
     np.testing.assert_allclose(got.cpu().numpy(), to.spmm_sum(indptr, indices, x), atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("n,d_in,d_out", [(3000, 100, 256), (1001, 128, 256), (777, 256, 256), (500, 20, 32), (333, 64, 40), (64, 7, 9)])
+def test_sage_fused_vs_oracle(n, d_in, d_out):
+    """K1F: aggregation + projection + scale/shift/ReLU in one launch, incl. a hub row (> 512 in-edges ->
+    cooperative pass), isolated rows, a row count that is not a multiple of the 32-row tile, odd d_in/d_out."""
+    from glnn_amd import ops
+    indptr, indices = random_graph(n, 10, seed=n, power=0.6, isolated=5, hub=700 if n > 800 else 0)
+    r = np.random.RandomState(n)
+    x = r.standard_normal((n, d_in)).astype(np.float32)
+    w = (r.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+    sc, sh = r.uniform(.5, 1.5, d_out).astype(np.float32), r.standard_normal(d_out).astype(np.float32)
+    want = np.maximum(to.linear(to.sage_gcn_agg(indptr, indices, x), w) * sc + sh, 0)
+    got = ops.sage_fused(dev(indptr), dev(indices), dev(x), n, dev(w), ep_scale=dev(sc), ep_shift=dev(sh), relu=True)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+    plain = ops.sage_fused(dev(indptr), dev(indices), dev(x), n, dev(w))
+    np.testing.assert_allclose(plain.cpu().numpy(), to.linear(to.sage_gcn_agg(indptr, indices, x), w), atol=TOL, rtol=0)
+
+
 def test_degrees():
     from glnn_amd import ops
     n = 1000
