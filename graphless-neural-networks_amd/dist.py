@@ -90,9 +90,13 @@ class ShardedTeacher:
                 be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                         out=out, x_self=hw[sh.lo:sh.hi])
             else:
-                agg = be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, x_self=x[sh.lo:sh.hi])
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
-                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+                if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                    be.sage_fused(g.indptr, g.indices, x, sh.rows, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out,
+                                  x_self=x[sh.lo:sh.hi])
+                else:
+                    agg = be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, x_self=x[sh.lo:sh.hi])
+                    be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
             y_own = out
             if not last:
                 x = all_gather_rows(self._full_buffer(("y", l), d_out, x.device), sh, self.group)
