@@ -82,11 +82,19 @@ def main():
     from glnn_amd.models import Model
     from glnn_amd.student import StudentEngine
 
+    # test-only knobs: GLNN_SINGLE_DEVICE=1 maps every rank to cuda:0 and GLNN_DIST_BACKEND=gloo swaps the transport, so
+    # that the N > 1 code path can be smoke-tested on a 1-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("GLNN_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GLNN_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
