@@ -10,6 +10,8 @@ Teacher (layer-wise full-neighbour inference, reference models.py:121-148)
     Layer-1 input features are static -> replicated once, outside the timed loop.
   * layers with in > out project FIRST (dense, row-parallel, weights replicated) and all-gather the narrow
     projected rows, then aggregate: the last products layer moves 47 floats per node, not 256.
+  * layers with 2*in <= out exchange the narrow AGGREGATE and replicate the projection: the first products layer
+    moves 100 floats per node, not 256.  Per forward the exchange is N*(100+47)*4 = 1.44 GB instead of 2.97 GB.
 Student (reference train_and_eval.py:59-86): data parallel, gradients summed with ONE all-reduce over a flat
   gradient buffer before the fused Adam launch (glnn_amd.student.StudentEngine(grad_sync=...)).
 
@@ -89,6 +91,18 @@ class ShardedTeacher:
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
                 be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                         out=out, x_self=hw[sh.lo:sh.hi])
+            elif sh.world > 1 and not last and 2 * d_in <= d_out:
+                # widening layer (products layer 1: 100 -> 256): exchange the NARROW aggregate and let every rank
+                # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
+                # instead of 2.5 GB on products) for the price of a replicated [N, d_in] x [d_in, d_out] GEMM.
+                agg = self._full_buffer(("agg", l), d_in, x.device)
+                be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.lo:sh.hi], x_self=x[sh.lo:sh.hi])
+                all_gather_rows(agg, sh, self.group)
+                y_full = self._full_buffer(("y", l), d_out, x.device)
+                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)
+                x = y_full
+                y_own = y_full[sh.lo:sh.hi]
+                continue
             else:
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
                 if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
