@@ -311,3 +311,77 @@ def test_gather_scatter_rows():
     ops.scatter_rows(got, dev(rows), y)
     want = np.zeros_like(x); want[rows] = x[rows]
     np.testing.assert_array_equal(y.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------- edge cases
+def test_edge_cases_empty_single_and_giant_rows():
+    from glnn_amd import ops
+    # (1) zero destination rows: a no-op that must not fault
+    ip0 = torch.zeros(1, dtype=torch.int64, device=DEV); ix0 = torch.zeros(0, dtype=torch.int32, device=DEV)
+    x = torch.randn(5, 8, device=DEV)
+    assert ops.spmm(ip0, ix0, x, 0, ops.AGG_SAGE_GCN).shape == (0, 8)
+    assert ops.sage_fused(ip0, ix0, x, 0, torch.randn(16, 8, device=DEV)).shape == (0, 16)
+    # (2) a graph with no edges at all: SAGE-gcn returns the self features, SUM returns zeros
+    ip = torch.zeros(6, dtype=torch.int64, device=DEV)
+    np.testing.assert_array_equal(ops.spmm(ip, ix0, x, 5, ops.AGG_SAGE_GCN).cpu().numpy(), x.cpu().numpy())
+    assert float(ops.spmm(ip, ix0, x, 5, ops.AGG_SUM).abs().max()) == 0.0
+    # (3) one destination row with 20,000 in-edges (ogbn-products' max degree is 17,481) next to empty rows:
+    #     the whole-workgroup long-row role in both the stand-alone and the fused kernel
+    n, d = 4000, 100
+    r = np.random.RandomState(0)
+    src = r.randint(0, n, 20000); dst = np.full(20000, 1234)
+    indptr, indices = csr_from_edges(src, dst, n)
+    xx = r.standard_normal((n, d)).astype(np.float32)
+    want = to.sage_gcn_agg(indptr, indices, xx)
+    got = ops.spmm(dev(indptr), dev(indices), dev(xx), n, ops.AGG_SAGE_GCN)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+    w = (r.standard_normal((64, d)) / 10).astype(np.float32)
+    gotf = ops.sage_fused(dev(indptr), dev(indices), dev(xx), n, dev(w))
+    np.testing.assert_allclose(gotf.cpu().numpy(), to.linear(want, w), atol=TOL, rtol=0)
+    # (4) bit-for-bit run-to-run determinism (no float atomics anywhere)
+    again = ops.spmm(dev(indptr), dev(indices), dev(xx), n, ops.AGG_SAGE_GCN)
+    assert torch.equal(got, again)
+    assert torch.equal(gotf, ops.sage_fused(dev(indptr), dev(indices), dev(xx), n, dev(w)))
+
+
+def test_argument_errors_are_raised_not_crashes():
+    from glnn_amd import GlnnError, ops
+    x = torch.randn(10, 6, device=DEV)[:, :5]            # row stride 6: not a multiple of 4 -> as_feat copies; fine
+    ip = torch.zeros(11, dtype=torch.int64, device=DEV); ix = torch.zeros(0, dtype=torch.int32, device=DEV)
+    assert ops.spmm(ip, ix, x, 10, ops.AGG_SUM).shape == (10, 5)
+    with pytest.raises(ValueError):
+        ops.spmm(ip.int(), ix, x, 10, ops.AGG_SUM)        # indptr must be int64
+    with pytest.raises(ValueError):
+        ops.gemm(torch.randn(4, 8, device=DEV), torch.randn(3, 7, device=DEV))
+    with pytest.raises(GlnnError):
+        ops.sage_fused(ip, ix, torch.randn(10, 300, device=DEV), 10, torch.randn(16, 300, device=DEV))   # d_in > 256
+    with pytest.raises(GlnnError):
+        ops.spmm(ip, ix, torch.randn(10, 8, device=DEV), 10, 7)                                        # unknown mode
+
+
+def test_full_size_student_pass_properties():
+    """A full products-sized soft-label pass (597 steps of B=4096 over 2,449,029 rows) through train_mini_batch:
+    finite decreasing loss, BatchNorm counters advanced by exactly the step count, Adam step counter in sync."""
+    from glnn_amd import data
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.models import Model
+    torch.manual_seed(0)
+    n = 2449029
+    feats, labels, out_t, _ = data.make_node_data("ogbn-products", seed=0, device=DEV, n=n)
+    w = torch.randn(100, 47, device=DEV)
+    out_t = torch.log_softmax(feats @ w, dim=1)               # a learnable teacher
+    model = Model(dict(model_name="MLP", num_layers=3, feat_dim=100, hidden_dim=256, label_dim=47, dropout_ratio=0.5,
+                       norm_type="batch", device=DEV))
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=0)
+    crit = torch.nn.KLDivLoss(reduction="batchmean", log_target=True)
+    l1 = te.train_mini_batch(model, feats, out_t, 4096, crit, opt, 1.0)
+    l2 = te.train_mini_batch(model, feats, out_t, 4096, crit, opt, 1.0)
+    steps = n // 4096
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1
+    assert int(model.encoder.norms[0].num_batches_tracked) == 2 * steps
+    assert int(opt.state[next(model.parameters())]["step"]) == 2 * steps
+    out, loss, score = te.evaluate_mini_batch(model, feats, labels, torch.nn.NLLLoss(), 4096, lambda o, y: 0.0)
+    assert out.shape == (n, 47) and torch.isfinite(out).all()
+    assert float((out.exp().sum(1) - 1).abs().max()) < 1e-4
+    agree = (out.argmax(1) == out_t.argmax(1)).float().mean().item()
+    assert agree > 0.5, agree                                  # the student tracks the teacher after two passes
