@@ -381,7 +381,8 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
                                  const float* col_scale, const float* x_self, int64_t ld_self,
                                  const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
                                  void* stream) {
-  GLNN_REQUIRE(indptr && indices && x && out, "glnn_spmm_csr_f32: null pointer");
+  if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
+  GLNN_REQUIRE(indptr && x && out, "glnn_spmm_csr_f32: null pointer");   // indices may be NULL iff the graph has no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
   GLNN_REQUIRE(d >= 1, "glnn_spmm_csr_f32: d=%d must be >= 1", d);
   GLNN_REQUIRE(mode == GLNN_AGG_SUM || mode == GLNN_AGG_SAGE_GCN, "glnn_spmm_csr_f32: unknown mode %d", mode);
@@ -467,7 +468,8 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
                                    int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
                                    int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
                                    int64_t ldo, void* stream) {
-  GLNN_REQUIRE(indptr && indices && x && x_self && w_packed && out, "glnn_sage_fused_f32: null pointer");
+  if (n_dst == 0) return GLNN_OK;
+  GLNN_REQUIRE(indptr && x && x_self && w_packed && out, "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_sage_fused_f32: bad n_dst/n_src");
   GLNN_REQUIRE(d_in >= 1 && d_in <= 256 && d_out >= 1 && d_out <= 256, "glnn_sage_fused_f32: d_in and d_out must be in [1,256]");
   const int dpad = (d_in + 3) & ~3;

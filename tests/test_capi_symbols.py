@@ -51,6 +51,7 @@ def test_invalid_arguments_are_reported_not_crashed():
     h = _lib.lib()
     rc = h.glnn_spmm_csr_f32(None, None, 4, 4, None, 4, 4, 0, None, None, None, 0, None, None, 0, None, 4, None)
     assert rc == -1 and b"null pointer" in h.glnn_last_error()
+    assert h.glnn_spmm_csr_f32(None, None, 0, 0, None, 4, 4, 0, None, None, None, 0, None, None, 0, None, 4, None) == 0   # empty: no-op
     rc = h.glnn_gemm_f32(None, 4, None, None, None, 0.0, 0, 4, 4, None, 4, 0, 4, None, None, None, 0, None, 4, None, 0, None)
     assert rc == -1
 
