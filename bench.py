@@ -117,7 +117,7 @@ def main():
     teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1],
                          label_dim=SAGE_DIMS[-1], dropout_ratio=0.5, norm_type="batch", device=dev))
     teacher.eval()
-    shards = RowShards(n, world, rank)
+    shards = RowShards(n, world, rank, chunks=4 if world > 1 else 1)
     if world > 1:
         shard_graph = g.row_range(shards.lo, shards.hi)
         sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops)

@@ -22,15 +22,30 @@ import torch.distributed as dist
 
 
 class RowShards:
-    """Equal contiguous row ranges; the last ranks may be short (buffers are padded to world*rpr rows)."""
+    """Equal contiguous row ranges; the last ranks may be short (buffers are padded to world*rpr rows).
+    `chunks` > 1 additionally cuts every range into equal sub-ranges (rpr is rounded up to a multiple) for the
+    chunked, overlapped exchange of ShardedTeacher."""
 
-    def __init__(self, n, world, rank):
-        self.n, self.world, self.rank = int(n), int(world), int(rank)
-        self.rpr = (self.n + self.world - 1) // self.world
+    def __init__(self, n, world, rank, chunks=1):
+        self.n, self.world, self.rank, self.chunks = int(n), int(world), int(rank), max(1, int(chunks))
+        rpr = (self.n + self.world - 1) // self.world
+        self.cr = (rpr + self.chunks - 1) // self.chunks          # rows per chunk
+        self.rpr = self.cr * self.chunks
         self.lo = min(self.n, self.rank * self.rpr)
         self.hi = min(self.n, self.lo + self.rpr)
         self.rows = self.hi - self.lo
         self.n_pad = self.rpr * self.world
+
+    def chunk_rows(self, c):
+        """(offset inside the own range, row count) of chunk c of this rank."""
+        off = c * self.cr
+        return off, max(0, min(self.rows - off, self.cr))
+
+    def cm_position(self, v):
+        """Row of node id v in the CHUNK-MAJOR layout [chunk][rank][cr]: the layout in which the per-chunk
+        all-gathers of ShardedTeacher land contiguously."""
+        r, i = v // self.rpr, v % self.rpr
+        return ((i // self.cr) * self.world + r) * self.cr + i % self.cr
 
 
 def _storage_rows(buf):
@@ -60,11 +75,18 @@ def all_gather_rows(buf, shards, group=None):
 
 class ShardedTeacher:
     """SAGE layer-wise inference over a row-sharded graph.  `graph_shard` = full graph's rows [lo,hi)
-    (glnn_amd.graph.CSRGraph.row_range), column indices global."""
+    (glnn_amd.graph.CSRGraph.row_range), column indices global.
+
+    With shards.chunks > 1 the exchange of a widening layer is CHUNKED AND OVERLAPPED: the own rows are aggregated
+    chunk by chunk, each chunk's all-gather is issued asynchronously as soon as its aggregation is queued (it runs on
+    the collective's stream while the next chunk aggregates), and the replicated projection consumes the chunks in
+    arrival order.  The gathered activations then live in a chunk-major row order ([chunk][rank][rows]); the next
+    layer reads them through a column-index array relabelled once at construction -- no data is ever re-packed."""
 
     def __init__(self, encoder, graph_shard, shards, be, group=None):
         self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
         self._bufs = {}
+        self._indices_cm = None
 
     def _full_buffer(self, key, d, device):
         k = (key, d)
@@ -72,29 +94,94 @@ class ShardedTeacher:
             self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
         return self._bufs[k]
 
+    def _indices(self, layout):
+        if layout == "nat":
+            return self.g.indices
+        if self._indices_cm is None:      # one-time relabelling (outside any timed loop after the first forward)
+            self._indices_cm = self.sh.cm_position(self.g.indices.long()).to(torch.int32)
+        return self._indices_cm
+
+    def _pieces(self, layout):
+        """Own rows as (offset in own range, rows, slice into the full activation buffer) pieces."""
+        sh = self.sh
+        if layout == "nat":
+            return [(0, sh.rows, slice(sh.lo, sh.hi))]
+        out = []
+        for c in range(sh.chunks):
+            off, nr = sh.chunk_rows(c)
+            if nr > 0:
+                p0 = (c * sh.world + sh.rank) * sh.cr
+                out.append((off, nr, slice(p0, p0 + nr)))
+        return out
+
+    def _aggregate_project(self, x, layout, w, tail, out_own):
+        """Aggregate-first layer on the own rows (piecewise when x is chunk-major)."""
+        be, g = self.be, self.g
+        ep_scale, ep_shift, relu = tail
+        d_in, d_out = w.shape[1], w.shape[0]
+        idx = self._indices(layout)
+        for off, nr, sl in self._pieces(layout):
+            ip = g.indptr[off:off + nr + 1]            # absolute offsets into the one indices array
+            if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr], x_self=x[sl])
+            else:
+                agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl])
+                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
+
+    def _widening_layer_overlapped(self, l, x, w, tail):
+        """2*d_in <= d_out, world > 1, natural input layout: chunked aggregate -> async all-gather -> replicated GEMM."""
+        be, g, sh = self.be, self.g, self.sh
+        ep_scale, ep_shift, relu = tail
+        d_in, d_out = w.shape[1], w.shape[0]
+        agg = self._full_buffer(("agg", l), d_in, x.device)      # chunk-major [C][P][cr]
+        base = _storage_rows(agg)
+        span = sh.world * sh.cr
+        works = []
+        for c in range(sh.chunks):
+            off, nr = sh.chunk_rows(c)
+            p0 = (c * sh.world + sh.rank) * sh.cr
+            if nr > 0:
+                be.spmm(g.indptr[off:off + nr + 1], g.indices, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr],
+                        x_self=x[sh.lo + off:sh.lo + off + nr])
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+        y = self._full_buffer(("ycm", l), d_out, x.device)
+        for c in range(sh.chunks):
+            works[c]()
+            be.gemm(agg[c * span:(c + 1) * span], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[c * span:(c + 1) * span])
+        return y
+
     def forward(self, x_full):
         """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
         enc, sh, be, g = self.enc, self.sh, self.be, self.g
         x = be.as_feat(x_full)
+        layout = "nat"
         L = enc.num_layers
         y_own = None
         for l, layer in enumerate(enc.layers):
             w = layer.fc_neigh.weight
-            ep_scale, ep_shift, relu = enc._tail(l)
+            tail = enc._tail(l)
+            ep_scale, ep_shift, relu = tail
             d_in, d_out = w.shape[1], w.shape[0]
             last = l == L - 1
             if d_in > d_out:
-                # project own rows, exchange the narrow rows, aggregate own rows
+                # narrowing layer: project own rows, exchange the narrow rows, aggregate own rows (products layer 3:
+                # 47 floats per node on the wire instead of 256)
                 hw = self._full_buffer(("hw", l), d_out, x.device)
-                be.gemm(x[sh.lo:sh.hi], w, out=hw[sh.lo:sh.hi])
+                for off, nr, sl in self._pieces(layout):
+                    be.gemm(x[sl], w, out=hw[sh.lo + off:sh.lo + off + nr])
                 all_gather_rows(hw, sh, self.group)
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
                 be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                         out=out, x_self=hw[sh.lo:sh.hi])
-            elif sh.world > 1 and not last and 2 * d_in <= d_out:
+            elif sh.world > 1 and not last and 2 * d_in <= d_out and layout == "nat":
                 # widening layer (products layer 1: 100 -> 256): exchange the NARROW aggregate and let every rank
                 # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
                 # instead of 2.5 GB on products) for the price of a replicated [N, d_in] x [d_in, d_out] GEMM.
+                if sh.chunks > 1:
+                    x = self._widening_layer_overlapped(l, x, w, tail)
+                    layout = "cm"
+                    y_own = None
+                    continue
                 agg = self._full_buffer(("agg", l), d_in, x.device)
                 be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.lo:sh.hi], x_self=x[sh.lo:sh.hi])
                 all_gather_rows(agg, sh, self.group)
@@ -105,16 +192,28 @@ class ShardedTeacher:
                 continue
             else:
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
-                if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
-                    be.sage_fused(g.indptr, g.indices, x, sh.rows, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out,
-                                  x_self=x[sh.lo:sh.hi])
-                else:
-                    agg = be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, x_self=x[sh.lo:sh.hi])
-                    be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+                self._aggregate_project(x, layout, w, tail, out)
             y_own = out
             if not last:
                 x = all_gather_rows(self._full_buffer(("y", l), d_out, x.device), sh, self.group)
+                layout = "nat"
         return y_own
+
+
+def _all_gather_block(out_block, mine, shards, group):
+    """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot.
+    Returns a callable that makes the current stream wait for it."""
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_gather_into_tensor(out_block, mine, group=group, async_op=True)
+        return work.wait
+    tmp = [torch.empty_like(mine) for _ in range(shards.world)]
+    work = dist.all_gather(tmp, mine.contiguous(), group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        for r, t in enumerate(tmp):
+            out_block[r * shards.cr:(r + 1) * shards.cr].copy_(t)
+    return finish
 
 
 def make_grad_sync(flat_grads, world, group=None, average=False):

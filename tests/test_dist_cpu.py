@@ -70,7 +70,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, dims, seed, q):
+def _worker(rank, world, port, n, dims, seed, chunks, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -90,7 +90,7 @@ def _worker(rank, world, port, n, dims, seed, q):
                 bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
         enc.eval()
         x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
-        sh = RowShards(n, world, rank)
+        sh = RowShards(n, world, rank, chunks=chunks)
         be = OracleBackend()
         with torch.no_grad():
             y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be).forward(x)
@@ -102,8 +102,8 @@ def _worker(rank, world, port, n, dims, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,dims", [(1001, [12, 16, 16, 5]), (640, [8, 24, 6])])
-def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims):
+@pytest.mark.parametrize("n,dims,chunks", [(1001, [12, 16, 16, 5], 1), (640, [8, 24, 6], 1), (1003, [8, 24, 24, 6], 3), (90, [6, 16, 5], 4)])
+def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims, chunks):
     sys.path.insert(0, ROOT)
     from oracle import teacher_oracle as to
     from graphgen import random_graph
@@ -113,7 +113,7 @@ def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]

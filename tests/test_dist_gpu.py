@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, dims, q):
+def _worker(rank, world, port, n, dims, chunks, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, n, dims, q):
                 bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
         model.eval()
         want = model.inference(FullNeighborLoader(g, 1024), x)
-        sh = RowShards(nn_, world, rank)
+        sh = RowShards(nn_, world, rank, chunks=chunks)
         with torch.no_grad():
             y = ShardedTeacher(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops).forward(x)
         err = float((y - want[sh.lo:sh.hi]).abs().max())
@@ -48,12 +48,13 @@ def _worker(rank, world, port, n, dims, q):
         dist.destroy_process_group()
 
 
-def test_sharded_teacher_hip_two_ranks_one_gpu():
-    world, n, dims = 2, 9001, [128, 256, 256, 40]
+@pytest.mark.parametrize("dims,chunks", [([128, 256, 256, 40], 1), ([100, 256, 256, 47], 4)])
+def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks):
+    world, n = 2, 9001
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, chunks, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
