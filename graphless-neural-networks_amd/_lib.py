@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglnn_hip.so")
+LIB_PATH = os.environ.get("GLNN_LIB_PATH") or os.path.join(_HERE, "libglnn_hip.so")   # override: A/B of kernel variants
 
 c_i64, c_int, c_f32, c_vp, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_uint32
 

@@ -247,13 +247,17 @@ __device__ __forceinline__ float4 mask4(float4 v, int left) {   // keep elements
   return v;
 }
 
-template <int BN, bool B_KN, int XF>
+template <int BN, bool B_KN, int XF, int BKF>
 __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
+  constexpr int LDS_KF = BKF + 4;          // padded [row][k] stride; 9*i / 5*i mod 16 are bijections on the b128 lane groups
+  constexpr int KV = BKF / 4;              // float4 per tile row
+  constexpr int RSTEP = 256 / KV;          // rows covered by one pass of the 256 threads
+  constexpr int AQ = BM / RSTEP;
   constexpr int NT = BN / 64;
   constexpr int LDS_N = BN + 4;
-  constexpr int A_TILE = BM * LDS_K;
-  constexpr int B_TILE = B_KN ? BK * LDS_N : BN * LDS_K;
-  constexpr int BQ = B_KN ? (BK * BN / 4) / 256 : (BN * 8) / 256;
+  constexpr int A_TILE = BM * LDS_KF;
+  constexpr int B_TILE = B_KN ? BKF * LDS_N : BN * LDS_KF;
+  constexpr int BQ = B_KN ? (BKF * BN / 4) / 256 : BN / RSTEP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * A_TILE;
@@ -265,13 +269,13 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   const int li = lane & 31, kk = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int c4 = (tid & 7) * 4;          // k offset of this thread's float4 inside a [row][k] tile
-  const int r0 = tid >> 3;               // its first row; rows r0 + 32 q
+  const int c4 = (tid % KV) * 4;         // k offset of this thread's float4 inside a [row][k] tile
+  const int r0 = tid / KV;               // its first row; rows r0 + RSTEP q
 
-  const float* a_base[4];
+  const float* a_base[AQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int64_t mrow = m0 + r0 + 32 * q;
+  for (int q = 0; q < AQ; ++q) {
+    int64_t mrow = m0 + r0 + RSTEP * q;
     if (mrow > g.m - 1) mrow = g.m - 1;
     const int64_t src = g.a_rows ? g.a_rows[mrow] : mrow;
     a_base[q] = g.a + src * g.lda;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   if (!B_KN) {
 #pragma unroll
     for (int q = 0; q < BQ; ++q) {
-      int ng = n0 + r0 + 32 * q;
+      int ng = n0 + r0 + RSTEP * q;
       if (ng > g.n - 1) ng = g.n - 1;
       b_base[q] = g.b + (int64_t)ng * g.ldb;
     }
@@ -292,17 +296,17 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     for (int q = 0; q < BQ; ++q) b_base[q] = g.b + ng;
   }
 
-  float4 a_reg[4], b_reg[BQ], sc4, sh4;
+  float4 a_reg[AQ], b_reg[BQ], sc4, sh4;
   int kc_cur = 0;
   const int kpad = (g.k + 3) & ~3;
 
   auto load_tiles = [&](int kt) {
-    const int k0 = kt * BK;
+    const int k0 = kt * BKF;
     kc_cur = k0 + c4;
     int kcc = kc_cur;
     if (kcc > kpad - 4) kcc = kpad - 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a_reg[q] = ld4g(a_base[q] + kcc);
+    for (int q = 0; q < AQ; ++q) a_reg[q] = ld4g(a_base[q] + kcc);
     if (XF) {
       sc4 = ld4g(g.a_scale + kcc);
       sh4 = ld4g(g.a_shift + kcc);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     float* bs = Bs + buf * B_TILE;
     const int kleft = g.k - kc_cur;            // elements t < kleft of this float4 are inside K
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < AQ; ++q) {
       float4 v = a_reg[q];
       if (XF) {
         v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
         v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
         v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
         if (XF == 2) {
-          const uint32_t row = (uint32_t)(m0 + r0 + 32 * q);
+          const uint32_t row = (uint32_t)(m0 + r0 + RSTEP * q);
           v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 0) ? v.x * g.drop_scale : 0.f;
           v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 1) ? v.y * g.drop_scale : 0.f;
           v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 2) ? v.z * g.drop_scale : 0.f;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
         }
       }
       v = mask4(v, kleft);
-      *reinterpret_cast<float4*>(as + (r0 + 32 * q) * LDS_K + c4) = v;
+      *reinterpret_cast<float4*>(as + (r0 + RSTEP * q) * LDS_KF + c4) = v;
     }
 #pragma unroll
     for (int q = 0; q < BQ; ++q) {
@@ -347,11 +351,11 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
       if (B_KN) {
         const int f = tid + 256 * q;
         const int krow = f / (BN / 4);
-        if (kt * BK + krow >= g.k) v = zero4();
+        if (kt * BKF + krow >= g.k) v = zero4();
         *reinterpret_cast<float4*>(bs + krow * LDS_N + (f % (BN / 4)) * 4) = v;
       } else {
         v = mask4(v, kleft);
-        *reinterpret_cast<float4*>(bs + (r0 + 32 * q) * LDS_K + c4) = v;
+        *reinterpret_cast<float4*>(bs + (r0 + RSTEP * q) * LDS_KF + c4) = v;
       }
     }
   };
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk_all = (g.k + BK - 1) / BK;
+  const int nk_all = (g.k + BKF - 1) / BKF;
   const int kt_beg = blockIdx.z * g.ktiles_per_split;
   int kt_end = kt_beg + g.ktiles_per_split;
   if (kt_end > nk_all) kt_end = nk_all;
@@ -375,15 +379,15 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   for (int kt = kt_beg; kt < kt_end; ++kt) {
     const int cur = (kt - kt_beg) & 1;
     if (kt + 1 < kt_end) load_tiles(kt + 1);
-    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_KF + kk * 4;
     const float* bs = B_KN ? Bs + cur * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
-                           : Bs + cur * B_TILE + (wn * (BN / 2) + li) * LDS_K + kk * 4;
+                           : Bs + cur * B_TILE + (wn * (BN / 2) + li) * LDS_KF + kk * 4;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
+    for (int kg = 0; kg < BKF / 8; ++kg) {
       float af[2][4], bf[NT][4];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
+        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_KF + kg * 8);
         af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
       }
 #pragma unroll
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kg * 8 + t) * LDS_N + j * 32];
         } else {
-          const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
+          const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_KF + kg * 8);
           bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
         }
       }
@@ -750,16 +754,23 @@ int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g
   return rc;
 }
 
+#ifndef GLNN_GEMM_BKF
+#define GLNN_GEMM_BKF 32
+#endif
 template <int BN, bool B_KN>
-int launch_gemm(const GemmArgs& g, bool fast, hipStream_t st) {
-  constexpr int A_TILE = BM * LDS_K;
-  constexpr int B_TILE = B_KN ? BK * (BN + 4) : BN * LDS_K;
-  constexpr size_t smem = sizeof(float) * 2 * (A_TILE + B_TILE);
+int launch_gemm(GemmArgs& g, bool fast, hipStream_t st) {
+  constexpr int BKF = GLNN_GEMM_BKF;
+  constexpr size_t smem_generic = sizeof(float) * 2 * (BM * LDS_K + (B_KN ? BK * (BN + 4) : BN * LDS_K));
+  constexpr size_t smem_fast = sizeof(float) * 2 * (BM * (BKF + 4) + (B_KN ? BKF * (BN + 4) : BN * (BKF + 4)));
   static int cfg[4] = {1, 1, 1, 1};   // >0 = not configured yet
-  if (!fast) return launch_gemm_kernel(gemm_kernel_generic<BN, B_KN>, cfg[3], smem, g, BN, st);
-  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 0>, cfg[0], smem, g, BN, st);
-  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 1>, cfg[1], smem, g, BN, st);
-  return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 2>, cfg[2], smem, g, BN, st);
+  if (!fast) {
+    g.ksplits = 1; g.ktiles_per_split = (g.k + BK - 1) / BK;
+    return launch_gemm_kernel(gemm_kernel_generic<BN, B_KN>, cfg[3], smem_generic, g, BN, st);
+  }
+  if (BKF != BK) g.ktiles_per_split *= BK / BKF;     // split bookkeeping is in units of the fast kernel's k-tiles
+  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st);
+  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st);
+  return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 2, BKF>, cfg[2], smem_fast, g, BN, st);
 }
 
 }  // namespace

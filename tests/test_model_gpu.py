@@ -349,3 +349,20 @@ def test_train_sage_on_sampled_blocks_learns():
     loader = NodeDataLoader(g, torch.arange(n), MultiLayerNeighborSampler([5, 5]), batch_size=500, shuffle=True)
     losses = [te.train_sage(model, loader, x, y, torch.nn.NLLLoss(), opt) for _ in range(12)]
     assert losses[-1] < 0.85 * losses[0] and losses[-1] < min(losses[:3]), losses   # 5-of-~21 neighbour sampling is noisy
+
+
+def test_full_size_arxiv_teacher_forward_vs_oracle():
+    """BASELINE configs[1] at FULL size: ogbn-arxiv-shaped graph (169,343 nodes, 2,501,829 in-edges incl. reverse
+    edges, multi-edges and self-loops), SAGE 128-256-256-40 with BatchNorm, layer-wise full-neighbour inference on
+    the HIP path vs the CPU oracle (OpenMP) on identical inputs: max |diff| <= 1e-4."""
+    from glnn_amd import data
+    from glnn_amd.graph import FullNeighborLoader
+    g = data.make_graph("ogbn-arxiv", seed=0, device="cpu")
+    n = g.n_dst
+    assert n == 169343 and g.num_edges() == 2501829
+    x = np.random.RandomState(0).standard_normal((n, 128)).astype(np.float32)
+    model, layers, norms = _sage_model([128, 256, 256, 40], "batch", seed=3)
+    want = to.sage_inference(g.indptr.numpy(), g.indices.numpy(), x, layers, norms, threads=max(1, min(16, to.max_threads())))
+    got = model.inference(FullNeighborLoader(g.to(DEV), 512), torch.from_numpy(x).to(DEV))
+    assert got.shape == (n, 40)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
