@@ -38,19 +38,20 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 constexpr int kWave = 64;  // CDNA wavefront
 
-// Counter-based dropout: keep(row, col) under (seed, p).  lowbias32 integer hash of the element's
-// coordinates; the same function is evaluated by the forward operand transform, the weight-gradient
-// operand transform and the activation backward, so no mask is ever stored.
+// Counter-based dropout: keep(row, col) under (seed, p).  One lowbias32 integer hash per PAIR of adjacent columns,
+// 16 bits of it per element (p is quantised to 1/65536); the same function is evaluated by the forward operand
+// transform, the weight-gradient operand transform and the activation backward, so no mask is ever stored.
 __host__ __device__ inline uint32_t drop_hash(uint32_t seed, uint32_t row, uint32_t col) {
   uint32_t h = seed ^ (row * 0x9E3779B1u) ^ (col * 0x85EBCA77u + 0x632BE5ABu);
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
-__host__ __device__ inline uint32_t drop_threshold(float p) {   // keep iff (hash >> 8) >= threshold
-  return (uint32_t)(p * 16777216.0f);
+__host__ __device__ inline uint32_t drop_threshold(float p) {   // keep iff the element's 16 bits >= threshold
+  return (uint32_t)(p * 65536.0f);
 }
 __host__ __device__ inline bool drop_keep(uint32_t seed, uint32_t thr, uint32_t row, uint32_t col) {
-  return (drop_hash(seed, row, col) >> 8) >= thr;
+  const uint32_t h = drop_hash(seed, row, col >> 1);
+  return ((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thr;
 }
 
 }  // namespace glnn

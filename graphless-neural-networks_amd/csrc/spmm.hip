@@ -16,6 +16,8 @@
 //     overlaps the bulk), 8 waves per row, LDS fold in fixed order => deterministic results;
 //   * epilogue fused: +self, /(deg+1) (SAGE "gcn") or *row_scale (GraphConv / feature_prop), then
 //     optional per-column scale/shift (+ReLU) for the project-first form.
+#include <cstdlib>
+
 #include "glnn_common.h"
 
 namespace {
@@ -198,9 +200,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
 // aggregation of the others.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kFusedRows = 32;                     // destination rows per workgroup tile (64 rows / 16 waves measured 1.5x slower)
-constexpr int kFusedWaves = 8 * (kFusedRows / 32);  // one wave per (32-row tile, 32-column panel of W)
-constexpr int kFusedBlock = 64 * kFusedWaves;
+constexpr int kFusedWaves = 8;                      // one wave per 32-column panel of W (d_out <= 256)
+constexpr int kFusedBlock = 64 * kFusedWaves;       // 16-wave workgroups measured 1.5x slower (they drain badly)
 
 struct FusedArgs {
   const int64_t* indptr; const int32_t* indices; int64_t n_dst;
@@ -211,10 +212,11 @@ struct FusedArgs {
   float* out; int64_t ldo;
 };
 
-template <int LPR, int U>
+template <int LPR, int U, int RT>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains
 __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs a) {
+  constexpr int kFusedRows = 32 * RT;
   extern __shared__ __attribute__((aligned(16))) float lds_a[];      // [kFusedRows][kpad + 4]
-  __shared__ float4 s_part[kFusedWaves][64];
+  __shared__ float4 s_part[kFusedWaves / 2][64];   // 4 KiB: with the 33 KiB tile of K=256 this keeps 4 workgroups per CU
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col4 = (lane % LPR) * 4;
@@ -264,12 +266,13 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     if (e1 - e0 <= kLongRow) continue;
     const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane);
-    if (lane < LPR) s_part[wave][lane] = acc;
+    // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
+    if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
+    __syncthreads();
+    if (wave < 4 && lane < LPR) s_part[wave][lane] = add4(acc, s_part[wave][lane]);
     __syncthreads();
     if (wave == 0 && lane < LPR && col4 < kpad) {
-      float4 t = s_part[0][lane];
-#pragma unroll
-      for (int w = 1; w < kFusedWaves; ++w) t = add4(t, s_part[w][lane]);
+      const float4 t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (col_ok) {
         const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
@@ -284,16 +287,18 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     __syncthreads();
   }
 
-  // ---- phase B: [32 x K] (LDS) x W panel `wave` (packed, L2) on the MFMA ----------------------------
+  // ---- phase B: [32*RT x K] (LDS) x W panel `wave` (packed, L2) on the MFMA -------------------------
   const int n_tiles = (a.d_out + 31) / 32;
-  const int nt = wave & 7, rt = wave >> 3;            // column panel of W, 32-row sub-tile
+  const int nt = wave;                                 // column panel of W
   if (nt >= n_tiles) return;
   const int li = lane & 31, kk = lane >> 5;
   const float4* wp = reinterpret_cast<const float4*>(a.w_packed) + ((int64_t)nt * a.kgroups) * 64 + lane;
-  const float* ap = lds_a + (rt * 32 + li) * lda + kk * 4;
-  f32x16 acc;
+  const float* ap = lds_a + li * lda + kk * 4;
+  f32x16 acc[RT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   constexpr int PF = 4;                      // B fragments in flight
   float4 bq[PF];
 #pragma unroll
@@ -306,11 +311,17 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
         const float4 bv = bq[q];
         const int nxt = kg + PF;
         if (nxt < a.kgroups) bq[q] = wp[(int64_t)nxt * 64];
-        const float4 av = *reinterpret_cast<const float4*>(ap + kg * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        float4 av[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) av[t] = *reinterpret_cast<const float4*>(ap + t * 32 * lda + kg * 8);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv.x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv.y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv.z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv.w, acc[t], 0, 0, 0);
       }
     }
   }
@@ -320,14 +331,16 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     const float es = a.ep_scale ? a.ep_scale[col] : 1.f;
     const float eh = a.ep_shift ? a.ep_shift[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-      if (row < a.n_dst) {
-        float v = fmaf(acc[r], es, eh);
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.out[row * a.ldo + col] = v;
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (row < a.n_dst) {
+          float v = fmaf(acc[t][r], es, eh);
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.out[row * a.ldo + col] = v;
+        }
       }
-    }
   }
 }
 
@@ -481,18 +494,25 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.d_in = d_in; a.x_self = x_self;
   a.ld_self = ld_self; a.w_packed = w_packed; a.d_out = d_out; a.kgroups = (d_in + 7) / 8; a.ep_scale = ep_scale;
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
-  const int64_t blocks = (n_dst + kFusedRows - 1) / kFusedRows;
+  static const int rt_env = getenv("GLNN_FUSED_RT") ? atoi(getenv("GLNN_FUSED_RT")) : 0;   // tuning override (1 or 2)
+  const int rt = rt_env ? rt_env : 1;
+  const int rows_per_wg = 32 * rt;
+  const int64_t blocks = (n_dst + rows_per_wg - 1) / rows_per_wg;
   GLNN_REQUIRE(blocks < ((int64_t)1 << 31), "glnn_sage_fused_f32: n_dst too large for one launch");
-  const size_t smem = sizeof(float) * kFusedRows * (a.kgroups * 8 + 4);
+  const size_t smem = sizeof(float) * rows_per_wg * (a.kgroups * 8 + 4);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dv = dpad / 4;
   // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)
   const int kv = a.kgroups * 2;      // float4 per padded row
-  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, 8>),
+  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, 8, 2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 0 : -1;
   if (configured != 0) return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fused_f32: cannot raise the dynamic LDS limit");
-  if (kv <= 16 && dv <= 16) hipLaunchKernelGGL((sage_fused_kernel<16, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
-  else if (kv <= 32) hipLaunchKernelGGL((sage_fused_kernel<32, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
-  else hipLaunchKernelGGL((sage_fused_kernel<64, 8>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);
+#define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, 8, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
+  if (rt == 2) {
+    if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 2); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 2); else GLNN_FUSED_LAUNCH(64, 2);
+  } else {
+    if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 1); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 1); else GLNN_FUSED_LAUNCH(64, 1);
+  }
+#undef GLNN_FUSED_LAUNCH
   return glnn::check_launch("glnn_sage_fused_f32");
 }
