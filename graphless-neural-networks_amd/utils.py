@@ -17,34 +17,30 @@ OGB_data = ["ogbn-arxiv", "ogbn-products"]
 
 
 def set_seed(seed):
-    """reference utils.py:19-26"""
-    torch.manual_seed(seed)
-    np.random.seed(seed)
-    random.seed(seed)
+    """Seed every RNG the hot path draws from (reference utils.py:19-26): torch CPU (randperm of train_mini_batch,
+    parameter init), numpy, python; all CUDA generators when a GPU is present."""
+    for seeder in (torch.manual_seed, np.random.seed, random.seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
 
 
 def get_training_config(config_path, model_name, dataset):
-    """reference utils.py:29-41: `global` section overlaid by [dataset][model_name]; injects model_name."""
-    with open(config_path, "r") as conf:
-        full_config = yaml.load(conf, Loader=yaml.FullLoader)
-    dataset_specific_config = full_config["global"]
-    model_specific_config = full_config[dataset][model_name]
-    if model_specific_config is not None:
-        specific_config = dict(dataset_specific_config, **model_specific_config)
-    else:
-        specific_config = dataset_specific_config
-    specific_config["model_name"] = model_name
-    return specific_config
+    """Hyper-parameters of (dataset, model): the YAML's `global` section overlaid by [dataset][model_name], plus
+    `model_name` itself (reference utils.py:29-41).  An empty model section means "global only"."""
+    with open(config_path) as fh:
+        cfg = yaml.safe_load(fh)
+    merged = dict(cfg["global"])
+    merged.update(cfg[dataset][model_name] or {})
+    merged["model_name"] = model_name
+    return merged
 
 
 def check_writable(path, overwrite=True):
-    if not os.path.exists(path):
-        os.makedirs(path)
-    elif overwrite:
+    """Make sure `path` is a directory we can write to; overwrite=True empties an existing one."""
+    if overwrite and os.path.exists(path):
         shutil.rmtree(path)
-        os.makedirs(path)
+    os.makedirs(path, exist_ok=True)
 
 
 def check_readable(path):
@@ -52,54 +48,56 @@ def check_readable(path):
         raise ValueError(f"No such file or directory! {path}")
 
 
+def _pacific_now():
+    try:
+        import pytz
+        return datetime.now(pytz.timezone("US/Pacific"))
+    except Exception:  # pragma: no cover - pytz missing: local time
+        return datetime.now()
+
+
 def get_logger(filename, console_log=False, log_level=logging.INFO):
-    """reference utils.py:64-85 (US/Pacific timestamps when pytz is importable)."""
+    """File logger (+ optional console) with the reference's line format and US/Pacific clock (utils.py:59-85);
+    handlers of a previous run are dropped so repeated runs do not duplicate lines."""
     logger = logging.getLogger(__name__)
     logger.propagate = False
     logger.setLevel(log_level)
-    for hdlr in logger.handlers[:]:
-        logger.removeHandler(hdlr)
-    formatter = logging.Formatter("%(asctime)s: %(message)s", datefmt="%b%d %H-%M-%S")
-    try:
-        import pytz
-        tz = pytz.timezone("US/Pacific")
-        formatter.converter = lambda *a: datetime.now(tz).timetuple()
-    except Exception:  # pragma: no cover
-        pass
-    file_handler = logging.FileHandler(filename)
-    file_handler.setFormatter(formatter)
-    logger.addHandler(file_handler)
-    if console_log:
-        console_handler = logging.StreamHandler()
-        console_handler.setFormatter(formatter)
-        logger.addHandler(console_handler)
+    logger.handlers.clear()
+    fmt = logging.Formatter("%(asctime)s: %(message)s", datefmt="%b%d %H-%M-%S")
+    fmt.converter = lambda *_: _pacific_now().timetuple()
+    sinks = [logging.FileHandler(filename)] + ([logging.StreamHandler()] if console_log else [])
+    for sink in sinks:
+        sink.setFormatter(fmt)
+        logger.addHandler(sink)
     return logger
 
 
 def idx_split(idx, ratio, seed=0):
-    """reference utils.py:88-100"""
+    """Random two-way split of `idx` into int(n*ratio) and the rest, seeded (reference utils.py:88-100: the split is
+    a torch.randperm drawn right after set_seed(seed), so it is reproducible across the teacher and student runs)."""
     set_seed(seed)
-    n = len(idx)
-    cut = int(n * ratio)
-    idx_idx_shuffle = torch.randperm(n)
-    idx1_idx, idx2_idx = idx_idx_shuffle[:cut], idx_idx_shuffle[cut:]
-    return idx[idx1_idx], idx[idx2_idx]
+    order = torch.randperm(len(idx))
+    cut = int(len(idx) * ratio)
+    return idx[order[:cut]], idx[order[cut:]]
 
 
 def graph_split(idx_train, idx_val, idx_test, rate, seed):
-    """reference utils.py:103-127: hide `rate` of the test nodes for the inductive evaluation."""
+    """Inductive ("production") split (reference utils.py:103-127): `rate` of the test nodes are hidden
+    (idx_test_ind); the observed graph holds train + val + remaining test nodes IN THAT ORDER, so the obs_* index
+    sets are simply consecutive ranges of the observed numbering.
+    Returns (obs_idx_train, obs_idx_val, obs_idx_test, idx_obs, idx_test_ind)."""
     idx_test_ind, idx_test_tran = idx_split(idx_test, rate, seed)
     idx_obs = torch.cat([idx_train, idx_val, idx_test_tran])
-    n1, n2 = idx_train.shape[0], idx_val.shape[0]
-    obs_idx_all = torch.arange(idx_obs.shape[0])
-    return obs_idx_all[:n1], obs_idx_all[n1:n1 + n2], obs_idx_all[n1 + n2:], idx_obs, idx_test_ind
+    n_tr, n_va = len(idx_train), len(idx_val)
+    obs = torch.arange(len(idx_obs))
+    return obs[:n_tr], obs[n_tr:n_tr + n_va], obs[n_tr + n_va:], idx_obs, idx_test_ind
 
 
 def get_evaluator(dataset):
-    """The EFFECTIVE reference evaluator: the second definition (utils.py:151-156) shadows the OGB one."""
+    """Plain argmax accuracy for every dataset: the EFFECTIVE reference evaluator -- its second definition
+    (utils.py:151-156) shadows the OGB one (utils.py:130-148)."""
     def evaluator(out, labels):
-        pred = out.argmax(1)
-        return pred.eq(labels).float().mean().item()
+        return (out.argmax(1) == labels).float().mean().item()
     return evaluator
 
 
