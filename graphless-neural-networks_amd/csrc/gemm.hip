@@ -680,6 +680,153 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// TN, transposing loader (the fast weight-gradient path): C[i,j] = sum_m A[m,i] * B'[m,j].
+// Both operands are row-major along the NON-reduction index in global memory, which is the wrong way round
+// for the MFMA fragments (a lane wants 4 consecutive reduction terms).  Instead of reading them back with
+// 4x as many ds_read_b32 (the first TN kernel: 60 % MFMA busy), every thread loads a 4(m) x 4(col) block,
+// transposes it in registers and stores four 16-byte rows into [col][m] LDS tiles -- after that the main loop
+// is EXACTLY the NT kernel's (conflict-free ds_read_b128 fragments, 4 MFMAs per read).
+// Thread map: tid -> (rg: rows 4rg..4rg+3 of the 32-row k-tile, cg: columns 4cg..4cg+3), interleaved (below).
+// ---------------------------------------------------------------------------------------------
+template <int BNT, int XF>
+__global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
+  constexpr int NT = BNT / 64;
+  constexpr int A_TILE = BM * LDS_K, B_TILE = BNT * LDS_K;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][BM][LDS_K]   rows = output row index i, k = m
+  float* Bs = smem + 2 * A_TILE;         // [2][BNT][LDS_K]  rows = output col index j
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
+  const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BNT;
+  const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
+  int64_t mend = mbeg + g.rows_per_split;
+  if (mend > g.m) mend = g.m;
+
+  // interleaved map: within every 8 consecutive lanes rg takes 4 values and cg 2, so the four transposed b128
+  // stores of a lane group land on 8 distinct 16-byte slots (brute-forced: conflict-free; the plain
+  // tid/32, tid%32 map is 4-way conflicted); a wave still reads 256 contiguous bytes per global row
+  const int rg = (tid & 3) | (((tid >> 7) & 1) << 2), cg = (tid >> 2) & 31;
+  const bool b_active = cg < BNT / 4;                  // BNT = 64: half the column groups
+  int a_col = i0 + 4 * cg, b_col = j0 + 4 * cg;
+  const int kap = (g.ka + 3) & ~3, nbp = (g.nb + 3) & ~3;
+  if (a_col > kap - 4) a_col = kap - 4;               // clamped columns only feed outputs that are never stored
+  if (b_col > nbp - 4) b_col = nbp - 4;
+  float4 sc4 = zero4(), sh4 = zero4();
+  if (XF && b_active) {
+    sc4 = ld4g(g.b_scale + b_col);
+    sh4 = ld4g(g.b_shift + b_col);
+  }
+  float4 a_reg[4], b_reg[4];
+  int64_t mt_cur = 0;
+
+  auto load_tiles = [&](int64_t mt) {
+    mt_cur = mt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t mrow = mt + 4 * rg + r;
+      if (mrow > g.m - 1) mrow = g.m - 1;
+      a_reg[r] = ld4g(g.a + mrow * g.lda + a_col);
+      if (b_active) {
+        const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
+        b_reg[r] = ld4g(g.b + src * g.ldb + b_col);
+      }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float av[4][4], bv[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool in = mt_cur + 4 * rg + r < mend;        // rows past this split's end are reduction terms: zero them
+      const float4 a = in ? a_reg[r] : zero4();
+      av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
+      if (b_active) {
+        float4 b = b_reg[r];
+        if (XF) {
+          b.x = fmaxf(fmaf(b.x, sc4.x, sh4.x), 0.f);
+          b.y = fmaxf(fmaf(b.y, sc4.y, sh4.y), 0.f);
+          b.z = fmaxf(fmaf(b.z, sc4.z, sh4.z), 0.f);
+          b.w = fmaxf(fmaf(b.w, sc4.w, sh4.w), 0.f);
+          if (XF == 2) {
+            const uint32_t row = (uint32_t)(mt_cur + 4 * rg + r), c = (uint32_t)(j0 + 4 * cg);
+            b.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 0) ? b.x * g.drop_scale : 0.f;
+            b.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 1) ? b.y * g.drop_scale : 0.f;
+            b.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 2) ? b.z * g.drop_scale : 0.f;
+            b.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 3) ? b.w * g.drop_scale : 0.f;
+          }
+        }
+        if (!in) b = zero4();
+        bv[r][0] = b.x; bv[r][1] = b.y; bv[r][2] = b.z; bv[r][3] = b.w;
+      }
+    }
+    float* as = As + buf * A_TILE + (4 * cg) * LDS_K + 4 * rg;
+    float* bs = Bs + buf * B_TILE + (4 * cg) * LDS_K + 4 * rg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<float4*>(as + c * LDS_K) = make_float4(av[0][c], av[1][c], av[2][c], av[3][c]);
+      if (b_active) *reinterpret_cast<float4*>(bs + c * LDS_K) = make_float4(bv[0][c], bv[1][c], bv[2][c], bv[3][c]);
+    }
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t nkt = (mend - mbeg + BK - 1) / BK;
+  if (nkt > 0) {
+    load_tiles(mbeg);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int64_t kt = 0; kt < nkt; ++kt) {
+    const int cur = (int)(kt & 1);
+    if (kt + 1 < nkt) load_tiles(mbeg + (kt + 1) * BK);
+    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+    const float* bs = Bs + cur * B_TILE + (wn * (BNT / 2) + li) * LDS_K + kk * 4;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; ++kg) {
+      float af[2][4], bf[NT][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
+        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = j0 + wn * (BNT / 2) + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
+      }
+  }
+}
+
 // sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
 __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
                                     int64_t ldc, int ka, int nb) {
@@ -865,24 +1012,26 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   {
     constexpr size_t smem128 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (128 + 4));
     constexpr size_t smem64 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
+    constexpr size_t smem128t = sizeof(float) * 2 * (BM * LDS_K + 128 * LDS_K);
+    constexpr size_t smem64t = sizeof(float) * 2 * (BM * LDS_K + 64 * LDS_K);
     static int cfg[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     const dim3 grid(gi, gj, splits);
-#define GLNN_TN_LAUNCH(BNT_, FAST_, XF_, SLOT_, SMEM_)                                                        \
-  do {                                                                                                         \
-    if (cfg[SLOT_] > 0) cfg[SLOT_] = set_smem(gemm_tn_kernel<BNT_, FAST_, XF_>, SMEM_);                        \
-    if (cfg[SLOT_] != GLNN_OK) return cfg[SLOT_];                                                              \
-    hipLaunchKernelGGL((gemm_tn_kernel<BNT_, FAST_, XF_>), grid, dim3(256), SMEM_, st, g);                     \
+#define GLNN_TN_LAUNCH(KERNEL_, SLOT_, SMEM_)                                   \
+  do {                                                                          \
+    if (cfg[SLOT_] > 0) cfg[SLOT_] = set_smem(KERNEL_, SMEM_);                  \
+    if (cfg[SLOT_] != GLNN_OK) return cfg[SLOT_];                               \
+    hipLaunchKernelGGL(KERNEL_, grid, dim3(256), SMEM_, st, g);                 \
   } while (0)
     if (bnt == 128) {
-      if (!fast) GLNN_TN_LAUNCH(128, false, 0, 0, smem128);
-      else if (xf == 0) GLNN_TN_LAUNCH(128, true, 0, 1, smem128);
-      else if (xf == 1) GLNN_TN_LAUNCH(128, true, 1, 2, smem128);
-      else GLNN_TN_LAUNCH(128, true, 2, 3, smem128);
+      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel<128, false, 0>), 0, smem128);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0>), 1, smem128t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1>), 2, smem128t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2>), 3, smem128t);
     } else {
-      if (!fast) GLNN_TN_LAUNCH(64, false, 0, 4, smem64);
-      else if (xf == 0) GLNN_TN_LAUNCH(64, true, 0, 5, smem64);
-      else if (xf == 1) GLNN_TN_LAUNCH(64, true, 1, 6, smem64);
-      else GLNN_TN_LAUNCH(64, true, 2, 7, smem64);
+      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel<64, false, 0>), 4, smem64);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0>), 5, smem64t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1>), 6, smem64t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2>), 7, smem64t);
     }
 #undef GLNN_TN_LAUNCH
   }
