@@ -64,7 +64,9 @@ def all_gather_rows(buf, shards, group=None):
     base = _storage_rows(buf)
     mine = base[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(base, mine, group=group)
+        # source copied out of the destination: an aliased (in-place) all-gather is legal for RCCL itself, but this
+        # path cannot be exercised here (1 GPU), so it takes the unambiguous form; the copy is 1/world of the buffer
+        dist.all_gather_into_tensor(base, mine.clone(), group=group)
     else:   # gloo (CPU tests): list form
         tmp = [torch.empty_like(mine) for _ in range(shards.world)]
         dist.all_gather(tmp, mine.contiguous(), group=group)
@@ -204,7 +206,7 @@ def _all_gather_block(out_block, mine, shards, group):
     """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot.
     Returns a callable that makes the current stream wait for it."""
     if dist.get_backend(group) == "nccl":
-        work = dist.all_gather_into_tensor(out_block, mine, group=group, async_op=True)
+        work = dist.all_gather_into_tensor(out_block, mine.clone(), group=group, async_op=True)   # non-aliased source
         return work.wait
     tmp = [torch.empty_like(mine) for _ in range(shards.world)]
     work = dist.all_gather(tmp, mine.contiguous(), group=group, async_op=True)
