@@ -20,6 +20,9 @@ from .student import criterion_kind, get_engine
 from .utils import set_seed
 
 
+EVAL_BLOCK_ROWS = 1 << 19
+
+
 def train(model, data, feats, labels, criterion, optimizer, idx_train, lamb=1):
     """GNN full-batch training step (reference train_and_eval.py:12-29)."""
     model.train()
@@ -116,7 +119,12 @@ def evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, 
     model.eval()
     with torch.no_grad():
         if feats.is_cuda:
-            out_all = ops.log_softmax(model.inference(None, feats))
+            # big row blocks instead of ceil(N/B) mini-batches (same values), bounded so that a wide student over
+            # millions of rows does not materialise tens of GB of hidden activations at once
+            blk = max(int(batch_size), EVAL_BLOCK_ROWS)
+            out_all = torch.empty((feats.shape[0], model.encoder.layers[-1].out_features), dtype=torch.float32, device=feats.device)
+            for s0 in range(0, feats.shape[0], blk):
+                ops.log_softmax(model.inference(None, feats[s0:s0 + blk]), out=out_all[s0:s0 + blk])
         else:
             num_batches = int(np.ceil(len(feats) / batch_size))
             out_all = torch.cat([model.inference(None, feats[batch_size * i: batch_size * (i + 1)]).log_softmax(dim=1)
