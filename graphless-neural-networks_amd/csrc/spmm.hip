@@ -5,7 +5,8 @@
 // dgl GraphConv norm="both" aggregation (models.py:193) and update_all(copy_u,sum) (utils.py:185).
 //
 // Mapping
-//   * one 64-lane wavefront per destination row (rows of degree <= LONG_ROW), 8 waves per workgroup;
+//   * one 64-lane wavefront per destination row (rows of degree <= LONG_ROW), 8 waves per workgroup pulling the
+//     workgroup's rows from an LDS ticket counter (dynamic balance inside the workgroup);
 //   * a feature row of d floats is covered by LPR = 4..64 lanes moving float4 (LPR*16 B per row);
 //     the G = 64/LPR lane groups of the wave take different in-edges of the same row, U edges per
 //     group in flight, and are folded with two cross-lane adds at the end;
@@ -22,10 +23,32 @@
 
 namespace {
 
+// tuning knobs (compile-time).  Defaults = best of an interleaved sweep on ogbn-products shape, one MI355X:
+//   long-row threshold 64/96/128/192/256/512/2048 -> 128 (fused 100->256: 10.75 -> 9.8 ms, 256->256: 23.5 -> 22.3 ms
+//   vs 512; 64 over-uses the cooperative path); rows per wave 4/8/16 -> 16; stand-alone U 4/8 -> 8 (D=100: 9.45 ->
+//   8.8 ms); fused U 4/6/8/12 -> 8 (4..8 equal, 12 loses occupancy)
+#ifndef GLNN_SPMM_U
+#define GLNN_SPMM_U 8
+#endif
+#ifndef GLNN_FUSED_U
+#define GLNN_FUSED_U 8
+#endif
+#ifndef GLNN_ROWS_PER_WAVE
+#define GLNN_ROWS_PER_WAVE 16
+#endif
+#ifndef GLNN_LONG_ROW
+#define GLNN_LONG_ROW 128
+#endif
+#ifndef GLNN_LONG_BLOCK_ROWS
+#define GLNN_LONG_BLOCK_ROWS 4096
+#endif
+#ifndef GLNN_LONG_BLOCK_CAP
+#define GLNN_LONG_BLOCK_CAP 512
+#endif
 constexpr int kBlock = 512;              // 8 waves
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kRowsPerWave = 8;
-constexpr int kLongRow = 512;            // degree above which a whole workgroup takes the row
+constexpr int kRowsPerWave = GLNN_ROWS_PER_WAVE;
+constexpr int kLongRow = GLNN_LONG_ROW;  // degree above which a whole workgroup takes the row
 
 struct SpmmArgs {
   const int64_t* indptr;
@@ -170,12 +193,20 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     return;
   }
 
-  // ---- row role: one wave per row, rows interleaved across the 8 waves of the workgroup ----
+  // ---- row role: one wave per row; the 8 waves of the workgroup pull its 8*kRowsPerWave rows from an LDS ticket
+  //      (degrees vary by 100x: a static split leaves waves idle behind the heaviest one; measured -8 % at D=256) ----
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) s_ticket = 0;
+  __syncthreads();
   const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
   const int64_t row_base = blk * (kWavesPerBlock * kRowsPerWave);
 #pragma unroll 1
-  for (int r = 0; r < kRowsPerWave; ++r) {
-    const int64_t v = row_base + (int64_t)r * kWavesPerBlock + wave;
+  while (true) {
+    int lr = 0;
+    if (lane == 0) lr = atomicAdd(&s_ticket, 1);
+    lr = __builtin_amdgcn_readfirstlane(lr);
+    if (lr >= kWavesPerBlock * kRowsPerWave) break;
+    const int64_t v = row_base + lr;
     if (v >= a.n_dst) break;
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     const int64_t deg = e1 - e0;
@@ -190,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
 // for aggregate-first layers (d_in <= 256, d_out <= 256): the aggregated rows never go to HBM.
 //   phase A  the 8 waves of a workgroup aggregate a tile of 32 destination rows (4 rows each, the same
 //            wave_gather_sum as the stand-alone kernel) and park the normalised rows in LDS;
-//            rows of degree > 512 in the tile are then taken by all 8 waves together;
+//            rows of degree > LONG_ROW in the tile are then taken by all 8 waves together;
 //   phase B  wave w multiplies the LDS tile [32 x K] with the w-th 32-column panel of W on the fp32 MFMA
 //            (v_mfma_f32_32x32x2_f32).  W arrives PRE-PACKED in MFMA B-fragment order (glnn_pack_weight_f32),
 //            so each k-group is one coalesced 1 KiB load per wave straight from L2 -- no LDS staging and no
@@ -421,9 +452,9 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self;
     a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
     a.relu = relu; a.out = out + c0; a.ldo = ldo;
-    int64_t n_long = n_dst / 4096;
+    int64_t n_long = n_dst / GLNN_LONG_BLOCK_ROWS;       // workgroups in the long-row role
     if (n_long < 1) n_long = 1;
-    if (n_long > 512) n_long = 512;
+    if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
     a.n_long_blocks = (int)n_long;
     const int64_t rows_per_block = kWavesPerBlock * kRowsPerWave;
     const int64_t row_blocks = (n_dst + rows_per_block - 1) / rows_per_block;
@@ -431,11 +462,11 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     const int grid = (int)(row_blocks + n_long);
     const int dv = (dt + 3) / 4;
     int rc;
-    if (dv <= 4) rc = launch_lpr<4, 4>(a, mode, st, grid);
-    else if (dv <= 8) rc = launch_lpr<8, 4>(a, mode, st, grid);
-    else if (dv <= 16) rc = launch_lpr<16, 4>(a, mode, st, grid);
-    else if (dv <= 32) rc = launch_lpr<32, 4>(a, mode, st, grid);
-    else rc = launch_lpr<64, 4>(a, mode, st, grid);
+    if (dv <= 4) rc = launch_lpr<4, GLNN_SPMM_U>(a, mode, st, grid);
+    else if (dv <= 8) rc = launch_lpr<8, GLNN_SPMM_U>(a, mode, st, grid);
+    else if (dv <= 16) rc = launch_lpr<16, GLNN_SPMM_U>(a, mode, st, grid);
+    else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid);
+    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid);
     if (rc != GLNN_OK) return rc;
   }
   return GLNN_OK;
@@ -504,10 +535,10 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   const int dv = dpad / 4;
   // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)
   const int kv = a.kgroups * 2;      // float4 per padded row
-  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, 8, 2>),
+  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, GLNN_FUSED_U, 2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 0 : -1;
   if (configured != 0) return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fused_f32: cannot raise the dynamic LDS limit");
-#define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, 8, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
+#define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
   if (rt == 2) {
     if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 2); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 2); else GLNN_FUSED_LAUNCH(64, 2);
   } else {

@@ -19,7 +19,13 @@ def t(fn, iters=5):
     return s.elapsed_time(e) / iters
 
 
-for d_in, d_out in [(100, 256), (256, 256), (128, 256)]:
+def agg47():
+    x = torch.randn(n, 47, device=dev); x = ops.as_feat(x); out = ops.feat_empty(n, 47, dev)
+    return t(lambda: ops.spmm(g.indptr, g.indices, x, n, ops.AGG_SAGE_GCN, out=out))
+
+
+print("spmm d=47:", " ".join(f"{agg47():.2f}" for _ in range(3)), flush=True)
+for d_in, d_out in [(100, 256), (256, 256)]:
     x = torch.randn(n, d_in, device=dev)
     w = torch.randn(d_out, d_in, device=dev) / d_in ** 0.5
     sc = torch.rand(d_out, device=dev) + 0.5; sh = torch.randn(d_out, device=dev)
