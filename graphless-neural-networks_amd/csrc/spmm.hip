@@ -71,6 +71,27 @@ struct SpmmArgs {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// stream-once data (column indices, the output rows) moved with the non-temporal hint so that it does not evict the
+// re-used feature rows from L2 / Infinity Cache (GLNN_NT_STREAMS=0 compiles the plain forms for A/B)
+#ifndef GLNN_NT_STREAMS
+#define GLNN_NT_STREAMS 1
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+#if GLNN_NT_STREAMS
+  f32x4_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
+#else
+  st4(p, v);
+#endif
+}
+__device__ __forceinline__ int ld_idx_stream(const int32_t* p) {
+#if GLNN_NT_STREAMS
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 fma4(float s, float4 v, float4 a) {
   return make_float4(fmaf(s, v.x, a.x), fmaf(s, v.y, a.y), fmaf(s, v.z, a.z), fmaf(s, v.w, a.w));
@@ -93,7 +114,7 @@ __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ in
   for (int64_t base = e0 + (int64_t)wave_id * 64; base < e1; base += (int64_t)n_waves * 64) {
     const int64_t rem = e1 - base;
     const int cnt = rem < 64 ? (int)rem : 64;
-    const int my_idx = lane < cnt ? indices[base + lane] : 0;
+    const int my_idx = lane < cnt ? ld_idx_stream(indices + base + lane) : 0;
     float my_cs = 1.f;
     if (CS) my_cs = lane < cnt ? col_scale[my_idx] : 0.f;
     for (int j = 0; j < cnt; j += G * U) {
@@ -147,7 +168,7 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
       yy[t] = 0.f;  // padding columns are written as zero
     }
   }
-  st4(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
+  st4_stream(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
 }
 
 template <int LPR, int U, int MODE, bool CS>
