@@ -491,8 +491,10 @@ struct GemmTnArgs {
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
 };
 
-template <int BNT, bool FAST, int XF>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
+template <int BNT>
+__global__ __launch_bounds__(256) void gemm_tn_kernel_generic(const GemmTnArgs g) {
+  // GENERIC variant (any alignment): per-element guarded loads, k(m)-major LDS tiles read back with ds_read_b32.
+  // Only shapes whose rows are not 16-byte aligned take it; everything else uses gemm_tn_kernel_t below.
   constexpr int NT = BNT / 64;
   constexpr int LDA_S = BM + 4, LDB_S = BNT + 4;
   constexpr int A_TILE = BK * LDA_S, B_TILE = BK * LDB_S;
@@ -513,42 +515,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
   constexpr int BQ = (BK * BNT / 4) / 256;   // 4 or 2
   float4 a_reg[AQ], b_reg[BQ];
 
-  // FAST: unconditional float4 loads from clamped addresses; rows past the split's end are zeroed on the way
-  // to LDS (they are reduction terms), column tails only feed output rows/cols that are never stored.
-  const int a_c4 = (tid % (BM / 4)) * 4, a_r0 = tid / (BM / 4);      // A tile: BK rows x BM cols
-  const int b_c4 = (tid % (BNT / 4)) * 4, b_r0 = tid / (BNT / 4);    // B tile: BK rows x BNT cols
-  constexpr int A_RSTEP = 256 / (BM / 4), B_RSTEP = 256 / (BNT / 4);
-  int a_col = i0 + a_c4, b_col = j0 + b_c4;
-  if (FAST) {
-    const int kap = (g.ka + 3) & ~3, nbp = (g.nb + 3) & ~3;
-    if (a_col > kap - 4) a_col = kap - 4;
-    if (b_col > nbp - 4) b_col = nbp - 4;
-  }
-  float4 sc4 = zero4(), sh4 = zero4();
-  if (FAST && XF) {
-    sc4 = ld4g(g.b_scale + b_col);
-    sh4 = ld4g(g.b_shift + b_col);
-  }
-  int64_t mt_cur = 0;
-
   auto load_tiles = [&](int64_t mt) {
-    mt_cur = mt;
-    if (FAST) {
-#pragma unroll
-      for (int q = 0; q < AQ; ++q) {
-        int64_t mrow = mt + a_r0 + A_RSTEP * q;
-        if (mrow > g.m - 1) mrow = g.m - 1;
-        a_reg[q] = ld4g(g.a + mrow * g.lda + a_col);
-      }
-#pragma unroll
-      for (int q = 0; q < BQ; ++q) {
-        int64_t mrow = mt + b_r0 + B_RSTEP * q;
-        if (mrow > g.m - 1) mrow = g.m - 1;
-        const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
-        b_reg[q] = ld4g(g.b + src * g.ldb + b_col);
-      }
-      return;
-    }
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
       const int f = tid + 256 * q;
@@ -573,36 +540,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTnArgs g) {
     }
   };
   auto store_tiles = [&](int buf) {
-    if (FAST) {
-#pragma unroll
-      for (int q = 0; q < AQ; ++q) {
-        const int r = a_r0 + A_RSTEP * q;
-        float4 v = (mt_cur + r < mend) ? a_reg[q] : zero4();
-        *reinterpret_cast<float4*>(As + buf * A_TILE + r * LDA_S + a_c4) = v;
-      }
-#pragma unroll
-      for (int q = 0; q < BQ; ++q) {
-        const int r = b_r0 + B_RSTEP * q;
-        float4 v = b_reg[q];
-        if (XF) {
-          v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
-          v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
-          v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
-          v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
-          if (XF == 2) {
-            const uint32_t row = (uint32_t)(mt_cur + r);
-            const uint32_t c = (uint32_t)(j0 + b_c4);    // true column (dropout only runs with nb % 4 == 0)
-            v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 0) ? v.x * g.drop_scale : 0.f;
-            v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 1) ? v.y * g.drop_scale : 0.f;
-            v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 2) ? v.z * g.drop_scale : 0.f;
-            v.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 3) ? v.w * g.drop_scale : 0.f;
-          }
-        }
-        if (!(mt_cur + r < mend)) v = zero4();
-        *reinterpret_cast<float4*>(Bs + buf * B_TILE + r * LDB_S + b_c4) = v;
-      }
-      return;
-    }
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
       const int f = tid + 256 * q;
@@ -1023,12 +960,12 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
     hipLaunchKernelGGL(KERNEL_, grid, dim3(256), SMEM_, st, g);                 \
   } while (0)
     if (bnt == 128) {
-      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel<128, false, 0>), 0, smem128);
+      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<128>), 0, smem128);
       else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0>), 1, smem128t);
       else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1>), 2, smem128t);
       else GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2>), 3, smem128t);
     } else {
-      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel<64, false, 0>), 4, smem64);
+      if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<64>), 4, smem64);
       else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0>), 5, smem64t);
       else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1>), 6, smem64t);
       else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2>), 7, smem64t);

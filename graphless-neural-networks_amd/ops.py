@@ -68,7 +68,8 @@ def _mat(t, name):
 
 
 def _ld(t):
-    return t.stride(0)
+    # the stride of a size-1 dimension is arbitrary in torch/numpy: a single row is as wide as its columns
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
 def round4(d):

@@ -385,3 +385,34 @@ def test_full_size_student_pass_properties():
     assert float((out.exp().sum(1) - 1).abs().max()) < 1e-4
     agree = (out.argmax(1) == out_t.argmax(1)).float().mean().item()
     assert agree > 0.5, agree                                  # the student tracks the teacher after two passes
+
+
+# ------------------------------------------------------------------------------------------- randomized sweeps
+def test_randomized_shape_sweep_vs_oracle():
+    """40 seeded random (graph, width, mode) combinations through both aggregation kernels and the three GEMM forms."""
+    from glnn_amd import ops
+    rs = np.random.RandomState(2024)
+    for it in range(40):
+        n = int(rs.randint(1, 2500))
+        deg = float(rs.choice([0.5, 3, 12, 40]))
+        d = int(rs.choice([1, 3, 8, 31, 47, 64, 100, 129, 200, 256]))
+        indptr, indices = random_graph(n, deg, seed=it, power=float(rs.choice([0.0, 0.5, 0.9])), isolated=int(min(n // 3, rs.randint(0, 5))),
+                                       hub=int(rs.choice([0, 0, 300])) if n > 50 else 0)
+        x = rs.standard_normal((n, d)).astype(np.float32)
+        ip, ix, xd = dev(indptr), dev(indices), dev(x)
+        want = to.sage_gcn_agg(indptr, indices, x)
+        np.testing.assert_allclose(ops.spmm(ip, ix, xd, n, ops.AGG_SAGE_GCN).cpu().numpy(), want, atol=TOL, rtol=0, err_msg=f"it={it} n={n} d={d}")
+        rsc = rs.uniform(.2, 1, n).astype(np.float32)
+        np.testing.assert_allclose(ops.spmm(ip, ix, xd, n, ops.AGG_SUM, row_scale=dev(rsc), col_scale=dev(rsc)).cpu().numpy(),
+                                   to.spmm_sum(indptr, indices, x, rsc, rsc), atol=TOL, rtol=1e-5, err_msg=f"sum it={it}")
+        d_out = int(rs.choice([1, 5, 32, 47, 100, 256]))
+        w = (rs.standard_normal((d_out, d)) / np.sqrt(d)).astype(np.float32)
+        got = ops.sage_fused(ip, ix, xd, n, dev(w))
+        np.testing.assert_allclose(got.cpu().numpy(), to.linear(want, w), atol=TOL, rtol=0, err_msg=f"fused it={it} n={n} d={d} d_out={d_out}")
+        # GEMM forms on the same operands
+        np.testing.assert_allclose(ops.gemm(ops.as_feat(xd), dev(w)).cpu().numpy(), to.linear(x, w), atol=TOL, rtol=1e-5)
+        wk = np.ascontiguousarray(w.T)
+        np.testing.assert_allclose(ops.gemm(ops.as_feat(xd), dev(wk), w_is_kn=True).cpu().numpy(), to.linear(x, w), atol=TOL, rtol=1e-5)
+        dz = rs.standard_normal((n, d_out)).astype(np.float32) / 4
+        np.testing.assert_allclose(ops.gemm_tn(ops.as_feat(dev(dz)), ops.as_feat(xd)).cpu().numpy(),
+                                   dz.astype(np.float64).T @ x.astype(np.float64), atol=2e-4, rtol=1e-5, err_msg=f"tn it={it}")
