@@ -891,9 +891,13 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
     const int bn = n > 64 ? 128 : 64;
     const int64_t tiles = ((m + BM - 1) / BM) * ((n + bn - 1) / bn);
     const int nk = (k + BK - 1) / BK;
-    if (tiles < 256 && nk >= 8) {
+    if (tiles < 256 && nk >= 4) {
       int64_t sp = (512 + tiles - 1) / tiles;
-      if (sp > nk / 4) sp = nk / 4;                                   // >= 4 k-tiles per split
+      // big problems keep >= 4 k-tiles per split (the slab round trip must stay small next to the MFMA work); tiny
+      // ones (a handful of tiles, e.g. the B=512 student) are pure latency chains of dependent k-tiles: cut them to
+      // 2 k-tiles per workgroup
+      const int min_tiles_per_split = tiles <= 32 ? 2 : 4;
+      if (sp > nk / min_tiles_per_split) sp = nk / min_tiles_per_split;
       if (sp * m * n > workspace_floats) sp = workspace_floats / (m * n);
       if (sp > 1) {
         g.ktiles_per_split = (nk + (int)sp - 1) / (int)sp;
