@@ -366,3 +366,36 @@ def test_full_size_arxiv_teacher_forward_vs_oracle():
     got = model.inference(FullNeighborLoader(g.to(DEV), 512), torch.from_numpy(x).to(DEV))
     assert got.shape == (n, 40)
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+
+
+def test_full_size_xl_shard_properties():
+    """BASELINE configs[4] shard at FULL size: 12.5 M destination rows, 250 M in-edges into a 12.5 M-row source
+    matrix, D=128 (one GPU's share of the 100 M-node / 2 B-edge run).  Size-independent checks: the conservation
+    identity sum_v (deg_v+1)*out[v] == sum_u (outdeg_u+1)*x[u] in fp64, and bit-equality of a row-range relaunch."""
+    from glnn_amd import ops
+    from glnn_amd.graph import CSRGraph
+    rows, deg, d = 12_500_000, 20, 128
+    gen = torch.Generator(device=DEV); gen.manual_seed(7)
+    dst = torch.randint(0, rows, (rows * deg,), generator=gen, device=DEV)
+    src = torch.randint(0, rows, (rows * deg,), generator=gen, device=DEV)
+    order = torch.argsort(dst)
+    indices = src[order].to(torch.int32)
+    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=DEV)
+    torch.cumsum(torch.bincount(dst, minlength=rows), 0, out=indptr[1:])
+    outdeg = torch.bincount(src, minlength=rows).double()
+    del dst, src, order
+    g = CSRGraph(indptr, indices, rows)
+    assert g.num_edges() == 250_000_000
+    x = torch.randn(rows, d, device=DEV)
+    out = ops.spmm(g.indptr, g.indices, x, rows, ops.AGG_SAGE_GCN)
+    indeg = g.in_degrees().double()
+    lhs = torch.zeros(d, dtype=torch.float64, device=DEV)
+    rhs = torch.zeros(d, dtype=torch.float64, device=DEV)
+    for s0 in range(0, rows, 1 << 21):                       # fp64 reductions in slabs (bounded temporaries)
+        sl = slice(s0, s0 + (1 << 21))
+        lhs += ((indeg[sl] + 1).unsqueeze(1) * out[sl].double()).sum(0)
+        rhs += ((outdeg[sl] + 1).unsqueeze(1) * x[sl].double()).sum(0)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1)) < 1e-4
+    lo, hi = 5_000_000, 5_400_000
+    part = ops.spmm(g.indptr[lo:hi + 1], g.indices, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x[lo:hi])
+    assert torch.equal(part, out[lo:hi])
