@@ -6,7 +6,9 @@ bench.py's cpu_baseline leg; never by the product package.
 PARITY STATUS: "parity unpinned" by the reference itself -- the arithmetic is in
 the absent third-party dgl==0.6.1 and the reference has no tests.
 Pinned instead by known answers + scipy.sparse + torch.sparse_csr in
-tests/test_oracle_teacher.py.
+tests/test_oracle_teacher.py.  The COMPOSITION below (sweep, BN/ReLU order, raw last
+layer) is pinned by the reference's own models.py run with stubbed dgl layers:
+tests/golden/teacher_composition.npz (made by tests/golden/make_teacher_golden.py).
 
 The per-op arithmetic is the C restatement in oracle/glnn_oracle.c; this file
 only composes it the way the reference's Python does:

@@ -67,3 +67,27 @@ class Golden:
         if self.full or a.ndim == 0:
             return a
         return a.astype(np.float32).ravel()[:: self.stride]
+
+
+def teacher_composition():
+    """tests/golden/teacher_composition.npz: outputs of the reference's own SAGE.inference / GCN.forward_fitnet
+    (dgl layers stubbed by torch.sparse stand-ins; see make_teacher_golden.py).  Returns {prefix: dict}."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "teacher_composition.npz"))
+    out = {"sage": {"sd": {}}, "gcn": {"sd": {}}}
+    for k in z.files:
+        fam, rest = k.split(".", 1)
+        if rest.startswith("sd."):
+            out[fam]["sd"][rest[3:]] = z[k]
+        else:
+            out[fam][rest] = z[k]
+    return out
+
+
+def sage_layers_from_sd(sd, num_layers, batch_norm=True):
+    layers = [dict(weight=sd[f"encoder.layers.{i}.fc_neigh.weight"], bias=sd[f"encoder.layers.{i}.fc_neigh.bias"])
+              for i in range(num_layers)]
+    norms = [dict(weight=sd[f"encoder.norms.{i}.weight"], bias=sd[f"encoder.norms.{i}.bias"],
+                  running_mean=sd[f"encoder.norms.{i}.running_mean"], running_var=sd[f"encoder.norms.{i}.running_var"])
+             for i in range(num_layers - 1)] if batch_norm else None
+    return layers, norms

@@ -229,6 +229,44 @@ def test_gcn_forward_cora_shape_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
 
 
+def test_teacher_composition_vs_reference_golden():
+    """tests/golden/teacher_composition.npz holds what the reference's OWN models.py produced (SAGE.inference over a
+    block dataloader; GCN.forward_fitnet) with dgl's two layers stubbed by torch.sparse stand-ins.  The reference's
+    state_dict must load into this package's Model (strict) and reproduce those logits on the HIP path, through the
+    whole-graph fast path, the reference-style chunked sweep, and the sampled-block forward."""
+    from golden_inputs import teacher_composition
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    from glnn_amd.models import Model
+    gold = teacher_composition()
+    s = gold["sage"]
+    dims = [int(v) for v in s["dims"]]
+    model = Model(dict(model_name="SAGE", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                       dropout_ratio=0.5, norm_type="batch", device=DEV))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in s["sd"].items()}, strict=True)
+    model.eval()
+    n = len(s["indptr"]) - 1
+    g = CSRGraph(torch.from_numpy(s["indptr"]).to(DEV), torch.from_numpy(s["indices"]).to(DEV), n)
+    loader = FullNeighborLoader(g, int(s["batch_size"]))
+    x = torch.from_numpy(s["feats"]).to(DEV)
+    np.testing.assert_allclose(model.inference(loader, x).cpu().numpy(), s["logits"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(model.encoder.inference(loader, x, whole_graph=False).cpu().numpy(), s["logits"], atol=TOL, rtol=0)
+    with torch.no_grad():      # SAGE.forward over [g, g, g] as full-neighbour "blocks" is the same function in eval mode
+        np.testing.assert_allclose(model([g] * (len(dims) - 1), x).cpu().numpy(), s["logits"], atol=TOL, rtol=0)
+
+    c = gold["gcn"]
+    dims = [int(v) for v in c["dims"]]
+    gcn = Model(dict(model_name="GCN", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                     dropout_ratio=0.8, norm_type="none", device=DEV))
+    gcn.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in c["sd"].items()}, strict=True)
+    gcn.eval()
+    n = len(c["indptr"]) - 1
+    g = CSRGraph(torch.from_numpy(c["indptr"]).to(DEV), torch.from_numpy(c["indices"]).to(DEV), n)
+    with torch.no_grad():
+        h_list, logits = gcn.forward_fitnet(g, torch.from_numpy(c["feats"]).to(DEV))
+    np.testing.assert_allclose(logits.cpu().numpy(), c["logits"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(h_list[0].cpu().numpy(), c["h0"], atol=TOL, rtol=0)
+
+
 def test_feature_prop_vs_oracle():
     from glnn_amd import utils
     from glnn_amd.graph import CSRGraph

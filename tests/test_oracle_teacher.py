@@ -130,3 +130,30 @@ def test_gcn_forward_matches_dense_formula():
     h1 = np.maximum(ahat @ (x.astype(np.float64) @ w0) + b0, 0)
     want = ahat @ (h1 @ w1) + b1
     np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+
+
+# ---- composition pinned by the reference's own models.py (tests/golden/make_teacher_golden.py) ----
+def test_sage_inference_vs_reference_composition_golden():
+    """The reference's SAGE.inference loop (models.py:121-148) run over its dataloader of blocks, with dgl's
+    SAGEConv stubbed by a torch.sparse stand-in.  Pins the oracle's sweep, BN(eval)->ReLU order, the raw last
+    layer and the state_dict layout; chunked and whole-graph restatements must both reproduce it."""
+    from golden_inputs import sage_layers_from_sd, teacher_composition
+    g = teacher_composition()["sage"]
+    layers, norms = sage_layers_from_sd(g["sd"], len(g["dims"]) - 1)
+    whole = to.sage_inference(g["indptr"], g["indices"], g["feats"], layers, norms)
+    chunked = to.sage_inference(g["indptr"], g["indices"], g["feats"], layers, norms, batch_size=int(g["batch_size"]))
+    np.testing.assert_allclose(whole, g["logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(chunked, g["logits"], atol=1e-4, rtol=0)
+
+
+def test_gcn_forward_vs_reference_composition_golden():
+    """The reference's GCN.forward (models.py:189-199) with dgl's GraphConv(norm='both') stubbed; in > out on both
+    layers (weight-first order), dropout no-op in eval, h_list[0] is the post-activation conv output."""
+    from golden_inputs import teacher_composition
+    g = teacher_composition()["gcn"]
+    L = len(g["dims"]) - 1
+    layers = [dict(weight=g["sd"][f"encoder.layers.{i}.weight"], bias=g["sd"][f"encoder.layers.{i}.bias"]) for i in range(L)]
+    got = to.gcn_forward(g["indptr"], g["indices"], g["feats"], layers)
+    np.testing.assert_allclose(got, g["logits"], atol=1e-4, rtol=0)
+    h0 = to.graph_conv_both(g["indptr"], g["indices"], g["feats"], layers[0]["weight"], layers[0]["bias"], relu=True)
+    np.testing.assert_allclose(h0, g["h0"], atol=1e-4, rtol=0)
