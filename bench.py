@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; 1.0 = the metric's config)")
     ap.add_argument("--student-steps-per-step", type=int, default=10, help="student steps timed per --steps unit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--student-global-bn", action="store_true",
+                    help="N > 1: take the student's BatchNorm batch statistics over the global (N x B rows) batch through the "
+                         "exchange hook, i.e. exactly the single-GPU step on that batch (default: per-rank statistics)")
     ap.add_argument("--workload", default="products", choices=["products", "xl"],
                     help="products = the metric's config (default); xl = BASELINE.json configs[4]: 12.5M-node / 250M-edge shard per GPU "
                          "of a 100M-node / 2B-edge synthetic graph, 128-d features, SAGE layer-1 aggregation only (weak scaling)")
@@ -161,7 +164,9 @@ def main():
     student.train()
     opt = torch.optim.Adam(student.parameters(), lr=sd["lr"], weight_decay=sd["wd"])
     eng = StudentEngine(student, opt, sd["batch"])
-    if world > 1:   # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
+    if world > 1 and args.student_global_bn:     # one N*B-row batch split over ranks, global BN statistics, summed gradients
+        eng.enable_batch_split(world, rank)
+    elif world > 1:   # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
         eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
     out_t = ops.as_feat(out_t)
     k_student = args.steps * args.student_steps_per_step
@@ -203,6 +208,8 @@ def main():
                               "KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
                     "value": student_steps_per_s, "unit": "steps/s", "steps": k_student, "warmup": w_student,
                     "ms_per_step": 1e3 * t_student / k_student, "global_batch": world * sd["batch"],
+                    "batchnorm": "global batch statistics (exchange hook)" if (world > 1 and args.student_global_bn)
+                                 else "per-rank batch statistics",
                     "scaling": "weak", "gflop_per_step": 3 * 2 * sd["batch"] * (100 * 2048 + 2048 * 2048 + 2048 * 47) / 1e9},
     }
     result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3

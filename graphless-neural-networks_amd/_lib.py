@@ -45,6 +45,11 @@ MLP_MAX_LAYERS = 8
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
+ABI_VERSION = 2
+# glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
+EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
 class MlpStepDesc(ctypes.Structure):
     """glnn_mlp_step_desc of include/glnn_hip.h (field for field)."""
     _fields_ = ([("num_layers", ctypes.c_int32), ("batchnorm", ctypes.c_int32), ("dims", ctypes.c_int32 * (MLP_MAX_LAYERS + 1)),
@@ -56,7 +61,9 @@ class MlpStepDesc(ctypes.Structure):
                  ("da", c_vp), ("ld_da", c_i64), ("dz", c_vp), ("ld_dz", c_i64),
                  ("ws_bn", c_vp), ("ws_bn_floats", c_i64), ("ws_tn", c_vp), ("ws_tn_floats", c_i64),
                  ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64), ("ws_loss", c_vp), ("ws_loss_floats", c_i64),
-                 ("loss_out", c_vp), ("loss_accum", c_vp)])
+                 ("loss_out", c_vp), ("loss_accum", c_vp),
+                 ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
+                 ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp)])
 
 
 _lib = None
@@ -81,6 +88,8 @@ def lib():
         h.glnn_packed_weight_floats.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
+        if h.glnn_abi_version() != ABI_VERSION:
+            raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
         _lib = h
     return _lib
 

@@ -54,4 +54,21 @@ __host__ __device__ inline bool drop_keep(uint32_t seed, uint32_t thr, uint32_t 
   return ((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thr;
 }
 
+// The batch-split group of glnn_mlp_step_desc as the BatchNorm kernels see it (student.hip); NULL = single rank.
+struct BnGroup {
+  int world, rank;
+  glnn_exchange_fn exchange;
+  void* ctx;
+  float* send;
+  float* recv;
+  float* rows_out;   // device float: global row count of the step (written in the forward, read in the backward)
+};
+int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps, float momentum,
+             float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out, float* rstd_out,
+             float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream, const BnGroup* g);
+int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
+                const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
+                float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
+                void* stream, const BnGroup* g);
+
 }  // namespace glnn

@@ -20,6 +20,15 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   const float p = d->dropout_p;
   GLNN_REQUIRE(p == 0.f || drop_seeds, "glnn_mlp_fwd_bwd_f32: dropout needs per-layer seeds");
 
+  glnn::BnGroup grp_storage;
+  const glnn::BnGroup* grp = nullptr;
+  if (d->world > 1 && d->batchnorm) {
+    GLNN_REQUIRE(d->exchange && d->sync_send && d->sync_recv && d->sync_rows && d->rank >= 0 && d->rank < d->world,
+                 "glnn_mlp_fwd_bwd_f32: world=%d needs the exchange hook, sync buffers and a valid rank", d->world);
+    grp_storage = {d->world, d->rank, d->exchange, d->exchange_ctx, d->sync_send, d->sync_recv, d->sync_rows};
+    grp = &grp_storage;
+  }
+
   // ---- forward ----
   const float* src = feats;
   int64_t ld_src = ldx;
@@ -35,9 +44,9 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
                            d->ws_gemm, d->ws_gemm_floats, stream));
     if (!last) {
       if (d->batchnorm)
-        GLNN_TRY(glnn_bn_stats_f32(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
+        GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                    d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
-                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream));
+                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp));
       a_scale = d->a_scale[l];
       a_shift = d->a_shift[l];
       src = out;
@@ -65,9 +74,9 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
     if (d->batchnorm) {
-      GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
-                                    d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
-                                    d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream));
+      GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
+                                 d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
+                                 d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp));
     } else {
       GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
                                     nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,

@@ -161,27 +161,44 @@ __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__
 }
 
 struct BnFinArgs {
-  const float* ws_mean; const float* ws_m2; int nchunks; int64_t rows; int h;
+  // partial k of column c:  mean = ws_mean[k*pstride + c], M2 = ws_m2[k*pstride + c], count = ws_cnt ? ws_cnt[k*pstride + c]
+  // : rows of chunk k.  (Local chunks: pstride = h, ws_cnt = NULL.  Gathered per-rank triples: pstride = 3h.)
+  const float* ws_cnt; const float* ws_mean; const float* ws_m2; int nparts; int64_t pstride; int64_t rows; int h;
+  // emit mode (emit_cnt != NULL): write the combined (count, mean, M2) and stop -- the per-rank triple that is exchanged
+  float* emit_cnt; float* emit_mean; float* emit_m2;
   const float* gamma; const float* beta; float eps; float momentum;
   float* running_mean; float* running_var; int64_t* nbt;
-  float* mean_out; float* rstd_out; float* a_scale; float* a_shift;
+  float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
 };
 
 __global__ void bn_stats_stage2(const BnFinArgs a) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col == 0 && a.nbt) a.nbt[0] += 1;
+  if (col == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
   if (col >= a.h) return;
   double n = 0.0, mean = 0.0, m2 = 0.0;
-  for (int k = 0; k < a.nchunks; ++k) {
-    int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
-    if (r1 > a.rows) r1 = a.rows;
-    const double nb = (double)(r1 - r0);
-    const double mb = a.ws_mean[(int64_t)k * a.h + col], qb = a.ws_m2[(int64_t)k * a.h + col];
+  for (int k = 0; k < a.nparts; ++k) {
+    double nb;
+    if (a.ws_cnt) {
+      nb = (double)a.ws_cnt[(int64_t)k * a.pstride + col];
+    } else {
+      int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
+      if (r1 > a.rows) r1 = a.rows;
+      nb = (double)(r1 - r0);
+    }
+    if (nb <= 0.0) continue;                                   // a rank with an empty slice of the batch
+    const double mb = a.ws_mean[(int64_t)k * a.pstride + col], qb = a.ws_m2[(int64_t)k * a.pstride + col];
     const double delta = mb - mean, nn = n + nb;
     mean += delta * nb / nn;
     m2 += qb + delta * delta * n * nb / nn;
     n = nn;
   }
+  if (a.emit_cnt) {
+    a.emit_cnt[col] = (float)n;
+    a.emit_mean[col] = (float)mean;
+    a.emit_m2[col] = (float)m2;
+    return;
+  }
+  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
   const float var_b = (float)(m2 / n);                         // biased: used for normalisation
   const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
   const float meanf = (float)mean;
@@ -209,6 +226,10 @@ struct BnBwdArgs {
   float* dz; int64_t lddz; float* dgamma; float* dbeta;
   float* ws1; float* ws2; float* ws3;   // [nchunks][h] each; ws3 may be NULL (no bias gradient wanted)
   int nchunks;
+  // what bn_bwd_apply sums for S1/S2: nparts partials `pstride` floats apart starting at p1/p2 (local chunks: = ws1/ws2,
+  // nchunks, h; batch split over ranks: the gathered per-rank sums).  dgamma/dbeta = the LOCAL sums: all partials
+  // (local_part < 0) or partial `local_part` only.  rows_total: device float holding the global row count, or NULL.
+  const float* p1; const float* p2; int nparts; int64_t pstride; int local_part; const float* rows_total;
 };
 
 template <bool BN>
@@ -266,17 +287,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
   float S1 = 0.f, S2 = 0.f, mu = 0.f, rs = 1.f, sc = 1.f, sf = 0.f, g = 1.f;
   if (BN) {
     // every row lane sums the same partials in the same order -> identical S1/S2 in all four lanes, no LDS hop
-    for (int k = 0; k < a.nchunks; ++k) {
-      S1 += a.ws1[(int64_t)k * a.h + colc];
-      S2 += a.ws2[(int64_t)k * a.h + colc];
+    for (int k = 0; k < a.nparts; ++k) {
+      S1 += a.p1[(int64_t)k * a.pstride + colc];
+      S2 += a.p2[(int64_t)k * a.pstride + colc];
     }
     mu = a.mean[colc]; rs = a.rstd[colc]; sc = a.a_scale[colc]; sf = a.a_shift[colc]; g = a.gamma[colc];
     if (blockIdx.y == 0 && rl == 0 && col < a.h) {
-      a.dbeta[col] = S1;
-      a.dgamma[col] = S2;
+      a.dbeta[col] = a.local_part < 0 ? S1 : a.p1[(int64_t)a.local_part * a.pstride + col];
+      a.dgamma[col] = a.local_part < 0 ? S2 : a.p2[(int64_t)a.local_part * a.pstride + col];
     }
   }
-  const float inv_b = 1.0f / (float)a.rows;
+  const float inv_b = 1.0f / (a.rows_total ? a.rows_total[0] : (float)a.rows);
   const float c1 = S1 * inv_b, c2 = S2 * inv_b, grs = g * rs;
   float sdz = 0.f;
 #pragma unroll
@@ -314,6 +335,20 @@ __global__ void chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int 
   float s = 0.f;
   for (int k = 0; k < nchunks; ++k) s += ws[(int64_t)k * h + col];
   out[col] = s;
+}
+
+// send[0:h] = sum_k ws1[k], send[h:2h] = sum_k ws2[k]  (this rank's S1/S2, the 2h floats exchanged in the backward)
+__global__ void chunk_sum2_kernel(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks, int h,
+                                  float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= h) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    s1 += ws1[(int64_t)k * h + col];
+    s2 += ws2[(int64_t)k * h + col];
+  }
+  out[col] = s1;
+  out[h + col] = s2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -383,10 +418,16 @@ extern "C" int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t ro
   return glnn::check_launch("glnn_log_softmax_f32");
 }
 
-extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var,
-                                 int64_t* num_batches_tracked, float* mean_out, float* rstd_out, float* a_scale_out,
-                                 float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream) {
+static int run_exchange(const glnn::BnGroup* g, int64_t floats, void* stream, const char* what) {
+  const int rc = g->exchange(g->ctx, g->send, g->recv, floats, stream);
+  if (rc != 0) return glnn::fail(GLNN_ERR_INVALID_ARG, "%s: the exchange hook returned %d", what, rc);
+  return GLNN_OK;
+}
+
+int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out,
+                   float* rstd_out, float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats,
+                   void* stream, const glnn::BnGroup* g) {
   GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
@@ -395,19 +436,39 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
   float* ws_mean = workspace;
   float* ws_m2 = workspace + (int64_t)nchunks * h;
   hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2);
-  BnFinArgs a;
-  a.ws_mean = ws_mean; a.ws_m2 = ws_m2; a.nchunks = nchunks; a.rows = rows; a.h = h; a.gamma = gamma; a.beta = beta;
+  BnFinArgs a = {};
+  a.ws_mean = ws_mean; a.ws_m2 = ws_m2; a.nparts = nchunks; a.pstride = h; a.rows = rows; a.h = h; a.gamma = gamma; a.beta = beta;
   a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
   a.mean_out = mean_out; a.rstd_out = rstd_out; a.a_scale = a_scale_out; a.a_shift = a_shift_out;
-  hipLaunchKernelGGL(bn_stats_stage2, dim3((h + 127) / 128), dim3(128), 0, st, a);
+  const dim3 fgrid((h + 127) / 128);
+  if (g) {
+    // this rank's (count, mean, M2) -> all-gather -> the same fixed-order combine over the rank triples
+    BnFinArgs e = a;
+    e.emit_cnt = g->send; e.emit_mean = g->send + h; e.emit_m2 = g->send + 2 * h;
+    hipLaunchKernelGGL(bn_stats_stage2, fgrid, dim3(128), 0, st, e);
+    const int rc = glnn::check_launch("glnn_bn_stats_f32");
+    if (rc != GLNN_OK) return rc;
+    const int rx = run_exchange(g, 3ll * h, stream, "glnn_bn_stats_f32");
+    if (rx != GLNN_OK) return rx;
+    a.ws_cnt = g->recv; a.ws_mean = g->recv + h; a.ws_m2 = g->recv + 2 * h; a.nparts = g->world; a.pstride = 3ll * h;
+    a.rows_out = g->rows_out;
+  }
+  hipLaunchKernelGGL(bn_stats_stage2, fgrid, dim3(128), 0, st, a);
   return glnn::check_launch("glnn_bn_stats_f32");
 }
 
-extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
-                                    const float* gamma, const float* mean, const float* rstd, const float* a_scale,
-                                    const float* a_shift, float drop_p, uint32_t drop_seed, float* dz, int64_t lddz,
-                                    float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
-                                    int64_t workspace_floats, void* stream) {
+extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean_out, float* rstd_out, float* a_scale_out,
+                                 float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream) {
+  return glnn::bn_stats(z, ldz, rows, h, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
+                        rstd_out, a_scale_out, a_shift_out, workspace, workspace_floats, stream, nullptr);
+}
+
+int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
+                      const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
+                      uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
+                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -424,15 +485,34 @@ extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* 
   if (dz_col_sum) a.ws3 = w;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((h + 63) / 64, nchunks);
+  a.p1 = a.ws1; a.p2 = a.ws2; a.nparts = nchunks; a.pstride = h; a.local_part = -1; a.rows_total = nullptr;
   if (gamma) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
+    if (g) {
+      hipLaunchKernelGGL(chunk_sum2_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws1, a.ws2, nchunks, h, g->send);
+      const int rc = glnn::check_launch("glnn_bn_relu_bwd_f32");
+      if (rc != GLNN_OK) return rc;
+      const int rx = run_exchange(g, 2ll * h, stream, "glnn_bn_relu_bwd_f32");
+      if (rx != GLNN_OK) return rx;
+      a.p1 = g->recv; a.p2 = g->recv + h; a.nparts = g->world; a.pstride = 2ll * h; a.local_part = g->rank;
+      a.rows_total = g->rows_out;
+    }
     hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
   }
   if (dz_col_sum) hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws3, nchunks, h, dz_col_sum);
   return glnn::check_launch("glnn_bn_relu_bwd_f32");
+}
+
+extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
+                                    const float* gamma, const float* mean, const float* rstd, const float* a_scale,
+                                    const float* a_shift, float drop_p, uint32_t drop_seed, float* dz, int64_t lddz,
+                                    float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                                    int64_t workspace_floats, void* stream) {
+  return glnn::bn_relu_bwd(da, ldda, z, ldz, rows, h, gamma, mean, rstd, a_scale, a_shift, drop_p, drop_seed, dz, lddz, dgamma,
+                           dbeta, dz_col_sum, workspace, workspace_floats, stream, nullptr);
 }
 
 __global__ void dropout_mask_kernel(int64_t rows, int h, uint32_t thr, uint32_t seed, uint8_t* mask) {

@@ -228,3 +228,40 @@ def make_grad_sync(flat_grads, world, group=None, average=False):
         if average:
             flat_grads.mul_(1.0 / world)
     return sync
+
+
+class StatExchange:
+    """The host side of glnn_exchange_fn (include/glnn_hip.h): the all-gather of per-rank BatchNorm sums that
+    glnn_mlp_fwd_bwd_f32 asks for when one batch is split over ranks (global batch statistics keep the
+    step identical to the single-GPU reference step).  Owns the send/recv/row-count device buffers the descriptor
+    points at; `callback` is the C function pointer.  An exception inside the hook is kept in `.error` and reported
+    to the library as a non-zero status (ctypes cannot propagate it through the C frame)."""
+
+    def __init__(self, world, rank, max_hidden, device, group=None):
+        from . import _lib
+        self.world, self.rank, self.group = world, rank, group
+        f32 = dict(dtype=torch.float32, device=device)
+        self.send = torch.zeros(3 * max_hidden, **f32)
+        self.recv = torch.zeros(world * 3 * max_hidden, **f32)
+        self.rows = torch.zeros(1, **f32)
+        self.error = None
+        self.calls = 0
+        self.callback = _lib.EXCHANGE_FN(self._hook)
+
+    def _hook(self, ctx, send, recv, floats, stream):
+        try:
+            n = int(floats)
+            if send != self.send.data_ptr() or recv != self.recv.data_ptr() or n > self.send.numel():
+                raise RuntimeError("StatExchange: the library passed buffers this object does not own")
+            src, dst = self.send[:n], self.recv[:self.world * n]
+            if dist.get_backend(self.group) == "nccl":
+                dist.all_gather_into_tensor(dst, src, group=self.group)        # RCCL, ordered after the current stream
+            else:
+                parts = [torch.empty_like(src) for _ in range(self.world)]
+                dist.all_gather(parts, src.clone(), group=self.group)
+                torch.cat(parts, out=dst)
+            self.calls += 1
+            return 0
+        except BaseException as e:      # noqa: BLE001 -- must not unwind through the C caller
+            self.error = e
+            return 1

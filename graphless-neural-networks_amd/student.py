@@ -114,7 +114,27 @@ class StudentEngine:
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self._seed_arr = (ctypes.c_uint32 * _lib.MLP_MAX_LAYERS)()
+        self.exchange = None
         self.desc = self._build_desc()
+
+    def enable_batch_split(self, world, rank, group=None):
+        """Data-parallel over ONE batch: every rank steps on its slice of the batch rows.  BatchNorm statistics are
+        taken over the whole batch through the exchange hook (two small all-gathers per BN layer and step), the loss
+        is normalised by the global row count (`loss_scale_rows` is set per step by the caller or defaults to
+        world * local rows), gradients are SUMMED over ranks -> the update equals the single-GPU step on the whole
+        batch (tests/test_dist_gpu.py).  Dropout masks are drawn per rank."""
+        from .dist import StatExchange, make_grad_sync
+        if world <= 1:
+            return
+        hmax = max(self.dims[1:-1]) if self.L > 1 else 4
+        self.exchange = StatExchange(world, rank, hmax, self.dev, group)
+        d = self.desc
+        d.world, d.rank = world, rank
+        d.exchange = self.exchange.callback
+        d.sync_send, d.sync_recv, d.sync_rows = self.exchange.send.data_ptr(), self.exchange.recv.data_ptr(), self.exchange.rows.data_ptr()
+        self.grad_sync = make_grad_sync(self.flat_grads, world, group, average=False)
+        self.batch_split_world = world
+        self.base_seed = _mix32(self.base_seed ^ (0x9E3779B9 * (rank + 1)))      # independent dropout masks per rank
 
     def _build_desc(self):
         d = _lib.MlpStepDesc()
@@ -184,8 +204,11 @@ class StudentEngine:
         seeds = [self._seed(l) for l in range(L - 1)] if p > 0 else [0] * (L - 1)
 
         # ---- forward + loss + backward: ONE C call issuing the whole kernel sequence (csrc/mlp_step.hip) ----
-        if self.loss_scale_rows is not None:
-            lamb = lamb * m / float(self.loss_scale_rows)       # dlogits scale becomes lamb / global_rows
+        scale_rows = self.loss_scale_rows
+        if scale_rows is None and self.exchange is not None:
+            scale_rows = m * self.batch_split_world              # equal slices unless the caller says otherwise
+        if scale_rows is not None:
+            lamb = lamb * m / float(scale_rows)                 # dlogits scale becomes lamb / global_rows
         for i, sd in enumerate(seeds):
             self._seed_arr[i] = sd
         trow = idx if target_rows is None else target_rows
@@ -194,6 +217,9 @@ class StudentEngine:
             ops._p(target) if kind == ops.LOSS_NLL else None,
             ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
             ops._p(trow), float(lamb), self._seed_arr, ops._stream())
+        if rc != 0 and self.exchange is not None and self.exchange.error is not None:
+            err, self.exchange.error = self.exchange.error, None
+            raise RuntimeError("glnn_mlp_fwd_bwd_f32: the batch-statistics exchange failed") from err
         _lib.check(rc, "glnn_mlp_fwd_bwd_f32")
 
         # ---- (data-parallel) gradient exchange, then Adam ---------------------------------------

@@ -217,6 +217,18 @@ GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
  * The optimiser step is NOT included: call glnn_adam_step_f32 next (a gradient all-reduce may sit between).
  * ------------------------------------------------------------------------------------------ */
 #define GLNN_MLP_MAX_LAYERS 8
+
+/* Optional data-parallel hook (SURVEY.md 8e "Student"): when one batch is split over `world` ranks the
+ * BatchNorm batch statistics must be taken over the WHOLE batch for the step to equal the single-GPU
+ * reference step.  The library leaves the collective to the host: it fills `send` with `floats` values,
+ * calls exchange(ctx, send, recv, floats, stream) and expects recv = the concatenation of every rank's
+ * `send` in rank order (an all-gather, enqueued on / ordered after `stream`; ncclAllGather in a native
+ * host, torch.distributed in the Python mirror).  Return 0 on success.  Two calls per BatchNorm layer and
+ * step: 3*h floats forward (count, mean, M2 per column -> Chan combine in fixed rank order, so every rank
+ * derives bit-identical statistics), 2*h floats backward (sum dy, sum dy*xhat).  dgamma/dbeta and all other
+ * gradients stay LOCAL sums: the caller's gradient all-reduce completes them. */
+typedef int (*glnn_exchange_fn)(void* ctx, const float* send, float* recv, int64_t floats, void* stream);
+
 typedef struct glnn_mlp_step_desc {
   int32_t num_layers;
   int32_t batchnorm;
@@ -260,6 +272,14 @@ typedef struct glnn_mlp_step_desc {
   int64_t ws_loss_floats;
   float* loss_out;
   float* loss_accum;
+  /* batch split over ranks (all zero / NULL = single rank) */
+  int32_t world;
+  int32_t rank;
+  glnn_exchange_fn exchange;
+  void* exchange_ctx;
+  float* sync_send;      /* >= 3 * max hidden floats */
+  float* sync_recv;      /* >= world * 3 * max hidden floats */
+  float* sync_rows;      /* 1 float: the global batch row count of the current step (written by the library) */
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,

@@ -1,0 +1,47 @@
+"""bench.py contract (one JSON line, required keys) at a shrunken graph, for N=1 and for the N=2 launch line the driver
+uses (`python -m torch.distributed.run ...`) with both ranks on cuda:0 over gloo (test-only knobs in bench.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config"}
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    out = _run([sys.executable, "bench.py", "--scale", "0.02", "--steps", "2", "--warmup", "1"])
+    assert REQUIRED <= out.keys()
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["unit"] == "edges/s" and out["value"] > 0
+    assert "workload" in out["config"] and out["dtype"] == "f32" and out["vs_baseline"] is None
+    rf, cb = out["roofline"], out["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1.2 and rf["unit"] == "GB/s"
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert out["student"]["value"] > 0
+
+
+@pytest.mark.parametrize("extra", [[], ["--student-global-bn"]])
+def test_bench_two_ranks_driver_launch_line(extra):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"] + extra,
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo"})
+    assert REQUIRED <= out.keys()
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["student"]["global_batch"] == 2 * 4096
+    assert ("global" in out["student"]["batchnorm"]) == bool(extra)

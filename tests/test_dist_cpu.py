@@ -140,3 +140,54 @@ def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims, chunks):
         covered[lo:hi] = True
         np.testing.assert_allclose(flat, np.full(10, 1.5))      # mean of 1 and 2
     assert covered.all()
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glnn_amd.dist import StatExchange
+        h = 5
+        ex = StatExchange(world, rank, h, "cpu")
+        # what the library does per BatchNorm layer: fill `send`, call the hook with the descriptor's pointers
+        rs = np.random.RandomState(10 + rank)
+        rows = 7 + 4 * rank
+        zloc = rs.standard_normal((rows, h)).astype(np.float32)
+        ex.send[:h] = rows
+        ex.send[h:2 * h] = torch.from_numpy(zloc.mean(0))
+        ex.send[2 * h:3 * h] = torch.from_numpy(((zloc - zloc.mean(0)) ** 2).sum(0))
+        rc = ex.callback(None, ex.send.data_ptr(), ex.recv.data_ptr(), 3 * h, None)
+        bad = ex.callback(None, ex.send.data_ptr() + 4, ex.recv.data_ptr(), 3 * h, None)     # foreign buffer -> refused
+        q.put((rank, rc, bad, repr(ex.error), ex.calls, ex.recv[:world * 3 * h].numpy().copy(), zloc))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stat_exchange_hook_world2_gloo():
+    """The glnn_exchange_fn host hook (glnn_amd.dist.StatExchange): rank-ordered all-gather of the (count, mean, M2)
+    triples; combining them in rank order (Chan) reproduces the whole-batch statistics on every rank."""
+    world, h = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    z = np.concatenate([r[6] for r in res])
+    for rank, rc, bad, err, calls, recv, _ in res:
+        assert rc == 0 and bad == 1 and "does not own" in err and calls == 1
+        np.testing.assert_array_equal(recv, res[0][5])                 # identical gathered buffer on every rank
+        n = mean = m2 = 0.0
+        for r in range(world):
+            nb, mb, qb = (recv[r * 3 * h + j * h:r * 3 * h + (j + 1) * h].astype(np.float64) for j in range(3))
+            delta, nn = mb - mean, n + nb
+            mean = mean + delta * nb / nn
+            m2 = m2 + qb + delta * delta * n * nb / nn
+            n = nn
+        np.testing.assert_allclose(mean, z.mean(0), atol=1e-6)
+        np.testing.assert_allclose(m2 / n, z.var(0), atol=1e-6)

@@ -67,3 +67,101 @@ def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks):
         covered += hi - lo
         np.testing.assert_allclose(flat, np.full(8, 1.5))
     assert covered >= n - 2
+
+
+def _student_setup(dims, norm, dropout, dev, seed=3):
+    from glnn_amd.models import Model
+    torch.manual_seed(seed)
+    model = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                       dropout_ratio=dropout, norm_type=norm, device=dev))
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    g = torch.Generator().manual_seed(seed)
+    n = 3000
+    feats = torch.randn(n, dims[0], generator=g).to(dev)
+    labels = torch.randint(0, dims[-1], (n,), generator=g).to(dev)
+    out_t = torch.log_softmax(torch.randn(n, dims[-1], generator=g), 1).to(dev)
+    batches = [torch.randperm(n, generator=g)[:b].to(dev) for b in (512, 512, 300, 512)]     # 300: unequal, odd chunk tail
+    return model, opt, feats, labels, out_t, batches
+
+
+def _run_student(model, opt, feats, labels, out_t, batches, world, rank, group_enabled):
+    from glnn_amd import ops
+    from glnn_amd.student import StudentEngine
+    model.train()
+    eng = StudentEngine(model, opt, 512)
+    if group_enabled:
+        eng.enable_batch_split(world, rank)
+    first_grads = None
+    for i, idx in enumerate(batches):
+        if group_enabled:                                  # uneven split on purpose: rank 0 takes ~60 %
+            cut = (idx.numel() * 3) // 5
+            mine = idx[:cut] if rank == 0 else idx[cut:]
+            eng.loss_scale_rows = idx.numel()
+        else:
+            mine = idx
+        mine = mine.contiguous()
+        if i % 2 == 0:
+            eng.step(feats, mine, ops.LOSS_NLL, labels, 0.3)
+        else:
+            eng.step(feats, mine, ops.LOSS_KL, out_t, 0.7)
+        if i == 0:
+            first_grads = {n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters()}
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    return sd, first_grads, (eng.exchange.calls if eng.exchange else 0)
+
+
+def _student_worker(rank, world, port, dims, norm, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        setup = _student_setup(dims, norm, 0.0, "cuda:0")
+        sd, grads, calls = _run_student(*setup, world, rank, True)
+        q.put((rank, sd, grads, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,norm", [([100, 256, 256, 47], "batch"), ([128, 192, 40], "batch"), ([50, 64, 64, 7], "none")])
+def test_student_batch_split_two_ranks_equals_single_gpu_step(dims, norm):
+    """a batch split over ranks (uneven slices, global BatchNorm statistics through the exchange hook,
+    summed gradients) must take the same optimisation steps as one GPU on the whole batch -- parameters, BN running
+    statistics and num_batches_tracked after 4 mixed NLL/KL steps."""
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_student_worker, args=(r, world, port, dims, norm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want, want_grads, _ = _run_student(*_student_setup(dims, norm, 0.0, "cuda:0"), 1, 0, False)
+    n_bn = len(dims) - 2 if norm == "batch" else 0
+    L = len(dims) - 1
+
+    def gauge(k):     # bias in front of a BatchNorm (zero true gradient: rounding noise that Adam amplifies) and the
+        if norm != "batch":                      # running_mean that tracks it -- see tests/parity_rules.py
+            return False
+        if "running_mean" in k:
+            return True
+        return ".layers." in k and k.endswith(".bias") and int(k.split(".")[2]) < L - 1
+
+    for rank, sd, grads, calls in res:
+        assert calls == 4 * 2 * n_bn, (rank, calls)          # 4 steps x (fwd + bwd) x BN layers
+        for k, gw in want_grads.items():                      # step-1 gradients (after the all-reduce): linear, tight
+            if not gauge(k):
+                scale = np.abs(gw).max() + 1e-12
+                assert np.abs(grads[k] - gw).max() <= 2e-5 * scale + 1e-9, (rank, k, np.abs(grads[k] - gw).max(), scale)
+        assert sd.keys() == want.keys()
+        for k in want:
+            if k.endswith("num_batches_tracked"):
+                assert sd[k] == want[k], k
+            elif not gauge(k):
+                d = np.abs(sd[k].astype(np.float64) - want[k])
+                assert d.mean() <= 1e-5 and d.max() <= 0.01, (rank, k, d.mean(), d.max())      # max: one lr-sized Adam flip
+    for k in want:            # the two ranks hold bit-identical models (same gathered sums, same order)
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
