@@ -17,9 +17,22 @@
 // consume k pairs (t, 4+t).  Both operands use the same pairing, and a dot product does not care about
 // the order of its terms.  LDS rows are padded to 36 floats: conflict-free for ds_read_b128's 16-lane
 // groups (slot = 9*i mod 16 is a bijection on each group).
+#include <type_traits>
+#include <utility>
+
 #include "glnn_common.h"
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -296,68 +309,78 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     for (int q = 0; q < BQ; ++q) b_base[q] = g.b + ng;
   }
 
-  float4 a_reg[AQ], b_reg[BQ], sc4, sh4;
-  int kc_cur = 0;
   const int kpad = (g.k + 3) & ~3;
 
-  auto load_tiles = [&](int kt) {
-    const int k0 = kt * BKF;
-    kc_cur = k0 + c4;
-    int kcc = kc_cur;
-    if (kcc > kpad - 4) kcc = kpad - 4;
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) a_reg[q] = ld4g(a_base[q] + kcc);
+  // Global -> register -> LDS staging in P = AQ + BQ independent pieces (one float4 per thread each), so that the main
+  // loop can place one piece between MFMAs instead of a monolithic load / store phase.
+  constexpr int P = AQ + BQ;
+  struct Stage {
+    float4 a[AQ], b[BQ], sc, sh;
+    int kc, k0;       // k of this thread's float4 / of the tile: the store side masks and seeds with them
+  };
+  Stage st;      // ONE register set: a second set (loads two tiles ahead) made hipcc copy half-tuples at the back-edge
+  auto load_prep = [&](Stage& s, int kt) {
+    s.k0 = kt * BKF;
+    s.kc = s.k0 + c4;
     if (XF) {
-      sc4 = ld4g(g.a_scale + kcc);
-      sh4 = ld4g(g.a_shift + kcc);
+      const int kcc = s.kc > kpad - 4 ? kpad - 4 : s.kc;
+      s.sc = ld4g(g.a_scale + kcc);
+      s.sh = ld4g(g.a_shift + kcc);
     }
-#pragma unroll
-    for (int q = 0; q < BQ; ++q) {
+  };
+  auto load_piece = [&](Stage& s, int p) {
+    const int kcc = s.kc > kpad - 4 ? kpad - 4 : s.kc;   // clamped: tiles past K re-read valid addresses, masked at the store
+    if (p < AQ) {
+      s.a[p] = ld4g(a_base[p] + kcc);
+    } else {
+      const int q = p - AQ;
       if (B_KN) {
-        int kg = k0 + (tid + 256 * q) / (BN / 4);
+        int kg = s.k0 + (tid + 256 * q) / (BN / 4);
         if (kg > g.k - 1) kg = g.k - 1;
-        b_reg[q] = ld4g(b_base[q] + (int64_t)kg * g.ldb);
+        s.b[q] = ld4g(b_base[q] + (int64_t)kg * g.ldb);
       } else {
-        b_reg[q] = ld4g(b_base[q] + kcc);
+        s.b[q] = ld4g(b_base[q] + kcc);
       }
     }
   };
-  auto store_tiles = [&](int buf, int kt) {
-    float* as = As + buf * A_TILE;
-    float* bs = Bs + buf * B_TILE;
-    const int kleft = g.k - kc_cur;            // elements t < kleft of this float4 are inside K
-#pragma unroll
-    for (int q = 0; q < AQ; ++q) {
-      float4 v = a_reg[q];
+  auto store_piece = [&](const Stage& s, int buf, int p) {
+    const int kleft = g.k - s.kc;            // elements t < kleft of this float4 are inside K
+    if (p < AQ) {
+      float4 v = s.a[p];
       if (XF) {
-        v.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f);
-        v.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
-        v.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f);
-        v.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+        v.x = fmaxf(fmaf(v.x, s.sc.x, s.sh.x), 0.f);
+        v.y = fmaxf(fmaf(v.y, s.sc.y, s.sh.y), 0.f);
+        v.z = fmaxf(fmaf(v.z, s.sc.z, s.sh.z), 0.f);
+        v.w = fmaxf(fmaf(v.w, s.sc.w, s.sh.w), 0.f);
         if (XF == 2) {
-          const uint32_t row = (uint32_t)(m0 + r0 + RSTEP * q);
-          v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 0) ? v.x * g.drop_scale : 0.f;
-          v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 1) ? v.y * g.drop_scale : 0.f;
-          v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 2) ? v.z * g.drop_scale : 0.f;
-          v.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)kc_cur + 3) ? v.w * g.drop_scale : 0.f;
+          const uint32_t row = (uint32_t)(m0 + r0 + RSTEP * p);
+          v.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)s.kc + 0) ? v.x * g.drop_scale : 0.f;
+          v.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)s.kc + 1) ? v.y * g.drop_scale : 0.f;
+          v.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)s.kc + 2) ? v.z * g.drop_scale : 0.f;
+          v.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, (uint32_t)s.kc + 3) ? v.w * g.drop_scale : 0.f;
         }
       }
       v = mask4(v, kleft);
-      *reinterpret_cast<float4*>(as + (r0 + RSTEP * q) * LDS_KF + c4) = v;
-    }
-#pragma unroll
-    for (int q = 0; q < BQ; ++q) {
-      float4 v = b_reg[q];
+      *reinterpret_cast<float4*>(As + buf * A_TILE + (r0 + RSTEP * p) * LDS_KF + c4) = v;
+    } else {
+      const int q = p - AQ;
+      float4 v = s.b[q];
+      float* bs = Bs + buf * B_TILE;
       if (B_KN) {
         const int f = tid + 256 * q;
         const int krow = f / (BN / 4);
-        if (kt * BKF + krow >= g.k) v = zero4();
+        if (s.k0 + krow >= g.k) v = zero4();
         *reinterpret_cast<float4*>(bs + krow * LDS_N + (f % (BN / 4)) * 4) = v;
       } else {
         v = mask4(v, kleft);
         *reinterpret_cast<float4*>(bs + (r0 + RSTEP * q) * LDS_KF + c4) = v;
       }
     }
+  };
+  auto load_tiles = [&](Stage& s, int kt) {
+    load_prep(s, kt);
+#pragma unroll
+    for (int p = 0; p < P; ++p) load_piece(s, p);
   };
 
   f32x16 acc[2][NT];
@@ -372,44 +395,86 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   const int kt_beg = blockIdx.z * g.ktiles_per_split;
   int kt_end = kt_beg + g.ktiles_per_split;
   if (kt_end > nk_all) kt_end = nk_all;
-  load_tiles(kt_beg);
-  store_tiles(0, kt_beg);
+  // Main loop, software-pipelined inside every wave (two workgroups per CU run in lockstep, so a wave cannot count on
+  // its SIMD neighbour to cover a separate load / ds_write / barrier phase -- measured: 277 us for the bare ds_read+MFMA
+  // loop, 296 with a trailing ds_write+barrier phase, 327 with the global loads; hipBLASLt 282 on the same box):
+  //   k-groups 0..G-2 : MFMAs of group g while the fragments of group g+1 are read from LDS
+  //   then            : ds_write of tile t+1 (global loads issued one whole tile earlier) into the other buffer,
+  //                     global loads of tile t+2 issued
+  //   last group      : first half of its MFMAs | barrier | ds_read of tile t+1's first fragments | second half
+  constexpr int G = BKF / 8;
+  float fa[2][2][4], fb[2][NT][4];
+  auto read_frags = [&](int buf, int kg, float (&af)[2][4], float (&bf)[NT][4]) {
+    const float* as = As + buf * A_TILE + (wm * 64 + li) * LDS_KF + kk * 4;
+    const float* bs = B_KN ? Bs + buf * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
+                           : Bs + buf * B_TILE + (wn * (BN / 2) + li) * LDS_KF + kk * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_KF + kg * 8);
+      af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (B_KN) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kg * 8 + t) * LDS_N + j * 32];
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_KF + kg * 8);
+        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+      }
+    }
+  };
+  // MFMAs [m_beg, m_end) of one k-group's 8*NT, in the order t (k-pair) -> i (row block) -> j (col block)
+  constexpr int MG = 8 * NT;
+  auto mfma_range = [&](const float (&af)[2][4], const float (&bf)[NT][4], int m_beg, int m_end) {
+#pragma unroll
+    for (int mm = m_beg; mm < m_end; ++mm) {
+      const int t = mm / (2 * NT), i = (mm / NT) % 2, j = mm % NT;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  load_tiles(st, kt_beg);
+#pragma unroll
+  for (int p = 0; p < P; ++p) store_piece(st, 0, p);
   __syncthreads();
+  read_frags(0, 0, fa[0], fb[0]);
+  load_tiles(st, kt_beg + 1);
 
   for (int kt = kt_beg; kt < kt_end; ++kt) {
     const int cur = (kt - kt_beg) & 1;
-    if (kt + 1 < kt_end) load_tiles(kt + 1);
-    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_KF + kk * 4;
-    const float* bs = B_KN ? Bs + cur * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
-                           : Bs + cur * B_TILE + (wn * (BN / 2) + li) * LDS_KF + kk * 4;
+    // groups 0 .. G-3: MFMAs while the next group's fragments are read
 #pragma unroll
-    for (int kg = 0; kg < BKF / 8; ++kg) {
-      float af[2][4], bf[NT][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_KF + kg * 8);
-        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (B_KN) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) bf[j][t] = bs[(kg * 8 + t) * LDS_N + j * 32];
-        } else {
-          const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_KF + kg * 8);
-          bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    for (int kg = 0; kg + 2 < G; ++kg) {
+      read_frags(cur, kg + 1, fa[(kg + 1) & 1], fb[(kg + 1) & 1]);
+      mfma_range(fa[kg & 1], fb[kg & 1], 0, MG);
     }
-    if (kt + 1 < kt_end) store_tiles(cur ^ 1, kt + 1);
+    // group G-2: + tile kt+1 (loads issued most of a tile ago) goes registers -> the other LDS buffer, one piece per
+    // MG/P MFMAs.  Past the last tile this writes a buffer nobody reads and the loads below re-read clamped, in-bounds
+    // addresses: unconditional, so that the loop body stays one basic block.
+    read_frags(cur, G - 1, fa[(G - 1) & 1], fb[(G - 1) & 1]);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      store_piece(st, cur ^ 1, p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_range(fa[(G - 2) & 1], fb[(G - 2) & 1], p * MG / P, (p + 1) * MG / P);
+    }
+    // group G-1, first half: + the freed registers are re-loaded with tile kt+2, one piece per MFMA slot
+    load_prep(st, kt + 2);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_piece(st, p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_range(fa[(G - 1) & 1], fb[(G - 1) & 1], p * (MG / 2) / P, (p + 1) * (MG / 2) / P);
+    }
+    // barrier | the next tile's first fragment reads | second half of group G-1
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    read_frags(cur ^ 1, 0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_range(fa[(G - 1) & 1], fb[(G - 1) & 1], MG / 2, MG);
   }
 
   if (g.ksplits > 1) {

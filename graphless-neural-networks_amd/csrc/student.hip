@@ -171,26 +171,31 @@ struct BnFinArgs {
   float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
 };
 
+__device__ __forceinline__ double part_count(const BnFinArgs& a, int k, int col) {
+  if (a.ws_cnt) return (double)a.ws_cnt[(int64_t)k * a.pstride + col];
+  int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
+  if (r1 > a.rows) r1 = a.rows;
+  return (double)(r1 - r0);
+}
+
 __global__ void bn_stats_stage2(const BnFinArgs a) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
   if (col >= a.h) return;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
+  // combine of the partial (count, mean, M2) triples in double, fixed order, without a loop-carried divide:
+  //   N = sum n_k ;  mean = sum n_k*mean_k / N ;  M2 = sum [ M2_k + n_k*(mean_k - mean)^2 ]
+  double n = 0.0, sum = 0.0;
   for (int k = 0; k < a.nparts; ++k) {
-    double nb;
-    if (a.ws_cnt) {
-      nb = (double)a.ws_cnt[(int64_t)k * a.pstride + col];
-    } else {
-      int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
-      if (r1 > a.rows) r1 = a.rows;
-      nb = (double)(r1 - r0);
-    }
-    if (nb <= 0.0) continue;                                   // a rank with an empty slice of the batch
-    const double mb = a.ws_mean[(int64_t)k * a.pstride + col], qb = a.ws_m2[(int64_t)k * a.pstride + col];
-    const double delta = mb - mean, nn = n + nb;
-    mean += delta * nb / nn;
-    m2 += qb + delta * delta * n * nb / nn;
-    n = nn;
+    const double nb = part_count(a, k, col);
+    n += nb;
+    sum += nb * (double)a.ws_mean[(int64_t)k * a.pstride + col];
+  }
+  const double mean = sum / n;
+  double m2 = 0.0;
+  for (int k = 0; k < a.nparts; ++k) {
+    const double nb = part_count(a, k, col);
+    const double dm = (double)a.ws_mean[(int64_t)k * a.pstride + col] - mean;
+    m2 += (double)a.ws_m2[(int64_t)k * a.pstride + col] + nb * dm * dm;     // nb == 0: an empty slice contributes nothing
   }
   if (a.emit_cnt) {
     a.emit_cnt[col] = (float)n;
