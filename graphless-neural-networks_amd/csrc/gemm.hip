@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
 // is EXACTLY the NT kernel's (conflict-free ds_read_b128 fragments, 4 MFMAs per read).
 // Thread map: tid -> (rg: rows 4rg..4rg+3 of the 32-row k-tile, cg: columns 4cg..4cg+3), interleaved (below).
 // ---------------------------------------------------------------------------------------------
-template <int BNT, int XF>
+template <int BNT, int XF, bool ROWS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   constexpr int NT = BNT / 64;
   constexpr int A_TILE = BM * LDS_K, B_TILE = BNT * LDS_K;
@@ -722,53 +722,70 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   }
   float4 a_reg[4], b_reg[4];
   int64_t mt_cur = 0;
-
-  auto load_tiles = [&](int64_t mt) {
-    mt_cur = mt;
+  int64_t src_row[4];        // ROWS: gathered source rows of the NEXT B loads, fetched one tile ahead (no dependent load in the loop)
+  auto load_rows = [&](int64_t mt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int64_t mrow = mt + 4 * rg + r;
       if (mrow > g.m - 1) mrow = g.m - 1;
+      src_row[r] = g.b_rows[mrow];
+    }
+  };
+
+  // Staging in pieces, so that the main loop can put them between MFMAs: 8 global loads (4 reduction rows x {A, B}), the
+  // per-row operand transform / split-end mask, and 4 x {A, B} transposed b128 stores (store c = column c of the 4x4 block,
+  // so it needs all four rows).
+  auto load_piece = [&](int p) {
+    const int r = p & 3;
+    int64_t mrow = mt_cur + 4 * rg + r;
+    if (mrow > g.m - 1) mrow = g.m - 1;
+    if (p < 4) {
       a_reg[r] = ld4g(g.a + mrow * g.lda + a_col);
-      if (b_active) {
-        const int64_t src = g.b_rows ? g.b_rows[mrow] : mrow;
-        b_reg[r] = ld4g(g.b + src * g.ldb + b_col);
+    } else if (b_active) {
+      if (ROWS) {
+        b_reg[r] = ld4g(g.b + src_row[r] * g.ldb + b_col);
+        int64_t nrow = mrow + BK;                       // the row this lane loads one tile later
+        if (nrow > g.m - 1) nrow = g.m - 1;
+        src_row[r] = g.b_rows[nrow];
+      } else {
+        b_reg[r] = ld4g(g.b + mrow * g.ldb + b_col);
       }
     }
   };
-  auto store_tiles = [&](int buf) {
-    float av[4][4], bv[4][4];
+  auto load_tiles = [&](int64_t mt) {
+    mt_cur = mt;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool in = mt_cur + 4 * rg + r < mend;        // rows past this split's end are reduction terms: zero them
-      const float4 a = in ? a_reg[r] : zero4();
-      av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
-      if (b_active) {
-        float4 b = b_reg[r];
-        if (XF) {
-          b.x = fmaxf(fmaf(b.x, sc4.x, sh4.x), 0.f);
-          b.y = fmaxf(fmaf(b.y, sc4.y, sh4.y), 0.f);
-          b.z = fmaxf(fmaf(b.z, sc4.z, sh4.z), 0.f);
-          b.w = fmaxf(fmaf(b.w, sc4.w, sh4.w), 0.f);
-          if (XF == 2) {
-            const uint32_t row = (uint32_t)(mt_cur + 4 * rg + r), c = (uint32_t)(j0 + 4 * cg);
-            b.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 0) ? b.x * g.drop_scale : 0.f;
-            b.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 1) ? b.y * g.drop_scale : 0.f;
-            b.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 2) ? b.z * g.drop_scale : 0.f;
-            b.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 3) ? b.w * g.drop_scale : 0.f;
-          }
+    for (int p = 0; p < 8; ++p) load_piece(p);
+  };
+  float av[4][4], bv[4][4];
+  auto prep_row = [&](int r) {
+    const bool in = mt_cur + 4 * rg + r < mend;        // rows past this split's end are reduction terms: zero them
+    const float4 a = in ? a_reg[r] : zero4();
+    av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
+    if (b_active) {
+      float4 b = b_reg[r];
+      if (XF) {
+        b.x = fmaxf(fmaf(b.x, sc4.x, sh4.x), 0.f);
+        b.y = fmaxf(fmaf(b.y, sc4.y, sh4.y), 0.f);
+        b.z = fmaxf(fmaf(b.z, sc4.z, sh4.z), 0.f);
+        b.w = fmaxf(fmaf(b.w, sc4.w, sh4.w), 0.f);
+        if (XF == 2) {
+          const uint32_t row = (uint32_t)(mt_cur + 4 * rg + r), c = (uint32_t)(j0 + 4 * cg);
+          b.x = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 0) ? b.x * g.drop_scale : 0.f;
+          b.y = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 1) ? b.y * g.drop_scale : 0.f;
+          b.z = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 2) ? b.z * g.drop_scale : 0.f;
+          b.w = glnn::drop_keep(g.drop_seed, g.drop_thr, row, c + 3) ? b.w * g.drop_scale : 0.f;
         }
-        if (!in) b = zero4();
-        bv[r][0] = b.x; bv[r][1] = b.y; bv[r][2] = b.z; bv[r][3] = b.w;
       }
+      if (!in) b = zero4();
+      bv[r][0] = b.x; bv[r][1] = b.y; bv[r][2] = b.z; bv[r][3] = b.w;
     }
+  };
+  auto store_col = [&](int buf, int c) {
     float* as = As + buf * A_TILE + (4 * cg) * LDS_K + 4 * rg;
     float* bs = Bs + buf * B_TILE + (4 * cg) * LDS_K + 4 * rg;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<float4*>(as + c * LDS_K) = make_float4(av[0][c], av[1][c], av[2][c], av[3][c]);
-      if (b_active) *reinterpret_cast<float4*>(bs + c * LDS_K) = make_float4(bv[0][c], bv[1][c], bv[2][c], bv[3][c]);
-    }
+    *reinterpret_cast<float4*>(as + c * LDS_K) = make_float4(av[0][c], av[1][c], av[2][c], av[3][c]);
+    if (b_active) *reinterpret_cast<float4*>(bs + c * LDS_K) = make_float4(bv[0][c], bv[1][c], bv[2][c], bv[3][c]);
   };
 
   f32x16 acc[2][NT];
@@ -779,40 +796,73 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr int G = BK / 8;                 // k-groups per tile (k = 8 kg + 4 kk + t)
+  constexpr int MG = 8 * NT;                // MFMAs per k-group
+  float fa[2][2][4], fb[2][NT][4];
+  auto read_frags = [&](int buf, int kg, float (&af)[2][4], float (&bf)[NT][4]) {
+    const float* as = As + buf * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+    const float* bs = Bs + buf * B_TILE + (wn * (BNT / 2) + li) * LDS_K + kk * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
+      af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
+      bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+    }
+  };
+  auto mfma_range = [&](const float (&af)[2][4], const float (&bf)[NT][4], int m_beg, int m_end) {
+#pragma unroll
+    for (int mm = m_beg; mm < m_end; ++mm) {
+      const int t = mm / (2 * NT), i = (mm / NT) % 2, j = mm % NT;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // Same software pipeline as gemm_kernel_fast (see there): fragment reads one k-group ahead; tile t+1 goes registers ->
+  // LDS between the MFMAs of group G-2, the loads of tile t+2 are issued between those of the first half of group G-1,
+  // the barrier sits inside group G-1 and the next tile's first fragment reads hide behind its second half.  Rows past the
+  // split's end are zeroed by prep_row and re-read clamped, in-bounds addresses: unconditional, one basic block.
   const int64_t nkt = (mend - mbeg + BK - 1) / BK;
-  if (nkt > 0) {
-    load_tiles(mbeg);
-    store_tiles(0);
-  }
+  if (ROWS && b_active) load_rows(mbeg);
+  load_tiles(mbeg);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) prep_row(r);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) store_col(0, c);
   __syncthreads();
+  read_frags(0, 0, fa[0], fb[0]);
+  load_tiles(mbeg + BK);
   for (int64_t kt = 0; kt < nkt; ++kt) {
     const int cur = (int)(kt & 1);
-    if (kt + 1 < nkt) load_tiles(mbeg + (kt + 1) * BK);
-    const float* as = As + cur * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
-    const float* bs = Bs + cur * B_TILE + (wn * (BNT / 2) + li) * LDS_K + kk * 4;
 #pragma unroll
-    for (int kg = 0; kg < BK / 8; ++kg) {
-      float af[2][4], bf[NT][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
-        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(bs + j * 32 * LDS_K + kg * 8);
-        bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    for (int kg = 0; kg + 2 < G; ++kg) {
+      read_frags(cur, kg + 1, fa[(kg + 1) & 1], fb[(kg + 1) & 1]);
+      mfma_range(fa[kg & 1], fb[kg & 1], 0, MG);
     }
-    if (kt + 1 < nkt) store_tiles(cur ^ 1);
+    read_frags(cur, G - 1, fa[(G - 1) & 1], fb[(G - 1) & 1]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (p < 4) prep_row(p); else store_col(cur ^ 1, p - 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_range(fa[(G - 2) & 1], fb[(G - 2) & 1], p * MG / 8, (p + 1) * MG / 8);
+    }
+    mt_cur = mbeg + (kt + 2) * BK;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      load_piece(p);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_range(fa[(G - 1) & 1], fb[(G - 1) & 1], p * (MG / 2) / 8, (p + 1) * (MG / 2) / 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    read_frags(cur ^ 1, 0, fa[0], fb[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_range(fa[(G - 1) & 1], fb[(G - 1) & 1], MG / 2, MG);
   }
 
   float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
@@ -1020,7 +1070,8 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
     constexpr size_t smem64 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
     constexpr size_t smem128t = sizeof(float) * 2 * (BM * LDS_K + 128 * LDS_K);
     constexpr size_t smem64t = sizeof(float) * 2 * (BM * LDS_K + 64 * LDS_K);
-    static int cfg[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    static int cfg[14] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    const bool rows = b_rows != nullptr;
     const dim3 grid(gi, gj, splits);
 #define GLNN_TN_LAUNCH(KERNEL_, SLOT_, SMEM_)                                   \
   do {                                                                          \
@@ -1030,14 +1081,20 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   } while (0)
     if (bnt == 128) {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<128>), 0, smem128);
-      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0>), 1, smem128t);
-      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1>), 2, smem128t);
-      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2>), 3, smem128t);
+      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0, false>), 1, smem128t);
+      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1, false>), 2, smem128t);
+      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2, false>), 3, smem128t);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0, true>), 8, smem128t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1, true>), 9, smem128t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2, true>), 10, smem128t);
     } else {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<64>), 4, smem64);
-      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0>), 5, smem64t);
-      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1>), 6, smem64t);
-      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2>), 7, smem64t);
+      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0, false>), 5, smem64t);
+      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1, false>), 6, smem64t);
+      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2, false>), 7, smem64t);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0, true>), 11, smem64t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1, true>), 12, smem64t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2, true>), 13, smem64t);
     }
 #undef GLNN_TN_LAUNCH
   }
