@@ -883,6 +883,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
 __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
                                     int64_t ldc, int ka, int nb) {
   const int64_t total = (int64_t)ka * nb;
+  if (((nb | ldc | slab) & 3) == 0 && glnn::aligned16(ws) && glnn::aligned16(c)) {       // float4 path (workgroup-uniform)
+    const int64_t total4 = total >> 2;
+    const int nb4 = nb >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 s = *reinterpret_cast<const float4*>(ws + 4 * i);
+      for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t r = i / nb4, cc = (i - r * nb4) * 4;
+      *reinterpret_cast<float4*>(c + r * ldc + cc) = s;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += ws[k * slab + i];

@@ -29,7 +29,7 @@ inline int check_launch(const char* what) {
   return GLNN_OK;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define GLNN_REQUIRE(cond, ...)                                     \
   do {                                                              \
