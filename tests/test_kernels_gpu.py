@@ -188,6 +188,29 @@ def test_gemm_tn_gather_and_transform():
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
 
 
+@pytest.mark.parametrize("m,ka,nb,rows_on", [(1000, 64, 48, True), (777, 130, 200, True), (2048, 256, 256, False), (333, 40, 60, False)])
+def test_gemm_tn_dropout_transform_all_instantiations(m, ka, nb, rows_on):
+    """TN weight gradient with the full operand transform (BN affine + ReLU + dropout) with and without gathered source
+    rows, for both column-tile widths: dW = dz^T @ (mask * relu(x[rows]*sc+sh) / (1-p)), the mask being the kernel's own
+    counter-based one (glnn_dropout_mask_u8), rows m not a multiple of the 32-row k-tile."""
+    from glnn_amd import ops
+    r = np.random.RandomState(m + nb)
+    nrows = 2 * m
+    dz = (r.standard_normal((m, ka)) / 8).astype(np.float32)
+    x = r.standard_normal((nrows if rows_on else m, nb)).astype(np.float32)
+    rows = r.randint(0, nrows, m).astype(np.int64) if rows_on else None
+    sc, sh = r.uniform(0.5, 1.5, nb).astype(np.float32), r.standard_normal(nb).astype(np.float32) * .2
+    p, seed = 0.35, 4242
+    mask = ops.dropout_mask(m, nb, p, seed, DEV).cpu().numpy().astype(np.float64)
+    xs = x[rows] if rows_on else x
+    act = np.maximum(xs.astype(np.float64) * sc + sh, 0) * mask / (1 - p)
+    want = dz.astype(np.float64).T @ act
+    got = ops.gemm_tn(ops.as_feat(dev(dz)), ops.as_feat(dev(x)), b_rows=dev(rows) if rows_on else None, b_scale=dev(sc),
+                      b_shift=dev(sh), m=m, drop_p=p, drop_seed=seed)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+    assert 0.55 < mask.mean() < 0.75
+
+
 # ------------------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("rows,c", [(512, 40), (4096, 47), (140, 7), (37, 100)])
 @pytest.mark.parametrize("kind", ["nll", "kl"])
