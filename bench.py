@@ -145,6 +145,8 @@ def main():
     barrier()
     if rank == 0 and world == 1:
         ops.set_timing(timing)
+    from glnn_amd import dist as gdist
+    gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         teacher_forward()
@@ -204,6 +206,11 @@ def main():
                    "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
                    "graph": "seeded power-law multigraph, random node order", "scale": args.scale,
                    "parallelism": "1 GPU" if world == 1 else f"node-range row shards x{world}, all-gather per layer; student dp{world}"},
+        "exchange": None if world == 1 else {
+            "GB_received_per_rank_per_forward": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / args.steps,
+            "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
+            "what": "all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
+                    "with the aggregation), 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none"},
         "student": {"metric": "student distill steps/s (MLP3w8 100-2048-2048-47, B=4096 per rank, dropout 0.2, BN, "
                               "KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
                     "value": student_steps_per_s, "unit": "steps/s", "steps": k_student, "warmup": w_student,

@@ -48,6 +48,14 @@ class RowShards:
         return ((i // self.cr) * self.world + r) * self.cr + i % self.cr
 
 
+EXCHANGE_STATS = {"collectives": 0, "floats_received": 0}      # per process; tests and bench read / reset it
+
+
+def _count(out_block):
+    EXCHANGE_STATS["collectives"] += 1
+    EXCHANGE_STATS["floats_received"] += out_block.numel()
+
+
 def _storage_rows(buf):
     """The contiguous [rows, ld] tensor behind a feature view [rows, d] (ld = row stride >= d)."""
     if buf.is_contiguous():
@@ -63,6 +71,7 @@ def all_gather_rows(buf, shards, group=None):
         return buf
     base = _storage_rows(buf)
     mine = base[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
+    _count(base)
     if dist.get_backend(group) == "nccl":
         # source copied out of the destination: an aliased (in-place) all-gather is legal for RCCL itself, but this
         # path cannot be exercised here (1 GPU), so it takes the unambiguous form; the copy is 1/world of the buffer
@@ -152,22 +161,67 @@ class ShardedTeacher:
             be.gemm(agg[c * span:(c + 1) * span], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[c * span:(c + 1) * span])
         return y
 
+    def _plain_then_narrow_overlapped(self, l, x, layout):
+        """Aggregate-first layer l followed by a narrowing layer l+1, chunks > 1: the own rows of layer l are produced
+        chunk by chunk, each chunk is projected with W_{l+1} at once (layer l+1 projects first) and the all-gather of
+        its narrow rows is issued while the next chunk of layer l still aggregates -- the only data layer l+1 needs from
+        other ranks.  Then layer l+1 aggregates the own rows from the chunk-major gathered buffer.  Returns its output."""
+        enc, sh, be, g = self.enc, self.sh, self.be, self.g
+        w1, w2 = enc.layers[l].fc_neigh.weight, enc.layers[l + 1].fc_neigh.weight
+        tail1, tail2 = enc._tail(l), enc._tail(l + 1)
+        d_mid, d_out = w1.shape[0], w2.shape[0]
+        last = l + 1 == enc.num_layers - 1
+        y_own = self._full_buffer(("y", l), d_mid, x.device)[sh.lo:sh.hi]
+        hw = self._full_buffer(("hwcm", l + 1), d_out, x.device)          # chunk-major [C][P][cr]
+        base = _storage_rows(hw)
+        span = sh.world * sh.cr
+        idx = self._indices(layout)
+        works = []
+        for c in range(sh.chunks):
+            off, nr = sh.chunk_rows(c)
+            p0 = (c * sh.world + sh.rank) * sh.cr
+            if nr > 0:
+                # own rows [off, off+nr) of layer l; their self rows sit at sh.lo+off (natural) or in chunk c's slot (cm)
+                xs = x[sh.lo + off:sh.lo + off + nr] if layout == "nat" else x[p0:p0 + nr]
+                ip = g.indptr[off:off + nr + 1]
+                es, eh, rl = tail1
+                if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256:
+                    be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr], x_self=xs)
+                else:
+                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
+                    be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
+                be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+        out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l + 1), d_out, x.device)[sh.lo:sh.hi]
+        for wk in works:
+            wk()
+        es, eh, rl = tail2
+        idx_cm = self._indices("cm")
+        for off, nr, sl in self._pieces("cm"):
+            be.spmm(g.indptr[off:off + nr + 1], idx_cm, hw, nr, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=rl,
+                    out=out[off:off + nr], x_self=hw[sl])
+        return out
+
     def forward(self, x_full):
         """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
         enc, sh, be, g = self.enc, self.sh, self.be, self.g
         x = be.as_feat(x_full)
-        layout = "nat"
+        layout = "nat"          # row order of x: natural node ids, or chunk-major ("cm")
+        complete = True         # x holds every node's row (False: only this rank's own rows are valid)
         L = enc.num_layers
+        dims = [(lay.fc_neigh.weight.shape[1], lay.fc_neigh.weight.shape[0]) for lay in enc.layers]
         y_own = None
-        for l, layer in enumerate(enc.layers):
-            w = layer.fc_neigh.weight
+        l = 0
+        while l < L:
+            w = enc.layers[l].fc_neigh.weight
             tail = enc._tail(l)
             ep_scale, ep_shift, relu = tail
-            d_in, d_out = w.shape[1], w.shape[0]
+            d_in, d_out = dims[l]
             last = l == L - 1
+            next_narrow = not last and dims[l + 1][0] > dims[l + 1][1]
             if d_in > d_out:
                 # narrowing layer: project own rows, exchange the narrow rows, aggregate own rows (products layer 3:
-                # 47 floats per node on the wire instead of 256)
+                # 47 floats per node on the wire instead of 256).  Needs only the OWN rows of x.
                 hw = self._full_buffer(("hw", l), d_out, x.device)
                 for off, nr, sl in self._pieces(layout):
                     be.gemm(x[sl], w, out=hw[sh.lo + off:sh.lo + off + nr])
@@ -175,6 +229,8 @@ class ShardedTeacher:
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
                 be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                         out=out, x_self=hw[sh.lo:sh.hi])
+            elif not complete:
+                raise RuntimeError("ShardedTeacher: internal error, an aggregating layer needs every node's input row")
             elif sh.world > 1 and not last and 2 * d_in <= d_out and layout == "nat":
                 # widening layer (products layer 1: 100 -> 256): exchange the NARROW aggregate and let every rank
                 # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
@@ -182,29 +238,41 @@ class ShardedTeacher:
                 if sh.chunks > 1:
                     x = self._widening_layer_overlapped(l, x, w, tail)
                     layout = "cm"
-                    y_own = None
-                    continue
-                agg = self._full_buffer(("agg", l), d_in, x.device)
-                be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.lo:sh.hi], x_self=x[sh.lo:sh.hi])
-                all_gather_rows(agg, sh, self.group)
-                y_full = self._full_buffer(("y", l), d_out, x.device)
-                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)
-                x = y_full
-                y_own = y_full[sh.lo:sh.hi]
+                else:
+                    agg = self._full_buffer(("agg", l), d_in, x.device)
+                    be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.lo:sh.hi], x_self=x[sh.lo:sh.hi])
+                    all_gather_rows(agg, sh, self.group)
+                    y_full = self._full_buffer(("y", l), d_out, x.device)
+                    be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)
+                    x = y_full
+                y_own = None          # (a widening layer is never the last one)
+                l += 1
                 continue
+            elif sh.world > 1 and sh.chunks > 1 and next_narrow:
+                out = self._plain_then_narrow_overlapped(l, x, layout)      # layers l and l+1
+                l += 1
+                last = l == L - 1
+                next_narrow = False
             else:
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
                 self._aggregate_project(x, layout, w, tail, out)
             y_own = out
             if not last:
-                x = all_gather_rows(self._full_buffer(("y", l), d_out, x.device), sh, self.group)
+                d_cur = dims[l][1]
+                buf = self._full_buffer(("y", l), d_cur, x.device)
+                if dims[l + 1][0] > dims[l + 1][1]:
+                    x, complete = buf, False          # the next (narrowing) layer projects its own rows only: no exchange
+                else:
+                    x, complete = all_gather_rows(buf, sh, self.group), True
                 layout = "nat"
+            l += 1
         return y_own
 
 
 def _all_gather_block(out_block, mine, shards, group):
     """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot.
     Returns a callable that makes the current stream wait for it."""
+    _count(out_block)
     if dist.get_backend(group) == "nccl":
         work = dist.all_gather_into_tensor(out_block, mine.clone(), group=group, async_op=True)   # non-aliased source
         return work.wait

@@ -44,4 +44,8 @@ def test_bench_two_ranks_driver_launch_line(extra):
     assert REQUIRED <= out.keys()
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["student"]["global_batch"] == 2 * 4096
+    ex = out["exchange"]       # per forward: n_pad * (100 + 48) floats = the narrow sides only (layer 2 exchanges nothing)
+    n_pad = -(-out["config"]["nodes"] // 8) * 8
+    assert abs(ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * 148) < 0.02 * 4e-9 * n_pad * 148, ex
+    assert ex["collectives_per_forward"] == 8
     assert ("global" in out["student"]["batchnorm"]) == bool(extra)

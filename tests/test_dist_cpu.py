@@ -92,12 +92,15 @@ def _worker(rank, world, port, n, dims, seed, chunks, q):
         x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
         sh = RowShards(n, world, rank, chunks=chunks)
         be = OracleBackend()
+        from glnn_amd import dist as gdist
+        gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
         with torch.no_grad():
             y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be).forward(x)
+        stats = dict(gdist.EXCHANGE_STATS, n_pad=sh.n_pad)
         # DP gradient exchange
         flat = torch.full((10,), float(rank + 1))
         make_grad_sync(flat, world, average=True)()
-        q.put((rank, sh.lo, sh.hi, y_own.numpy().copy(), flat.numpy().copy()))
+        q.put((rank, sh.lo, sh.hi, y_own.numpy().copy(), flat.numpy().copy(), stats))
     finally:
         dist.destroy_process_group()
 
@@ -135,9 +138,23 @@ def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims, chunks):
     x = np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32)
     want = to.sage_inference(indptr, indices, x, layers, norms)
     covered = np.zeros(n, bool)
-    for rank, lo, hi, y, flat in res:
+    # what a forward may move: per node, the NARROW side of every layer boundary that needs remote rows -- the aggregate of
+    # a widening layer (2*in <= out), the projected rows of a narrowing layer (in > out), the output of any other layer
+    # unless the next layer is narrowing (it projects its own rows only)
+    r4 = lambda d: (d + 3) // 4 * 4
+    per_node = 0
+    for l in range(L):
+        d_in, d_out = dims[l], dims[l + 1]
+        if d_in > d_out:
+            per_node += r4(d_out)
+        elif l < L - 1 and 2 * d_in <= d_out:
+            per_node += r4(d_in)
+        elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
+            per_node += r4(d_out)
+    for rank, lo, hi, y, flat, stats in res:
         np.testing.assert_allclose(y, want[lo:hi], atol=1e-4, rtol=0)
         covered[lo:hi] = True
+        assert stats["floats_received"] == stats["n_pad"] * per_node, (stats, per_node)
         np.testing.assert_allclose(flat, np.full(10, 1.5))      # mean of 1 and 2
     assert covered.all()
 
