@@ -80,6 +80,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GlnnError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch first: its wheel bundles its own HIP runtime, and a process must end up with ONE of them.  Loading this
+        # library before torch binds it to /opt/rocm's libamdhip64 while torch later initialises its bundled copy -- every
+        # launch from here then fails with "no ROCm-capable device is detected" (seen as build(); smoke() in one process).
+        import torch  # noqa: F401
         h = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(h, name)          # AttributeError => missing export: fail loudly
