@@ -260,15 +260,19 @@ __device__ __forceinline__ float4 mask4(float4 v, int left) {   // keep elements
   return v;
 }
 
-template <int BN, bool B_KN, int XF, int BKF>
+// BMT x BN block tile, 4 waves as 2 x 2: a wave owns (BMT/2) x (BN/2) = MI x NT MFMA blocks.  BMT = 64 (with BN = 64: one block per
+// wave) is the latency form for outputs of a few dozen tiles -- a B=512 student GEMM is 8 tiles of 128x128, i.e. 32 busy SIMDs
+// out of 1024 and a serial chain of 64 MFMAs per k-tile and wave; 64x64 tiles quarter that chain and quadruple the workgroups.
+template <int BMT, int BN, bool B_KN, int XF, int BKF>
 __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
+  constexpr int MI = BMT / 64;             // 32-row MFMA blocks per wave
   constexpr int LDS_KF = BKF + 4;          // padded [row][k] stride; 9*i / 5*i mod 16 are bijections on the b128 lane groups
   constexpr int KV = BKF / 4;              // float4 per tile row
   constexpr int RSTEP = 256 / KV;          // rows covered by one pass of the 256 threads
-  constexpr int AQ = BM / RSTEP;
+  constexpr int AQ = BMT / RSTEP;
   constexpr int NT = BN / 64;
   constexpr int LDS_N = BN + 4;
-  constexpr int A_TILE = BM * LDS_KF;
+  constexpr int A_TILE = BMT * LDS_KF;
   constexpr int B_TILE = B_KN ? BKF * LDS_N : BN * LDS_KF;
   constexpr int BQ = B_KN ? (BKF * BN / 4) / 256 : BN / RSTEP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kk = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int64_t m0 = (int64_t)blockIdx.x * BMT;
   const int n0 = blockIdx.y * BN;
   const int c4 = (tid % KV) * 4;         // k offset of this thread's float4 inside a [row][k] tile
   const int r0 = tid / KV;               // its first row; rows r0 + RSTEP q
@@ -383,9 +387,9 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     for (int p = 0; p < P; ++p) load_piece(s, p);
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MI][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -403,13 +407,13 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   //                     global loads of tile t+2 issued
   //   last group      : first half of its MFMAs | barrier | ds_read of tile t+1's first fragments | second half
   constexpr int G = BKF / 8;
-  float fa[2][2][4], fb[2][NT][4];
-  auto read_frags = [&](int buf, int kg, float (&af)[2][4], float (&bf)[NT][4]) {
-    const float* as = As + buf * A_TILE + (wm * 64 + li) * LDS_KF + kk * 4;
+  float fa[2][MI][4], fb[2][NT][4];
+  auto read_frags = [&](int buf, int kg, float (&af)[MI][4], float (&bf)[NT][4]) {
+    const float* as = As + buf * A_TILE + (wm * (BMT / 2) + li) * LDS_KF + kk * 4;
     const float* bs = B_KN ? Bs + buf * B_TILE + (kk * 4) * LDS_N + wn * (BN / 2) + li
                            : Bs + buf * B_TILE + (wn * (BN / 2) + li) * LDS_KF + kk * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_KF + kg * 8);
       af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
     }
@@ -424,12 +428,12 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
       }
     }
   };
-  // MFMAs [m_beg, m_end) of one k-group's 8*NT, in the order t (k-pair) -> i (row block) -> j (col block)
-  constexpr int MG = 8 * NT;
-  auto mfma_range = [&](const float (&af)[2][4], const float (&bf)[NT][4], int m_beg, int m_end) {
+  // MFMAs [m_beg, m_end) of one k-group's 4*MI*NT, in the order t (k-pair) -> i (row block) -> j (col block)
+  constexpr int MG = 4 * MI * NT;
+  auto mfma_range = [&](const float (&af)[MI][4], const float (&bf)[NT][4], int m_beg, int m_end) {
 #pragma unroll
     for (int mm = m_beg; mm < m_end; ++mm) {
-      const int t = mm / (2 * NT), i = (mm / NT) % 2, j = mm % NT;
+      const int t = mm / (MI * NT), i = (mm / NT) % MI, j = mm % NT;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     }
   };
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     for (int j = 0; j < NT; ++j) {
       const int col = n0 + wn * (BN / 2) + j * 32 + li;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * kk;
+      for (int i = 0; i < MI; ++i) {
+        const int64_t rbase = m0 + wm * (BMT / 2) + i * 32 + 4 * kk;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = rbase + (r & 3) + 8 * (r >> 2);
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const bool full_tile = (m0 + BM <= g.m) && (n0 + BN <= g.n);     // workgroup-uniform
+  const bool full_tile = (m0 + BMT <= g.m) && (n0 + BN <= g.n);     // workgroup-uniform
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = n0 + wn * (BN / 2) + j * 32 + li;
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
     const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * kk;
+    for (int i = 0; i < MI; ++i) {
+      const int64_t rbase = m0 + wm * (BMT / 2) + i * 32 + 4 * kk;
       float* cp = g.c + rbase * g.ldc + col;
       float rs[16];
       if (g.row_scale) {
@@ -691,17 +695,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
 // is EXACTLY the NT kernel's (conflict-free ds_read_b128 fragments, 4 MFMAs per read).
 // Thread map: tid -> (rg: rows 4rg..4rg+3 of the 32-row k-tile, cg: columns 4cg..4cg+3), interleaved (below).
 // ---------------------------------------------------------------------------------------------
-template <int BNT, int XF, bool ROWS>
+template <int BMT, int BNT, int XF, bool ROWS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
+  constexpr int MI = BMT / 64;
   constexpr int NT = BNT / 64;
-  constexpr int A_TILE = BM * LDS_K, B_TILE = BNT * LDS_K;
+  constexpr int A_TILE = BMT * LDS_K, B_TILE = BNT * LDS_K;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                      // [2][BM][LDS_K]   rows = output row index i, k = m
   float* Bs = smem + 2 * A_TILE;         // [2][BNT][LDS_K]  rows = output col index j
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
-  const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BNT;
+  const int i0 = blockIdx.x * BMT, j0 = blockIdx.y * BNT;
   const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
   int64_t mend = mbeg + g.rows_per_split;
   if (mend > g.m) mend = g.m;
@@ -710,7 +715,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   // stores of a lane group land on 8 distinct 16-byte slots (brute-forced: conflict-free; the plain
   // tid/32, tid%32 map is 4-way conflicted); a wave still reads 256 contiguous bytes per global row
   const int rg = (tid & 3) | (((tid >> 7) & 1) << 2), cg = (tid >> 2) & 31;
-  const bool b_active = cg < BNT / 4;                  // BNT = 64: half the column groups
+  const bool a_active = cg < BMT / 4;                  // 64-wide tiles: half the column groups
+  const bool b_active = cg < BNT / 4;
   int a_col = i0 + 4 * cg, b_col = j0 + 4 * cg;
   const int kap = (g.ka + 3) & ~3, nbp = (g.nb + 3) & ~3;
   if (a_col > kap - 4) a_col = kap - 4;               // clamped columns only feed outputs that are never stored
@@ -740,7 +746,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
     int64_t mrow = mt_cur + 4 * rg + r;
     if (mrow > g.m - 1) mrow = g.m - 1;
     if (p < 4) {
-      a_reg[r] = ld4g(g.a + mrow * g.lda + a_col);
+      if (a_active) a_reg[r] = ld4g(g.a + mrow * g.lda + a_col);
     } else if (b_active) {
       if (ROWS) {
         b_reg[r] = ld4g(g.b + src_row[r] * g.ldb + b_col);
@@ -784,26 +790,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   auto store_col = [&](int buf, int c) {
     float* as = As + buf * A_TILE + (4 * cg) * LDS_K + 4 * rg;
     float* bs = Bs + buf * B_TILE + (4 * cg) * LDS_K + 4 * rg;
-    *reinterpret_cast<float4*>(as + c * LDS_K) = make_float4(av[0][c], av[1][c], av[2][c], av[3][c]);
+    if (a_active) *reinterpret_cast<float4*>(as + c * LDS_K) = make_float4(av[0][c], av[1][c], av[2][c], av[3][c]);
     if (b_active) *reinterpret_cast<float4*>(bs + c * LDS_K) = make_float4(bv[0][c], bv[1][c], bv[2][c], bv[3][c]);
   };
 
-  f32x16 acc[2][NT];
+  f32x16 acc[MI][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   constexpr int G = BK / 8;                 // k-groups per tile (k = 8 kg + 4 kk + t)
-  constexpr int MG = 8 * NT;                // MFMAs per k-group
-  float fa[2][2][4], fb[2][NT][4];
-  auto read_frags = [&](int buf, int kg, float (&af)[2][4], float (&bf)[NT][4]) {
-    const float* as = As + buf * A_TILE + (wm * 64 + li) * LDS_K + kk * 4;
+  constexpr int MG = 4 * MI * NT;           // MFMAs per k-group
+  float fa[2][MI][4], fb[2][NT][4];
+  auto read_frags = [&](int buf, int kg, float (&af)[MI][4], float (&bf)[NT][4]) {
+    const float* as = As + buf * A_TILE + (wm * (BMT / 2) + li) * LDS_K + kk * 4;
     const float* bs = Bs + buf * B_TILE + (wn * (BNT / 2) + li) * LDS_K + kk * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * LDS_K + kg * 8);
       af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
     }
@@ -813,10 +819,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
       bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
     }
   };
-  auto mfma_range = [&](const float (&af)[2][4], const float (&bf)[NT][4], int m_beg, int m_end) {
+  auto mfma_range = [&](const float (&af)[MI][4], const float (&bf)[NT][4], int m_beg, int m_end) {
 #pragma unroll
     for (int mm = m_beg; mm < m_end; ++mm) {
-      const int t = mm / (2 * NT), i = (mm / NT) % 2, j = mm % NT;
+      const int t = mm / (MI * NT), i = (mm / NT) % MI, j = mm % NT;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
     }
   };
@@ -870,10 +876,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   for (int j = 0; j < NT; ++j) {
     const int col = j0 + wn * (BNT / 2) + j * 32 + li;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int row = i0 + wm * (BMT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
       }
   }
@@ -950,10 +956,10 @@ int set_smem(K kernel, size_t bytes) {
 }
 
 template <typename K>
-int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g, int bn, hipStream_t st) {
+int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g, int bn, hipStream_t st, int bm = BM) {
   if (configured > 0) configured = set_smem(kernel, smem);
   if (configured != GLNN_OK) return configured;
-  const int64_t gm = (g.m + BM - 1) / BM;
+  const int64_t gm = (g.m + bm - 1) / bm;
   const int gn = (g.n + bn - 1) / bn;
   if (gm > 0x7fffffffLL) return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_gemm_f32: m too large");
   hipLaunchKernelGGL(kernel, dim3((unsigned)gm, (unsigned)gn, (unsigned)g.ksplits), dim3(256), smem, st, g);
@@ -981,9 +987,21 @@ int launch_gemm(GemmArgs& g, bool fast, hipStream_t st) {
     return launch_gemm_kernel(gemm_kernel_generic<BN, B_KN>, cfg[3], smem_generic, g, BN, st);
   }
   if (BKF != BK) g.ktiles_per_split *= BK / BKF;     // split bookkeeping is in units of the fast kernel's k-tiles
-  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st);
-  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st);
-  return launch_gemm_kernel(gemm_kernel_fast<BN, B_KN, 2, BKF>, cfg[2], smem_fast, g, BN, st);
+  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st);
+  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st);
+  return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 2, BKF>, cfg[2], smem_fast, g, BN, st);
+}
+
+// 64 x 64 tiles (one MFMA block per wave): the latency form for outputs of a few dozen tiles
+template <bool B_KN>
+int launch_gemm_small(GemmArgs& g, hipStream_t st) {
+  constexpr int BKF = GLNN_GEMM_BKF;
+  constexpr size_t smem = sizeof(float) * 2 * (64 * (BKF + 4) + (B_KN ? BKF * (64 + 4) : 64 * (BKF + 4)));
+  static int cfg[3] = {1, 1, 1};
+  if (BKF != BK) g.ktiles_per_split *= BK / BKF;
+  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 0, BKF>, cfg[0], smem, g, 64, st, 64);
+  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 1, BKF>, cfg[1], smem, g, 64, st, 64);
+  return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 2, BKF>, cfg[2], smem, g, 64, st, 64);
 }
 
 }  // namespace
@@ -1015,6 +1033,27 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   // fast path: all float4 loads legal and all-or-nothing at the k (and, for [k,n], n) boundary
   const bool fast = g.a_vec && g.b_vec && lda >= ((k + 3) & ~3) && ldb >= (((b_layout ? n : k) + 3) & ~3) &&
                     (!a_scale || (k % 4 == 0 && glnn::aligned16(a_scale) && glnn::aligned16(a_shift)));
+  // latency regime: fewer than 64 tiles of 128 x (128|64) -> 64 x 64 tiles, four times the workgroups, a quarter of the
+  // serial MFMA chain per k-tile; split-K only when the chain is still long (>= 16 k-tiles)
+  {
+    const int bn = n > 64 ? 128 : 64;
+    const int64_t tiles = ((m + BM - 1) / BM) * ((n + bn - 1) / bn);
+    if (fast && tiles <= 64) {
+      const int nk = (k + BK - 1) / BK;
+      const int64_t tiles_s = ((m + 63) / 64) * ((n + 63) / 64);
+      if (workspace && nk >= 16 && tiles_s < 512) {
+        int64_t sp = (512 + tiles_s - 1) / tiles_s;
+        if (sp > nk / 4) sp = nk / 4;
+        if (sp * m * n > workspace_floats) sp = workspace_floats / (m * n);
+        if (sp > 1) {
+          g.ktiles_per_split = (nk + (int)sp - 1) / (int)sp;
+          g.ksplits = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+          g.ws = workspace;
+        }
+      }
+      return b_layout ? launch_gemm_small<true>(g, st) : launch_gemm_small<false>(g, st);
+    }
+  }
   // split-K when the output has too few tiles to fill 256 CUs twice over and K is deep enough
   if (fast && workspace) {
     const int bn = n > 64 ? 128 : 64;
@@ -1054,15 +1093,22 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   g.b = b; g.ldb = ldb; g.b_rows = b_rows; g.b_scale = b_scale; g.b_shift = b_shift; g.nb = nb;
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
-  const int bnt = nb > 64 ? 128 : 64;
-  const int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;
+  int bnt = nb > 64 ? 128 : 64;
+  int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;
+  const bool fast = g.a_vec && g.b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
+                    (!b_scale || (nb % 4 == 0 && glnn::aligned16(b_scale) && glnn::aligned16(b_shift)));
+  // latency regime (see gemm_kernel_fast): a few dozen output tiles -> 64 x 64 tiles, a quarter of the per-wave MFMA chain
+  const bool small = fast && gi * gj <= 64;
+  if (small) { bnt = 64; gi = (ka + 63) / 64; gj = (nb + 63) / 64; }
   // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
   int splits = 1;
   const int64_t slab = (int64_t)ka * nb;
   const int64_t colsum_need = col_sum_a ? (int64_t)64 * ka : 0;
-  if (workspace && gi * gj < 512) {
-    splits = (512 + gi * gj - 1) / (gi * gj);
-    const int64_t max_by_rows = (m + 4 * BK - 1) / (4 * BK);      // at least 4 k-tiles per split
+  const int wg_target = small ? 1024 : 512;           // 64 x 64 tiles: four workgroups fit a CU, and a k-tile step is load-latency bound
+  const int min_ktiles = small ? 2 : 4;
+  if (workspace && gi * gj < wg_target) {
+    splits = (wg_target + gi * gj - 1) / (gi * gj);
+    const int64_t max_by_rows = (m + min_ktiles * BK - 1) / (min_ktiles * BK);      // at least min_ktiles k-tiles per split
     if (splits > max_by_rows) splits = (int)max_by_rows;
     const int64_t avail = workspace_floats - colsum_need;
     if ((int64_t)splits * slab > avail) splits = (int)(avail / slab);
@@ -1076,15 +1122,14 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   g.splits = splits;
   float* ws_partial = workspace ? workspace + colsum_need : nullptr;
   if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
-  const bool fast = g.a_vec && g.b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
-                    (!b_scale || (nb % 4 == 0 && glnn::aligned16(b_scale) && glnn::aligned16(b_shift)));
   const int xf = !b_scale ? 0 : (g.drop_thr ? 2 : 1);
   {
     constexpr size_t smem128 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (128 + 4));
     constexpr size_t smem64 = sizeof(float) * 2 * (BK * (BM + 4) + BK * (64 + 4));
     constexpr size_t smem128t = sizeof(float) * 2 * (BM * LDS_K + 128 * LDS_K);
     constexpr size_t smem64t = sizeof(float) * 2 * (BM * LDS_K + 64 * LDS_K);
-    static int cfg[14] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    constexpr size_t smem_s = sizeof(float) * 2 * (64 * LDS_K + 64 * LDS_K);
+    static int cfg[20] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     const bool rows = b_rows != nullptr;
     const dim3 grid(gi, gj, splits);
 #define GLNN_TN_LAUNCH(KERNEL_, SLOT_, SMEM_)                                   \
@@ -1093,22 +1138,29 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
     if (cfg[SLOT_] != GLNN_OK) return cfg[SLOT_];                               \
     hipLaunchKernelGGL(KERNEL_, grid, dim3(256), SMEM_, st, g);                 \
   } while (0)
-    if (bnt == 128) {
+    if (small) {
+      if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 0, false>), 14, smem_s);
+      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 1, false>), 15, smem_s);
+      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 2, false>), 16, smem_s);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 0, true>), 17, smem_s);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 1, true>), 18, smem_s);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 2, true>), 19, smem_s);
+    } else if (bnt == 128) {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<128>), 0, smem128);
-      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0, false>), 1, smem128t);
-      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1, false>), 2, smem128t);
-      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2, false>), 3, smem128t);
-      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 0, true>), 8, smem128t);
-      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 1, true>), 9, smem128t);
-      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<128, 2, true>), 10, smem128t);
+      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 0, false>), 1, smem128t);
+      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 1, false>), 2, smem128t);
+      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 2, false>), 3, smem128t);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 0, true>), 8, smem128t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 1, true>), 9, smem128t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 2, true>), 10, smem128t);
     } else {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<64>), 4, smem64);
-      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0, false>), 5, smem64t);
-      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1, false>), 6, smem64t);
-      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2, false>), 7, smem64t);
-      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 0, true>), 11, smem64t);
-      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 1, true>), 12, smem64t);
-      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 2, true>), 13, smem64t);
+      else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 0, false>), 5, smem64t);
+      else if (xf == 1 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 1, false>), 6, smem64t);
+      else if (!rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 2, false>), 7, smem64t);
+      else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 0, true>), 11, smem64t);
+      else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 1, true>), 12, smem64t);
+      else GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 64, 2, true>), 13, smem64t);
     }
 #undef GLNN_TN_LAUNCH
   }
