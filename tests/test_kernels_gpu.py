@@ -439,3 +439,58 @@ def test_randomized_shape_sweep_vs_oracle():
         dz = rs.standard_normal((n, d_out)).astype(np.float32) / 4
         np.testing.assert_allclose(ops.gemm_tn(ops.as_feat(dev(dz)), ops.as_feat(xd)).cpu().numpy(),
                                    dz.astype(np.float64).T @ x.astype(np.float64), atol=2e-4, rtol=1e-5, err_msg=f"tn it={it}")
+
+
+def test_randomized_gemm_sweep_all_variants():
+    """30 seeded random GEMM problems across the tile regimes (64x64 latency tiles, 128x64, 128x128), the three forms,
+    operand transforms (BN affine + ReLU, + dropout through the kernel's own mask), row gathers, epilogues and split-K
+    (workspace on/off); float64 numpy is the reference."""
+    from glnn_amd import ops
+    import os
+    rs = np.random.RandomState(int(os.environ.get("GLNN_SWEEP_SEED", "77")))     # other seeds: ad-hoc soak runs
+    for it in range(30):
+        m = int(rs.choice([1, 37, 512, 700, 4096, 9000, 20011]))
+        k = int(rs.choice([4, 20, 100, 128, 256, 516, 1024]))
+        n = int(rs.choice([1, 7, 47, 64, 100, 256, 300, 1024]))
+        xf = int(rs.randint(0, 3))
+        gather = bool(rs.randint(0, 2))
+        use_ws = bool(rs.randint(0, 2))
+        nsrc = m + int(rs.randint(0, 50))
+        a = rs.standard_normal((nsrc, k)).astype(np.float32)
+        w = (rs.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+        rows = rs.randint(0, nsrc, m).astype(np.int64) if gather else None
+        a_eff = (a[rows] if gather else a[:m]).astype(np.float64)
+        kw = {}
+        p, seed = 0.3, 1000 + it
+        if xf:
+            sc, sh = rs.uniform(.5, 1.5, k).astype(np.float32), (rs.standard_normal(k) * .2).astype(np.float32)
+            a_eff = np.maximum(a_eff * sc + sh, 0)
+            kw.update(a_scale=dev(sc), a_shift=dev(sh))
+            if xf == 2:
+                a_eff = a_eff * ops.dropout_mask(m, k, p, seed, DEV).cpu().numpy() / (1 - p)
+                kw.update(drop_p=p, drop_seed=seed)
+        es, eh = rs.uniform(.5, 1.5, n).astype(np.float32), rs.standard_normal(n).astype(np.float32)
+        relu = bool(rs.randint(0, 2))
+        want = a_eff @ w.astype(np.float64).T * es + eh
+        if relu:
+            want = np.maximum(want, 0)
+        ws = torch.empty(1 << 23, device=DEV) if use_ws else None
+        ad = ops.as_feat(dev(a))
+        tag = f"it={it} m={m} k={k} n={n} xf={xf} gather={gather} ws={use_ws}"
+        got = ops.gemm(ad, ops.as_feat(dev(w)), a_rows=dev(rows) if gather else None, m=m, ep_scale=dev(es), ep_shift=dev(eh), relu=relu,
+                       workspace=ws, **kw)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-4, rtol=1e-5, err_msg="NT " + tag)
+        got = ops.gemm(ad, ops.as_feat(dev(np.ascontiguousarray(w.T))), w_is_kn=True, a_rows=dev(rows) if gather else None, m=m,
+                       ep_scale=dev(es), ep_shift=dev(eh), relu=relu, workspace=ws, **kw)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-4, rtol=1e-5, err_msg="KN " + tag)
+        # TN: dW[n_out, k] = dz^T @ a_eff   (the transform / gather / dropout sit on the second operand)
+        dz = (rs.standard_normal((m, n)) / 8).astype(np.float32)
+        kt = {}
+        if xf:
+            kt.update(b_scale=kw["a_scale"], b_shift=kw["a_shift"])
+            if xf == 2:
+                kt.update(drop_p=p, drop_seed=seed)
+        colsum = torch.empty(n, device=DEV)
+        got = ops.gemm_tn(ops.as_feat(dev(dz)), ad, b_rows=dev(rows) if gather else None, m=m, col_sum_a=colsum, **kt)
+        np.testing.assert_allclose(got.cpu().numpy(), dz.astype(np.float64).T @ a_eff, atol=3e-4, rtol=1e-5, err_msg="TN " + tag)
+        np.testing.assert_allclose(colsum.cpu().numpy(), dz.astype(np.float64).sum(0), atol=2e-4, rtol=1e-5, err_msg="colsum " + tag)
