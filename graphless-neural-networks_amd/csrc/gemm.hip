@@ -993,12 +993,16 @@ int launch_gemm(GemmArgs& g, bool fast, hipStream_t st) {
 }
 
 // 64 x 64 tiles (one MFMA block per wave): the latency form for outputs of a few dozen tiles
+#ifndef GLNN_GEMM_SMALL_BKF
+#define GLNN_GEMM_SMALL_BKF 32
+#endif
 template <bool B_KN>
 int launch_gemm_small(GemmArgs& g, hipStream_t st) {
-  constexpr int BKF = GLNN_GEMM_BKF;
+  constexpr int BKF = GLNN_GEMM_SMALL_BKF;
   constexpr size_t smem = sizeof(float) * 2 * (64 * (BKF + 4) + (B_KN ? BKF * (64 + 4) : 64 * (BKF + 4)));
   static int cfg[3] = {1, 1, 1};
-  if (BKF != BK) g.ktiles_per_split *= BK / BKF;
+  if (BKF < BK) g.ktiles_per_split *= BK / BKF;
+  if (BKF > BK) g.ktiles_per_split = (g.ktiles_per_split + BKF / BK - 1) / (BKF / BK);
   if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 0, BKF>, cfg[0], smem, g, 64, st, 64);
   if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 1, BKF>, cfg[1], smem, g, 64, st, 64);
   return launch_gemm_kernel(gemm_kernel_fast<64, 64, B_KN, 2, BKF>, cfg[2], smem, g, 64, st, 64);
