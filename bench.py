@@ -197,7 +197,7 @@ def main():
         return
 
     result = {
-        "metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products",
+        "metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products 1/2/4/8 GPU",
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_teacher / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -219,7 +219,8 @@ def main():
                                  else "per-rank batch statistics",
                     "scaling": "weak", "gflop_per_step": 3 * 2 * sd["batch"] * (100 * 2048 + 2048 * 2048 + 2048 * 47) / 1e9},
     }
-    result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3
+    result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3      # per GPU
+    result["student"]["frac_of_fp32_mfma_peak"] = result["student"]["tflops"] / 157.3      # v_mfma_f32_32x32x2_f32 dense peak
 
     # ---- roofline of the dominant kernel (N = 1): per-launch HIP events from the timed region -------------
     if world == 1 and timing:
