@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
 SAGE_DIMS = [100, 256, 256, 47]  # reference train.conf.yaml:196-204 (ogbn-products SAGE, hidden 256, BN)
 STUDENT = dict(name="MLP3w8", dims=[100, 2048, 2048, 47], batch=4096, dropout=0.2, lr=0.01, wd=0.0)   # :187-194
+GRAPH = "ogbn-products"
+CPU_SAMPLE_SCALE = 0.05
+# --workload arxiv = BASELINE.json configs[1] + [2]: ogbn-arxiv-shaped SAGE teacher forward (train.conf.yaml:170-177) and the
+# MLP3w4 student the reference's experiments/glnn_arxiv.sh uses (:149-154).  Features (87 MB) fit the 256 MB Infinity Cache,
+# so the HBM fraction of its roofline object is not meaningful -- edges/s is the number.
+ARXIV = dict(graph="ogbn-arxiv", sage_dims=[128, 256, 256, 40], cpu_sample_scale=1.0,
+             student=dict(name="MLP3w4", dims=[128, 1024, 1024, 40], batch=512, dropout=0.5, lr=0.01, wd=0.0))
 
 
 def agg_width(d_in, d_out):
@@ -71,7 +78,7 @@ def main():
     ap.add_argument("--student-global-bn", action="store_true",
                     help="N > 1: take the student's BatchNorm batch statistics over the global (N x B rows) batch through the "
                          "exchange hook, i.e. exactly the single-GPU step on that batch (default: per-rank statistics)")
-    ap.add_argument("--workload", default="products", choices=["products", "xl"],
+    ap.add_argument("--workload", default="products", choices=["products", "arxiv", "xl"],
                     help="products = the metric's config (default); xl = BASELINE.json configs[4]: 12.5M-node / 250M-edge shard per GPU "
                          "of a 100M-node / 2B-edge synthetic graph, 128-d features, SAGE layer-1 aggregation only (weak scaling)")
     args = ap.parse_args()
@@ -109,12 +116,15 @@ def main():
 
     if args.workload == "xl":
         return run_xl(args, rank, world, dev, barrier)
+    global SAGE_DIMS, STUDENT, GRAPH, CPU_SAMPLE_SCALE
+    if args.workload == "arxiv":
+        SAGE_DIMS, STUDENT, GRAPH, CPU_SAMPLE_SCALE = ARXIV["sage_dims"], ARXIV["student"], ARXIV["graph"], ARXIV["cpu_sample_scale"]
 
     # ---- synthetic ogbn-products-shaped inputs, generated in HBM (seed 0, identical on every rank) --------
     torch.manual_seed(0)
-    g = data.make_graph("ogbn-products", seed=0, device=dev, scale=args.scale)
+    g = data.make_graph(GRAPH, seed=0, device=dev, scale=args.scale)
     n, nnz = g.n_dst, g.num_edges()
-    feats, labels, out_t, _ = data.make_node_data("ogbn-products", seed=0, device=dev, n=n)
+    feats, labels, out_t, _ = data.make_node_data(GRAPH, seed=0, device=dev, n=n)
     feats = ops.as_feat(feats)
 
     teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1],
@@ -197,12 +207,13 @@ def main():
         return
 
     result = {
-        "metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products 1/2/4/8 GPU",
+        "metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products 1/2/4/8 GPU" if GRAPH == "ogbn-products"
+                  else f"aggregated edges/sec (teacher fwd) + student distill steps/sec, {GRAPH} (BASELINE configs[1]+[2])",
         "value": edges_per_s, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * t_teacher / args.steps, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "ogbn-products-shaped SAGE teacher forward (3 layers 100-256-256-47, BN, layer-wise "
-                               "full-neighbour inference, reference models.py:121-148) + MLP3w8 student KL distillation step",
+        "config": {"workload": f"{GRAPH}-shaped SAGE teacher forward (3 layers {'-'.join(map(str, SAGE_DIMS))}, BN, layer-wise "
+                               f"full-neighbour inference, reference models.py:121-148) + {STUDENT['name']} student KL distillation step",
                    "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
                    "graph": "seeded power-law multigraph, random node order", "scale": args.scale,
                    "parallelism": "1 GPU" if world == 1 else f"node-range row shards x{world}, all-gather per layer; student dp{world}"},
@@ -211,13 +222,14 @@ def main():
             "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
             "what": "all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
                     "with the aggregation), 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none"},
-        "student": {"metric": "student distill steps/s (MLP3w8 100-2048-2048-47, B=4096 per rank, dropout 0.2, BN, "
-                              "KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
+        "student": {"metric": f"student distill steps/s ({sd['name']} {'-'.join(map(str, sd['dims']))}, B={sd['batch']} per rank, dropout "
+                              f"{sd['dropout']}, BN, KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
                     "value": student_steps_per_s, "unit": "steps/s", "steps": k_student, "warmup": w_student,
                     "ms_per_step": 1e3 * t_student / k_student, "global_batch": world * sd["batch"],
                     "batchnorm": "global batch statistics (exchange hook)" if (world > 1 and args.student_global_bn)
                                  else "per-rank batch statistics",
-                    "scaling": "weak", "gflop_per_step": 3 * 2 * sd["batch"] * (100 * 2048 + 2048 * 2048 + 2048 * 47) / 1e9},
+                    "scaling": "weak",
+                    "gflop_per_step": 3 * 2 * sd["batch"] * sum(a * b for a, b in zip(sd["dims"][:-1], sd["dims"][1:])) / 1e9},
     }
     result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3      # per GPU
     result["student"]["frac_of_fp32_mfma_peak"] = result["student"]["tflops"] / 157.3      # v_mfma_f32_32x32x2_f32 dense peak
@@ -247,12 +259,14 @@ def main():
         result["roofline"] = {
             "bound": "hbm", "kernel": f"{dom['kernel']} (D={dom['d']})",
             "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(dom["kernel"].split(">")[0] + ">"),
+            "traffic": pmc_traffic(dom["kernel"].split(">")[0] + ">") if (GRAPH == "ogbn-products" and args.scale == 1.0) else None,
             "algorithmic_bytes_per_launch": dom["alg_GB"] * 1e9, "avg_launch_ms": dom["avg_ms"],
             "all_aggregation_launches": sorted(layers, key=lambda r: r["d"]),
             "aggregation_total": {"alg_GB": tot_b / 1e9, "ms": tot_ms, "GBps": tot_b / tot_ms / 1e6, "frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS},
             "dense_projection_ms_per_forward": gemm_ms,
-            "note": "achieved = SURVEY 8(d) algorithmic bytes nnz*(4D+4)+n*(8D+8) / mean HIP-event launch time over the timed region",
+            "note": "achieved = SURVEY 8(d) algorithmic bytes nnz*(4D+4)+n*(8D+8) / mean HIP-event launch time over the timed region"
+                    + ("" if GRAPH == "ogbn-products" else "; the feature matrix fits the 256 MB Infinity Cache at this shape, so the "
+                       "rate is a cache rate and the HBM fraction is not meaningful (SURVEY 8d)"),
         }
 
     # ---- CPU baseline on the host cores (oracle = 'port'; bounded sample) ---------------------------------
@@ -327,8 +341,8 @@ def cpu_baseline(sd):
     from oracle import teacher_oracle as to
     from glnn_amd import data
     threads = to.max_threads()
-    scale = 0.05
-    g = data.make_graph("ogbn-products", seed=0, device="cpu", scale=scale)
+    scale = CPU_SAMPLE_SCALE
+    g = data.make_graph(GRAPH, seed=0, device="cpu", scale=scale)
     n, nnz = g.n_dst, g.num_edges()
     rs = np.random.RandomState(0)
     x = rs.standard_normal((n, SAGE_DIMS[0])).astype(np.float32)
@@ -376,12 +390,12 @@ def cpu_baseline(sd):
         sreps += 2
     t_step = (time.perf_counter() - t2) / sreps
     return {"value": 3 * nnz / t_teacher, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"3-layer SAGE forward (100-256-256-47, BN eval) on a 1/20-scale products-shaped graph "
+            "sample": f"3-layer SAGE forward ({'-'.join(map(str, SAGE_DIMS))}, BN eval) on a {scale}-scale {GRAPH}-shaped graph "
                       f"(n={n}, nnz={nnz}), oracle/glnn_oracle.c with OpenMP on {threads} threads, {reps} reps; "
                       "the reference's own dgl CPU path cannot be timed (dgl not installed)",
             "aggregation_only_edges_per_s": nnz / t_agg,
             "student_steps_per_s": 1.0 / t_step,
-            "student_sample": f"numpy/BLAS oracle train step, MLP3w8 dims, B={B}, {sreps} steps, numpy threads = BLAS default"}
+            "student_sample": f"numpy/BLAS oracle train step, {sd['name']} dims, B={B}, {sreps} steps, numpy threads = BLAS default"}
 
 
 if __name__ == "__main__":
