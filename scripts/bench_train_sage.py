@@ -1,0 +1,41 @@
+"""Sampled-block SAGE teacher training (reference train_sage, train_and_eval.py:28-56; fan-out 5,10,15, B=512) on the
+synthetic ogbn-arxiv graph: steps/s of sampling + gather + forward + backward + Adam (development aid)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from glnn_amd import data, train_and_eval as te
+from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+from glnn_amd.models import Model
+dev = "cuda:0"
+torch.manual_seed(0)
+g = data.make_graph("ogbn-arxiv", seed=0, device=dev)
+n = g.n_dst
+feats, labels, _, _ = data.make_node_data("ogbn-arxiv", seed=0, device=dev, n=n)
+model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=128, hidden_dim=256, label_dim=40, dropout_ratio=0.2, norm_type="batch", device=dev))
+opt = torch.optim.Adam(model.parameters(), lr=0.01)
+idx_train = torch.randperm(n)[:90941].to(dev)
+loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=True, drop_last=False)
+crit = torch.nn.NLLLoss()
+for ep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    loss = te.train_sage(model, loader, feats, labels, crit, opt)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"epoch {ep}: {len(loader)} steps in {dt:.2f} s = {len(loader) / dt:.1f} steps/s, loss {loss:.4f}", flush=True)
+
+# where the step goes: sampling + block building vs forward/backward/Adam
+torch.cuda.synchronize(); t0 = time.perf_counter()
+batches = []
+for i, b in enumerate(loader):
+    batches.append(b)
+    if i == 49:
+        break
+torch.cuda.synchronize(); t_s = (time.perf_counter() - t0) / 50
+model.train()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for input_nodes, output_nodes, blocks in batches:
+    logits = model(blocks, feats[input_nodes])
+    loss = crit(logits.log_softmax(1), labels[output_nodes])
+    opt.zero_grad(); loss.backward(); opt.step()
+torch.cuda.synchronize(); t_c = (time.perf_counter() - t0) / 50
+print(f"per step: sampling + blocks {1e3 * t_s:.2f} ms, gather + fwd + bwd + Adam {1e3 * t_c:.2f} ms; "
+      f"sources per batch {int(sum(b[0].numel() for b in batches) / 50)}", flush=True)
