@@ -35,6 +35,7 @@ SIGNATURES = {
                              c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
+    "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
     "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],

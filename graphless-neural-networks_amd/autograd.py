@@ -63,3 +63,47 @@ class SpmmFn(torch.autograd.Function):
             dx = ops.spmm(rev.indptr, rev.indices, dy, ctx.n_src, ops.AGG_SUM, col_scale=inv.contiguous())
             dx[: g.num_dst_nodes()] += dy * inv.unsqueeze(1)
         return None, dx, None
+
+
+class _NormActDropFn(torch.autograd.Function):
+    """dropout(relu(BatchNorm_train(z))) (or dropout(relu(z)) without a norm) as ONE differentiable op on the HIP path:
+    glnn_bn_stats_f32 (batch statistics + running-stat update) -> glnn_act_fwd_f32; backward = glnn_bn_relu_bwd_f32 with the
+    same counter-based dropout seed.  Replaces `self.norms[l](h)` -> `self.activation(h)` -> `self.dropout(h)` of the
+    reference's training-mode forwards (models.py:48-52, 113-117)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, bn, p, seed):
+        z = ops.as_feat(z.detach())
+        if bn is not None:
+            mean, rstd, a_scale, a_shift = ops.bn_stats(z, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
+                                                        bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
+            ctx.save_for_backward(z, gamma.detach(), mean, rstd, a_scale, a_shift)
+        else:
+            a_scale = a_shift = None
+            ctx.save_for_backward(z)
+        ctx.has_bn, ctx.p, ctx.seed = bn is not None, p, seed
+        return ops.act_fwd(z, a_scale, a_shift, drop_p=p, drop_seed=seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = ops.as_feat(dy.contiguous())
+        if ctx.has_bn:
+            z, gamma, mean, rstd, a_scale, a_shift = ctx.saved_tensors
+            dz, dgamma, dbeta = ops.bn_relu_bwd(dy, z, gamma, mean, rstd, a_scale, a_shift, drop_p=ctx.p, drop_seed=ctx.seed)
+            return dz, dgamma, dbeta, None, None, None
+        (z,) = ctx.saved_tensors
+        dz, _, _ = ops.bn_relu_bwd(dy, z, drop_p=ctx.p, drop_seed=ctx.seed)
+        return dz, None, None, None, None, None
+
+
+_drop_counter = [0]
+
+
+def norm_act_drop(z, bn, p):
+    """Training-mode tail of a hidden layer.  bn: nn.BatchNorm1d (reference defaults) or None; p: dropout probability.
+    The dropout stream is counter-based: seed = hash(torch.initial_seed(), call counter)."""
+    _drop_counter[0] += 1
+    seed = (int(torch.initial_seed()) * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA77) & 0xFFFFFFFF if p > 0 else 0
+    if bn is not None:
+        return _NormActDropFn.apply(z, bn.weight, bn.bias, bn, float(p), seed)
+    return _NormActDropFn.apply(z, None, None, None, float(p), seed)

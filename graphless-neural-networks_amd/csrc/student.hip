@@ -537,12 +537,55 @@ extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* 
                            dbeta, dz_col_sum, workspace, workspace_floats, stream, nullptr);
 }
 
+// y = dropout(relu(z * a_scale + a_shift)): the materialised form of the operand transform the GEMM loaders apply on the
+// fly, for consumers that GATHER the activation (the next SAGE layer's aggregation over a sampled block).
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
+                                                      const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                      uint32_t thr, uint32_t seed, float dscale, float* __restrict__ y, int64_t ldy) {
+  const int h4 = (h + 3) >> 2;
+  const int64_t total = rows * h4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / h4;
+    const int c = (int)(i - r * h4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(z + r * ldz + c);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float x = 0.f;
+      if (c + t < h) {
+        x = a_scale ? fmaf(o[t], a_scale[c + t], a_shift[c + t]) : o[t];
+        x = fmaxf(x, 0.f);
+        if (thr) x = glnn::drop_keep(seed, thr, (uint32_t)r, (uint32_t)(c + t)) ? x * dscale : 0.f;
+      }
+      o[t] = x;                          // padding columns are written as zero
+    }
+    *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 __global__ void dropout_mask_kernel(int64_t rows, int h, uint32_t thr, uint32_t seed, uint8_t* mask) {
   const int64_t total = rows * h;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / h;
     mask[i] = (thr == 0 || glnn::drop_keep(seed, thr, (uint32_t)r, (uint32_t)(i - r * h))) ? 1 : 0;
   }
+}
+
+extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale, const float* a_shift,
+                                float drop_p, uint32_t drop_seed, float* y, int64_t ldy, void* stream) {
+  GLNN_REQUIRE(z && y, "glnn_act_fwd_f32: null pointer");
+  GLNN_REQUIRE(rows >= 0 && h >= 1, "glnn_act_fwd_f32: bad sizes");
+  const int64_t hp = (h + 3) & ~3;
+  GLNN_REQUIRE(ldz >= hp && ldy >= hp && ldz % 4 == 0 && ldy % 4 == 0 && glnn::aligned16(z) && glnn::aligned16(y),
+               "glnn_act_fwd_f32: rows must be float4 rows (leading dimensions multiples of 4, >= round4(h), 16-byte aligned)");
+  GLNN_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "glnn_act_fwd_f32: a_scale and a_shift go together");
+  GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_act_fwd_f32: drop_p must be in [0,1)");
+  if (rows == 0) return GLNN_OK;
+  int64_t blocks = (rows * (hp / 4) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, ldz, rows, h, a_scale,
+                     a_shift, glnn::drop_threshold(drop_p), drop_seed, 1.0f / (1.0f - drop_p), y, ldy);
+  return glnn::check_launch("glnn_act_fwd_f32");
 }
 
 extern "C" int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t drop_seed, uint8_t* mask, void* stream) {

@@ -12,7 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .autograd import linear_fn
+from .autograd import linear_fn, norm_act_drop
 from .nn import GraphConv, SAGEConv
 
 
@@ -25,6 +25,19 @@ def _bn_eval_fold(bn, bias):
 
 def _hip_eval_ok(module, x):
     return x.is_cuda and not module.training and not torch.is_grad_enabled()
+
+
+def _hip_train_tail_ok(module, h):
+    """Training-mode hidden-layer tail on the fused HIP op: BatchNorm1d (reference defaults) or no norm, ReLU."""
+    if not (module.training and h.is_cuda and module.norm_type in ("none", "batch")):
+        return False
+    act = getattr(module, "activation", F.relu)
+    if act is not F.relu and getattr(act, "__name__", "") != "relu":
+        return False
+    if module.norm_type == "batch":
+        bn = module.norms[0]
+        return bn.affine and bn.track_running_stats and bn.momentum is not None
+    return True
 
 
 class MLP(nn.Module):
@@ -62,6 +75,9 @@ class MLP(nn.Module):
             h = linear_fn(h, layer.weight, layer.bias) if h.is_cuda else layer(h)
             if l != self.num_layers - 1:
                 h_list.append(h)
+                if _hip_train_tail_ok(self, h):
+                    h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
+                    continue
                 if self.norm_type != "none":
                     h = self.norms[l](h)
                 h = F.relu(h)
@@ -126,6 +142,10 @@ class SAGE(nn.Module):
             h = layer(block, (h, h_dst))
             if l != self.num_layers - 1:
                 h_list.append(h)
+                if _hip_train_tail_ok(self, h):
+                    # norm -> relu -> dropout as one op on the HIP path (same module state: running stats, affine)
+                    h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
+                    continue
                 if self.norm_type != "none":
                     h = self.norms[l](h)
                 h = self.activation(h)

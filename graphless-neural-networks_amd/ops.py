@@ -321,6 +321,19 @@ def adam_step(table, lr, step, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-
     _lib.check(rc, "glnn_adam_step_f32")
 
 
+def act_fwd(z, a_scale=None, a_shift=None, drop_p=0.0, drop_seed=0, out=None):
+    """glnn_act_fwd_f32: out = dropout(relu(z * a_scale + a_shift)) (plain ReLU without a_scale/a_shift)."""
+    _need_cuda(z, a_scale, a_shift, out)
+    _mat(z, "act_fwd z")
+    rows, h = z.shape
+    if out is None:
+        out = feat_empty(rows, h, z.device)
+    rc = _lib.lib().glnn_act_fwd_f32(_p(z), _ld(z), rows, h, _p(_vec(a_scale, h, "a_scale")), _p(_vec(a_shift, h, "a_shift")),
+                                     float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(out), _ld(out), _stream())
+    _lib.check(rc, "glnn_act_fwd_f32")
+    return out
+
+
 def dropout_mask(rows, h, drop_p, drop_seed, device):
     mask = torch.empty((rows, h), dtype=torch.uint8, device=device)
     rc = _lib.lib().glnn_dropout_mask_u8(rows, h, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(mask), _stream())

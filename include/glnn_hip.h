@@ -287,6 +287,14 @@ GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* f
                                   const float* target_logp, int64_t ldt, const int64_t* target_rows,
                                   float lamb, const uint32_t* drop_seeds, void* stream);
 
+/* y = dropout(relu(z * a_scale + a_shift)) materialised (a_scale/a_shift NULL: plain ReLU): the `norms[l](h)` ->
+ * `activation` -> `dropout` tail of a TRAINING-mode SAGE layer (reference models.py:113-117), whose output the next
+ * layer's aggregation gathers.  a_scale/a_shift come from glnn_bn_stats_f32; the backward is glnn_bn_relu_bwd_f32 with
+ * the same (drop_p, drop_seed).  z, y: float4 rows (leading dimensions % 4 == 0, >= round4(h)); padding columns of y = 0. */
+GLNN_API int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale,
+                              const float* a_shift, float drop_p, uint32_t drop_seed, float* y, int64_t ldy,
+                              void* stream);
+
 /* The dropout keep-mask the kernels above evaluate on the fly (nn.Dropout, reference models.py:52):
  * mask[r*h + c] = 1 if element (r,c) is kept under (drop_p, drop_seed).  torch's Philox stream cannot
  * be reproduced by a custom kernel, so parity tests run the oracle with THIS mask as an input. */

@@ -211,6 +211,45 @@ def test_gemm_tn_dropout_transform_all_instantiations(m, ka, nb, rows_on):
     assert 0.55 < mask.mean() < 0.75
 
 
+@pytest.mark.parametrize("rows,h,bn,p", [(1000, 47, True, 0.3), (37, 256, True, 0.0), (4096, 100, False, 0.5), (1, 5, False, 0.0)])
+def test_act_fwd_and_its_backward_pair(rows, h, bn, p):
+    """glnn_act_fwd_f32 = dropout(relu(z*scale+shift)) with the kernels' counter-based mask, and glnn_bn_relu_bwd_f32 as its
+    backward (same seed): checked against float64 numpy through the mask glnn_dropout_mask_u8 reports."""
+    from glnn_amd import ops
+    r = np.random.RandomState(rows + h)
+    z = r.standard_normal((rows, h)).astype(np.float32)
+    seed = 99
+    mask = ops.dropout_mask(rows, h, p, seed, DEV).cpu().numpy().astype(np.float64) if p > 0 else np.ones((rows, h))
+    zd = ops.as_feat(dev(z))
+    if bn:
+        gamma, beta = r.uniform(.5, 1.5, h).astype(np.float32), (r.standard_normal(h) * .2).astype(np.float32)
+        rm, rv, nbt = torch.zeros(h, device=DEV), torch.ones(h, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        mean, rstd, sc, sh = ops.bn_stats(zd, dev(gamma), dev(beta), rm, rv, nbt)
+        z64 = z.astype(np.float64)
+        mu, var = z64.mean(0), z64.var(0)
+        xhat = (z64 - mu) / np.sqrt(var + 1e-5)
+        pre = xhat * gamma + beta
+    else:
+        sc = sh = None
+        pre = z.astype(np.float64)
+    want = np.maximum(pre, 0) * mask / (1 - p)
+    y = ops.act_fwd(zd, sc, sh, drop_p=p, drop_seed=seed)
+    assert y.stride(0) % 4 == 0
+    np.testing.assert_allclose(y.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+    dy = r.standard_normal((rows, h)).astype(np.float32)
+    dpre = dy.astype(np.float64) * mask / (1 - p) * (pre > 0)
+    if bn and rows > 1:
+        dz, dg, db = ops.bn_relu_bwd(ops.as_feat(dev(dy)), zd, dev(gamma), mean, rstd, sc, sh, drop_p=p, drop_seed=seed)
+        dxhat = dpre * gamma
+        want_dz = (dxhat - dxhat.mean(0) - xhat * (dxhat * xhat).mean(0)) / np.sqrt(var + 1e-5)
+        np.testing.assert_allclose(dz.cpu().numpy(), want_dz, atol=2e-4, rtol=1e-4)
+        np.testing.assert_allclose(dg.cpu().numpy(), (dpre * xhat).sum(0), atol=2e-3, rtol=1e-4)
+        np.testing.assert_allclose(db.cpu().numpy(), dpre.sum(0), atol=2e-3, rtol=1e-4)
+    elif not bn:
+        dz, _, _ = ops.bn_relu_bwd(ops.as_feat(dev(dy)), zd, drop_p=p, drop_seed=seed)
+        np.testing.assert_allclose(dz.cpu().numpy(), dpre, atol=TOL, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------- K4
 @pytest.mark.parametrize("rows,c", [(512, 40), (4096, 47), (140, 7), (37, 100)])
 @pytest.mark.parametrize("kind", ["nll", "kl"])
