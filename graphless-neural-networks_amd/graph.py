@@ -207,13 +207,18 @@ class NodeDataLoader:
             torch.cumsum(cnt.long(), 0, out=indptr[1:])
             valid = torch.arange(fanout, device=dev).unsqueeze(0) < cnt.unsqueeze(1)
             src = smp[valid].long()                          # row-major: edges stay grouped by destination
-        is_seed = torch.zeros(g.n_src, dtype=torch.bool, device=dev)
-        is_seed[seeds] = True
-        uniq = torch.unique(src)
-        input_nodes = torch.cat([seeds, uniq[~is_seed[uniq]]])
-        remap = torch.empty(g.n_src, dtype=torch.int64, device=dev)
-        remap[input_nodes] = torch.arange(input_nodes.numel(), device=dev)
-        block = CSRGraph(indptr, remap[src].to(torch.int32), seeds.numel(), input_nodes.numel())
+        # sources of the block = seeds first, then the other referenced nodes in ascending id order (what sort-based
+        # unique() gave before): one flag scatter + one prefix sum over the node range instead of a device sort per layer
+        ns = seeds.numel()
+        flag = torch.zeros(g.n_src, dtype=torch.int64, device=dev)
+        flag[src] = 1
+        flag[seeds] = 0
+        remap = torch.cumsum(flag, 0)
+        remap += ns - 1                                      # flagged node -> ns + (its rank among the flagged)
+        extra = torch.nonzero(flag).squeeze(1)
+        remap[seeds] = torch.arange(ns, device=dev)
+        input_nodes = torch.cat([seeds, extra])
+        block = CSRGraph(indptr, remap[src].to(torch.int32), ns, input_nodes.numel())
         block._nnz = int(src.numel())
         return input_nodes, block
 
