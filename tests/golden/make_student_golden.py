@@ -80,14 +80,45 @@ CASES = {
     "nonorm_fullbatch": dict(dims=[60, 32, 7], norm="none", B=512, n=300, n_l=140, lamb=0.0, lr=0.01, wd=5e-3, epochs=2, full=True, seed=2),
     "arxiv_dims": dict(dims=[128, 256, 256, 40], norm="batch", B=512, n=1536, n_l=600, lamb=0.0, lr=0.01, wd=0.0, epochs=1, full=False, seed=3),
     "products_dims_narrow": dict(dims=[100, 256, 256, 47], norm="batch", B=4096, n=8192, n_l=4100, lamb=0.5, lr=0.01, wd=0.0, epochs=1, full=False, seed=4),
+    # the students the reference's experiments actually run, at FULL width (experiments/glnn_arxiv.sh:7, glnn_products.sh:7;
+    # train.conf.yaml:149-154, 187-194); lamb = 0 is the CLI default (train_student.py:154-159): the hard pass still steps
+    "mlp3w4": dict(dims=[128, 1024, 1024, 40], norm="batch", B=512, n=1536, n_l=600, lamb=0.0, lr=0.01, wd=0.0, epochs=1, full=False, seed=5),
+    "mlp3w8": dict(dims=[100, 2048, 2048, 47], norm="batch", B=4096, n=8192, n_l=4100, lamb=0.0, lr=0.01, wd=0.0, epochs=1, full=False, seed=6, stride=211),
+    # dropout > 0 with the keep-mask applied OUTSIDE: the reference's nn.Dropout is swapped for a multiply by the
+    # counter-based mask of libglnn_hip.so (restated in numpy: oracle/dropout_mask.py), seeds as StudentEngine derives them
+    "bn_small_dropout": dict(dims=[24, 48, 48, 10], norm="batch", B=32, n=200, n_l=70, lamb=0.3, lr=0.01, wd=5e-4, epochs=2, full=True, seed=7,
+                             dropout=0.4, drop_base_seed=0x00C0FFEE),
 }
 
 SAMPLE_STRIDE = 53
 
 
+_stride = [SAMPLE_STRIDE]        # per case (cfg["stride"]): the 4.5 M-parameter MLP3w8 is sampled more sparsely
+
+
 def sample(a):
     a = np.asarray(a, dtype=np.float32).ravel()
-    return a[::SAMPLE_STRIDE].copy()
+    return a[::_stride[0]].copy()
+
+
+class MaskDropout(torch.nn.Module):
+    """Stands in for the reference MLP's `self.dropout` (models.py:18,52) in the dropout case: multiplies by the keep-mask
+    of (optimiser step, hidden layer) and 1/(1-p); identity in eval mode like nn.Dropout.  The reference calls it once per
+    hidden layer per forward, in layer order, so a call counter identifies (step, layer)."""
+
+    def __init__(self, p, base_seed, hidden_layers):
+        super().__init__()
+        self.p, self.base_seed, self.hidden_layers = p, base_seed, hidden_layers
+        self.calls = 0
+
+    def forward(self, h):
+        if not self.training:
+            return h
+        from oracle.dropout_mask import engine_seed, keep_mask
+        step, layer = self.calls // self.hidden_layers + 1, self.calls % self.hidden_layers
+        self.calls += 1
+        keep = keep_mask(h.shape[0], h.shape[1], self.p, engine_seed(self.base_seed, step, layer)).astype(np.float32)
+        return h * torch.from_numpy(keep) * np.float32(1.0 / (1.0 - self.p))
 
 
 def run_case(name, cfg):
@@ -96,6 +127,7 @@ def run_case(name, cfg):
 
     dims, norm = cfg["dims"], cfg["norm"]
     L = len(dims) - 1
+    _stride[0] = int(cfg.get("stride", SAMPLE_STRIDE))
     feats, labels, out_t, idx_l = make_inputs(cfg["seed"], cfg["n"], dims[0], dims[-1], cfg["n_l"])
     sd0 = make_state(cfg["seed"], dims, norm)
 
@@ -104,6 +136,9 @@ def run_case(name, cfg):
     torch.manual_seed(cfg["seed"])
     model = ref_models.Model(conf)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd0.items()})
+    p_drop = float(cfg.get("dropout", 0.0))
+    if p_drop > 0:
+        model.encoder.dropout = MaskDropout(p_drop, cfg["drop_base_seed"], L - 1)
     # exactly train_student.py:274-279
     optimizer = torch.optim.Adam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
     criterion_l = torch.nn.NLLLoss()
@@ -140,6 +175,8 @@ def run_case(name, cfg):
             out[f"step_{kind}_gradnorm.{pname}"] = np.float64(np.linalg.norm(g.astype(np.float64)))
         optimizer.zero_grad()
         model.load_state_dict(sd_before)            # undo the BN running-stat update
+        if p_drop > 0:
+            model.encoder.dropout.calls = 0         # every single-step probe and the passes below start at optimiser step 1
 
     # ---- full passes through the reference's train_mini_batch, recording perms and step losses
     perms, step_losses = [], []
@@ -193,13 +230,60 @@ def run_case(name, cfg):
     out["eval_loss"] = np.float64(loss_e)
     out["eval_score"] = np.float64(score_e)
 
+    # ---- the reference's OWN sensitivity to rounding: the same passes (same permutations) from initial weights moved by one
+    # fp32 ulp (x * (1 +- 2^-23), seeded signs).  Whatever two runs of the reference disagree by under a perturbation the
+    # size of a single rounding error is the floor below which a trained state / its eval outputs are not determined;
+    # tests/parity_rules.py derives its post-training tolerances from these numbers instead of from a hand-set constant.
+    rs_n = np.random.RandomState(cfg["seed"] + 77)
+    sd1 = {}
+    for k, v in sd0.items():
+        a = np.asarray(v)
+        sd1[k] = (a * (1.0 + rs_n.choice([-1.0, 1.0], size=a.shape) * 2.0 ** -23)).astype(np.float32) if a.dtype == np.float32 else a
+    model2 = ref_models.Model(conf)
+    model2.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd1.items()})
+    if p_drop > 0:
+        model2.encoder.dropout = MaskDropout(p_drop, cfg["drop_base_seed"], L - 1)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
+    replay = iter(perms)
+    losses2 = []
+
+    class Rec2(Rec):
+        def __call__(self, o, y):
+            l = self.crit(o, y)
+            losses2.append(float(l.item()))
+            return l
+
+    torch.randperm = lambda *a, **k: torch.from_numpy(next(replay).astype(np.int64))
+    try:
+        for _ in range(cfg["epochs"]):
+            ref_te.train_mini_batch(model2, feats_l, labels_l, cfg["B"], Rec2(criterion_l), opt2, cfg["lamb"])
+            ref_te.train_mini_batch(model2, feats_t, out_tt, cfg["B"], Rec2(criterion_t), opt2, 1 - cfg["lamb"])
+    finally:
+        torch.randperm = real_randperm
+    out["noise.step_losses"] = np.float64(np.abs(np.asarray(losses2) - np.asarray(step_losses)).max())
+    sda, sdb = model.state_dict(), model2.state_dict()
+    for k in sda:
+        if sda[k].ndim > 0:
+            d = (sda[k] - sdb[k]).abs().double()
+            out[f"noise.final.{k}"] = np.asarray([d.max().item(), d.mean().item()], np.float64)
+    st2 = opt2.state_dict()["state"]
+    for i, (pname, _) in enumerate(model.named_parameters()):
+        for key in ("exp_avg", "exp_avg_sq"):
+            out[f"noise.adam.{key}.{pname}"] = np.float64((st[i][key] - st2[i][key]).abs().max().item())
+    o2, loss_e2, _ = ref_te.evaluate_mini_batch(model2, tf, tl, criterion_l, cfg["B"], evaluator)
+    d = (o_all - o2).abs().double()
+    out["noise.eval_out"] = np.asarray([d.max().item(), d.mean().item()], np.float64)
+    out["noise.eval_loss"] = np.float64(abs(loss_e - loss_e2))
+
     # ---- config + (small cases) inputs
     for k in ("B", "n", "n_l", "lamb", "lr", "wd", "epochs", "seed"):
         out[f"cfg.{k}"] = np.float64(cfg[k])
     out["cfg.dims"] = np.asarray(dims, np.int64)
     out["cfg.norm"] = np.asarray(norm)
+    out["cfg.dropout"] = np.float64(p_drop)
+    out["cfg.drop_base_seed"] = np.int64(cfg.get("drop_base_seed", 0))
     out["cfg.full"] = np.int64(1 if cfg["full"] else 0)
-    out["cfg.sample_stride"] = np.int64(SAMPLE_STRIDE)
+    out["cfg.sample_stride"] = np.int64(_stride[0])
     if cfg["full"]:
         out["in.feats"], out["in.labels"], out["in.out_t"], out["in.idx_l"] = feats, labels, out_t, idx_l
         for k, v in sd0.items():
@@ -212,6 +296,9 @@ def run_case(name, cfg):
 if __name__ == "__main__":
     _stub_modules()
     sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))      # repo root: oracle.dropout_mask
     torch.set_num_threads(1)
+    only = sys.argv[1:]
     for name, cfg in CASES.items():
-        run_case(name, cfg)
+        if not only or name in only:
+            run_case(name, cfg)

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["bn_small", "nonorm_fullbatch", "arxiv_dims", "products_dims_narrow"]
+CASES = ["bn_small", "nonorm_fullbatch", "arxiv_dims", "products_dims_narrow", "mlp3w4", "mlp3w8", "bn_small_dropout"]
 
 
 def make_inputs(seed, n, f, c, n_l):
@@ -49,6 +49,8 @@ class Golden:
         self.lamb, self.lr, self.wd = float(z["cfg.lamb"]), float(z["cfg.lr"]), float(z["cfg.wd"])
         self.epochs, self.seed = int(z["cfg.epochs"]), int(z["cfg.seed"])
         self.full = bool(int(z["cfg.full"]))
+        self.dropout = float(z["cfg.dropout"]) if "cfg.dropout" in z.files else 0.0
+        self.drop_base_seed = int(z["cfg.drop_base_seed"]) if "cfg.drop_base_seed" in z.files else 0
         self.stride = int(z["cfg.sample_stride"])
         self.feats, self.labels, self.out_t, self.idx_l = make_inputs(self.seed, self.n, self.dims[0], self.dims[-1], self.n_l)
         self.sd0 = make_state(self.seed, self.dims, self.norm)
@@ -60,6 +62,15 @@ class Golden:
         self.param_names = [f"encoder.layers.{i}.{s}" for i in range(len(self.dims) - 1) for s in ("weight", "bias")]
         if self.norm == "batch":
             self.param_names += [f"encoder.norms.{i}.{s}" for i in range(len(self.dims) - 2) for s in ("weight", "bias")]
+
+    def masks(self, step, rows):
+        """Keep-masks of optimiser step `step` (1-based) for every hidden layer (None without dropout): the ones the golden
+        run fed to the reference's MLP (oracle/dropout_mask.py restates the library's counter-based mask)."""
+        if self.dropout == 0.0:
+            return None
+        from oracle.dropout_mask import engine_seed, keep_mask
+        return [keep_mask(rows, self.dims[l + 1], self.dropout, engine_seed(self.drop_base_seed, step, l)).astype(np.float32)
+                for l in range(len(self.dims) - 2)]
 
     def view(self, a):
         """How an array is stored in this fixture (full, or strided sample)."""

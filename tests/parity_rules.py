@@ -8,12 +8,24 @@ two implementations (or two BLAS builds under the reference itself) agree on the
 makes a few weight entries whose true gradient is ~0 wander by a fraction of lr.  So:
   * outputs (losses per step, eval log-probs) are held to the 1e-4 bar -- they are gauge-invariant;
   * well-conditioned state (last layer, BN affine, running_var) is held to 1e-4;
-  * hidden-layer weights: mean |diff| <= 1e-4 and max |diff| <= lr (a handful of sign-flipped entries);
+  * hidden-layer weights: mean |diff| <= 1e-4 and max |diff| <= lr (a handful of sign-flipped entries); at the
+    full widths the reference runs (MLP3w4 1024, MLP3w8 2048) the flipped entries of W_l perturb the next steps'
+    gradients of everything upstream, so the BatchNorm affine parameters of those configs get the same rule
+    (measured numpy-oracle vs reference, MLP3w4 after 4 steps: gamma_0 mean 6e-5, max 5e-4 = lr/20) -- the
+    per-step losses, which see all of it, still agree to 1e-4;
   * gauge entries are skipped when weight_decay == 0, and held to 1e-4 otherwise;
-  * EVAL-mode outputs after training in a gauge case: the bias noise enters through
-    (b_final - EMA_t(b_t)) / sqrt(running_var) and shows up as ~1e-3 in the log-probs after a few steps
-    (measured: 2e-3 between the numpy oracle and torch on the same CPU) -> eval_tol() = 1e-2 there,
-    1e-4 everywhere else.  Eval-mode forward at IDENTICAL state is pinned to 1e-4 separately.
+  * EVAL-mode outputs after training: the bar comes from the REFERENCE ITSELF.  Every fixture stores `noise.*`:
+    what two runs of the reference's own train_mini_batch / evaluate_mini_batch disagree by when the initial
+    weights of one are moved by a single fp32 ulp (tests/golden/make_student_golden.py).  Without the gauge
+    freedom that is ~3e-6 (bn_small, nonorm_fullbatch, dropout case) and eval_tol() is the 1e-4 bar.  In the
+    BatchNorm + weight_decay=0 configs the reference disagrees with ITSELF by 2.3e-3 (arxiv dims), 3.1e-3
+    (products dims), 4.1e-3 (MLP3w4), 3.5e-2 (MLP3w8, 3 steps) in the eval log-probs -- the bias noise enters
+    through (b_final - EMA_t(b_t)) / sqrt(running_var) and Adam's first steps amplify it -- so no implementation,
+    the reference included, reproduces those outputs to 1e-4; eval_tol() = 4 x that measured self-noise (max and
+    mean both checked).  A gauge-fixed comparison (our trained state with the reference's final bias /
+    running_mean substituted) was tried and does not help: 2.0e-3 -> 1.5e-3 on arxiv dims, because the
+    perturbed hidden weights, not the gauge entries themselves, carry most of the difference.
+    Eval-mode forward at IDENTICAL state is pinned to 1e-4 separately (test_eval_forward_at_identical_state).
 """
 import re
 
@@ -44,7 +56,8 @@ def check_final_state(g, sd, tol=TOL):
             continue
         d = np.abs(g.view(v).astype(np.float64) - ref)
         m = re.match(r"encoder\.layers\.(\d+)\.weight", k)
-        if m and int(m.group(1)) < L - 1 and g.norm == "batch" and g.wd == 0:
+        affine = re.match(r"encoder\.norms\.\d+\.(weight|bias)", k)
+        if ((m and int(m.group(1)) < L - 1) or affine) and g.norm == "batch" and g.wd == 0:
             assert d.mean() <= tol and d.max() <= g.lr, (k, d.mean(), d.max())
         else:
             assert d.max() <= tol, (k, d.max())
@@ -54,5 +67,25 @@ def has_gauge(g):
     return g.norm == "batch" and g.wd == 0
 
 
+NOISE_FACTOR = 4.0
+
+
 def eval_tol(g):
-    return 1e-2 if has_gauge(g) else TOL
+    """max-abs tolerance of eval-mode log-probs AFTER training: the 1e-4 bar, or 4x the reference's own
+    one-ulp self-noise where that is larger (the gauge configs)."""
+    return max(TOL, NOISE_FACTOR * float(g.z["noise.eval_out"][0]))
+
+
+def eval_mean_tol(g):
+    return max(TOL / 5, NOISE_FACTOR * float(g.z["noise.eval_out"][1]))
+
+
+def eval_loss_tol(g):
+    return max(TOL, NOISE_FACTOR * float(g.z["noise.eval_loss"]), eval_mean_tol(g))
+
+
+def moment_tols(g, pname):
+    """(atol exp_avg, atol exp_avg_sq): Adam moments are gradient-scale quantities.  Held to the 1e-4 bar in the gauge
+    configs (their gradients from step 2 on are taken at the perturbed weights described above; measured: a few entries
+    at 1.6e-5 on MLP3w4) and 10x tighter elsewhere."""
+    return (1e-4, 1e-6) if has_gauge(g) else (1e-5, 1e-7)

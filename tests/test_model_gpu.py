@@ -9,7 +9,7 @@ from golden_inputs import CASES, Golden
 from graphgen import random_graph
 from oracle import student_oracle as so
 from oracle import teacher_oracle as to
-from parity_rules import check_final_state, eval_tol, has_gauge
+from parity_rules import check_final_state, eval_loss_tol, eval_mean_tol, eval_tol, has_gauge
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -52,10 +52,11 @@ def test_single_step_gradients_vs_reference_golden(name):
     g = Golden(name)
     feats_l, labels_l = g.feats[g.idx_l], g.labels[g.idx_l]
     for kind, x, y in (("nll", feats_l, labels_l), ("kl", g.feats, g.out_t)):
-        model, opt = _student(g)
+        model, opt = _student(g, dropout=g.dropout)
         model.train()
         bsz = min(g.B, x.shape[0])
         eng = StudentEngine(model, opt, bsz)
+        eng.base_seed = g.drop_base_seed          # dropout case: the masks the golden run fed to the reference's MLP
         lam = float(g.z[f"step_{kind}_lamb"])
         xd = ops.as_feat(torch.from_numpy(x).to(DEV))
         yd = torch.from_numpy(y).to(DEV)
@@ -75,7 +76,8 @@ def test_distill_passes_vs_reference_golden(name, monkeypatch):
     reference's own criterion / optimizer objects; permutations replayed from the golden run."""
     from glnn_amd import train_and_eval as te
     g = Golden(name)
-    model, opt = _student(g)
+    torch.manual_seed(g.drop_base_seed)            # the engine seeds its dropout stream from torch.initial_seed()
+    model, opt = _student(g, dropout=g.dropout)
     criterion_l = torch.nn.NLLLoss()
     criterion_t = torch.nn.KLDivLoss(reduction="batchmean", log_target=True)
     perms = iter(g.perms)
@@ -93,7 +95,8 @@ def test_distill_passes_vs_reference_golden(name, monkeypatch):
     evaluator = lambda o, y: o.argmax(1).eq(y).float().mean().item()
     out, loss_e, score_e = te.evaluate_mini_batch(model, feats, labels, criterion_l, g.B, evaluator)
     np.testing.assert_allclose(g.view(out.cpu().numpy()), g.z["eval_out"], atol=eval_tol(g), rtol=0)
-    assert abs(loss_e - float(g.z["eval_loss"])) < eval_tol(g)
+    assert np.abs(g.view(out.cpu().numpy()) - g.z["eval_out"]).mean() <= eval_mean_tol(g)
+    assert abs(loss_e - float(g.z["eval_loss"])) < eval_loss_tol(g)
     assert abs(score_e - float(g.z["eval_score"])) < (1e-6 if not has_gauge(g) else 5e-3)
 
 
@@ -114,6 +117,16 @@ def test_eval_forward_at_identical_state_vs_oracle():
     assert len(h_list) == len(g.dims) - 2
     for got_z, want_z in zip(h_list, cache["z"]):
         np.testing.assert_allclose(got_z.cpu().numpy(), want_z, atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize("rows,h,p,seed", [(32, 48, 0.4, 0x00C0FFEE), (4096, 2048, 0.2, 12345), (513, 257, 0.5, 0xFFFFFFFF), (1, 1, 0.9, 7)])
+def test_dropout_mask_kernel_equals_numpy_restatement(rows, h, p, seed):
+    """glnn_dropout_mask_u8 (what every fused kernel evaluates on the fly) == oracle/dropout_mask.py, bit for bit: the
+    restatement is what fed the reference's MLP when the dropout golden was generated."""
+    from glnn_amd import ops
+    from oracle.dropout_mask import keep_mask
+    got = ops.dropout_mask(rows, h, p, seed, DEV).cpu().numpy()
+    assert np.array_equal(got, keep_mask(rows, h, p, seed))
 
 
 def test_training_step_with_dropout_matches_oracle_given_the_mask():
@@ -442,33 +455,45 @@ def test_full_size_arxiv_teacher_forward_vs_oracle():
 
 
 def test_full_size_xl_shard_properties():
-    """BASELINE configs[4] shard at FULL size: 12.5 M destination rows, 250 M in-edges into a 12.5 M-row source
-    matrix, D=128 (one GPU's share of the 100 M-node / 2 B-edge run).  Size-independent checks: the conservation
-    identity sum_v (deg_v+1)*out[v] == sum_u (outdeg_u+1)*x[u] in fp64, and bit-equality of a row-range relaunch."""
+    """BASELINE configs[4] at FULL size on one GPU: one rank's shard of the 100 M-node / 2 B-edge graph = 12.5 M destination
+    rows with 250 M in-edges whose sources are drawn over ALL 100 M nodes, gathering from the replicated 100 M x 128 fp32
+    feature matrix (51.2 GB, resident: an MI355X holds 288 GB) -- the locality the real 8-GPU run has, not that of a
+    12.5 M-row source matrix.  Size-independent checks: the conservation identity
+        sum_v (deg_v + 1) * out[v]  ==  sum_u outdeg_u * x[u]  +  sum_{v in shard} x[v]      (fp64)
+    and bit-equality of a row-range relaunch."""
     from glnn_amd import ops
     from glnn_amd.graph import CSRGraph
-    rows, deg, d = 12_500_000, 20, 128
+    rows, deg, d, world, rank = 12_500_000, 20, 128, 8, 3
+    n_total = rows * world
+    lo_shard = rank * rows
     gen = torch.Generator(device=DEV); gen.manual_seed(7)
     dst = torch.randint(0, rows, (rows * deg,), generator=gen, device=DEV)
-    src = torch.randint(0, rows, (rows * deg,), generator=gen, device=DEV)
+    src = torch.randint(0, n_total, (rows * deg,), generator=gen, device=DEV)
     order = torch.argsort(dst)
     indices = src[order].to(torch.int32)
     indptr = torch.zeros(rows + 1, dtype=torch.int64, device=DEV)
     torch.cumsum(torch.bincount(dst, minlength=rows), 0, out=indptr[1:])
-    outdeg = torch.bincount(src, minlength=rows).double()
+    outdeg = torch.bincount(src, minlength=n_total).double()
     del dst, src, order
-    g = CSRGraph(indptr, indices, rows)
-    assert g.num_edges() == 250_000_000
-    x = torch.randn(rows, d, device=DEV)
-    out = ops.spmm(g.indptr, g.indices, x, rows, ops.AGG_SAGE_GCN)
+    g = CSRGraph(indptr, indices, rows, n_total)
+    assert g.num_edges() == 250_000_000 and int(indices.max()) > 7 * rows          # sources really span the 100 M rows
+    x = torch.empty(n_total, d, device=DEV)
+    for s0 in range(0, n_total, 1 << 23):                    # 51.2 GB, filled in slabs
+        x[s0:s0 + (1 << 23)].normal_(generator=gen)
+    x_self = x[lo_shard:lo_shard + rows]
+    out = ops.spmm(g.indptr, g.indices, x, rows, ops.AGG_SAGE_GCN, x_self=x_self)
     indeg = g.in_degrees().double()
     lhs = torch.zeros(d, dtype=torch.float64, device=DEV)
     rhs = torch.zeros(d, dtype=torch.float64, device=DEV)
-    for s0 in range(0, rows, 1 << 21):                       # fp64 reductions in slabs (bounded temporaries)
-        sl = slice(s0, s0 + (1 << 21))
+    step = 1 << 21                                           # fp64 reductions in slabs (bounded temporaries)
+    for s0 in range(0, rows, step):
+        sl = slice(s0, s0 + step)
         lhs += ((indeg[sl] + 1).unsqueeze(1) * out[sl].double()).sum(0)
-        rhs += ((outdeg[sl] + 1).unsqueeze(1) * x[sl].double()).sum(0)
+        rhs += x_self[sl].double().sum(0)
+    for s0 in range(0, n_total, step):
+        sl = slice(s0, s0 + step)
+        rhs += (outdeg[sl].unsqueeze(1) * x[sl].double()).sum(0)
     assert float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1)) < 1e-4
     lo, hi = 5_000_000, 5_400_000
-    part = ops.spmm(g.indptr[lo:hi + 1], g.indices, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x[lo:hi])
+    part = ops.spmm(g.indptr[lo:hi + 1], g.indices, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x_self[lo:hi])
     assert torch.equal(part, out[lo:hi])
