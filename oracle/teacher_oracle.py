@@ -240,3 +240,12 @@ def feature_prop(indptr, indices, feats, k, threads=1):
         x = spmm_sum(indptr, indices, x, threads=threads)
         x = x * norm[:, None]
     return np.ascontiguousarray(x, np.float32)
+
+
+def min_cut_loss(indptr, indices, logp):
+    """compute_min_cut_loss (reference utils.py:159-168): tr(S^T A S) / tr(S^T D S), S = exp(out), D = diag(in-degree);
+    the dense N x N adjacency of the reference replaced by sum(S * (A S)) (the trace of a product is orientation-free)."""
+    s = np.exp(np.asarray(logp, dtype=np.float64))
+    a_s = spmm_sum(indptr, indices, s.astype(np.float32)).astype(np.float64)
+    deg = np.diff(np.asarray(indptr)).astype(np.float64)
+    return float((s * a_s).sum() / (deg[:, None] * s * s).sum())

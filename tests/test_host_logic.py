@@ -127,3 +127,54 @@ def test_evaluator_is_plain_argmax_accuracy():
     ev = utils.get_evaluator("ogbn-arxiv")
     out = torch.tensor([[0.1, 0.9], [0.8, 0.2], [0.3, 0.7]])
     assert abs(ev(out, torch.tensor([1, 0, 0])) - 2 / 3) < 1e-7
+
+
+# ---------------------------------------------------------------------------------- reference-generated goldens
+def _host_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "host_logic.npz"))
+
+
+def test_graph_split_and_idx_split_equal_reference_bit_for_bit():
+    """tests/golden/host_logic.npz holds what the reference's utils.graph_split / idx_split returned (utils.py:88-127)."""
+    from glnn_amd import utils
+    z = _host_golden()
+    idx_train, idx_val, idx_test = (torch.from_numpy(z[f"split.{k}"]) for k in ("idx_train", "idx_val", "idx_test"))
+    for rate, seed in ((0.2, 0), (0.5, 3)):
+        got = utils.graph_split(idx_train, idx_val, idx_test, rate, seed)
+        for name, t in zip(("obs_idx_train", "obs_idx_val", "obs_idx_test", "idx_obs", "idx_test_ind"), got):
+            want = z[f"graph_split.r{rate}_s{seed}.{name}"]
+            assert t.dtype == torch.int64 and np.array_equal(t.numpy(), want), (rate, seed, name)
+    a, b = utils.idx_split(idx_test, 0.37, seed=9)
+    assert np.array_equal(a.numpy(), z["idx_split.a"]) and np.array_equal(b.numpy(), z["idx_split.b"])
+
+
+@pytest.mark.parametrize("seed,ltr,lva", [(0, 6, 9), (4, 3, 5)])
+def test_cpf_ingestion_equals_reference_bit_for_bit(seed, ltr, lva, monkeypatch):
+    """The reference's own load_cpf_data (dataloader.py:82-111: load_npz_to_sparse_graph -> standardize -> LCC ->
+    binarize_labels -> get_train_val_test_split / sample_per_class -> normalize_adj pattern -> dgl.graph) was run on
+    tests/golden/cpf/tiny_cpf.npz; this loader must return the same graph, features, labels and splits exactly."""
+    from glnn_amd.dataloader import load_cpf_data
+    from glnn_amd.graph import CSRGraph
+    z = _host_golden()
+    tag = f"cpf.s{seed}_{ltr}_{lva}"
+    monkeypatch.chdir(os.path.join(ROOT, "tests", "golden"))
+    g, labels, tr, va, te = load_cpf_data("tiny_cpf", "cpf", seed, ltr, lva)
+    n = int(z[f"{tag}.num_nodes"])
+    assert g.num_nodes() == n
+    want = CSRGraph.from_edges(torch.from_numpy(z[f"{tag}.row"].astype(np.int64)), torch.from_numpy(z[f"{tag}.col"].astype(np.int64)), n)
+    assert torch.equal(g.indptr, want.indptr) and torch.equal(g.indices, want.indices)     # dgl.graph((row, col)): row -> col
+    assert np.array_equal(g.ndata["feat"].numpy(), z[f"{tag}.feat"]) and g.ndata["feat"].dtype == torch.float32
+    assert np.array_equal(labels.numpy(), z[f"{tag}.labels"]) and labels.dtype == torch.int64
+    for got, name in ((tr, "idx_train"), (va, "idx_val"), (te, "idx_test")):
+        assert got.dtype == torch.int64 and np.array_equal(got.numpy(), z[f"{tag}.{name}"]), name
+
+
+def test_oracle_feature_prop_and_min_cut_vs_reference_golden():
+    """utils.feature_prop (utils.py:171-189; its normalisation is reference code, copy_u/sum a scipy stand-in) and the dense
+    compute_min_cut_loss (utils.py:159-168) as the reference computed them, vs the CPU oracle's restatement."""
+    from oracle import teacher_oracle as to
+    z = _host_golden()
+    ip, ix = z["mincut.indptr"], z["mincut.indices"]
+    for k in (1, 3):
+        np.testing.assert_allclose(to.feature_prop(ip, ix, z["fprop.feats"], k), z[f"fprop.k{k}"], atol=1e-5, rtol=1e-5)
+    assert abs(to.min_cut_loss(ip, ix, z["mincut.logp"]) - float(z["mincut.value"])) < 1e-5

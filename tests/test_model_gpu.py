@@ -291,6 +291,24 @@ def test_feature_prop_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), to.feature_prop(indptr, indices, x, 2), atol=TOL, rtol=0)
 
 
+def test_feature_prop_and_min_cut_vs_reference_golden():
+    """tests/golden/host_logic.npz: what the reference's utils.feature_prop (utils.py:171-189) and its dense
+    compute_min_cut_loss (utils.py:159-168) returned on a 220-node multigraph (isolated rows, a hub, multi-edges);
+    here both run on the aggregation kernel (no dense adjacency)."""
+    import os
+    from glnn_amd import utils
+    from glnn_amd.graph import CSRGraph
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic.npz"))
+    ip, ix = z["mincut.indptr"], z["mincut.indices"]
+    g = CSRGraph(torch.from_numpy(ip).to(DEV), torch.from_numpy(ix).to(DEV), len(ip) - 1)
+    for k in (1, 3):
+        got = utils.feature_prop(torch.from_numpy(z["fprop.feats"]).to(DEV), g, k)
+        np.testing.assert_allclose(got.cpu().numpy(), z[f"fprop.k{k}"], atol=TOL, rtol=0)
+    got = utils.compute_min_cut_loss(g, torch.from_numpy(z["mincut.logp"]))       # the reference passes a CPU `out` too (:160)
+    assert abs(got - float(z["mincut.value"])) < TOL
+    assert abs(got - to.min_cut_loss(ip, ix, z["mincut.logp"])) < 1e-5
+
+
 def test_teacher_autograd_matches_torch_dense():
     """Aggregation + projection backward (the teacher-training direction) vs dense torch autograd."""
     from glnn_amd import ops
