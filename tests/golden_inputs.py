@@ -102,3 +102,18 @@ def sage_layers_from_sd(sd, num_layers, batch_norm=True):
                   running_mean=sd[f"encoder.norms.{i}.running_mean"], running_var=sd[f"encoder.norms.{i}.running_var"])
              for i in range(num_layers - 1)] if batch_norm else None
     return layers, norms
+
+
+def teacher_training():
+    """tests/golden/teacher_training.npz (make_teacher_train_golden.py): the reference's train_sage over fixed blocks (two
+    norm variants) and its full-graph GCN `train`.  Returns the raw npz plus helpers to rebuild the batches."""
+    z = np.load(os.path.join(GOLDEN_DIR, "teacher_training.npz"))
+    batches = []
+    for b in range(3):
+        blocks = [(z[f"sage.b{b}.l{l}.indptr"], z[f"sage.b{b}.l{l}.indices"], int(z[f"sage.b{b}.l{l}.n_src"])) for l in range(3)]
+        batches.append((z[f"sage.b{b}.input_nodes"], z[f"sage.b{b}.output_nodes"], blocks))
+    return z, batches
+
+
+def sub_dict(z, prefix):
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
