@@ -15,13 +15,13 @@ c_i64, c_int, c_f32, c_vp, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float,
 SIGNATURES = {
     "glnn_abi_version": [],
     "glnn_device_info": [c_vp, c_vp, c_vp, c_int],
-    "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+    "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
                           c_int, c_vp, c_i64, c_vp],
     "glnn_packed_weight_floats": [c_int, c_int],
     "glnn_pack_weight_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp],
     "glnn_sage_fused_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
                             c_i64, c_vp],
-    "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp],
+    "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp, c_i64, c_vp],
     "glnn_gemm_tn_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_int, c_vp, c_i64, c_vp, c_vp,
@@ -33,11 +33,16 @@ SIGNATURES = {
                           c_vp, c_vp, c_i64, c_vp],
     "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64,
                              c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_col_sum_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
+    "glnn_block_workspace_bytes": [c_i64, c_i64],
+    "glnn_block_build": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_csr_transpose_workspace_bytes": [c_i64, c_i64],
+    "glnn_csr_transpose": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
     "glnn_scatter_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
 }
@@ -46,7 +51,7 @@ MLP_MAX_LAYERS = 8
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
@@ -91,6 +96,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
         h.glnn_packed_weight_floats.restype = c_i64
+        h.glnn_block_workspace_bytes.restype = c_i64
+        h.glnn_csr_transpose_workspace_bytes.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
         if h.glnn_abi_version() != ABI_VERSION:

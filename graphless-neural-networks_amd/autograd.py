@@ -1,7 +1,8 @@
 """torch.autograd.Function shims over the C-ABI kernels, so that `loss.backward()` /
 `optimizer.step()` in the reference's generic loops (train_and_eval.py:12-56: `train`, `train_sage`)
-keep working on HIP: the dense projections and the neighbour aggregation run on libglnn_hip.so in both
-directions.  (The student's hot loop does not go through autograd at all -- see student.py.)"""
+keep working on HIP for callers that differentiate `Model.forward` themselves: the dense projections, the neighbour
+aggregation and the norm/ReLU/dropout tails run on libglnn_hip.so in both directions.  The training loops of this package
+do not go through autograd at all -- see student.py (StudentEngine) and teacher.py (TeacherEngine)."""
 import torch
 
 from . import ops
@@ -31,7 +32,7 @@ class _LinearFn(torch.autograd.Function):
             if ctx.kn:
                 dw = ops.gemm_tn(x, dy)                             # x^T @ dy -> [in,out]
                 if ctx.has_bias:
-                    db_buf = dy.sum(0)
+                    ops.col_sum(dy, out=db_buf)
             else:
                 dw = ops.gemm_tn(dy, x, col_sum_a=db_buf)           # dy^T @ x -> [out,in]
             db = db_buf
@@ -43,26 +44,84 @@ def linear_fn(x, w, b, w_is_kn=False):
 
 
 class SpmmFn(torch.autograd.Function):
-    """Neighbour aggregation with a backward through the reversed graph (A^T dY): the teacher
-    TRAINING direction (reference train_and_eval.py:12-56), same kernel on the transposed CSR."""
+    """Neighbour aggregation with its backward over the transposed graph (A^T dY on the SAME gather kernel, over
+    glnn_csr_transpose): the teacher TRAINING direction (reference train_and_eval.py:12-56).
+      AGG_SUM       y = row_scale * A (col_scale * x)          dx = col_scale * A^T (row_scale * dy)
+      AGG_SAGE_GCN  y = (A x + x[:n_dst]) / (deg + 1)          dx = (A^T + I_dst) (dy / (deg + 1))"""
 
     @staticmethod
-    def forward(ctx, graph, x, mode):
-        ctx.graph, ctx.mode, ctx.n_src = graph, mode, x.shape[0]
-        return ops.spmm(graph.indptr, graph.indices, x.detach(), graph.num_dst_nodes(), mode)
+    def forward(ctx, graph, x, mode, row_scale=None, col_scale=None):
+        ctx.graph, ctx.mode, ctx.n_src, ctx.rs, ctx.cs = graph, mode, x.shape[0], row_scale, col_scale
+        return ops.spmm(graph.indptr, graph.indices, x.detach(), graph.num_dst_nodes(), mode, row_scale=row_scale, col_scale=col_scale)
 
     @staticmethod
     def backward(ctx, dy):
+        if not ctx.needs_input_grad[1]:          # e.g. the outermost block: its input is feats[input_nodes]
+            return None, None, None, None, None
         g = ctx.graph
-        rev = g.reverse()
         dy = ops.as_feat(dy.contiguous())
         if ctx.mode == ops.AGG_SUM:
-            dx = ops.spmm(rev.indptr, rev.indices, dy, ctx.n_src, ops.AGG_SUM)
+            t = g.transposed(False)
+            dx = ops.spmm(t.indptr, t.indices, dy, ctx.n_src, ops.AGG_SUM, row_scale=ctx.cs, col_scale=ctx.rs)
         else:
-            inv = 1.0 / (g.in_degrees().to(torch.float32) + 1.0)
-            dx = ops.spmm(rev.indptr, rev.indices, dy, ctx.n_src, ops.AGG_SUM, col_scale=inv.contiguous())
-            dx[: g.num_dst_nodes()] += dy * inv.unsqueeze(1)
-        return None, dx, None
+            t = g.transposed(True)
+            dx = ops.spmm(t.indptr, t.indices, dy, ctx.n_src, ops.AGG_SUM, col_scale=g.inv_deg_plus1())
+        return None, dx, None, None, None
+
+
+def graphconv_fwd(g, a, w, b, relu):
+    """dgl GraphConv(norm='both') forward on HIP (reference models.py:193): returns (y, mid, first).
+    first (in > out): y = act(rs * A (cs * (a W)) + b), mid = a;  else: mid = rs * A (cs * a), y = act(mid W + b)."""
+    rs, cs = g.degree_norms()
+    n = g.num_dst_nodes()
+    first = w.shape[0] > w.shape[1]
+    if first:
+        hw = ops.gemm(a, w, w_is_kn=True, row_scale=cs)
+        return ops.spmm(g.indptr, g.indices, hw, n, ops.AGG_SUM, row_scale=rs, ep_shift=b, relu=relu), a, True
+    mid = ops.spmm(g.indptr, g.indices, a, n, ops.AGG_SUM, row_scale=rs, col_scale=cs)
+    return ops.gemm(mid, w, w_is_kn=True, ep_shift=b, relu=relu), mid, False
+
+
+def graphconv_bwd(g, dz, mid, first, w, gw, want_da):
+    """Backward of graphconv_fwd given dz = d/d(pre-activation): writes dW into gw, returns d/da (or None)."""
+    rs, cs = g.degree_norms()
+    n = g.num_dst_nodes()
+    t = g.transposed(False)
+    if first:
+        dhw = ops.spmm(t.indptr, t.indices, dz, n, ops.AGG_SUM, row_scale=cs, col_scale=rs)      # cs * A^T (rs * dz)
+        ops.gemm_tn(mid, dhw, out=gw)                                                       # a^T dhw -> [in, out]
+        return ops.gemm(dhw, w) if want_da else None                                        # dhw W^T
+    ops.gemm_tn(mid, dz, out=gw)
+    if not want_da:
+        return None
+    return ops.spmm(t.indptr, t.indices, ops.gemm(dz, w), n, ops.AGG_SUM, row_scale=cs, col_scale=rs)
+
+
+class GraphConvFn(torch.autograd.Function):
+    """One dgl GraphConv(norm='both', activation=relu|None) layer as a differentiable op on the HIP path."""
+
+    @staticmethod
+    def forward(ctx, graph, feat, w, b, relu):
+        a = ops.as_feat(feat.detach())
+        y, mid, first = graphconv_fwd(graph, a, w.detach(), None if b is None else b.detach(), relu)
+        ctx.graph, ctx.first, ctx.relu, ctx.has_bias = graph, first, relu, b is not None
+        ctx.save_for_backward(mid, y, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mid, y, w = ctx.saved_tensors
+        dy = ops.as_feat(dy.contiguous())
+        db = torch.empty(w.shape[1], dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        if ctx.relu:
+            dz, _, _ = ops.bn_relu_bwd(dy, y, dz_col_sum=db)              # y = relu(z): y > 0 <=> z > 0
+        else:
+            dz = dy
+            if db is not None:
+                ops.col_sum(dz, out=db)
+        gw = torch.empty_like(w)
+        da = graphconv_bwd(ctx.graph, dz, mid, ctx.first, w.detach(), gw, ctx.needs_input_grad[1])
+        return None, da, gw, db, None
 
 
 class _NormActDropFn(torch.autograd.Function):

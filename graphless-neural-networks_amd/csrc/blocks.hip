@@ -1,0 +1,425 @@
+// Block construction and CSR transposition on the GPU: the integer / index half of the teacher TRAINING path
+// (SURVEY.md section 8f rows 1 and 2).  HBM- and latency-bound integer work, sized by the batch's FRONTIER, never by N.
+//
+// Replaces (see include/glnn_hip.h):
+//   * dgl.dataloading.NodeDataLoader's per-batch block construction -- `to_block` relabelling of the sampled /
+//     full-neighbour frontier (reference train_and_eval.py:176-205, consumed at :41 and models.py:109,134-137):
+//     glnn_block_build = row counts -> exclusive scan (block indptr) -> hash-table insert of the frontier's node ids
+//     -> scan over first occurrences (dense local ids, "destinations first, then first appearance") -> relabel;
+//   * the reversed graph autograd walks in loss.backward() through dgl's SpMM (train_and_eval.py:27,54):
+//     glnn_csr_transpose = counting sort by source (histogram -> scan -> atomic fill) + a canonical per-row sort, so
+//     that A^T dY runs on the SAME gather kernel (glnn_spmm_csr_f32) deterministically.
+//
+// Building blocks
+//   * scan_kernel: single-pass exclusive scan with decoupled look-back (one launch; workgroup order taken from an
+//     atomic ticket so that every predecessor a workgroup waits on is already resident); value source and consumer are
+//     functors, so the producer (row counts, first-occurrence flags, histogram) and the consumer (indptr write, id
+//     assignment, cursor reset) are fused into the scan instead of being separate passes;
+//   * an open-addressing hash table (linear probing, atomicCAS on int32 keys) over 2..4x the frontier size.
+// Workspaces arrive filled with the byte 0x7F by ONE hipMemsetAsync: 0x7F7F7F7F is the table's EMPTY key / "no position"
+// value, the look-back status words read as state EMPTY, and the ticket counters start at 0x7F7F7F7F.
+#include "glnn_common.h"
+
+namespace {
+
+constexpr int kFill32 = 0x7F7F7F7F;
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+// look-back status word: top 2 bits = state (01 = EMPTY, what the 0x7F memset leaves; 10 = aggregate; 11 = inclusive prefix)
+constexpr unsigned long long kStAgg = 2ull << 62, kStPrefix = 3ull << 62, kStMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ void st_release(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_acquire(unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// out(i, exclusive prefix, value) for i in [0,n); *total = sum.  status: >= ceil(n/1024) words, ticket: 1 int, both 0x7F-filled.
+template <class V, class W>
+__global__ __launch_bounds__(kScanThreads) void scan_kernel(V val, int64_t n, unsigned long long* status, int* ticket, W out,
+                                                            int64_t* total) {
+  __shared__ int s_bid;
+  __shared__ int s_wave[kScanThreads / 64];
+  __shared__ long long s_prefix;
+  if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1) - kFill32;
+  __syncthreads();
+  const int bid = s_bid;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)bid * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int tsum = 0;
+#pragma unroll
+  for (int t = 0; t < kScanItems; ++t) {
+    v[t] = (base + t < n) ? val(base + t) : 0;
+    tsum += v[t];
+  }
+  int inc = tsum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(inc, off);
+    if (lane >= off) inc += y;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int wave_off = 0, block_sum = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    if (w < wave) wave_off += s_wave[w];
+    block_sum += s_wave[w];
+  }
+  if (threadIdx.x == 0) {
+    long long prefix = 0;
+    if (bid == 0) {
+      st_release(status, kStPrefix | (unsigned long long)block_sum);
+    } else {
+      st_release(status + bid, kStAgg | (unsigned long long)block_sum);
+      int j = bid - 1;
+      while (true) {
+        const unsigned long long s = ld_acquire(status + j);
+        const unsigned long long state = s >> 62;
+        if (state < 2) {            // EMPTY: the predecessor has its ticket (it is resident) but has not published yet
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        prefix += (long long)(s & kStMask);
+        if (state == 3) break;
+        --j;
+      }
+      st_release(status + bid, kStPrefix | (unsigned long long)(prefix + block_sum));
+    }
+    s_prefix = prefix;
+    if (bid == (int)gridDim.x - 1 && total) *total = prefix + block_sum;
+  }
+  __syncthreads();
+  long long ex = s_prefix + wave_off + (inc - tsum);
+#pragma unroll
+  for (int t = 0; t < kScanItems; ++t) {
+    if (base + t < n) out(base + t, ex, v[t]);
+    ex += v[t];
+  }
+}
+
+template <class V, class W>
+int launch_scan(V val, int64_t n, unsigned long long* status, int* ticket, W out, int64_t* total, hipStream_t st, const char* what) {
+  const int64_t blocks = (n + kScanTile - 1) / kScanTile;
+  if (blocks == 0) return GLNN_OK;
+  hipLaunchKernelGGL((scan_kernel<V, W>), dim3((unsigned)blocks), dim3(kScanThreads), 0, st, val, n, status, ticket, out, total);
+  return glnn::check_launch(what);
+}
+
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ int ht_insert(int* keys, unsigned mask, int key) {
+  unsigned slot = hash32((unsigned)key) & mask;
+  while (true) {
+    const int prev = atomicCAS(&keys[slot], kFill32, key);
+    if (prev == kFill32 || prev == key) return (int)slot;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ block builder
+struct BlockArgs {
+  const int64_t* g_indptr;      // graph CSR (full-neighbour mode), else NULL
+  const int32_t* g_indices;
+  const int64_t* seeds; int64_t ns;
+  const int32_t* smp_src; const int32_t* smp_cnt; int fanout;     // sampled mode, else NULL
+  int64_t nnz_cap;              // upper bound of the block's edge count (grid size of the per-edge passes)
+  int64_t* indptr;              // out [ns+1]
+  int32_t* indices;             // out [nnz_cap] local ids
+  int32_t* gindices;            // out [nnz_cap] global ids (optional)
+  int64_t* input_nodes;         // out [ns + nnz_cap]
+  int64_t* counts;              // out device [2]: nnz, n_src
+  int* keys; int* seed_pos; int* first_pos; int* local_of_slot; unsigned mask;    // hash table (4 arrays of mask+1)
+  int* slot_of_edge;            // [nnz_cap]
+};
+
+struct RowCount {
+  BlockArgs a;
+  __device__ int operator()(int64_t i) const {
+    if (a.smp_cnt) return a.smp_cnt[i];
+    const int64_t v = a.seeds[i];
+    return (int)(a.g_indptr[v + 1] - a.g_indptr[v]);
+  }
+};
+struct WriteIndptr {
+  BlockArgs a;
+  __device__ void operator()(int64_t i, long long ex, int v) const {
+    a.indptr[i] = ex;
+    if (i == a.ns - 1) a.indptr[a.ns] = ex + v;
+  }
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(256) void block_insert_kernel(const BlockArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (FULL) {
+    // one wave per row: lanes stride the row's in-edges; wave w < ns also registers seed w
+    const int64_t i = t >> 6;
+    const int lane = (int)(t & 63);
+    if (i >= a.ns) return;
+    const int64_t v = a.seeds[i];
+    if (lane == 0) {
+      const int slot = ht_insert(a.keys, a.mask, (int)v);
+      atomicMin(&a.seed_pos[slot], (int)i);
+      a.input_nodes[i] = v;
+    }
+    const int64_t g0 = a.g_indptr[v], cnt = a.g_indptr[v + 1] - g0, e0 = a.indptr[i];
+    for (int64_t k = lane; k < cnt && e0 + k < a.nnz_cap; k += 64) {       // (counts[0] reports the true nnz: the caller checks it against nnz_cap)
+      const int key = a.g_indices[g0 + k];
+      const int slot = ht_insert(a.keys, a.mask, key);
+      atomicMin(&a.first_pos[slot], (int)(e0 + k));
+      a.slot_of_edge[e0 + k] = slot;
+      if (a.gindices) a.gindices[e0 + k] = key;
+    }
+  } else {
+    if (t < a.ns) {
+      const int64_t v = a.seeds[t];
+      const int slot = ht_insert(a.keys, a.mask, (int)v);
+      atomicMin(&a.seed_pos[slot], (int)t);
+      a.input_nodes[t] = v;
+      return;
+    }
+    const int64_t s = t - a.ns;
+    const int64_t i = s / a.fanout;
+    const int k = (int)(s - i * a.fanout);
+    if (i >= a.ns || k >= a.smp_cnt[i]) return;
+    const int64_t e = a.indptr[i] + k;
+    const int key = a.smp_src[i * a.fanout + k];
+    const int slot = ht_insert(a.keys, a.mask, key);
+    atomicMin(&a.first_pos[slot], (int)e);
+    a.slot_of_edge[e] = slot;
+    if (a.gindices) a.gindices[e] = key;
+  }
+}
+
+struct FirstSeen {           // 1 iff edge e is the first occurrence of a node that is not a destination of the block
+  BlockArgs a;
+  __device__ int operator()(int64_t e) const {
+    if (e >= a.indptr[a.ns]) return 0;
+    const int slot = a.slot_of_edge[e];
+    return (a.first_pos[slot] == (int)e && a.seed_pos[slot] == kFill32) ? 1 : 0;
+  }
+};
+struct AssignLocal {
+  BlockArgs a;
+  __device__ void operator()(int64_t e, long long ex, int flag) const {
+    if (flag) {
+      const int slot = a.slot_of_edge[e];
+      a.local_of_slot[slot] = (int)(a.ns + ex);
+      a.input_nodes[a.ns + ex] = a.keys[slot];
+    }
+  }
+};
+
+__global__ __launch_bounds__(256) void block_relabel_kernel(const BlockArgs a, const int64_t* n_new) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) {
+    a.counts[0] = a.indptr[a.ns];
+    a.counts[1] = a.ns + *n_new;
+  }
+  if (e >= a.indptr[a.ns]) return;
+  const int slot = a.slot_of_edge[e];
+  const int sp = a.seed_pos[slot];
+  a.indices[e] = (sp != kFill32) ? sp : a.local_of_slot[slot];
+}
+
+__global__ void block_empty_counts_kernel(int64_t* counts, int64_t* indptr, int64_t ns) {
+  counts[0] = 0;
+  counts[1] = ns;
+  if (indptr) indptr[0] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ CSR transpose
+struct TrArgs {
+  const int64_t* indptr; const int32_t* indices; int64_t n_dst, n_src, nnz; int add_self;
+  int64_t* t_indptr; int32_t* t_indices; int32_t* tmp; int* cursor;
+};
+
+__global__ __launch_bounds__(256) void tr_count_kernel(const TrArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += stride) atomicAdd(&a.cursor[a.indices[e]], 1);
+}
+struct TrCount {
+  TrArgs a;
+  __device__ int operator()(int64_t u) const { return a.cursor[u] + ((a.add_self && u < a.n_dst) ? 1 : 0); }
+};
+struct TrWrite {
+  TrArgs a;
+  __device__ void operator()(int64_t u, long long ex, int v) const {
+    a.t_indptr[u] = ex;
+    if (u == a.n_src - 1) a.t_indptr[a.n_src] = ex + v;
+    if (a.add_self && u < a.n_dst) {
+      a.tmp[ex] = (int)u;          // the self entry u <- u of the SAGE-"gcn" aggregator's backward
+      a.cursor[u] = 1;
+    } else {
+      a.cursor[u] = 0;
+    }
+  }
+};
+// one wave per destination row of the ORIGINAL graph: scatter v into the rows of its sources
+__global__ __launch_bounds__(256) void tr_fill_kernel(const TrArgs a) {
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t v = w; v < a.n_dst; v += n_waves) {
+    const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const int u = a.indices[e];
+      const int pos = atomicAdd(&a.cursor[u], 1);
+      a.tmp[a.t_indptr[u] + pos] = (int)v;
+    }
+  }
+}
+// one wave per row of the transposed graph: the atomic fill left its entries in arbitrary order; rank them by value
+// (equal values are interchangeable) so that the fp32 sums of the aggregation kernel are reproducible run to run.
+__global__ __launch_bounds__(256) void tr_sort_kernel(const TrArgs a) {
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t u = w; u < a.n_src; u += n_waves) {
+    const int64_t s0 = a.t_indptr[u];
+    const int len = (int)(a.t_indptr[u + 1] - s0);
+    const int32_t* src = a.tmp + s0;
+    int32_t* dst = a.t_indices + s0;
+    if (len <= 64) {
+      const int key = lane < len ? src[lane] : 0x7FFFFFFF;
+      int rank = 0;
+      for (int j = 0; j < len; ++j) {
+        const int kj = __shfl(key, j);
+        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
+      }
+      if (lane < len) dst[rank] = key;
+    } else {
+      for (int i = lane; i < len; i += 64) {
+        const int key = src[i];
+        int rank = 0;
+        for (int j = 0; j < len; ++j) {
+          const int kj = src[j];
+          rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+        }
+        dst[rank] = key;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t glnn_block_workspace_bytes(int64_t ns, int64_t nnz_cap) {
+  if (ns < 0 || nnz_cap < 0) return -1;
+  uint64_t cap = 64;
+  while (cap < (uint64_t)(2 * (ns + nnz_cap))) cap <<= 1;
+  const int64_t scan_words = (ns + kScanTile - 1) / kScanTile + (nnz_cap + kScanTile - 1) / kScanTile + 2;
+  return (int64_t)(4 * cap * sizeof(int)) + nnz_cap * (int64_t)sizeof(int) + scan_words * 8 + 64;
+}
+
+extern "C" int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds, int64_t ns,
+                                const int32_t* smp_src, const int32_t* smp_cnt, int fanout, int64_t nnz_cap,
+                                int64_t* indptr, int32_t* indices, int32_t* gindices, int64_t* input_nodes, int64_t* counts,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  GLNN_REQUIRE(ns >= 0 && nnz_cap >= 0, "glnn_block_build: negative size");
+  GLNN_REQUIRE(counts && indptr, "glnn_block_build: null counts/indptr");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (ns == 0 || nnz_cap == 0) {
+    if (ns > 0) {
+      GLNN_REQUIRE(seeds && input_nodes, "glnn_block_build: null pointer");
+      if (hipMemsetAsync(indptr, 0, sizeof(int64_t) * (size_t)(ns + 1), st) != hipSuccess ||
+          hipMemcpyAsync(input_nodes, seeds, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset/memcpy failed");
+    }
+    hipLaunchKernelGGL(block_empty_counts_kernel, dim3(1), dim3(1), 0, st, counts, ns == 0 ? indptr : nullptr, ns);
+    return glnn::check_launch("glnn_block_build");
+  }
+  const bool full = smp_src == nullptr;
+  GLNN_REQUIRE(seeds && indices && input_nodes && workspace, "glnn_block_build: null pointer");
+  GLNN_REQUIRE(full ? (g_indptr && g_indices && !smp_cnt) : (smp_cnt && fanout >= 1 && nnz_cap >= ns * (int64_t)fanout),
+               "glnn_block_build: pass either the graph CSR (full neighbourhood) or smp_src/smp_cnt/fanout with nnz_cap >= ns*fanout");
+  GLNN_REQUIRE(ns + nnz_cap < ((int64_t)1 << 30), "glnn_block_build: frontier too large for 32-bit positions");
+  GLNN_REQUIRE(workspace_bytes >= glnn_block_workspace_bytes(ns, nnz_cap) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+               "glnn_block_build: workspace needs %lld bytes, 8-byte aligned", (long long)glnn_block_workspace_bytes(ns, nnz_cap));
+  uint64_t cap = 64;
+  while (cap < (uint64_t)(2 * (ns + nnz_cap))) cap <<= 1;
+  const int64_t b1 = (ns + kScanTile - 1) / kScanTile, b2 = (nnz_cap + kScanTile - 1) / kScanTile;
+  // layout: [status1 b1][status2 b2][ticket1, ticket2 (one 8-byte word)][n_new (8 bytes)] | keys, seed_pos, first_pos | -- 0x7F-filled up to here
+  //         local_of_slot | slot_of_edge
+  unsigned long long* status1 = reinterpret_cast<unsigned long long*>(workspace);
+  unsigned long long* status2 = status1 + b1;
+  int* tickets = reinterpret_cast<int*>(status2 + b2);
+  int64_t* n_new = reinterpret_cast<int64_t*>(tickets + 2);
+  int* keys = reinterpret_cast<int*>(n_new + 1);
+  BlockArgs a;
+  a.g_indptr = g_indptr; a.g_indices = g_indices; a.seeds = seeds; a.ns = ns; a.smp_src = smp_src; a.smp_cnt = smp_cnt;
+  a.fanout = fanout; a.nnz_cap = nnz_cap; a.indptr = indptr; a.indices = indices; a.gindices = gindices; a.input_nodes = input_nodes;
+  a.counts = counts; a.keys = keys; a.seed_pos = keys + cap; a.first_pos = keys + 2 * cap; a.local_of_slot = keys + 3 * cap;
+  a.mask = (unsigned)(cap - 1); a.slot_of_edge = keys + 4 * cap;
+  const size_t fill_bytes = (size_t)((b1 + b2 + 2) * 8) + 3 * cap * sizeof(int);
+  if (hipMemsetAsync(workspace, 0x7F, fill_bytes, st) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset failed");
+  int rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
+  if (rc != GLNN_OK) return rc;
+  if (full) {
+    const int64_t threads = ns * 64;
+    hipLaunchKernelGGL((block_insert_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+  } else {
+    const int64_t threads = ns + ns * (int64_t)fanout;
+    hipLaunchKernelGGL((block_insert_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
+  }
+  rc = glnn::check_launch("glnn_block_build(insert)");
+  if (rc != GLNN_OK) return rc;
+  rc = launch_scan(FirstSeen{a}, nnz_cap, status2, tickets + 1, AssignLocal{a}, n_new, st, "glnn_block_build(scan first occurrences)");
+  if (rc != GLNN_OK) return rc;
+  hipLaunchKernelGGL(block_relabel_kernel, dim3((unsigned)((nnz_cap + 255) / 256)), dim3(256), 0, st, a, n_new);
+  return glnn::check_launch("glnn_block_build(relabel)");
+}
+
+extern "C" int64_t glnn_csr_transpose_workspace_bytes(int64_t n_src, int64_t nnz_out) {
+  if (n_src < 0 || nnz_out < 0) return -1;
+  return ((n_src + kScanTile - 1) / kScanTile + 2) * 8 + (n_src + nnz_out) * (int64_t)sizeof(int) + 64;
+}
+
+extern "C" int glnn_csr_transpose(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, int64_t nnz,
+                                  int add_self, int64_t* t_indptr, int32_t* t_indices, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && nnz >= 0 && n_src < ((int64_t)1 << 31), "glnn_csr_transpose: bad size");
+  GLNN_REQUIRE(t_indptr, "glnn_csr_transpose: null t_indptr");
+  GLNN_REQUIRE(!add_self || n_dst <= n_src, "glnn_csr_transpose: add_self needs n_dst <= n_src (a block's destinations are its first sources)");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nnz_out = nnz + (add_self ? n_dst : 0);
+  if (n_src == 0) return hipMemsetAsync(t_indptr, 0, sizeof(int64_t), st) == hipSuccess ? GLNN_OK : glnn::fail(GLNN_ERR_HIP, "glnn_csr_transpose: memset failed");
+  GLNN_REQUIRE(indptr && (indices || nnz == 0) && (t_indices || nnz_out == 0) && workspace, "glnn_csr_transpose: null pointer");
+  GLNN_REQUIRE(workspace_bytes >= glnn_csr_transpose_workspace_bytes(n_src, nnz_out) && (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+               "glnn_csr_transpose: workspace needs %lld bytes, 8-byte aligned", (long long)glnn_csr_transpose_workspace_bytes(n_src, nnz_out));
+  const int64_t b = (n_src + kScanTile - 1) / kScanTile;
+  unsigned long long* status = reinterpret_cast<unsigned long long*>(workspace);
+  int* ticket = reinterpret_cast<int*>(status + b);
+  int* cursor = ticket + 4;
+  TrArgs a;
+  a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.n_src = n_src; a.nnz = nnz; a.add_self = add_self;
+  a.t_indptr = t_indptr; a.t_indices = t_indices; a.cursor = cursor; a.tmp = cursor + n_src;
+  if (hipMemsetAsync(workspace, 0x7F, (size_t)(b * 8 + 16), st) != hipSuccess ||
+      hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)n_src, st) != hipSuccess)
+    return glnn::fail(GLNN_ERR_HIP, "glnn_csr_transpose: memset failed");
+  if (nnz > 0) {
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  }
+  int rc = launch_scan(TrCount{a}, n_src, status, ticket, TrWrite{a}, nullptr, st, "glnn_csr_transpose(scan)");
+  if (rc != GLNN_OK) return rc;
+  if (nnz > 0 && n_dst > 0) {
+    int64_t blocks = (n_dst * 64 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(tr_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  }
+  if (nnz_out > 0) {
+    int64_t blocks = (n_src * 64 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(tr_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  }
+  return glnn::check_launch("glnn_csr_transpose");
+}

@@ -61,6 +61,7 @@ struct SpmmArgs {
   const float* col_scale;
   const float* x_self;
   int64_t ld_self;
+  const int64_t* self_rows;     // optional: the self row of destination v is x_self[self_rows[v]] (global feature matrix)
   const float* ep_scale;
   const float* ep_shift;
   int relu;
@@ -149,7 +150,8 @@ template <int MODE>
 __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4) {
   float4 y;
   if (MODE == GLNN_AGG_SAGE_GCN) {
-    const float4 s = ld4(a.x_self + v * a.ld_self + col4);
+    const int64_t sr = a.self_rows ? a.self_rows[v] : v;
+    const float4 s = ld4(a.x_self + sr * a.ld_self + col4);
     const float dp1 = (float)deg + 1.0f;
     y = make_float4((acc.x + s.x) / dp1, (acc.y + s.y) / dp1, (acc.z + s.z) / dp1, (acc.w + s.w) / dp1);
   } else {
@@ -422,28 +424,34 @@ int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid) {
   return glnn::check_launch("glnn_spmm_csr_f32");
 }
 
+__device__ __forceinline__ float degree_transform(float deg, int transform) {
+  if (transform == GLNN_DEG_RSQRT_CLAMP1) return rsqrtf(fmaxf(deg, 1.0f));     // deg.clamp(min=1) ** -0.5
+  if (transform == GLNN_DEG_INV_PLUS1) return 1.0f / (deg + 1.0f);
+  return deg;
+}
+
 __global__ void degrees_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int64_t n_dst,
-                               int64_t nnz, float* in_deg, float* out_deg_as_int) {
+                               int64_t nnz, float* in_deg, float* out_deg_as_int, int transform) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (in_deg)
-    for (int64_t v = i; v < n_dst; v += stride) in_deg[v] = (float)(indptr[v + 1] - indptr[v]);
+    for (int64_t v = i; v < n_dst; v += stride) in_deg[v] = degree_transform((float)(indptr[v + 1] - indptr[v]), transform);
   if (out_deg_as_int) {
     int* cnt = reinterpret_cast<int*>(out_deg_as_int);
     for (int64_t e = i; e < nnz; e += stride) atomicAdd(&cnt[indices[e]], 1);
   }
 }
 
-__global__ void int_to_float_kernel(float* p, int64_t n) {
+__global__ void int_to_float_kernel(float* p, int64_t n, int transform) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = (float)reinterpret_cast<int*>(p)[i];
+  if (i < n) p[i] = degree_transform((float)reinterpret_cast<int*>(p)[i], transform);
 }
 
 }  // namespace
 
 extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
                                  const float* x, int64_t ldx, int d, int mode, const float* row_scale,
-                                 const float* col_scale, const float* x_self, int64_t ld_self,
+                                 const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
                                  const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
                                  void* stream) {
   if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
@@ -459,6 +467,8 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     GLNN_REQUIRE(x_self && ld_self % 4 == 0 && ld_self >= dpad && glnn::aligned16(x_self),
                  "glnn_spmm_csr_f32: SAGE_GCN needs x_self with ld multiple of 4");
     GLNN_REQUIRE(!row_scale && !col_scale, "glnn_spmm_csr_f32: scales are not used in SAGE_GCN mode");
+  } else {
+    GLNN_REQUIRE(!self_rows, "glnn_spmm_csr_f32: self_rows belongs to SAGE_GCN mode");
   }
   if (n_dst == 0) return GLNN_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -470,7 +480,7 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     a.indptr = indptr; a.indices = indices; a.n_dst = n_dst;
     a.x = x + c0; a.ldx = ldx; a.d = dt;
     a.row_scale = row_scale; a.col_scale = col_scale;
-    a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self;
+    a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self; a.self_rows = self_rows;
     a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
     a.relu = relu; a.out = out + c0; a.ldo = ldo;
     int64_t n_long = n_dst / GLNN_LONG_BLOCK_ROWS;       // workgroups in the long-row role
@@ -494,8 +504,9 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
 }
 
 extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
-                                int64_t nnz, float* in_deg, float* out_deg, void* stream) {
+                                int64_t nnz, int transform, float* in_deg, float* out_deg, void* stream) {
   GLNN_REQUIRE(indptr, "glnn_degrees_f32: null indptr");
+  GLNN_REQUIRE(transform >= GLNN_DEG_RAW && transform <= GLNN_DEG_INV_PLUS1, "glnn_degrees_f32: unknown transform %d", transform);
   GLNN_REQUIRE(!out_deg || indices, "glnn_degrees_f32: out_deg needs indices");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GLNN_REQUIRE(nnz >= 0 && n_dst >= 0 && n_src >= 0, "glnn_degrees_f32: negative size");
@@ -507,9 +518,9 @@ extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, i
   int grid = (int)((work + 255) / 256);
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(degrees_kernel, dim3(grid), dim3(256), 0, st, indptr, indices, n_dst, nnz, in_deg, out_deg);
+  hipLaunchKernelGGL(degrees_kernel, dim3(grid), dim3(256), 0, st, indptr, indices, n_dst, nnz, in_deg, out_deg, transform);
   if (out_deg && n_src > 0)
-    hipLaunchKernelGGL(int_to_float_kernel, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, st, out_deg, n_src);
+    hipLaunchKernelGGL(int_to_float_kernel, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, st, out_deg, n_src, transform);
   return glnn::check_launch("glnn_degrees_f32");
 }
 

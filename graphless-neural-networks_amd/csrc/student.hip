@@ -588,6 +588,37 @@ extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h
   return glnn::check_launch("glnn_act_fwd_f32");
 }
 
+// column sums of a [rows, h] matrix: per-128-row-chunk partials (4 row lanes x 64 columns per workgroup), then the fixed-order
+// chunk sum the BatchNorm backward uses -- the bias gradient of a layer whose dz is not produced by glnn_bn_relu_bwd_f32
+// (the last GraphConv of the full-graph GCN step, reference train_and_eval.py:12-29).
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int h,
+                                                              float* __restrict__ ws) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < h ? col : h - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += 4) s += x[r * ldx + colc];
+  __shared__ float sh[4][64];
+  sh[rl][lc] = s;
+  __syncthreads();
+  if (rl == 0 && col < h) ws[(int64_t)blockIdx.y * h + col] = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
+}
+
+extern "C" int glnn_col_sum_f32(const float* x, int64_t ldx, int64_t rows, int h, float* out, float* workspace,
+                                int64_t workspace_floats, void* stream) {
+  GLNN_REQUIRE(x && out && rows >= 1 && h >= 1 && ldx >= h, "glnn_col_sum_f32: bad arguments");
+  const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
+  GLNN_REQUIRE(workspace && workspace_floats >= (int64_t)nchunks * h, "glnn_col_sum_f32: workspace needs >= %lld floats",
+               (long long)nchunks * h);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(col_sum_partial_kernel, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, x, ldx, rows, h, workspace);
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, workspace, nchunks, h, out);
+  return glnn::check_launch("glnn_col_sum_f32");
+}
+
 extern "C" int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t drop_seed, uint8_t* mask, void* stream) {
   GLNN_REQUIRE(mask && rows >= 1 && h >= 1 && drop_p >= 0.f && drop_p < 1.f, "glnn_dropout_mask_u8: bad arguments");
   int64_t blocks = (rows * h + 255) / 256;

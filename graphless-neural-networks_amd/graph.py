@@ -19,6 +19,8 @@ class CSRGraph:
         self.ndata = {}
         self._nnz = None
         self._cache = {}
+        self.gindices = None       # outermost training block only: the edges' GLOBAL source ids (see NodeDataLoader)
+        self.dst_nodes = None
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -80,23 +82,48 @@ class CSRGraph:
         """(in_deg.clamp(1)^-1/2, out_deg.clamp(1)^-1/2) as fp32 device vectors, computed once by
         glnn_degrees_f32 (GraphConv norm='both' / feature_prop, reference utils.py:178-179)."""
         if "norms" not in self._cache:
-            if self.indptr.is_cuda:
-                from . import ops
-                in_deg, out_deg = ops.degrees(self.indptr, self.indices, self.n_dst, self.n_src, self.num_edges())
-            else:
-                in_deg, out_deg = self.in_degrees().float(), self.out_degrees().float()
-            self._cache["norms"] = (in_deg.clamp(min=1).pow(-0.5), out_deg.clamp(min=1).pow(-0.5))
+            from . import ops
+            self._cache["norms"] = ops.degrees(self.indptr, self.indices, self.n_dst, self.n_src, self.num_edges(),
+                                               transform=ops.DEG_RSQRT_CLAMP1)
         return self._cache["norms"]
 
+    def inv_deg_plus1(self):
+        """1 / (in_deg + 1) per destination row (fp32, cached): the divisor of the SAGE-"gcn" aggregator, i.e. the
+        col_scale of its backward over the transposed block."""
+        if "inv1" not in self._cache:
+            from . import ops
+            self._cache["inv1"] = ops.degrees(self.indptr, None, self.n_dst, self.n_src, 0, want_out=False, transform=ops.DEG_INV_PLUS1)[0]
+        return self._cache["inv1"]
+
+    def has_zero_in_degree(self):
+        """dgl GraphConv's `(graph.in_degrees() == 0).any()` check, evaluated once per graph."""
+        if "zero_in" not in self._cache:
+            self._cache["zero_in"] = bool((self.in_degrees() == 0).any()) if self.n_dst else False
+        return self._cache["zero_in"]
+
+    def transposed(self, add_self=False):
+        """The transposed graph (CSR over the original SOURCE nodes, rows sorted), cached: what the aggregation's
+        backward gathers over (glnn_csr_transpose).  add_self: plus one entry u <- u per destination u < n_dst, the
+        h_dst term of the SAGE-"gcn" aggregator."""
+        key = ("tr", bool(add_self))
+        if key not in self._cache:
+            from . import ops
+            t_indptr, t_indices = ops.csr_transpose(self.indptr, self.indices, self.n_dst, self.n_src, self.num_edges(), add_self)
+            t = CSRGraph(t_indptr, t_indices, self.n_src, self.n_dst)
+            t._nnz = self.num_edges() + (self.n_dst if add_self else 0)
+            self._cache[key] = t
+        return self._cache[key]
+
     def reverse(self):
-        """Transposed graph (CSR over the original SOURCE nodes), cached: used by the aggregation backward."""
-        if "rev" not in self._cache:
-            dst_all = torch.repeat_interleave(torch.arange(self.n_dst, device=self.device), self.in_degrees())
+        """dgl-style reversed graph (every edge u->v becomes v->u): the transposed CSR."""
+        if self.indptr.is_cuda:
+            return self.transposed(False)
+        if "rev" not in self._cache:        # host-side index algebra for graphs that live on the CPU
+            dst_all = torch.repeat_interleave(torch.arange(self.n_dst), self.in_degrees())
             src = self.indices.long()
             order = torch.argsort(src, stable=True)
-            counts = torch.bincount(src, minlength=self.n_src)
-            indptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=self.device)
-            torch.cumsum(counts, 0, out=indptr[1:])
+            indptr = torch.zeros(self.n_src + 1, dtype=torch.int64)
+            torch.cumsum(torch.bincount(src, minlength=self.n_src), 0, out=indptr[1:])
             self._cache["rev"] = CSRGraph(indptr, dst_all[order].to(torch.int32), self.n_src, self.n_dst)
         return self._cache["rev"]
 
@@ -137,24 +164,19 @@ class FullNeighborLoader:
         return (self.graph.n_dst + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
+        from . import ops
         g = self.graph
-        dev = g.device
+        if not g.indptr.is_cuda:
+            raise RuntimeError("FullNeighborLoader: blocks are built on the GPU (move the graph with g.to(device))")
         n = g.n_dst
-        for s in range(0, n, self.batch_size):
-            e = min(n, s + self.batch_size)
-            lo, hi = int(g.indptr[s].item()), int(g.indptr[e].item())
-            src = g.indices[lo:hi].long()
-            output_nodes = torch.arange(s, e, device=dev)
-            is_out = torch.zeros(g.n_src, dtype=torch.bool, device=dev)
-            is_out[s:e] = True
-            uniq = torch.unique(src)
-            extra = uniq[~is_out[uniq]]
-            input_nodes = torch.cat([output_nodes, extra])
-            remap = torch.empty(g.n_src, dtype=torch.int64, device=dev)
-            remap[input_nodes] = torch.arange(input_nodes.numel(), device=dev)
-            block = CSRGraph((g.indptr[s:e + 1] - lo).contiguous(), remap[src].to(torch.int32), e - s,
-                             input_nodes.numel())
-            block._nnz = hi - lo
+        bounds = list(range(0, n, self.batch_size)) + [n]
+        offs = g.indptr[torch.tensor(bounds, device=g.device)].tolist()          # ONE read-back for the whole sweep
+        for b in range(len(bounds) - 1):
+            s, e = bounds[b], bounds[b + 1]
+            output_nodes = torch.arange(s, e, device=g.device)
+            indptr, indices, _, input_nodes, nnz, n_src = ops.block_build(output_nodes, g.indptr, g.indices, nnz_cap=offs[b + 1] - offs[b])
+            block = CSRGraph(indptr, indices, e - s, n_src)
+            block._nnz = nnz
             yield input_nodes, output_nodes, [block]
 
 
@@ -184,42 +206,31 @@ class NodeDataLoader:
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self._epoch = 0
         self._seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFF
-        if isinstance(sampler, MultiLayerFullNeighborSampler) and sampler.n_layers == 1:
-            self.graph = g        # lets SAGE.inference take the whole-graph path when nids covers every node
+        # the whole-graph path of SAGE.inference is only valid when the loader sweeps EVERY node in id order
+        if isinstance(sampler, MultiLayerFullNeighborSampler) and sampler.n_layers == 1 and not shuffle \
+                and self.nids.numel() == g.num_dst_nodes() and bool((self.nids.cpu() == torch.arange(g.num_dst_nodes())).all()):
+            self.graph = g
 
     def __len__(self):
         n = self.nids.numel()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _block(self, seeds, fanout, rng_seed):
+    def _block(self, seeds, fanout, rng_seed, want_global=False):
+        """One 1-hop block over `seeds` on the device (glnn_sample_neighbors + glnn_block_build): work and memory are
+        proportional to the frontier (ns * fanout), not to the graph; one host read-back (edge / source-node counts)."""
         from . import ops
-        g, dev = self.g, self.g.device
-        if fanout is None:                                   # full neighbourhood
-            deg = (g.indptr[seeds + 1] - g.indptr[seeds])
-            starts = g.indptr[seeds]
-            indptr = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(deg, 0, out=indptr[1:])
-            pos = torch.arange(int(indptr[-1].item()), device=dev) - torch.repeat_interleave(indptr[:-1] - starts, deg)
-            src = g.indices[pos].long()
+        g = self.g
+        if fanout is None:                                   # full neighbourhood: the edge count bounds the buffers
+            deg_sum = int((g.indptr[seeds + 1] - g.indptr[seeds]).sum().item())
+            indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, g.indptr, g.indices, nnz_cap=deg_sum,
+                                                                              want_global=want_global)
         else:
             smp, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, fanout, rng_seed)
-            indptr = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(cnt.long(), 0, out=indptr[1:])
-            valid = torch.arange(fanout, device=dev).unsqueeze(0) < cnt.unsqueeze(1)
-            src = smp[valid].long()                          # row-major: edges stay grouped by destination
-        # sources of the block = seeds first, then the other referenced nodes in ascending id order (what sort-based
-        # unique() gave before): one flag scatter + one prefix sum over the node range instead of a device sort per layer
-        ns = seeds.numel()
-        flag = torch.zeros(g.n_src, dtype=torch.int64, device=dev)
-        flag[src] = 1
-        flag[seeds] = 0
-        remap = torch.cumsum(flag, 0)
-        remap += ns - 1                                      # flagged node -> ns + (its rank among the flagged)
-        extra = torch.nonzero(flag).squeeze(1)
-        remap[seeds] = torch.arange(ns, device=dev)
-        input_nodes = torch.cat([seeds, extra])
-        block = CSRGraph(indptr, remap[src].to(torch.int32), ns, input_nodes.numel())
-        block._nnz = int(src.numel())
+            indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=want_global)
+        block = CSRGraph(indptr, indices, seeds.numel(), n_src)
+        block._nnz = nnz
+        if want_global:
+            block.gindices, block.dst_nodes = gidx, seeds       # the same edges with global source ids (TeacherEngine, layer 0)
         return input_nodes, block
 
     def __iter__(self):
@@ -236,6 +247,6 @@ class NodeDataLoader:
             seeds, blocks = output_nodes, []
             for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
                 rng = (self._seed * 1000003 + self._epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
-                seeds, blk = self._block(seeds, fanouts[l], rng)
+                seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0))
                 blocks.insert(0, blk)
             yield seeds, output_nodes, blocks

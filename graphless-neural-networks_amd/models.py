@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from .autograd import linear_fn, norm_act_drop
 from .nn import GraphConv, SAGEConv
 
@@ -23,21 +23,31 @@ def _bn_eval_fold(bn, bias):
     return s.contiguous(), ((b - bn.running_mean) * s + bn.bias.detach()).contiguous()
 
 
-def _hip_eval_ok(module, x):
-    return x.is_cuda and not module.training and not torch.is_grad_enabled()
+def _need_hip(x, what):
+    if not x.is_cuda:
+        raise _lib.GlnnError(f"{what}: tensors must live on the GPU -- this package computes on libglnn_hip.so only, there is no "
+                             "CPU path (the reference's default --device -1 selects the CPU: pass --device 0)")
 
 
-def _hip_train_tail_ok(module, h):
-    """Training-mode hidden-layer tail on the fused HIP op: BatchNorm1d (reference defaults) or no norm, ReLU."""
-    if not (module.training and h.is_cuda and module.norm_type in ("none", "batch")):
-        return False
+def _check_tail(module):
+    """The hidden-layer tails implemented on HIP: BatchNorm1d with the reference's defaults or no norm, ReLU, dropout."""
+    if module.norm_type not in ("none", "batch"):
+        raise NotImplementedError("norm_type 'layer' (used by the reference only for the BGNN house_class dataset, which is outside "
+                                  "the MI355X hot-path scope) has no HIP kernel")
     act = getattr(module, "activation", F.relu)
     if act is not F.relu and getattr(act, "__name__", "") != "relu":
-        return False
+        raise NotImplementedError("only ReLU hidden activations (what the reference constructs, models.py:371,381)")
+    for bn in module.norms:
+        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+            raise NotImplementedError("BatchNorm1d with the reference's defaults (affine, running stats, momentum 0.1)")
+
+
+def _eval_tail(module, l, z):
+    """Eval-mode `norms[l] -> relu -> dropout` of a hidden layer on a materialised z: one glnn_act_fwd_f32."""
     if module.norm_type == "batch":
-        bn = module.norms[0]
-        return bn.affine and bn.track_running_stats and bn.momentum is not None
-    return True
+        a_scale, a_shift = _bn_eval_fold(module.norms[l], None)
+        return ops.act_fwd(z, a_scale, a_shift)
+    return ops.act_fwd(z)
 
 
 class MLP(nn.Module):
@@ -67,21 +77,19 @@ class MLP(nn.Module):
             self.norms.append(nn.LayerNorm(hidden_dim))
 
     def forward(self, feats):
-        if _hip_eval_ok(self, feats) and self.norm_type in ("none", "batch"):
-            return self._forward_hip_eval(feats)
+        _need_hip(feats, "MLP.forward")
+        _check_tail(self)
+        if not self.training:
+            with torch.no_grad():
+                return self._forward_hip_eval(feats)
         h = feats
         h_list = []
         for l, layer in enumerate(self.layers):
-            h = linear_fn(h, layer.weight, layer.bias) if h.is_cuda else layer(h)
+            h = linear_fn(h, layer.weight, layer.bias)
             if l != self.num_layers - 1:
                 h_list.append(h)
-                if _hip_train_tail_ok(self, h):
-                    h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
-                    continue
-                if self.norm_type != "none":
-                    h = self.norms[l](h)
-                h = F.relu(h)
-                h = self.dropout(h)
+                # norm -> relu -> dropout as one differentiable HIP op (same module state: running stats, affine)
+                h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
         return h_list, h
 
     def _forward_hip_eval(self, feats):
@@ -134,22 +142,25 @@ class SAGE(nn.Module):
             self.norms.append(nn.LayerNorm(hidden_dim))
 
     def forward(self, blocks, feats):
-        """Sampled-block forward (reference models.py:101-119)."""
+        """Sampled-block forward (reference models.py:101-119): training mode through the differentiable HIP ops of
+        glnn_amd.autograd, eval mode on the plain kernels (BatchNorm running stats folded into one activation pass)."""
+        _need_hip(feats, "SAGE.forward")
+        _check_tail(self)
         h = feats
         h_list = []
         for l, (layer, block) in enumerate(zip(self.layers, blocks)):
             h_dst = h[: block.num_dst_nodes()]
-            h = layer(block, (h, h_dst))
-            if l != self.num_layers - 1:
-                h_list.append(h)
-                if _hip_train_tail_ok(self, h):
-                    # norm -> relu -> dropout as one op on the HIP path (same module state: running stats, affine)
+            if self.training:
+                h = layer(block, (h, h_dst))
+                if l != self.num_layers - 1:
+                    h_list.append(h)
                     h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
-                    continue
-                if self.norm_type != "none":
-                    h = self.norms[l](h)
-                h = self.activation(h)
-                h = self.dropout(h)
+            else:
+                with torch.no_grad():
+                    h = layer(block, (h, h_dst))
+                    if l != self.num_layers - 1:
+                        h_list.append(h)
+                        h = _eval_tail(self, l, h)
         return h_list, h
 
     def _tail(self, l):
@@ -173,8 +184,8 @@ class SAGE(nn.Module):
         of a layer in ONE launch over the resident CSR (each dst row is independent, so the result is identical
         to the chunked sweep); whole_graph=False walks the chunks exactly like the reference does
         (gather input rows -> block conv -> fused BN/ReLU -> scatter)."""
-        if not feats.is_cuda:
-            raise RuntimeError("SAGE.inference runs on the HIP path only (feats must be on the GPU)")
+        _need_hip(feats, "SAGE.inference")
+        whole_graph = whole_graph and getattr(dataloader, "graph", None) is not None     # loaders that do not sweep arange(N)
         with torch.no_grad():
             x = ops.as_feat(feats)
             for l, layer in enumerate(self.layers):
@@ -221,15 +232,19 @@ class GCN(nn.Module):
             self.norms.append(nn.LayerNorm(hidden_dim))
 
     def forward(self, g, feats):
+        """reference models.py:189-199: GraphConv (ReLU inside the conv on hidden layers) -> norm -> dropout."""
+        _need_hip(feats, "GCN.forward")
+        if self.norm_type != "none":
+            raise NotImplementedError("GCN with a norm layer: every GCN section of the reference's train.conf.yaml uses "
+                                      "norm_type 'none'; BatchNorm/LayerNorm after a GraphConv has no HIP path")
         h = feats
         h_list = []
         for l, layer in enumerate(self.layers):
             h = layer(g, h)
             if l != self.num_layers - 1:
                 h_list.append(h)
-                if self.norm_type != "none":
-                    h = self.norms[l](h)
-                h = self.dropout(h)
+                if self.training and self.dropout.p > 0:
+                    h = norm_act_drop(h, None, self.dropout.p)        # h >= 0 already: relu is the identity here
         return h_list, h
 
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .autograd import SpmmFn, linear_fn
+from .autograd import GraphConvFn, SpmmFn, graphconv_fwd, linear_fn
 
 
 FUSED_SAGE_MAX_IN = int(os.environ.get("GLNN_FUSED_SAGE_MAX_IN", "256"))   # aggregate-first layers with d_in, d_out <= 256 take the single-launch K1F kernel.  Interleaved
@@ -78,28 +78,13 @@ class GraphConv(nn.Module):
             nn.init.zeros_(self.bias)
 
     def forward(self, graph, feat):
-        if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+        if not self._allow_zero_in_degree and graph.has_zero_in_degree():
             raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid "
                                "(dgl GraphConv semantics; add self-loops or set allow_zero_in_degree).")
-        rs, cs = graph.degree_norms()          # in_deg.clamp(1)^-1/2 (dst), out_deg.clamp(1)^-1/2 (src)
         act = self._activation
         relu = act is not None and getattr(act, "__name__", "") == "relu"
         if act is not None and not relu:
             raise NotImplementedError("GraphConv: only activation=F.relu or None is used by the reference")
-        n = graph.num_dst_nodes()
-        needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
-        if needs_grad:
-            h = feat * cs.unsqueeze(1)
-            if self._in_feats > self._out_feats:
-                rst = SpmmFn.apply(graph, linear_fn(h, self.weight, None, w_is_kn=True), ops.AGG_SUM)
-            else:
-                rst = linear_fn(SpmmFn.apply(graph, h, ops.AGG_SUM), self.weight, None, w_is_kn=True)
-            rst = rst * rs.unsqueeze(1)
-            if self.bias is not None:
-                rst = rst + self.bias
-            return torch.relu(rst) if relu else rst
-        if self._in_feats > self._out_feats:
-            hw = ops.gemm(ops.as_feat(feat), self.weight, w_is_kn=True, row_scale=cs)
-            return ops.spmm(graph.indptr, graph.indices, hw, n, ops.AGG_SUM, row_scale=rs, ep_shift=self.bias, relu=relu)
-        agg = ops.spmm(graph.indptr, graph.indices, feat, n, ops.AGG_SUM, col_scale=cs)
-        return ops.gemm(agg, self.weight, w_is_kn=True, row_scale=rs, ep_shift=self.bias, relu=relu)
+        if torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad):
+            return GraphConvFn.apply(graph, feat, self.weight, self.bias, relu)
+        return graphconv_fwd(graph, ops.as_feat(feat), self.weight, self.bias, relu)[0]

@@ -95,14 +95,17 @@ def as_feat(t):
 
 # ---------------------------------------------------------------------------------------------
 def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None,
-         relu=False, out=None, x_self=None):
+         relu=False, out=None, x_self=None, self_rows=None):
     """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d].
-    x_self (SAGE_GCN only): the destination rows' own features, default x[:n_dst] (a row shard passes its slice)."""
-    _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out, x_self)
+    x_self (SAGE_GCN only): the destination rows' own features, default x[:n_dst] (a row shard passes its slice).
+    self_rows (SAGE_GCN only, int64 [n_dst]): destination v's own row is x_self[self_rows[v]] (global-id blocks)."""
+    _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out, x_self, self_rows)
     x = as_feat(x)
+    if self_rows is not None and (self_rows.dtype != torch.int64 or not self_rows.is_contiguous() or self_rows.numel() < n_dst):
+        raise ValueError("spmm: self_rows must be a contiguous int64 vector of n_dst row ids")
     if x_self is None:
         x_self = x
-    elif x_self.shape[0] < n_dst or x_self.shape[1] != x.shape[1]:
+    elif (self_rows is None and x_self.shape[0] < n_dst) or x_self.shape[1] != x.shape[1]:
         raise ValueError("spmm: x_self must hold n_dst rows of the same width as x")
     n_src, d = x.shape
     if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
@@ -112,16 +115,17 @@ def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_sca
     _mat(out, "spmm out")
     with _Timed("spmm", d=d, n_dst=n_dst, mode=mode):
         rc = _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out,
-                        as_feat(x_self))
+                        as_feat(x_self), self_rows)
     _lib.check(rc, "glnn_spmm_csr_f32")
     return out
 
 
-def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self):
+def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self,
+               self_rows=None):
     return _lib.lib().glnn_spmm_csr_f32(
         _p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
         _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
-        _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self),
+        _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self), _p(self_rows),
         _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
         _p(out), _ld(out), _stream())
 
@@ -158,11 +162,15 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
     return out
 
 
-def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True):
+DEG_RAW, DEG_RSQRT_CLAMP1, DEG_INV_PLUS1 = 0, 1, 2
+
+
+def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True, transform=DEG_RAW, want_in=True):
+    """glnn_degrees_f32: (t(in_deg) [n_dst], t(out_deg) [n_src]) as fp32; transform: DEG_RAW | DEG_RSQRT_CLAMP1 | DEG_INV_PLUS1."""
     _need_cuda(indptr, indices)
-    in_deg = torch.empty(n_dst, dtype=torch.float32, device=indptr.device)
+    in_deg = torch.empty(n_dst, dtype=torch.float32, device=indptr.device) if want_in else None
     out_deg = torch.empty(n_src, dtype=torch.float32, device=indptr.device) if want_out else None
-    rc = _lib.lib().glnn_degrees_f32(_p(indptr), _p(indices), n_dst, n_src, nnz, _p(in_deg), _p(out_deg), _stream())
+    rc = _lib.lib().glnn_degrees_f32(_p(indptr), _p(indices), n_dst, n_src, nnz, transform, _p(in_deg), _p(out_deg), _stream())
     _lib.check(rc, "glnn_degrees_f32")
     return in_deg, out_deg
 
@@ -298,6 +306,19 @@ def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=N
     return dz, dgamma, dbeta
 
 
+def col_sum(x, out=None):
+    """glnn_col_sum_f32: column sums of a [rows, h] matrix (a bias gradient)."""
+    _need_cuda(x, out)
+    _mat(x, "col_sum x")
+    rows, h = x.shape
+    if out is None:
+        out = torch.empty(h, dtype=torch.float32, device=x.device)
+    ws = torch.empty(((rows + 127) // 128) * h, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().glnn_col_sum_f32(_p(x), _ld(x), rows, h, _p(out), _p(ws), ws.numel(), _stream())
+    _lib.check(rc, "glnn_col_sum_f32")
+    return out
+
+
 class TensorTable:
     """Device-side pointer table for the multi-tensor Adam (built once per optimiser)."""
 
@@ -351,6 +372,63 @@ def sample_neighbors(indptr, indices, seeds, fanout, rng_seed):
                                           _p(src), _p(cnt), _stream())
     _lib.check(rc, "glnn_sample_neighbors")
     return src, cnt
+
+
+def _i32(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)[:int(n)]
+
+
+def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_cnt=None, nnz_cap=None, want_global=False):
+    """glnn_block_build: one 1-hop block over the destination nodes `seeds` (int64 device vector).
+    Sampled mode: smp_src [ns, fanout] / smp_cnt [ns] from sample_neighbors.  Full-neighbour mode: the graph CSR and
+    nnz_cap (an upper bound of the block's edge count).  Returns (indptr [ns+1], indices [nnz] local ids,
+    gindices [nnz] global ids or None, input_nodes [n_src], nnz, n_src); ONE host read-back (the two counts)."""
+    _need_cuda(seeds, graph_indptr, graph_indices, smp_src, smp_cnt)
+    dev = seeds.device
+    if seeds.dtype != torch.int64 or not seeds.is_contiguous():
+        raise ValueError("block_build: seeds must be a contiguous int64 vector")
+    ns = seeds.numel()
+    if smp_src is not None:
+        fanout = smp_src.shape[1]
+        if smp_src.dtype != torch.int32 or smp_cnt.dtype != torch.int32 or smp_src.shape[0] != ns or not smp_src.is_contiguous():
+            raise ValueError("block_build: smp_src [ns, fanout] / smp_cnt [ns] must be contiguous int32")
+        nnz_cap = ns * fanout
+    else:
+        fanout = 0
+        if graph_indptr is None or graph_indices is None or nnz_cap is None:
+            raise ValueError("block_build: full-neighbour mode needs the graph CSR and nnz_cap")
+    nnz_cap = int(nnz_cap)
+    indptr = torch.empty(ns + 1, dtype=torch.int64, device=dev)
+    indices = _i32(nnz_cap, dev)
+    gindices = _i32(nnz_cap, dev) if want_global else None
+    input_nodes = torch.empty(ns + nnz_cap, dtype=torch.int64, device=dev)
+    counts = torch.empty(2, dtype=torch.int64, device=dev)
+    wsb = int(_lib.lib().glnn_block_workspace_bytes(ns, nnz_cap))
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
+    rc = _lib.lib().glnn_block_build(_p(graph_indptr) if smp_src is None else None, _p(graph_indices) if smp_src is None else None,
+                                     _p(seeds), ns, _p(smp_src), _p(smp_cnt), fanout, nnz_cap, _p(indptr), _p(indices), _p(gindices),
+                                     _p(input_nodes), _p(counts), _p(ws), ws.numel() * 8, _stream())
+    _lib.check(rc, "glnn_block_build")
+    nnz, n_src = (int(v) for v in counts.tolist())          # the only host sync of the block
+    if nnz > nnz_cap:
+        raise _lib.GlnnError(f"block_build: the block has {nnz} edges, more than nnz_cap = {nnz_cap}")
+    return indptr, indices[:nnz], (gindices[:nnz] if want_global else None), input_nodes[:n_src], nnz, n_src
+
+
+def csr_transpose(indptr, indices, n_dst, n_src, nnz, add_self=False):
+    """glnn_csr_transpose: (t_indptr [n_src+1], t_indices [nnz (+ n_dst)]) of the CSR-by-destination graph; rows sorted.
+    add_self: one extra entry u <- u per destination u (the h_dst term of the SAGE-gcn aggregator's backward)."""
+    _need_cuda(indptr, indices)
+    dev = indptr.device
+    nnz_out = int(nnz) + (int(n_dst) if add_self else 0)
+    t_indptr = torch.empty(n_src + 1, dtype=torch.int64, device=dev)
+    t_indices = _i32(nnz_out, dev)
+    wsb = int(_lib.lib().glnn_csr_transpose_workspace_bytes(n_src, nnz_out))
+    ws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
+    rc = _lib.lib().glnn_csr_transpose(_p(indptr), _p(indices) if nnz else None, n_dst, n_src, int(nnz), 1 if add_self else 0,
+                                       _p(t_indptr), _p(t_indices) if nnz_out else None, _p(ws), ws.numel() * 8, _stream())
+    _lib.check(rc, "glnn_csr_transpose")
+    return t_indptr, t_indices
 
 
 def gather_rows(x, rows, out=None):

@@ -249,3 +249,30 @@ def criterion_kind(criterion):
     if isinstance(criterion, nn.KLDivLoss) and criterion.reduction == "batchmean" and criterion.log_target:
         return ops.LOSS_KL
     return None
+
+
+def student_supported(model, criterion, optimizer, feats=None, labels=None):
+    """The ONE eligibility check of the fused student path (train_mini_batch and StudentEngine agree by construction):
+    returns the loss kind, raises NotImplementedError / RuntimeError with the reason otherwise."""
+    kind = criterion_kind(criterion)
+    if kind is None:
+        raise NotImplementedError("student step: the criterion must be nn.NLLLoss() or nn.KLDivLoss(reduction='batchmean', "
+                                  "log_target=True) (reference train_student.py:278-279)")
+    enc = model.encoder
+    if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch"):
+        raise NotImplementedError("student step: MLP students with norm_type none|batch (the hot-path configs)")
+    if enc.num_layers > _lib.MLP_MAX_LAYERS:
+        raise NotImplementedError(f"student step: at most {_lib.MLP_MAX_LAYERS} layers")
+    grp = optimizer.param_groups
+    if type(optimizer) is not torch.optim.Adam or len(grp) != 1 or grp[0].get("amsgrad") or grp[0].get("maximize"):
+        raise NotImplementedError("student step: torch.optim.Adam with one param group, no amsgrad/maximize (train_student.py:275-277)")
+    for bn in enc.norms:
+        if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+            raise NotImplementedError("student step: BatchNorm1d with the reference's defaults")
+    if next(model.parameters()).device.type != "cuda":
+        raise RuntimeError("student step: the model must be on the GPU (HIP path only; pass --device 0, the reference's default "
+                           "--device -1 selects the CPU)")
+    for t, name in ((feats, "feats"), (labels, "labels")):
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"student step: {name} must be on the GPU (HIP path only)")
+    return kind

@@ -1,0 +1,242 @@
+"""Teacher TRAINING step on libglnn_hip.so: forward + NLL + backward + Adam as an explicit launch sequence.
+
+One `TeacherEngine.step_sage()` is the loop body of the reference's `train_sage` (reference train_and_eval.py:39-54)
+
+    blocks = [blk.int().to(device) ...]; batch_feats = feats[input_nodes]; logits = model(blocks, batch_feats)
+    out = logits.log_softmax(1); loss = criterion(out, labels[output_nodes]); total += loss.item()
+    loss *= lamb; optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+and one `step_gcn()` is the reference's full-graph `train` (train_and_eval.py:12-29), with NO autograd graph and NO host
+synchronisation:
+
+  SAGE layer l   agg_l = (A_l h_l + h_l[:n_dst]) / (deg+1)          glnn_spmm_csr_f32 (SAGE_GCN); for the OUTERMOST block the
+                                                                    gather goes straight into `feats` through the block's
+                                                                    global source ids (feats[input_nodes] is never built)
+                 z_l = agg_l W_l^T + b_l                            glnn_gemm_f32
+                 h_{l+1} = dropout(relu(BN_train(z_l)))             glnn_bn_stats_f32 + glnn_act_fwd_f32
+  loss           log_softmax + NLL, d(lamb*loss)/dlogits            glnn_softmax_loss_f32 (labels indexed by output_nodes)
+  backward       dW_l = dz_l^T agg_l (+ db_l)                       glnn_gemm_tn_f32
+                 dagg_l = dz_l W_l                                  glnn_gemm_f32
+                 dh_l = (A_l^T + I_dst) (dagg_l / (deg+1))          glnn_spmm_csr_f32 over glnn_csr_transpose(add_self)
+                 dz_{l-1} = BN / ReLU / dropout backward            glnn_bn_relu_bwd_f32 (also yields db_{l-1}, dgamma, dbeta)
+  update         one fused multi-tensor Adam launch                 glnn_adam_step_f32
+
+  GCN layer      GraphConv(norm='both'): weight first iff in > out (dgl), D_out^-1/2 / D_in^-1/2 folded into the GEMM row
+                 scale and the aggregation's row / column scales, bias + ReLU in the epilogue; backward over the transposed
+                 graph with the two scales swapped.
+
+The engine works IN PLACE on the Model's parameters / BatchNorm buffers and on the torch optimizer's state tensors, exactly
+like glnn_amd.student.StudentEngine, so state_dict(), early-stopping snapshots and optimizer.state_dict() keep working."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .autograd import graphconv_bwd, graphconv_fwd
+from .student import _mix32
+
+
+def _is_relu(act):
+    return act is F.relu or getattr(act, "__name__", "") == "relu"
+
+
+def check_supported(model, criterion, optimizer):
+    """Raise unless (model, criterion, optimizer) is what train_teacher.py:232-238 builds for a SAGE / GCN teacher."""
+    enc = model.encoder
+    name = model.model_name
+    if "MLP" in name or not ("SAGE" in name or "GCN" in name):
+        raise NotImplementedError(f"TeacherEngine: SAGE or GCN teachers only (got {name})")
+    if not (isinstance(criterion, nn.NLLLoss) and criterion.reduction == "mean" and criterion.weight is None
+            and criterion.ignore_index == -100):
+        raise NotImplementedError("TeacherEngine: the criterion must be nn.NLLLoss() (reference train_teacher.py:237)")
+    grp = optimizer.param_groups
+    if type(optimizer) is not torch.optim.Adam or len(grp) != 1 or grp[0].get("amsgrad") or grp[0].get("maximize"):
+        raise NotImplementedError("TeacherEngine: torch.optim.Adam, one param group, no amsgrad/maximize (train_teacher.py:234-236)")
+    if "SAGE" in name:
+        if enc.norm_type not in ("none", "batch") or not _is_relu(enc.activation):
+            raise NotImplementedError("TeacherEngine: SAGE with norm_type none|batch and ReLU (the reference's configs)")
+    else:
+        if enc.norm_type != "none":
+            raise NotImplementedError("TeacherEngine: GCN with norm_type 'none' (every GCN section of train.conf.yaml)")
+        for lay in enc.layers[:-1]:
+            if not _is_relu(lay._activation):
+                raise NotImplementedError("TeacherEngine: GraphConv(activation=F.relu) on hidden layers (models.py:170-187)")
+    for bn in enc.norms:
+        if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+            raise NotImplementedError("TeacherEngine: BatchNorm1d with the reference's defaults")
+    if next(model.parameters()).device.type != "cuda":
+        raise RuntimeError("TeacherEngine needs the model on the GPU (HIP path only; the reference's --device -1 default "
+                           "selects the CPU: pass --device 0)")
+
+
+class TeacherEngine:
+    def __init__(self, model, optimizer):
+        self.model, self.enc, self.opt = model, model.encoder, optimizer
+        self.kind = "sage" if "SAGE" in model.model_name else "gcn"
+        self.L = self.enc.num_layers
+        self.bn = self.enc.norm_type == "batch"
+        self.p = float(self.enc.dropout.p)
+        params = list(model.parameters())
+        self.params = params
+        dev = params[0].device
+        self.dev = dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+        self.flat_grads = torch.zeros(sum(sizes), **f32)
+        self.grads, off = [], 0
+        for p, sz in zip(params, sizes):
+            self.grads.append(self.flat_grads[off:off + p.numel()].view_as(p))
+            off += sz
+        for p, g in zip(params, self.grads):
+            p.grad = g
+        self._g = {id(p): g for p, g in zip(params, self.grads)}
+        exp_avg, exp_avg_sq = [], []
+        for p in params:
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p)
+                st["exp_avg_sq"] = torch.zeros_like(p)
+            exp_avg.append(st["exp_avg"])
+            exp_avg_sq.append(st["exp_avg_sq"])
+        self.step_count = int(optimizer.state[params[0]]["step"])
+        self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
+        self.loss_out = torch.zeros(1, **f32)
+        self.loss_accum = torch.zeros(1, **f32)
+        self.ws_loss = torch.empty(1024, **f32)
+        self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
+        self.grad_sync = None
+
+    # ------------------------------------------------------------------------------------------
+    def grad(self, p):
+        return self._g[id(p)]
+
+    def _seed(self, layer):
+        return _mix32(self.base_seed ^ _mix32(self.step_count * 131 + layer + 1)) if self.p > 0 else 0
+
+    def _adam(self):
+        g = self.opt.param_groups[0]
+        if self.grad_sync is not None:
+            self.grad_sync()
+        ops.adam_step(self.table, g["lr"], self.step_count, weight_decay=g["weight_decay"], beta1=g["betas"][0], beta2=g["betas"][1],
+                      eps=g["eps"])
+
+    def sync_optimizer_state(self):
+        for p in self.params:
+            self.opt.state[p]["step"] = torch.tensor(float(self.step_count))
+
+    def _tail_fwd(self, l, z):
+        """norms[l] -> relu -> dropout of hidden layer l (models.py:113-117), materialised for the next layer's gather."""
+        seed = self._seed(l)
+        if self.bn:
+            bn = self.enc.norms[l]
+            stats = ops.bn_stats(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, eps=bn.eps,
+                                 momentum=bn.momentum)
+        else:
+            stats = (None, None, None, None)
+        return ops.act_fwd(z, stats[2], stats[3], drop_p=self.p, drop_seed=seed), stats, seed
+
+    def _tail_bwd(self, l, dh, z, stats, seed, bias_grad):
+        """dz_l (in place on dh) + dgamma / dbeta + the bias gradient of the layer in front."""
+        mean, rstd, a_scale, a_shift = stats
+        if self.bn:
+            bn = self.enc.norms[l]
+            ops.bn_relu_bwd(dh, z, bn.weight, mean, rstd, a_scale, a_shift, dz=dh, dgamma=self.grad(bn.weight), dbeta=self.grad(bn.bias),
+                            drop_p=self.p, drop_seed=seed, dz_col_sum=bias_grad)
+        else:
+            ops.bn_relu_bwd(dh, z, dz=dh, drop_p=self.p, drop_seed=seed, dz_col_sum=bias_grad)
+        return dh
+
+    # ------------------------------------------------------------------------------------------ GraphSAGE on blocks
+    @torch.no_grad()
+    def step_sage(self, blocks, feats, labels, output_nodes, lamb=1.0, input_nodes=None):
+        """One optimisation step on a batch of sampled blocks (blocks[0] outermost).  `feats` is the GLOBAL feature matrix:
+        when blocks[0] carries global source ids (glnn_amd.graph.NodeDataLoader) its aggregation gathers from it directly,
+        otherwise feats[input_nodes] is gathered once (blocks that came from elsewhere)."""
+        enc, L = self.enc, self.L
+        ops._need_cuda(feats, labels, output_nodes, input_nodes)
+        if len(blocks) != L:
+            raise ValueError(f"TeacherEngine.step_sage: {len(blocks)} blocks for {L} layers")
+        x = ops.as_feat(feats)
+        self.step_count += 1
+        saved, h = [], None
+        for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):
+            w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+            n_dst = blk.num_dst_nodes()
+            if l == 0 and blk.gindices is not None:
+                agg = ops.spmm(blk.indptr, blk.gindices, x, n_dst, ops.AGG_SAGE_GCN, x_self=x, self_rows=blk.dst_nodes)
+            else:
+                if l == 0:
+                    if input_nodes is None:
+                        raise ValueError("TeacherEngine.step_sage: blocks without global ids need input_nodes")
+                    h = ops.gather_rows(x, input_nodes)
+                if h.shape[0] != blk.num_src_nodes():
+                    raise ValueError(f"TeacherEngine.step_sage: layer {l} got {h.shape[0]} rows for a block with {blk.num_src_nodes()} sources")
+                agg = ops.spmm(blk.indptr, blk.indices, h, n_dst, ops.AGG_SAGE_GCN)
+            z = ops.gemm(agg, w, ep_shift=b)
+            if l != L - 1:
+                h, stats, seed = self._tail_fwd(l, z)
+                saved.append((agg, z, stats, seed))
+            else:
+                saved.append((agg, z, None, 0))
+        logits = saved[-1][1]
+        _, dz = ops.softmax_loss(logits, ops.LOSS_NLL, float(lamb), labels=labels, label_rows=output_nodes, loss_out=self.loss_out,
+                                 loss_accum=self.loss_accum, workspace=self.ws_loss)
+        for l in range(L - 1, -1, -1):
+            layer, blk = enc.layers[l], blocks[l]
+            w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+            agg = saved[l][0]
+            # hidden layers get their bias gradient from the activation backward (column sums of dz) below
+            ops.gemm_tn(dz, agg, out=self.grad(w), col_sum_a=self.grad(b) if l == L - 1 else None)
+            if l == 0:
+                break
+            dagg = ops.gemm(dz, w, w_is_kn=True)
+            t = blk.transposed(add_self=True)
+            dh = ops.spmm(t.indptr, t.indices, dagg, blk.num_src_nodes(), ops.AGG_SUM, col_scale=blk.inv_deg_plus1())
+            _, z_prev, stats, seed = saved[l - 1]
+            dz = self._tail_bwd(l - 1, dh, z_prev, stats, seed, self.grad(enc.layers[l - 1].fc_neigh.bias))
+        self._adam()
+
+    # ------------------------------------------------------------------------------------------ full-graph GCN
+    @torch.no_grad()
+    def step_gcn(self, g, feats, labels, idx_train, lamb=1.0):
+        enc, L, p = self.enc, self.L, self.p
+        ops._need_cuda(feats, labels, idx_train, g.indptr)
+        if g.has_zero_in_degree() and not all(lay._allow_zero_in_degree for lay in enc.layers):
+            raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid "
+                               "(dgl GraphConv semantics; add self-loops or set allow_zero_in_degree).")
+        n = g.num_dst_nodes()
+        self.step_count += 1
+        a = ops.as_feat(feats)
+        saved = []
+        for l, layer in enumerate(enc.layers):
+            last = l == L - 1
+            y, mid, first = graphconv_fwd(g, a, layer.weight, layer.bias, relu=not last)
+            seed = self._seed(l)
+            saved.append((mid, first, y, seed))
+            if not last:
+                a = ops.act_fwd(y, drop_p=p, drop_seed=seed) if p > 0 else y       # y >= 0 already (ReLU inside the conv)
+        logits = saved[-1][2]
+        logits_tr = ops.gather_rows(logits, idx_train)                            # out[idx_train] (train_and_eval.py:22)
+        _, dl = ops.softmax_loss(logits_tr, ops.LOSS_NLL, float(lamb), labels=labels, label_rows=idx_train, loss_out=self.loss_out,
+                                 loss_accum=self.loss_accum, workspace=self.ws_loss)
+        dz = ops.feat_empty(n, logits.shape[1], self.dev, zero=True)
+        ops.scatter_rows(dl, idx_train, dz)
+        ops.col_sum(dz, out=self.grad(enc.layers[-1].bias))
+        for l in range(L - 1, -1, -1):
+            layer = enc.layers[l]
+            mid, first, _, _ = saved[l]
+            da = graphconv_bwd(g, dz, mid, first, layer.weight, self.grad(layer.weight), want_da=l > 0)
+            if l == 0:
+                break
+            _, _, y_prev, seed_prev = saved[l - 1]        # dropout backward, then the ReLU inside conv l-1 (y > 0 <=> z > 0)
+            dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, drop_p=p, drop_seed=seed_prev, dz_col_sum=self.grad(enc.layers[l - 1].bias))
+        self._adam()
+
+
+def get_engine(model, optimizer):
+    eng = getattr(model, "_glnn_teacher_engine", None)
+    if eng is None or eng.opt is not optimizer or any(a is not b for a, b in zip(eng.params, model.parameters())):
+        eng = TeacherEngine(model, optimizer)
+        object.__setattr__(model, "_glnn_teacher_engine", eng)
+    return eng

@@ -2,13 +2,15 @@
 names, arguments and return values, re-pointed at the HIP hot path.
 
   * train_mini_batch / evaluate_mini_batch (the student's loops, :59-86 / :108-136) run on the fused
-    StudentEngine when the (model, criterion, optimizer) triple is what train_student.py:274-279 builds;
-    anything else takes the generic autograd loop (still HIP kernels through glnn_amd.autograd).
+    StudentEngine; the (model, criterion, optimizer) triple must be what train_student.py:274-279 builds --
+    anything else raises (one shared eligibility check: glnn_amd.student.student_supported).
   * evaluate (:89-105) calls Model.inference -> SAGE.inference on the aggregation kernel.
   * The per-step `loss.item()` host sync of the reference (:80) is replaced by a device-side running sum
     read ONCE per pass; the returned mean of per-batch losses is the same number.
-  * Teacher TRAINING (`train_sage` on fan-out-sampled blocks from glnn_amd.graph.NodeDataLoader, `train` for
-    full-graph GCN) goes through the autograd shims: aggregation and projections run on HIP in both directions."""
+  * Teacher TRAINING (`train_sage` on fan-out-sampled blocks from glnn_amd.graph.NodeDataLoader, `train` for the
+    full-graph GCN) runs on glnn_amd.teacher.TeacherEngine: blocks built on the device, forward, loss, backward over the
+    transposed blocks and Adam as one launch sequence without autograd or host syncs.
+  There is no eager / CPU path in this module: inputs that are not on the GPU raise."""
 import copy
 
 import numpy as np
@@ -16,7 +18,8 @@ import torch
 
 from . import ops
 from .graph import FullNeighborLoader, MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
-from .student import criterion_kind, get_engine
+from . import teacher
+from .student import get_engine, student_supported
 from .utils import set_seed
 
 
@@ -24,38 +27,36 @@ EVAL_BLOCK_ROWS = 1 << 19
 
 
 def train(model, data, feats, labels, criterion, optimizer, idx_train, lamb=1):
-    """GNN full-batch training step (reference train_and_eval.py:12-29)."""
+    """GNN full-batch training step (reference train_and_eval.py:12-29; `data` is the whole graph): one
+    TeacherEngine.step_gcn -- forward, NLL over idx_train, backward over the transposed graph, Adam -- on libglnn_hip.so.
+    Returns the unscaled loss like the reference's `loss.item()`."""
+    teacher.check_supported(model, criterion, optimizer)
+    if "GCN" not in model.model_name:
+        raise NotImplementedError("train(): the full-graph step is implemented for the GCN teacher (SAGE trains with train_sage)")
     model.train()
-    logits = model(data, feats)
-    out = logits.log_softmax(dim=1)
-    loss = criterion(out[idx_train], labels[idx_train])
-    loss_val = loss.item()
-    loss *= lamb
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
-    return loss_val
+    eng = teacher.get_engine(model, optimizer)
+    eng.step_gcn(data, feats, labels, idx_train, float(lamb))
+    eng.sync_optimizer_state()
+    return eng.loss_out.item()
 
 
 def train_sage(model, dataloader, feats, labels, criterion, optimizer, lamb=1):
-    """Sampled-block SAGE training (reference train_and_eval.py:32-56); `dataloader` yields
-    (input_nodes, output_nodes, blocks) with glnn_amd CSR blocks."""
-    device = feats.device
+    """Sampled-block GraphSAGE training (reference train_and_eval.py:32-56): one TeacherEngine.step_sage per batch of
+    `dataloader` (glnn_amd.graph.NodeDataLoader: blocks sampled and relabelled on the device; the outermost block gathers
+    straight from `feats`, so `feats[input_nodes]` is never materialised).  The per-step `loss.item()` of the reference
+    (:49) is a device-side running sum read ONCE per epoch; the returned mean of the per-batch losses is the same number."""
+    teacher.check_supported(model, criterion, optimizer)
+    if "SAGE" not in model.model_name:
+        raise NotImplementedError("train_sage(): GraphSAGE teachers only")
     model.train()
-    total_loss = 0
-    for step, (input_nodes, output_nodes, blocks) in enumerate(dataloader):
-        blocks = [blk.int().to(device) for blk in blocks]
-        batch_feats = feats[input_nodes]
-        batch_labels = labels[output_nodes]
-        logits = model(blocks, batch_feats)
-        out = logits.log_softmax(dim=1)
-        loss = criterion(out, batch_labels)
-        total_loss += loss.item()
-        loss *= lamb
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
-    return total_loss / len(dataloader)
+    eng = teacher.get_engine(model, optimizer)
+    eng.loss_accum.zero_()
+    steps = 0
+    for input_nodes, output_nodes, blocks in dataloader:
+        eng.step_sage(blocks, feats, labels, output_nodes, float(lamb), input_nodes=input_nodes)
+        steps += 1
+    eng.sync_optimizer_state()
+    return eng.loss_accum.item() / max(steps, 1)
 
 
 def _batch_indices(n, batch_size):
@@ -67,26 +68,13 @@ def _batch_indices(n, batch_size):
 
 
 def train_mini_batch(model, feats, labels, batch_size, criterion, optimizer, lamb=1):
-    """One pass of the MLP over `feats` in random mini-batches (reference train_and_eval.py:59-86).
-    `labels` is int64 [N] with NLLLoss or fp32 teacher log-probs [N, C] with KLDivLoss(log_target)."""
+    """One pass of the MLP over `feats` in random mini-batches (reference train_and_eval.py:59-86) on the fused
+    StudentEngine.  `labels` is int64 [N] with NLLLoss or fp32 teacher log-probs [N, C] with KLDivLoss(log_target).
+    Anything other than the (MLP, NLLLoss | KLDivLoss(batchmean, log_target), Adam) triple train_student.py:274-279
+    builds raises: there is no generic / eager loop behind this function."""
+    kind = student_supported(model, criterion, optimizer, feats, labels)
     model.train()
     num_batches, idx_batch = _batch_indices(feats.shape[0], batch_size)
-    kind = criterion_kind(criterion)
-    fused = kind is not None and feats.is_cuda and "MLP" in model.model_name and type(optimizer) is torch.optim.Adam \
-        and model.encoder.norm_type in ("none", "batch")
-    if not fused:
-        total_loss = 0
-        for i in range(num_batches):
-            idx = idx_batch[i].to(feats.device)
-            logits = model(None, feats[idx])
-            out = logits.log_softmax(dim=1)
-            loss = criterion(out, labels[idx])
-            total_loss += loss.item()
-            loss *= lamb
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-        return total_loss / num_batches
     eng = get_engine(model, optimizer, idx_batch.shape[1])
     x = ops.as_feat(feats)
     target = labels if kind == ops.LOSS_NLL else ops.as_feat(labels)
@@ -103,7 +91,7 @@ def evaluate(model, data, feats, labels, criterion, evaluator, idx_eval=None):
     model.eval()
     with torch.no_grad():
         logits = model.inference(data, feats)
-        out = ops.log_softmax(logits) if logits.is_cuda else logits.log_softmax(dim=1)
+        out = ops.log_softmax(logits)
         if idx_eval is None:
             loss = criterion(out, labels)
             score = evaluator(out, labels)
@@ -114,21 +102,16 @@ def evaluate(model, data, feats, labels, criterion, evaluator, idx_eval=None):
 
 
 def evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, idx_eval=None):
-    """reference train_and_eval.py:108-136.  Eval-mode rows are independent, so on the GPU the whole
-    matrix goes through ONE chain of GEMMs instead of ceil(N/B) chunks; the output is the same [N, C]."""
+    """reference train_and_eval.py:108-136.  Eval-mode rows are independent, so the matrix goes through ONE chain of GEMMs
+    per big row block instead of ceil(N/B) mini-batches; the output is the same [N, C]."""
+    ops._need_cuda(feats)
     model.eval()
     with torch.no_grad():
-        if feats.is_cuda:
-            # big row blocks instead of ceil(N/B) mini-batches (same values), bounded so that a wide student over
-            # millions of rows does not materialise tens of GB of hidden activations at once
-            blk = max(int(batch_size), EVAL_BLOCK_ROWS)
-            out_all = torch.empty((feats.shape[0], model.encoder.layers[-1].out_features), dtype=torch.float32, device=feats.device)
-            for s0 in range(0, feats.shape[0], blk):
-                ops.log_softmax(model.inference(None, feats[s0:s0 + blk]), out=out_all[s0:s0 + blk])
-        else:
-            num_batches = int(np.ceil(len(feats) / batch_size))
-            out_all = torch.cat([model.inference(None, feats[batch_size * i: batch_size * (i + 1)]).log_softmax(dim=1)
-                                 for i in range(num_batches)])
+        # row blocks bounded so that a wide student over millions of rows does not materialise tens of GB of activations
+        blk = max(int(batch_size), EVAL_BLOCK_ROWS)
+        out_all = torch.empty((feats.shape[0], model.encoder.layers[-1].out_features), dtype=torch.float32, device=feats.device)
+        for s0 in range(0, feats.shape[0], blk):
+            ops.log_softmax(model.inference(None, feats[s0:s0 + blk]), out=out_all[s0:s0 + blk])
         if idx_eval is None:
             loss = criterion(out_all, labels)
             score = evaluator(out_all, labels)

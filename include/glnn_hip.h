@@ -55,7 +55,10 @@ GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int
  * mode GLNN_AGG_SAGE_GCN  out[v,:] = (sum_{u->v} x[u,:] + x_self[v,:]) / (in_deg(v) + 1)
  *        replaces the "gcn" aggregator of dgl SAGEConv, reference models.py:112,138
  *        (ctor :84-99); x_self is h_dst = the first n_dst rows of the block's source features
- *        (models.py:109,137), normally x_self == x.
+ *        (models.py:109,137), normally x_self == x.  self_rows (optional, SAGE_GCN only): the self row of
+ *        destination v is x_self[self_rows[v]] -- with `indices` holding GLOBAL node ids and x = x_self = the whole
+ *        feature matrix this folds `batch_feats = feats[input_nodes]` (train_and_eval.py:42) into the first layer's
+ *        gather: the outermost block of a training batch is aggregated straight out of `feats`.
  * Epilogue (both modes), per output element, in this order, each optional:
  *        y = y * ep_scale[j] + ep_shift[j] ;  y = max(y, 0) if relu
  *   (bias, eval-mode BatchNorm and ReLU of models.py:139-143 when the dense projection was
@@ -69,9 +72,9 @@ GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int
 GLNN_API int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
                                int64_t n_src, const float* x, int64_t ldx, int d, int mode,
                                const float* row_scale, const float* col_scale,
-                               const float* x_self, int64_t ld_self, const float* ep_scale,
-                               const float* ep_shift, int relu, float* out, int64_t ldo,
-                               void* stream);
+                               const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                               const float* ep_scale, const float* ep_shift, int relu, float* out,
+                               int64_t ldo, void* stream);
 
 /* K1F  Fused SAGE-"gcn" layer for aggregate-first layers (d_in, d_out <= 256):
  *   out[v,:] = epi( ((sum_{u->v} x[u,:] + x_self[v,:]) / (in_deg(v)+1)) @ W^T ),  epi = *ep_scale +ep_shift, ReLU
@@ -87,12 +90,17 @@ GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, 
                                  int d_out, const float* ep_scale, const float* ep_shift, int relu,
                                  float* out, int64_t ldo, void* stream);
 
-/* in_deg[v] = indptr[v+1]-indptr[v] (as float); out_deg[u] = #edges with source u.
- * replaces g.in_degrees()/g.out_degrees() used by GraphConv and utils.py:178.  Either may be NULL.
- * nnz = indptr[n_dst] (host value).  out_deg need not be zeroed by the caller. */
+/* in_deg[v] = t(indptr[v+1]-indptr[v]); out_deg[u] = t(#edges with source u), as floats, t = `transform`:
+ *   GLNN_DEG_RAW          the degree itself            g.in_degrees() / g.out_degrees()
+ *   GLNN_DEG_RSQRT_CLAMP1 deg.clamp(min=1) ** -0.5     the norm of dgl GraphConv(norm="both") and utils.py:178-179
+ *   GLNN_DEG_INV_PLUS1    1 / (deg + 1)                the divisor of the SAGE-"gcn" aggregator (its backward's col_scale)
+ * Either output may be NULL.  nnz = indptr[n_dst] (host value).  out_deg need not be zeroed by the caller. */
+#define GLNN_DEG_RAW 0
+#define GLNN_DEG_RSQRT_CLAMP1 1
+#define GLNN_DEG_INV_PLUS1 2
 GLNN_API int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
-                              int64_t n_src, int64_t nnz, float* in_deg, float* out_deg,
-                              void* stream);
+                              int64_t n_src, int64_t nnz, int transform, float* in_deg,
+                              float* out_deg, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3  Dense projection on the fp32 MFMA path (v_mfma_f32_32x32x2_f32, exact fp32).
@@ -187,6 +195,12 @@ GLNN_API int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z,
                                   float* dz, int64_t lddz, float* dgamma, float* dbeta,
                                   float* dz_col_sum,
                                   float* workspace, int64_t workspace_floats, void* stream);
+
+/* out[j] = sum over rows of x[:, j] (fixed summation order): the bias gradient of a layer whose dz does not come out of
+ * glnn_bn_relu_bwd_f32 (last GraphConv of the full-graph GCN step, reference train_and_eval.py:12-29).
+ * workspace >= ceil(rows/128) * h floats. */
+GLNN_API int glnn_col_sum_f32(const float* x, int64_t ldx, int64_t rows, int h, float* out,
+                              float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K6  Fused multi-tensor Adam, torch.optim.Adam semantics (L2 weight decay folded into the
@@ -308,6 +322,39 @@ GLNN_API int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t dr
 GLNN_API int glnn_sample_neighbors(const int64_t* indptr, const int32_t* indices, const int64_t* seeds,
                                    int64_t n_seeds, int fanout, uint32_t rng_seed, int32_t* out_src,
                                    int32_t* out_cnt, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Block construction for mini-batch teacher training / chunked inference: what dgl.dataloading.NodeDataLoader does on
+ * the CPU per batch in the reference (train_and_eval.py:176-205; blocks consumed at :41 and models.py:109,134-137),
+ * here on the device and sized by the batch's FRONTIER (hash table + two single-pass scans), never by N.
+ *   seeds [ns]        the block's destination nodes (global ids)
+ *   sampled mode      smp_src [ns, fanout] / smp_cnt [ns] from glnn_sample_neighbors, nnz_cap >= ns * fanout
+ *   full mode         smp_src = smp_cnt = NULL: every in-edge of every seed from (g_indptr, g_indices);
+ *                     nnz_cap >= the block's edge count (the caller's bound; counts[0] reports the true number)
+ * Outputs (caller-owned): indptr [ns+1]; indices [nnz_cap] LOCAL source ids (block CSR over its destinations, edges in
+ * the order of smp_src / of the graph's rows); gindices [nnz_cap] the same edges' GLOBAL source ids (optional);
+ * input_nodes [ns + nnz_cap]: the block's source nodes = its destinations first (models.py:109), then every other
+ * source in order of first appearance; counts (device int64[2]) = {nnz, number of source nodes}.
+ * workspace: glnn_block_workspace_bytes(ns, nnz_cap) bytes, 8-byte aligned.  Node ids must be < 0x7F7F7F7F. */
+GLNN_API int64_t glnn_block_workspace_bytes(int64_t ns, int64_t nnz_cap);
+GLNN_API int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds,
+                              int64_t ns, const int32_t* smp_src, const int32_t* smp_cnt, int fanout,
+                              int64_t nnz_cap, int64_t* indptr, int32_t* indices, int32_t* gindices,
+                              int64_t* input_nodes, int64_t* counts, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
+/* Transposed CSR (rows = the original SOURCE nodes, entries = destinations, sorted within a row): the graph
+ * loss.backward() walks through dgl's SpMM in the reference (train_and_eval.py:27,54) -- A^T dY is then the same
+ * glnn_spmm_csr_f32 gather on the result, deterministic, no float atomics:
+ *     d/dx of SUM(row_scale, col_scale)  =  SUM over the transposed CSR with row_scale <-> col_scale swapped;
+ *     d/dx of SAGE_GCN                   =  SUM over the transposed CSR built with add_self != 0 (one extra entry u <- u
+ *                                           for every destination u < n_dst: the h_dst term) and col_scale = 1/(deg+1).
+ * t_indptr [n_src+1], t_indices [nnz + (add_self ? n_dst : 0)]; nnz = indptr[n_dst] (host value);
+ * workspace: glnn_csr_transpose_workspace_bytes(n_src, nnz + (add_self ? n_dst : 0)) bytes, 8-byte aligned. */
+GLNN_API int64_t glnn_csr_transpose_workspace_bytes(int64_t n_src, int64_t nnz_out);
+GLNN_API int glnn_csr_transpose(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                int64_t nnz, int add_self, int64_t* t_indptr, int32_t* t_indices,
+                                void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K7  row gather: out[i,:] = x[rows[i],:]  (feats[idx], reference train_and_eval.py:42,76,
  *     models.py:136) and scatter y[rows[i],:] = x[i,:] (models.py:145). */

@@ -1,5 +1,6 @@
-"""smoke(): one small invocation of each half of the hot path on cuda:0, checked against the CPU
-oracle (the oracle is the checker here, never the product path)."""
+"""__graft_entry__.smoke(): one small invocation of each half of the hot path on cuda:0 -- teacher forward, student
+distillation step, one sampled-block teacher training step -- checked against the CPU oracle.  Lives at the repo root, NOT in
+the product package: it imports `oracle/` (the oracle is the checker here, never the product path)."""
 import os
 import sys
 
@@ -8,16 +9,18 @@ import torch
 
 
 def smoke():
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    root = os.path.dirname(os.path.abspath(__file__))
     if root not in sys.path:
         sys.path.insert(0, root)
     from oracle import student_oracle as so
     from oracle import teacher_oracle as to
+    from oracle import teacher_train_oracle as tt
 
-    from . import data, ops
-    from .graph import FullNeighborLoader
-    from .models import Model
-    from .student import StudentEngine
+    from glnn_amd import data, ops
+    from glnn_amd.graph import FullNeighborLoader, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.student import StudentEngine
+    from glnn_amd.teacher import TeacherEngine
 
     if not torch.cuda.is_available():
         raise RuntimeError("smoke() needs cuda:0 (MI355X)")
@@ -56,4 +59,23 @@ def smoke():
     err_l = abs(float(loss) - eng.loss_out.item())
     err_g = max(float(np.abs(p.grad.cpu().numpy() - gr).max()) for p, gr in zip(student.parameters(), grads))
     assert err_l < 1e-4 and err_g < 1e-4, f"student step mismatch loss {err_l} grad {err_g}"
-    print(f"smoke ok: teacher max|err| {err_t:.2e}, student loss err {err_l:.2e}, grad err {err_g:.2e}")
+    # ---- teacher TRAINING: one sampled-block GraphSAGE step (blocks built on the device) vs the numpy oracle on the same blocks
+    gd = g.to(dev)
+    tm = Model(dict(model_name="SAGE", num_layers=2, feat_dim=128, hidden_dim=64, label_dim=40, dropout_ratio=0.0,
+                    norm_type="batch", device=dev))
+    sd_t = {k: v.cpu().numpy() for k, v in tm.state_dict().items()}
+    topt = torch.optim.Adam(tm.parameters(), lr=0.01, weight_decay=5e-4)
+    labels = torch.randint(0, 40, (n,))
+    loader = NodeDataLoader(gd, torch.arange(256), MultiLayerNeighborSampler([5, 5]), batch_size=256)
+    input_nodes, output_nodes, blocks = next(iter(loader))
+    tm.train()
+    teng = TeacherEngine(tm, topt)
+    teng.step_sage(blocks, ops.as_feat(feats.to(dev)), labels.to(dev), output_nodes, 1.0, input_nodes=input_nodes)
+    st_t = tt.TeacherState(sd_t, "sage", 2, "batch")
+    nb = [(b.indptr.cpu().numpy(), b.indices.cpu().numpy(), b.num_src_nodes()) for b in blocks]
+    loss_t, _ = tt.train_sage(st_t, [(input_nodes.cpu().numpy(), output_nodes.cpu().numpy(), nb)], feats.numpy(), labels.numpy(), 0.01, 5e-4)
+    err_tl = abs(loss_t - teng.loss_out.item())
+    err_tw = max(float(np.abs(p.detach().cpu().numpy() - w).max()) for p, w in zip(tm.parameters(), st_t.params()))
+    assert err_tl < 1e-4 and err_tw < 1e-4, f"teacher training step mismatch loss {err_tl} params {err_tw}"
+    print(f"smoke ok: teacher max|err| {err_t:.2e}, student loss err {err_l:.2e}, grad err {err_g:.2e}, "
+          f"teacher-train loss err {err_tl:.2e}, param err {err_tw:.2e}")

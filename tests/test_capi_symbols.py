@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in fns:
         assert hasattr(h, name), f"{name} declared in include/glnn_hip.h but not exported"
     h.glnn_abi_version.restype = ctypes.c_int
-    assert h.glnn_abi_version() == 2
+    assert h.glnn_abi_version() == 3
     h.glnn_last_error.restype = ctypes.c_char_p
     assert h.glnn_last_error() is not None
 
@@ -49,9 +49,9 @@ def test_binding_table_matches_header():
 def test_invalid_arguments_are_reported_not_crashed():
     from glnn_amd import _lib
     h = _lib.lib()
-    rc = h.glnn_spmm_csr_f32(None, None, 4, 4, None, 4, 4, 0, None, None, None, 0, None, None, 0, None, 4, None)
+    rc = h.glnn_spmm_csr_f32(None, None, 4, 4, None, 4, 4, 0, None, None, None, 0, None, None, None, 0, None, 4, None)
     assert rc == -1 and b"null pointer" in h.glnn_last_error()
-    assert h.glnn_spmm_csr_f32(None, None, 0, 0, None, 4, 4, 0, None, None, None, 0, None, None, 0, None, 4, None) == 0   # empty: no-op
+    assert h.glnn_spmm_csr_f32(None, None, 0, 0, None, 4, 4, 0, None, None, None, 0, None, None, None, 0, None, 4, None) == 0   # empty: no-op
     rc = h.glnn_gemm_f32(None, 4, None, None, None, 0.0, 0, 4, 4, None, 4, 0, 4, None, None, None, 0, None, 4, None, 0, None)
     assert rc == -1
 

@@ -1,0 +1,393 @@
+"""GPU parity of the teacher TRAINING path: the device-side block builder and CSR transpose
+(integer work: bit-exact against numpy restatements), the neighbour sampler's statistics, and TeacherEngine's
+forward + loss + backward + Adam against the golden vectors the reference's own train_sage / train produced
+(tests/golden/teacher_training.npz) and against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import sub_dict, teacher_training
+from graphgen import random_graph
+from oracle import teacher_train_oracle as tt
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _graph(indptr, indices, n_src=None):
+    from glnn_amd.graph import CSRGraph
+    n = len(indptr) - 1
+    return CSRGraph(torch.from_numpy(np.asarray(indptr, np.int64)).to(DEV), torch.from_numpy(np.asarray(indices, np.int32)).to(DEV), n,
+                    n if n_src is None else n_src)
+
+
+# ------------------------------------------------------------------------------------------------ integer kernels
+@pytest.mark.parametrize("n,deg,kw", [(1000, 7, dict(power=0.6, hub=700, isolated=9)), (257, 3, dict(symmetric=True, self_loops=True)),
+                                      (5000, 20, dict(power=0.8, hub=4000)), (64, 1, {}), (3, 0.4, {})])
+@pytest.mark.parametrize("add_self", [False, True])
+def test_csr_transpose_equals_numpy_bit_for_bit(n, deg, kw, add_self):
+    """glnn_csr_transpose: rows = original sources, entries = destinations, sorted within a row (multi-edges kept);
+    add_self appends u <- u for every destination.  Hub rows (hundreds to thousands of entries) take the long-row sort."""
+    from glnn_amd import ops
+    indptr, indices = random_graph(n, deg, seed=n, **kw)
+    nnz = int(indptr[-1])
+    t_ip, t_ix = ops.csr_transpose(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n, n, nnz, add_self)
+    dst = np.repeat(np.arange(n), np.diff(indptr))
+    src = indices.astype(np.int64)
+    if add_self:
+        src, dst = np.concatenate([src, np.arange(n)]), np.concatenate([dst, np.arange(n)])
+    order = np.lexsort((dst, src))
+    want_ix = dst[order].astype(np.int32)
+    want_ip = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(src, minlength=n), out=want_ip[1:])
+    assert np.array_equal(t_ip.cpu().numpy(), want_ip)
+    assert np.array_equal(t_ix.cpu().numpy(), want_ix)
+    again = ops.csr_transpose(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n, n, nnz, add_self)
+    assert torch.equal(again[1], t_ix)                       # deterministic run to run
+
+
+def test_csr_transpose_of_a_block_and_empty_inputs():
+    from glnn_amd import ops
+    # a block: 3 destinations, 6 sources
+    indptr = np.array([0, 2, 2, 5], np.int64)
+    indices = np.array([4, 1, 5, 5, 0], np.int32)
+    t_ip, t_ix = ops.csr_transpose(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), 3, 6, 5, True)
+    assert t_ip.tolist() == [0, 2, 4, 5, 5, 6, 8]
+    assert t_ix.tolist() == [0, 2, 0, 1, 2, 0, 2, 2]
+    t_ip, t_ix = ops.csr_transpose(torch.zeros(5, dtype=torch.int64, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV), 4, 4, 0, False)
+    assert t_ip.tolist() == [0] * 5 and t_ix.numel() == 0
+
+
+def _first_appearance_block(seeds, rows):
+    """numpy restatement of glnn_block_build: rows[i] = global source ids of destination i, in order."""
+    pos = {int(v): i for i, v in enumerate(seeds)}
+    input_nodes = [int(v) for v in seeds]
+    indptr, local = [0], []
+    for r in rows:
+        for u in r:
+            u = int(u)
+            if u not in pos:
+                pos[u] = len(input_nodes)
+                input_nodes.append(u)
+            local.append(pos[u])
+        indptr.append(len(local))
+    return np.asarray(indptr, np.int64), np.asarray(local, np.int32), np.asarray(input_nodes, np.int64)
+
+
+@pytest.mark.parametrize("ns", [1, 37, 1000, 5000])
+def test_block_build_full_neighbourhood_equals_numpy(ns):
+    from glnn_amd import ops
+    n = 6000
+    indptr, indices = random_graph(n, 8, seed=5, power=0.7, hub=3000, isolated=20)
+    rs = np.random.RandomState(ns)
+    seeds = rs.permutation(n)[:ns].astype(np.int64)
+    rows = [indices[indptr[v]:indptr[v + 1]] for v in seeds]
+    w_ip, w_ix, w_in = _first_appearance_block(seeds, rows)
+    g_ip, g_ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    ip, ix, gix, inp, nnz, n_src = ops.block_build(torch.from_numpy(seeds).to(DEV), g_ip, g_ix, nnz_cap=int(w_ip[-1]) + 11, want_global=True)
+    assert nnz == w_ip[-1] and n_src == len(w_in)
+    assert np.array_equal(ip.cpu().numpy(), w_ip) and np.array_equal(ix.cpu().numpy(), w_ix) and np.array_equal(inp.cpu().numpy(), w_in)
+    assert np.array_equal(gix.cpu().numpy(), np.concatenate(rows) if nnz else np.zeros(0, np.int32))
+    assert np.array_equal(w_in[ix.cpu().numpy()], gix.cpu().numpy())          # local ids name the same nodes
+
+
+@pytest.mark.parametrize("ns,fanout", [(512, 15), (7000, 10), (3, 1), (20000, 5)])
+def test_block_build_from_sampled_neighbours(ns, fanout):
+    from glnn_amd import ops
+    n = 30000
+    indptr, indices = random_graph(n, 12, seed=9, power=0.6, hub=9000, isolated=50)
+    g_ip, g_ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    seeds = torch.from_numpy(np.random.RandomState(ns).permutation(n)[:ns].astype(np.int64)).to(DEV)
+    smp, cnt = ops.sample_neighbors(g_ip, g_ix, seeds, fanout, 1234)
+    ip, ix, gix, inp, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=True)
+    smp_h, cnt_h = smp.cpu().numpy(), cnt.cpu().numpy()
+    rows = [smp_h[i, :cnt_h[i]] for i in range(ns)]
+    w_ip, w_ix, w_in = _first_appearance_block(seeds.cpu().numpy(), rows)
+    assert nnz == w_ip[-1] and n_src == len(w_in)
+    assert np.array_equal(ip.cpu().numpy(), w_ip) and np.array_equal(ix.cpu().numpy(), w_ix) and np.array_equal(inp.cpu().numpy(), w_in)
+    deg = np.diff(indptr)[seeds.cpu().numpy()]
+    assert np.array_equal(cnt_h, np.minimum(deg, fanout))                      # dgl: all in-edges when in_deg <= fanout
+    for i in (0, ns // 2, ns - 1):                                             # sampled edges are edges of the graph, without replacement
+        v = int(seeds[i])
+        pool = indices[indptr[v]:indptr[v + 1]]
+        got = np.sort(rows[i])
+        assert len(got) == min(len(pool), fanout)
+        avail = np.sort(pool).tolist()
+        for u in got:
+            avail.remove(int(u))                                               # multi-edge multiplicity is respected
+
+
+def test_full_neighbour_loader_chunks_map_back_to_the_graph():
+    """The reference's dataloader_eval (train_and_eval.py:193-202) as glnn_amd.graph.FullNeighborLoader: chunks in node-id
+    order, the chunk's destinations first among the block's sources, block edges = the graph's edges."""
+    from glnn_amd.graph import FullNeighborLoader
+    n = 777
+    indptr, indices = random_graph(n, 6, seed=2, power=0.5, hub=300, isolated=7)
+    g = _graph(indptr, indices)
+    seen = 0
+    loader = FullNeighborLoader(g, 100)
+    assert len(loader) == 8
+    for input_nodes, output_nodes, blocks in loader:
+        b = blocks[0]
+        inp = input_nodes.cpu().numpy()
+        assert output_nodes.tolist() == list(range(seen, min(n, seen + 100)))
+        assert np.array_equal(inp[: len(output_nodes)], output_nodes.cpu().numpy()) and b.num_dst_nodes() == len(output_nodes)
+        assert len(np.unique(inp)) == len(inp) == b.num_src_nodes()
+        bi, bx = b.indptr.cpu().numpy(), b.indices.cpu().numpy()
+        for i, v in enumerate(output_nodes.tolist()):
+            assert np.array_equal(inp[bx[bi[i]:bi[i + 1]]], indices[indptr[v]:indptr[v + 1]])
+        seen += len(output_nodes)
+    assert seen == n
+
+
+def test_neighbour_sampler_is_uniform_without_replacement():
+    """chi-square on the selection frequency of each in-edge of a degree-40 row over 10^4 independent draws, fan-out 10
+    (expected 2500 per edge): glnn_sample_neighbors draws uniformly WITHOUT replacement; a row with duplicate (multi-)edges
+    returns each copy independently."""
+    from glnn_amd import ops
+    deg, fanout, draws = 40, 10, 10000
+    nbr = np.arange(100, 100 + deg).astype(np.int32)
+    nbr[7] = nbr[3]                                           # a multi-edge: node 103 appears twice in the row
+    indptr = torch.tensor([0, deg], dtype=torch.int64, device=DEV)
+    indices = torch.from_numpy(nbr).to(DEV)
+    seeds = torch.zeros(draws, dtype=torch.int64, device=DEV)                  # the same row `draws` times: the RNG is keyed by the seed index
+    smp, cnt = ops.sample_neighbors(indptr, indices, seeds, fanout, 20240917)
+    assert int(cnt.min()) == fanout and int(cnt.max()) == fanout
+    s = smp.cpu().numpy()
+    counts = np.bincount(s.ravel() - 100, minlength=deg).astype(np.float64)
+    counts[3] += counts[7]                                    # node 103 is drawn through either copy
+    per_slot = draws * fanout / deg
+    expected = np.full(deg, per_slot)
+    expected[3], expected[7] = 2 * per_slot, 0
+    keep = expected > 0
+    chi2 = (((counts - expected) ** 2)[keep] / expected[keep]).sum()
+    assert chi2 < 80.0, chi2                                  # 38 degrees of freedom: P(chi2 > 80) < 1e-4
+    # without replacement: per draw, node 103 at most twice (its two copies), every other node at most once
+    for row in s[:200]:
+        vals, c = np.unique(row, return_counts=True)
+        assert all(cc <= (2 if v == 103 else 1) for v, cc in zip(vals, c))
+    # a second RNG seed gives different draws; the same seed the same draws
+    smp2, _ = ops.sample_neighbors(indptr, indices, seeds, fanout, 20240917)
+    smp3, _ = ops.sample_neighbors(indptr, indices, seeds, fanout, 99)
+    assert torch.equal(smp, smp2) and not torch.equal(smp, smp3)
+
+
+# ------------------------------------------------------------------------------------------------ TeacherEngine
+def _teacher(kind, dims, norm, sd, wd):
+    from glnn_amd.models import Model
+    conf = dict(model_name=kind, num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.0,
+                norm_type=norm, device=DEV)
+    model = Model(conf)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=wd)       # train_teacher.py:234-236
+    return model, opt
+
+
+def _is_gauge(norm, k):
+    return norm == "batch" and ((k.endswith("fc_neigh.bias") and not k.startswith("encoder.layers.2")) or k.endswith("running_mean"))
+
+
+@pytest.mark.parametrize("norm", ["batch", "none"])
+def test_train_sage_vs_reference_golden(norm):
+    """glnn_amd.train_and_eval.train_sage (TeacherEngine) over the fixture's blocks vs the reference's own train_sage:
+    first-step gradients, per-epoch mean losses, final parameters / BatchNorm buffers / Adam step count."""
+    from glnn_amd import ops
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.teacher import TeacherEngine
+    z, batches = teacher_training()
+    tag = f"sage.{norm}"
+    dims = [int(d) for d in z["sage.dims"]]
+    feats, labels = torch.from_numpy(z["sage.feats"]).to(DEV), torch.from_numpy(z["sage.labels"]).to(DEV)
+    dev_batches = [(torch.from_numpy(i).to(DEV), torch.from_numpy(o).to(DEV), [_graph(ip, ix, ns) for ip, ix, ns in blks])
+                   for i, o, blks in batches]
+    model, opt = _teacher("SAGE", dims, norm, sub_dict(z, f"{tag}.init."), float(z[f"{tag}.wd"]))
+    model.train()
+    eng = TeacherEngine(model, opt)
+    inp, outn, blks = dev_batches[0]
+    snap = {k: v.clone() for k, v in model.state_dict().items()}
+    eng.step_sage(blks, ops.as_feat(feats), labels, outn, 1.0, input_nodes=inp)
+    for pname, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), z[f"{tag}.grad0.{pname}"], atol=1e-5, rtol=1e-4, err_msg=pname)
+    assert abs(eng.loss_out.item() - float(z[f"{tag}.step_losses"][0])) < TOL
+    # the full two epochs through the preserved train_sage surface, from a fresh model / optimizer
+    model, opt = _teacher("SAGE", dims, norm, {k: v.cpu().numpy() for k, v in snap.items()}, float(z[f"{tag}.wd"]))
+    crit = torch.nn.NLLLoss()
+    means = [te.train_sage(model, dev_batches, feats, labels, crit, opt) for _ in range(2)]
+    np.testing.assert_allclose(means, z[f"{tag}.epoch_losses"], atol=TOL, rtol=0)
+    assert int(opt.state[next(model.parameters())]["step"]) == 6
+    for k, v in model.state_dict().items():
+        want = z[f"{tag}.final.{k}"]
+        if v.ndim == 0:
+            assert int(v) == int(want), k
+        elif not _is_gauge(norm, k):
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=2e-4 if norm == "batch" else TOL, rtol=0, err_msg=k)
+
+
+def test_train_gcn_vs_reference_golden():
+    from glnn_amd import train_and_eval as te
+    z, _ = teacher_training()
+    dims = [int(d) for d in z["gcn.dims"]]
+    model, opt = _teacher("GCN", dims, "none", sub_dict(z, "gcn.init."), 1e-3)
+    g = _graph(z["gcn.indptr"], z["gcn.indices"])
+    feats, labels = torch.from_numpy(z["gcn.feats"]).to(DEV), torch.from_numpy(z["gcn.labels"]).to(DEV)
+    idx_train = torch.from_numpy(z["gcn.idx_train"]).to(DEV)
+    losses = [te.train(model, g, feats, labels, torch.nn.NLLLoss(), opt, idx_train) for _ in range(5)]
+    np.testing.assert_allclose(losses, z["gcn.losses"], atol=TOL, rtol=0)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), z[f"gcn.final.{k}"], atol=TOL, rtol=0, err_msg=k)
+
+
+def test_gcn_step_both_weight_orders_and_dropout_vs_oracle():
+    """GraphConv aggregates first when in <= out and multiplies first when in > out (dgl): a 12->20->20->5 GCN takes both
+    branches in one step; then the same with dropout 0.5, the oracle fed with the kernels' own keep-masks."""
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    from oracle.dropout_mask import keep_mask
+    n, dims = 500, [12, 20, 20, 5]
+    indptr, indices = random_graph(n, 4, seed=3, symmetric=True, self_loops=True)
+    rs = np.random.RandomState(3)
+    feats = rs.standard_normal((n, dims[0])).astype(np.float32)
+    labels = rs.randint(0, dims[-1], n).astype(np.int64)
+    idx_train = np.sort(rs.permutation(n)[:120]).astype(np.int64)
+    g = _graph(indptr, indices)
+    for p in (0.0, 0.5):
+        torch.manual_seed(11)
+        model = Model(dict(model_name="GCN", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type="none", device=DEV))
+        with torch.no_grad():
+            for lay in model.encoder.layers:
+                lay.bias.copy_(torch.randn_like(lay.bias) * 0.1)
+        sd0 = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=1e-3)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        eng.step_gcn(g, torch.from_numpy(feats).to(DEV), torch.from_numpy(labels).to(DEV), torch.from_numpy(idx_train).to(DEV), 1.0)
+        st = tt.TeacherState(sd0, "gcn", 3, "none")
+        masks = None
+        if p > 0:
+            eng.step_count = 1
+            masks = [keep_mask(n, dims[l + 1], p, eng._seed(l)).astype(np.float32) for l in range(2)]
+        logits, cache = tt.gcn_forward(st, indptr, indices, feats, masks=masks, p=p)
+        from oracle import student_oracle as so
+        loss, dl = so.loss_and_dlogits(logits[idx_train], labels[idx_train], "nll", 1.0)
+        dlogits = np.zeros_like(logits)
+        dlogits[idx_train] = dl
+        grads = tt.gcn_backward(st, cache, dlogits, p=p)
+        assert abs(eng.loss_out.item() - float(loss)) < TOL
+        for (pname, prm), gr in zip(model.named_parameters(), grads):
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=1e-5, rtol=1e-4, err_msg=f"p={p} {pname}")
+
+
+def test_train_sage_on_device_built_blocks_vs_oracle_and_global_gather():
+    """Blocks sampled and relabelled on the device (NodeDataLoader): (i) the engine's step equals the numpy oracle on the
+    same blocks; (ii) aggregating the outermost block straight out of `feats` through its global ids (no feats[input_nodes])
+    gives bit-identical gradients to the gathered form."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    from oracle import student_oracle as so
+    n, dims = 20000, [40, 64, 64, 9]
+    indptr, indices = random_graph(n, 10, seed=8, power=0.6, hub=5000, isolated=30)
+    rs = np.random.RandomState(8)
+    feats = rs.standard_normal((n, dims[0])).astype(np.float32)
+    labels = rs.randint(0, dims[-1], n).astype(np.int64)
+    g = _graph(indptr, indices)
+    loader = NodeDataLoader(g, torch.arange(700), MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=False, seed=5)
+    assert len(loader) == 2
+    batch = list(loader)[1]                                   # the short last batch (drop_last=False): 188 seeds
+    input_nodes, output_nodes, blocks = batch
+    assert output_nodes.tolist() == list(range(512, 700)) and blocks[0].gindices is not None
+    assert torch.equal(input_nodes[blocks[0].indices.long()], blocks[0].gindices.long())
+    for b_outer, b_inner in zip(blocks[:-1], blocks[1:]):
+        assert b_outer.num_dst_nodes() == b_inner.num_src_nodes()              # the inner block's sources are the outer's destinations
+    fd, ld = ops.as_feat(torch.from_numpy(feats).to(DEV)), torch.from_numpy(labels).to(DEV)
+    grads = {}
+    for mode in ("global", "gathered"):
+        torch.manual_seed(2)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.0,
+                           norm_type="batch", device=DEV))
+        sd0 = {k: v.cpu().numpy() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        saved = blocks[0].gindices
+        if mode == "gathered":
+            blocks[0].gindices = None
+        eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+        blocks[0].gindices = saved
+        grads[mode] = [p.grad.clone() for p in model.parameters()]
+        loss_gpu = eng.loss_out.item()
+    for a, b in zip(grads["global"], grads["gathered"]):
+        assert torch.equal(a, b)
+    st = tt.TeacherState(sd0, "sage", 3, "batch")
+    nb = [(b.indptr.cpu().numpy(), b.indices.cpu().numpy(), b.num_src_nodes()) for b in blocks]
+    inp = input_nodes.cpu().numpy()
+    logits, cache = tt.sage_forward(st, nb, feats[inp])
+    loss, dl = so.loss_and_dlogits(logits, labels[output_nodes.cpu().numpy()], "nll", 1.0)
+    assert abs(loss_gpu - float(loss)) < TOL
+    for g_gpu, g_ref, (pname, _) in zip(grads["global"], tt.sage_backward(st, cache, dl), model.named_parameters()):
+        np.testing.assert_allclose(g_gpu.cpu().numpy(), g_ref, atol=1e-5, rtol=1e-4, err_msg=pname)
+
+
+def test_autograd_surface_matches_the_engine():
+    """Callers that differentiate Model.forward themselves (loss.backward() as in the reference's loops) get the same
+    gradients as the engine: both run the same HIP kernels."""
+    from glnn_amd import ops
+    from glnn_amd.teacher import TeacherEngine
+    z, batches = teacher_training()
+    dims = [int(d) for d in z["sage.dims"]]
+    feats, labels = torch.from_numpy(z["sage.feats"]).to(DEV), torch.from_numpy(z["sage.labels"]).to(DEV)
+    inp, outn, blks = batches[0]
+    inp, outn = torch.from_numpy(inp).to(DEV), torch.from_numpy(outn).to(DEV)
+    blocks = [_graph(ip, ix, ns) for ip, ix, ns in blks]
+    model, opt = _teacher("SAGE", dims, "batch", sub_dict(z, "sage.batch.init."), 0.0)
+    model.train()
+    logits = model(blocks, ops.gather_rows(ops.as_feat(feats), inp))
+    loss = torch.nn.NLLLoss()(logits.log_softmax(dim=1), labels[outn])       # the caller's own torch code
+    loss.backward()
+    auto = [p.grad.clone() for p in model.parameters()]
+    model2, opt2 = _teacher("SAGE", dims, "batch", sub_dict(z, "sage.batch.init."), 0.0)
+    model2.train()
+    eng = TeacherEngine(model2, opt2)
+    eng.step_sage(blocks, ops.as_feat(feats), labels, outn, 1.0, input_nodes=inp)
+    for a, p, (pname, _) in zip(auto, model2.parameters(), model2.named_parameters()):
+        np.testing.assert_allclose(a.cpu().numpy(), p.grad.cpu().numpy(), atol=1e-6, rtol=1e-5, err_msg=pname)
+    # GCN through autograd as well
+    g = _graph(z["gcn.indptr"], z["gcn.indices"])
+    gdims = [int(d) for d in z["gcn.dims"]]
+    gcn, _ = _teacher("GCN", gdims, "none", sub_dict(z, "gcn.init."), 1e-3)
+    gcn.train()
+    gf, gl = torch.from_numpy(z["gcn.feats"]).to(DEV), torch.from_numpy(z["gcn.labels"]).to(DEV)
+    it = torch.from_numpy(z["gcn.idx_train"]).to(DEV)
+    out = gcn(g, gf).log_softmax(dim=1)
+    torch.nn.NLLLoss()(out[it], gl[it]).backward()
+    gcn2, gopt2 = _teacher("GCN", gdims, "none", sub_dict(z, "gcn.init."), 1e-3)
+    gcn2.train()
+    TeacherEngine(gcn2, gopt2).step_gcn(g, gf, gl, it, 1.0)
+    for p, q, (pname, _) in zip(gcn.parameters(), gcn2.parameters(), gcn2.named_parameters()):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.cpu().numpy(), atol=1e-6, rtol=1e-5, err_msg=pname)
+
+
+def test_unsupported_teacher_configurations_raise():
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.models import Model
+    z, _ = teacher_training()
+    dims = [int(d) for d in z["gcn.dims"]]
+    model, opt = _teacher("GCN", dims, "none", sub_dict(z, "gcn.init."), 1e-3)
+    g = _graph(z["gcn.indptr"], z["gcn.indices"])
+    feats, labels = torch.from_numpy(z["gcn.feats"]).to(DEV), torch.from_numpy(z["gcn.labels"]).to(DEV)
+    it = torch.from_numpy(z["gcn.idx_train"]).to(DEV)
+    with pytest.raises(NotImplementedError):
+        te.train(model, g, feats, labels, torch.nn.CrossEntropyLoss(), opt, it)
+    with pytest.raises(NotImplementedError):
+        te.train(model, g, feats, labels, torch.nn.NLLLoss(), torch.optim.SGD(model.parameters(), lr=0.1), it)
+    cpu_model = Model(dict(model_name="MLP", num_layers=2, feat_dim=8, hidden_dim=8, label_dim=3, dropout_ratio=0.0, norm_type="none",
+                           device="cpu"))
+    with pytest.raises(RuntimeError):
+        te.train_mini_batch(cpu_model, torch.randn(16, 8), torch.zeros(16, dtype=torch.int64), 8, torch.nn.NLLLoss(),
+                            torch.optim.Adam(cpu_model.parameters()))
+    with pytest.raises(Exception):
+        cpu_model(None, torch.randn(4, 8))                    # no CPU forward either
