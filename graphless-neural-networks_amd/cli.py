@@ -72,7 +72,12 @@ def get_student_args(argv=None):
 
 
 def _device(args):
-    return torch.device("cuda:" + str(args.device)) if torch.cuda.is_available() and args.device >= 0 else "cpu"
+    """The reference maps --device -1 (its default) to the CPU (train_teacher.py:162-165).  This build computes on
+    libglnn_hip.so only, so a CPU selection fails HERE -- before any output directory is created -- instead of mid-run."""
+    if args.device < 0 or not torch.cuda.is_available():
+        raise SystemExit("glnn_amd runs on the MI355X HIP path only and has no CPU path: pass --device 0 (the reference's "
+                         f"default --device -1 selects the CPU; torch.cuda.is_available() = {torch.cuda.is_available()})")
+    return torch.device("cuda:" + str(args.device))
 
 
 def _setting_dir(args, root, leaf):

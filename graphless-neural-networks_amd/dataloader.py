@@ -22,6 +22,7 @@ from . import data as synth
 from .graph import CSRGraph
 
 CPF_data = ["cora", "citeseer", "pubmed", "a-computer", "a-photo"]
+OGB_data = ["ogbn-arxiv", "ogbn-products"]
 
 
 def load_data(dataset, dataset_path, **kwargs):
@@ -29,8 +30,38 @@ def load_data(dataset, dataset_path, **kwargs):
         return load_synthetic_data(dataset, seed=kwargs.get("seed", 0))
     if dataset in CPF_data:
         return load_cpf_data(dataset, dataset_path, kwargs["seed"], kwargs["labelrate_train"], kwargs["labelrate_val"])
-    raise ValueError(f"Unknown dataset: {dataset} (this build ingests CPF .npz files and synthetic-* shapes; "
-                     "OGB / NonHom / BGNN loaders need ogb, pandas encoders and the datasets themselves)")
+    if dataset in OGB_data:
+        return load_ogb_data(dataset, dataset_path)
+    raise ValueError(f"Unknown dataset: {dataset} (this build ingests CPF .npz files, ogbn-arxiv / ogbn-products through the "
+                     "`ogb` package and synthetic-* shapes; the NonHom / BGNN loaders are outside the hot-path scope)")
+
+
+def load_ogb_data(dataset, dataset_path):
+    """ogbn-arxiv / ogbn-products (reference dataloader.py:61-79) WITHOUT dgl: `ogb.nodeproppred.NodePropPredDataset` is the
+    library-agnostic form of the DglNodePropPredDataset the reference uses (same files, same split).  arxiv is made
+    undirected exactly like the reference does: every edge gets its reverse appended (multi-edges kept, :74-76), then all
+    self-loops are removed and one self-loop per node is added (:77); products is used as stored."""
+    try:
+        from ogb.nodeproppred import NodePropPredDataset
+    except ImportError as e:
+        raise ImportError(f"{dataset} needs the `ogb` package and the dataset files under {dataset_path} (neither ships with this "
+                          f"image and there is no network here); use synthetic-{dataset} for a stand-in of the same shape") from e
+    data = NodePropPredDataset(dataset, dataset_path)
+    split = data.get_idx_split()
+    graph, labels = data[0]
+    n = int(graph["num_nodes"])
+    src = torch.as_tensor(np.asarray(graph["edge_index"][0]), dtype=torch.int64)
+    dst = torch.as_tensor(np.asarray(graph["edge_index"][1]), dtype=torch.int64)
+    if dataset == "ogbn-arxiv":
+        src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+        keep = src != dst
+        loops = torch.arange(n, dtype=torch.int64)
+        src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+    g = CSRGraph.from_edges(src, dst, n)
+    g.ndata["feat"] = torch.as_tensor(np.asarray(graph["node_feat"]), dtype=torch.float32)
+    labels = torch.as_tensor(np.asarray(labels)).squeeze().long()
+    as_idx = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int64)
+    return g, labels, as_idx(split["train"]), as_idx(split["valid"]), as_idx(split["test"])
 
 
 def load_synthetic_data(dataset, seed=0):

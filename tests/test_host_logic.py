@@ -171,3 +171,44 @@ def test_oracle_feature_prop_and_min_cut_vs_reference_golden():
     for k in (1, 3):
         np.testing.assert_allclose(to.feature_prop(ip, ix, z["fprop.feats"], k), z[f"fprop.k{k}"], atol=1e-5, rtol=1e-5)
     assert abs(to.min_cut_loss(ip, ix, z["mincut.logp"]) - float(z["mincut.value"])) < 1e-5
+
+
+def test_ogb_loader_arxiv_symmetrise_and_self_loops(monkeypatch):
+    """load_ogb_data against a stand-in `ogb` package (the real one and its datasets are absent here): ogbn-arxiv gets
+    reverse edges (multi-edges kept) and exactly one self-loop per node (reference dataloader.py:74-77); ogbn-products is
+    used as stored; a missing `ogb` raises ImportError, not ValueError."""
+    import sys
+    import types
+    from glnn_amd.dataloader import load_data
+    edge_index = np.array([[0, 0, 1, 2, 3, 3], [1, 1, 2, 2, 0, 3]])           # a duplicate edge 0->1, two self-loops (2, 3)
+
+    class FakeDataset:
+        def __init__(self, name, root):
+            self.name = name
+
+        def get_idx_split(self):
+            return {"train": np.array([0, 1]), "valid": np.array([2]), "test": np.array([3])}
+
+        def __getitem__(self, i):
+            return {"edge_index": edge_index, "node_feat": np.arange(8, dtype=np.float32).reshape(4, 2), "num_nodes": 4}, np.array([[0], [1], [0], [1]])
+
+    ogb = types.ModuleType("ogb")
+    npp = types.ModuleType("ogb.nodeproppred")
+    npp.NodePropPredDataset = FakeDataset
+    ogb.nodeproppred = npp
+    monkeypatch.setitem(sys.modules, "ogb", ogb)
+    monkeypatch.setitem(sys.modules, "ogb.nodeproppred", npp)
+    g, labels, tr, va, te = load_data("ogbn-arxiv", "./data")
+    dense = torch.zeros(4, 4)
+    for v in range(4):
+        for u in g.indices[g.indptr[v]:g.indptr[v + 1]].tolist():
+            dense[v, u] += 1
+    #                 in-edges of:   0            1            2            3        (row v, column u: edge u -> v)
+    assert dense.tolist() == [[1, 2, 0, 1], [2, 1, 1, 0], [0, 1, 1, 0], [1, 0, 0, 1]]
+    assert g.number_of_edges() == 2 * 4 + 4 and labels.tolist() == [0, 1, 0, 1] and g.ndata["feat"].shape == (4, 2)
+    assert tr.tolist() == [0, 1] and va.tolist() == [2] and te.tolist() == [3]
+    g2, *_ = load_data("ogbn-products", "./data")
+    assert g2.number_of_edges() == 6                                           # untouched
+    monkeypatch.setitem(sys.modules, "ogb.nodeproppred", None)
+    with pytest.raises(ImportError):
+        load_data("ogbn-arxiv", "./data")
