@@ -75,6 +75,20 @@ def make_graph(name, seed=0, device="cpu", scale=1.0):
     raise ValueError(f"Unknown dataset shape: {name}")
 
 
+def reorder_by_degree(g):
+    """Renumber the nodes of a square graph by descending in-degree (stable): new id r <- old id perm[r].  Returns
+    (graph with relabelled rows and columns, perm); x_new = x[perm].  One-time host-side style preparation (torch
+    index ops on the graph's device), the locality-ordered variant SURVEY.md 8(d) allows beside the random node order."""
+    if g.n_dst != g.n_src:
+        raise ValueError("reorder_by_degree: square graphs only")
+    deg = g.in_degrees()
+    perm = torch.argsort(deg, descending=True, stable=True)
+    rank = torch.empty_like(perm)
+    rank[perm] = torch.arange(perm.numel(), device=perm.device)
+    dst_old = torch.repeat_interleave(torch.arange(g.n_dst, device=g.device), deg)
+    return csr_from_edges(rank[g.indices.long()], rank[dst_old], g.n_dst), perm
+
+
 def make_uniform_graph(n, avg_deg, seed=0, device="cpu"):
     """Uniform random directed multigraph (the synthetic-XL config's per-shard generator)."""
     gen = torch.Generator(device=device)

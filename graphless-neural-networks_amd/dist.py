@@ -22,33 +22,66 @@ import torch.distributed as dist
 
 
 class RowShards:
-    """Equal contiguous row ranges; the last ranks may be short (buffers are padded to world*rpr rows).
-    `chunks` > 1 additionally cuts every range into equal sub-ranges (rpr is rounded up to a multiple) for the
-    chunked, overlapped exchange of ShardedTeacher."""
+    """Contiguous destination-row ranges, one per rank.  `bounds` (world+1 row offsets) defaults to equal row counts;
+    `balanced_bounds` cuts by WORK instead (a power-law graph whose node order correlates with degree -- e.g. the
+    degree-ordered layout -- would otherwise load the ranks very unevenly).  Every rank's rows live in a SLOT of `rpr` rows
+    (the longest range, rounded up to a multiple of `chunks`) of the padded activation buffers, so that the per-layer
+    exchange is one equal-sized all-gather whatever the ranges are:
+        layout "nat"  natural node ids (the replicated input features)
+        layout "own"  rank-major slots      position(v) = rank(v) * rpr + (v - lo[rank(v)])      (== v for equal ranges)
+        layout "cm"   chunk-major slots     [chunk][rank][cr]: what the chunked, overlapped exchange produces
+    Column indices are relabelled ONCE per layout (ShardedTeacher._cols); activations are never re-packed."""
 
-    def __init__(self, n, world, rank, chunks=1):
+    def __init__(self, n, world, rank, chunks=1, bounds=None):
         self.n, self.world, self.rank, self.chunks = int(n), int(world), int(rank), max(1, int(chunks))
-        rpr = (self.n + self.world - 1) // self.world
-        self.cr = (rpr + self.chunks - 1) // self.chunks          # rows per chunk
-        self.rpr = self.cr * self.chunks
-        self.lo = min(self.n, self.rank * self.rpr)
-        self.hi = min(self.n, self.lo + self.rpr)
+        if bounds is None:
+            per = (self.n + self.world - 1) // self.world
+            bounds = [min(self.n, r * per) for r in range(self.world + 1)]
+        self.bounds = [int(b) for b in bounds]
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n \
+                or any(a > b for a, b in zip(self.bounds[:-1], self.bounds[1:])):
+            raise ValueError(f"RowShards: bounds must be {self.world + 1} non-decreasing offsets from 0 to n")
+        longest = max(1, max(b - a for a, b in zip(self.bounds[:-1], self.bounds[1:])))
+        self.cr = (longest + self.chunks - 1) // self.chunks          # rows per chunk
+        self.rpr = self.cr * self.chunks                              # rows per slot
+        self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.rows = self.hi - self.lo
+        self.slot = self.rank * self.rpr
         self.n_pad = self.rpr * self.world
+        self.uniform = all(b == min(self.n, r * self.rpr) for r, b in enumerate(self.bounds))   # "own" == "nat"
+
+    @staticmethod
+    def balanced_bounds(indptr, world, row_cost=2.0):
+        """Row offsets that split cost(v) = in_degree(v) + row_cost evenly: per edge the aggregation moves one gathered
+        row, per destination row about two more (self row + output row), hence row_cost = 2."""
+        n = indptr.numel() - 1
+        cost = indptr.to(torch.float64) + row_cost * torch.arange(n + 1, dtype=torch.float64, device=indptr.device)
+        targets = cost[-1] * torch.arange(1, world, dtype=torch.float64, device=indptr.device) / world
+        cuts = torch.searchsorted(cost, targets).clamp_(0, n).tolist()
+        return [0] + [int(c) for c in cuts] + [n]
 
     def chunk_rows(self, c):
         """(offset inside the own range, row count) of chunk c of this rank."""
         off = c * self.cr
         return off, max(0, min(self.rows - off, self.cr))
 
-    def cm_position(self, v):
-        """Row of node id v in the CHUNK-MAJOR layout [chunk][rank][cr]: the layout in which the per-chunk
-        all-gathers of ShardedTeacher land contiguously."""
-        r, i = v // self.rpr, v % self.rpr
+    def position(self, v, layout):
+        """Row of node id(s) v (int64 tensor) in a buffer of the given layout."""
+        if layout == "nat" or (layout == "own" and self.uniform):
+            return v
+        b = torch.tensor(self.bounds, dtype=torch.int64, device=v.device)
+        r = torch.searchsorted(b[1:], v, right=True)
+        i = v - b[r]
+        if layout == "own":
+            return r * self.rpr + i
         return ((i // self.cr) * self.world + r) * self.cr + i % self.cr
+
+    def cm_position(self, v):
+        return self.position(v, "cm")
 
 
 EXCHANGE_STATS = {"collectives": 0, "floats_received": 0}      # per process; tests and bench read / reset it
+FORCE_COLLECTIVES = False      # tests: issue the collectives even for world == 1 (a 1-rank RCCL group exercises the transport calls)
 
 
 def _count(out_block):
@@ -64,24 +97,40 @@ def _storage_rows(buf):
 
 
 def all_gather_rows(buf, shards, group=None):
-    """In-place all-gather of the [n_pad, d] feature buffer `buf` (row stride ld) whose slot
-    [rank*rpr, (rank+1)*rpr) this rank has filled.  The collective runs on the contiguous padded storage, whole
-    rows including the [d, ld) padding columns, so that every rank's slab is ONE contiguous block."""
-    if shards.world == 1:
+    """In-place all-gather of the [n_pad, d] feature buffer `buf` (row stride ld) whose slot [rank*rpr, (rank+1)*rpr) this
+    rank has filled.  The collective runs on the contiguous padded storage, whole rows including the [d, ld) padding
+    columns, so that every rank's slab is ONE contiguous block.  RCCL: the in-place form (send buffer = this rank's slab of
+    the receive buffer, ncclAllGather's documented sendbuff == recvbuff + rank * sendcount case) -- no staging copy."""
+    if shards.world == 1 and not FORCE_COLLECTIVES:
         return buf
     base = _storage_rows(buf)
-    mine = base[shards.rank * shards.rpr:(shards.rank + 1) * shards.rpr]
+    mine = base[shards.slot:shards.slot + shards.rpr]
     _count(base)
     if dist.get_backend(group) == "nccl":
-        # source copied out of the destination: an aliased (in-place) all-gather is legal for RCCL itself, but this
-        # path cannot be exercised here (1 GPU), so it takes the unambiguous form; the copy is 1/world of the buffer
-        dist.all_gather_into_tensor(base, mine.clone(), group=group)
+        dist.all_gather_into_tensor(base, mine, group=group)
     else:   # gloo (CPU tests): list form
         tmp = [torch.empty_like(mine) for _ in range(shards.world)]
         dist.all_gather(tmp, mine.contiguous(), group=group)
         for r, t in enumerate(tmp):
             base[r * shards.rpr:(r + 1) * shards.rpr].copy_(t)
     return buf
+
+
+def _all_gather_block(out_block, mine, shards, group):
+    """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot inside it (in place).
+    Returns a callable that makes the current stream wait for it."""
+    _count(out_block)
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_gather_into_tensor(out_block, mine, group=group, async_op=True)
+        return work.wait
+    tmp = [torch.empty_like(mine) for _ in range(shards.world)]
+    work = dist.all_gather(tmp, mine.contiguous(), group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        for r, t in enumerate(tmp):
+            out_block[r * shards.cr:(r + 1) * shards.cr].copy_(t)
+    return finish
 
 
 class ShardedTeacher:
@@ -96,8 +145,10 @@ class ShardedTeacher:
 
     def __init__(self, encoder, graph_shard, shards, be, group=None):
         self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
+        if graph_shard.n_dst != shards.rows:
+            raise ValueError(f"ShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
         self._bufs = {}
-        self._indices_cm = None
+        self._col_cache = {}
 
     def _full_buffer(self, key, d, device):
         k = (key, d)
@@ -105,18 +156,21 @@ class ShardedTeacher:
             self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
         return self._bufs[k]
 
-    def _indices(self, layout):
-        if layout == "nat":
+    def _cols(self, layout):
+        """Column indices of the shard's edges for a source matrix in `layout` (one-time relabelling, cached)."""
+        if layout == "nat" or (layout == "own" and self.sh.uniform):
             return self.g.indices
-        if self._indices_cm is None:      # one-time relabelling (outside any timed loop after the first forward)
-            self._indices_cm = self.sh.cm_position(self.g.indices.long()).to(torch.int32)
-        return self._indices_cm
+        if layout not in self._col_cache:
+            self._col_cache[layout] = self.sh.position(self.g.indices.long(), layout).to(torch.int32)
+        return self._col_cache[layout]
 
     def _pieces(self, layout):
-        """Own rows as (offset in own range, rows, slice into the full activation buffer) pieces."""
+        """Own rows as (offset in own range, rows, slice into a buffer of `layout`) pieces."""
         sh = self.sh
         if layout == "nat":
             return [(0, sh.rows, slice(sh.lo, sh.hi))]
+        if layout == "own":
+            return [(0, sh.rows, slice(sh.slot, sh.slot + sh.rows))]
         out = []
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
@@ -125,12 +179,26 @@ class ShardedTeacher:
                 out.append((off, nr, slice(p0, p0 + nr)))
         return out
 
+    def _chunk_self(self, x, layout, c):
+        """The own rows of chunk c inside `x` (their self rows for the SAGE-gcn aggregator)."""
+        sh = self.sh
+        off, nr = sh.chunk_rows(c)
+        if layout == "cm":
+            p0 = (c * sh.world + sh.rank) * sh.cr
+            return x[p0:p0 + nr]
+        base = sh.lo if layout == "nat" else sh.slot
+        return x[base + off:base + off + nr]
+
+    def _own(self, key, d, device):
+        """This rank's slot of the "own"-layout buffer `key` (where a layer writes its output rows)."""
+        return self._full_buffer(key, d, device)[self.sh.slot:self.sh.slot + self.sh.rows]
+
     def _aggregate_project(self, x, layout, w, tail, out_own):
         """Aggregate-first layer on the own rows (piecewise when x is chunk-major)."""
         be, g = self.be, self.g
         ep_scale, ep_shift, relu = tail
         d_in, d_out = w.shape[1], w.shape[0]
-        idx = self._indices(layout)
+        idx = self._cols(layout)
         for off, nr, sl in self._pieces(layout):
             ip = g.indptr[off:off + nr + 1]            # absolute offsets into the one indices array
             if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
@@ -139,21 +207,21 @@ class ShardedTeacher:
                 agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl])
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
 
-    def _widening_layer_overlapped(self, l, x, w, tail):
-        """2*d_in <= d_out, world > 1, natural input layout: chunked aggregate -> async all-gather -> replicated GEMM."""
+    def _widening_layer_overlapped(self, l, x, layout, w, tail):
+        """2*d_in <= d_out, world > 1: chunked aggregate -> async all-gather -> replicated GEMM.  Returns a chunk-major buffer."""
         be, g, sh = self.be, self.g, self.sh
         ep_scale, ep_shift, relu = tail
         d_in, d_out = w.shape[1], w.shape[0]
         agg = self._full_buffer(("agg", l), d_in, x.device)      # chunk-major [C][P][cr]
         base = _storage_rows(agg)
         span = sh.world * sh.cr
+        idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
             p0 = (c * sh.world + sh.rank) * sh.cr
             if nr > 0:
-                be.spmm(g.indptr[off:off + nr + 1], g.indices, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr],
-                        x_self=x[sh.lo + off:sh.lo + off + nr])
+                be.spmm(g.indptr[off:off + nr + 1], idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=self._chunk_self(x, layout, c))
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
         y = self._full_buffer(("ycm", l), d_out, x.device)
         for c in range(sh.chunks):
@@ -171,18 +239,17 @@ class ShardedTeacher:
         tail1, tail2 = enc._tail(l), enc._tail(l + 1)
         d_mid, d_out = w1.shape[0], w2.shape[0]
         last = l + 1 == enc.num_layers - 1
-        y_own = self._full_buffer(("y", l), d_mid, x.device)[sh.lo:sh.hi]
+        y_own = self._own(("y", l), d_mid, x.device)
         hw = self._full_buffer(("hwcm", l + 1), d_out, x.device)          # chunk-major [C][P][cr]
         base = _storage_rows(hw)
         span = sh.world * sh.cr
-        idx = self._indices(layout)
+        idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
             p0 = (c * sh.world + sh.rank) * sh.cr
             if nr > 0:
-                # own rows [off, off+nr) of layer l; their self rows sit at sh.lo+off (natural) or in chunk c's slot (cm)
-                xs = x[sh.lo + off:sh.lo + off + nr] if layout == "nat" else x[p0:p0 + nr]
+                xs = self._chunk_self(x, layout, c)
                 ip = g.indptr[off:off + nr + 1]
                 es, eh, rl = tail1
                 if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256:
@@ -192,11 +259,11 @@ class ShardedTeacher:
                     be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
                 be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
-        out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l + 1), d_out, x.device)[sh.lo:sh.hi]
+        out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l + 1), d_out, x.device)
         for wk in works:
             wk()
         es, eh, rl = tail2
-        idx_cm = self._indices("cm")
+        idx_cm = self._cols("cm")
         for off, nr, sl in self._pieces("cm"):
             be.spmm(g.indptr[off:off + nr + 1], idx_cm, hw, nr, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=rl,
                     out=out[off:off + nr], x_self=hw[sl])
@@ -206,11 +273,12 @@ class ShardedTeacher:
         """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
         enc, sh, be, g = self.enc, self.sh, self.be, self.g
         x = be.as_feat(x_full)
-        layout = "nat"          # row order of x: natural node ids, or chunk-major ("cm")
+        layout = "nat"          # row order of x: natural node ids ("nat"), rank-major slots ("own") or chunk-major ("cm")
         complete = True         # x holds every node's row (False: only this rank's own rows are valid)
         L = enc.num_layers
         dims = [(lay.fc_neigh.weight.shape[1], lay.fc_neigh.weight.shape[0]) for lay in enc.layers]
         y_own = None
+        multi = sh.world > 1 or FORCE_COLLECTIVES
         l = 0
         while l < L:
             w = enc.layers[l].fc_neigh.weight
@@ -224,37 +292,38 @@ class ShardedTeacher:
                 # 47 floats per node on the wire instead of 256).  Needs only the OWN rows of x.
                 hw = self._full_buffer(("hw", l), d_out, x.device)
                 for off, nr, sl in self._pieces(layout):
-                    be.gemm(x[sl], w, out=hw[sh.lo + off:sh.lo + off + nr])
+                    be.gemm(x[sl], w, out=hw[sh.slot + off:sh.slot + off + nr])
                 all_gather_rows(hw, sh, self.group)
-                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
-                be.spmm(g.indptr, g.indices, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
-                        out=out, x_self=hw[sh.lo:sh.hi])
+                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l), d_out, x.device)
+                be.spmm(g.indptr, self._cols("own"), hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
+                        out=out, x_self=hw[sh.slot:sh.slot + sh.rows])
             elif not complete:
                 raise RuntimeError("ShardedTeacher: internal error, an aggregating layer needs every node's input row")
-            elif sh.world > 1 and not last and 2 * d_in <= d_out and layout == "nat":
+            elif multi and not last and 2 * d_in <= d_out:
                 # widening layer (products layer 1: 100 -> 256): exchange the NARROW aggregate and let every rank
                 # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
                 # instead of 2.5 GB on products) for the price of a replicated [N, d_in] x [d_in, d_out] GEMM.
                 if sh.chunks > 1:
-                    x = self._widening_layer_overlapped(l, x, w, tail)
+                    x = self._widening_layer_overlapped(l, x, layout, w, tail)
                     layout = "cm"
                 else:
                     agg = self._full_buffer(("agg", l), d_in, x.device)
-                    be.spmm(g.indptr, g.indices, x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.lo:sh.hi], x_self=x[sh.lo:sh.hi])
+                    (_, _, sl), = self._pieces(layout)
+                    be.spmm(g.indptr, self._cols(layout), x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.slot:sh.slot + sh.rows], x_self=x[sl])
                     all_gather_rows(agg, sh, self.group)
                     y_full = self._full_buffer(("y", l), d_out, x.device)
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)
-                    x = y_full
+                    x, layout = y_full, "own"
                 y_own = None          # (a widening layer is never the last one)
                 l += 1
                 continue
-            elif sh.world > 1 and sh.chunks > 1 and next_narrow:
+            elif multi and sh.chunks > 1 and next_narrow:
                 out = self._plain_then_narrow_overlapped(l, x, layout)      # layers l and l+1
                 l += 1
                 last = l == L - 1
                 next_narrow = False
             else:
-                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._full_buffer(("y", l), d_out, x.device)[sh.lo:sh.hi]
+                out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l), d_out, x.device)
                 self._aggregate_project(x, layout, w, tail, out)
             y_own = out
             if not last:
@@ -264,26 +333,9 @@ class ShardedTeacher:
                     x, complete = buf, False          # the next (narrowing) layer projects its own rows only: no exchange
                 else:
                     x, complete = all_gather_rows(buf, sh, self.group), True
-                layout = "nat"
+                layout = "own"
             l += 1
         return y_own
-
-
-def _all_gather_block(out_block, mine, shards, group):
-    """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot.
-    Returns a callable that makes the current stream wait for it."""
-    _count(out_block)
-    if dist.get_backend(group) == "nccl":
-        work = dist.all_gather_into_tensor(out_block, mine.clone(), group=group, async_op=True)   # non-aliased source
-        return work.wait
-    tmp = [torch.empty_like(mine) for _ in range(shards.world)]
-    work = dist.all_gather(tmp, mine.contiguous(), group=group, async_op=True)
-
-    def finish():
-        work.wait()
-        for r, t in enumerate(tmp):
-            out_block[r * shards.cr:(r + 1) * shards.cr].copy_(t)
-    return finish
 
 
 def make_grad_sync(flat_grads, world, group=None, average=False):

@@ -8,7 +8,11 @@ two implementations (or two BLAS builds under the reference itself) agree on the
 makes a few weight entries whose true gradient is ~0 wander by a fraction of lr.  So:
   * outputs (losses per step, eval log-probs) are held to the 1e-4 bar -- they are gauge-invariant;
   * well-conditioned state (last layer, BN affine, running_var) is held to 1e-4;
-  * hidden-layer weights: mean |diff| <= 1e-4 and max |diff| <= lr (a handful of sign-flipped entries); at the
+  * hidden-layer weights: mean |diff| <= max(1e-4, lr/20) and max |diff| <= 2 lr (entries whose first Adam steps are
+    +-lr with a noise-decided sign -- two such steps for a handful of the 1-4 M entries of the wide students: HIP vs
+    reference max 1.6e-2 on MLP3w4, reference vs itself 1.3e-2 on MLP3w8; measured on MLP3w4 after 4 steps, where the weights have moved by 1.3e-2 on average:
+    numpy oracle vs reference mean 7.7e-5, HIP vs reference 1.4e-4, reference vs itself under a one-ulp perturbation of
+    the initial weights max 7.8e-4 -- all ~1 % of the movement); at the
     full widths the reference runs (MLP3w4 1024, MLP3w8 2048) the flipped entries of W_l perturb the next steps'
     gradients of everything upstream, so the BatchNorm affine parameters of those configs get the same rule
     (measured numpy-oracle vs reference, MLP3w4 after 4 steps: gamma_0 mean 6e-5, max 5e-4 = lr/20) -- the
@@ -58,7 +62,7 @@ def check_final_state(g, sd, tol=TOL):
         m = re.match(r"encoder\.layers\.(\d+)\.weight", k)
         affine = re.match(r"encoder\.norms\.\d+\.(weight|bias)", k)
         if ((m and int(m.group(1)) < L - 1) or affine) and g.norm == "batch" and g.wd == 0:
-            assert d.mean() <= tol and d.max() <= g.lr, (k, d.mean(), d.max())
+            assert d.mean() <= max(tol, 0.05 * g.lr) and d.max() <= 2 * g.lr, (k, d.mean(), d.max())
         else:
             assert d.max() <= tol, (k, d.max())
 

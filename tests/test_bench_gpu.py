@@ -32,7 +32,10 @@ def test_bench_single_gpu_line():
     rf, cb = out["roofline"], out["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1.2 and rf["unit"] == "GB/s"
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["aggregation_torch_sparse_csr_edges_per_s"] > 0 and cb["student_steps_per_s"] > 0 and "PyTorch CPU ops" in cb["student_kind"]
     assert out["student"]["value"] > 0
+    rr = out["roofline_reordered"]
+    assert rr["order"].startswith("nodes renumbered") and rr["edges_per_s"] > 0 and rr["traffic"] is None
 
 
 @pytest.mark.parametrize("extra", [[], ["--student-global-bn"]])
@@ -45,7 +48,7 @@ def test_bench_two_ranks_driver_launch_line(extra):
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["student"]["global_batch"] == 2 * 4096
     ex = out["exchange"]       # per forward: n_pad * (100 + 48) floats = the narrow sides only (layer 2 exchanges nothing)
-    n_pad = -(-out["config"]["nodes"] // 8) * 8
-    assert abs(ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * 148) < 0.02 * 4e-9 * n_pad * 148, ex
+    n_pad = -(-out["config"]["nodes"] // 8) * 8        # work-balanced (uneven) row ranges pad every slot to the longest range
+    assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * 148 < 0.15 * 4e-9 * n_pad * 148, ex
     assert ex["collectives_per_forward"] == 8
     assert ("global" in out["student"]["batchnorm"]) == bool(extra)

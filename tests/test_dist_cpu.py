@@ -70,7 +70,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, dims, seed, chunks, q):
+def _worker(rank, world, port, n, dims, seed, chunks, balanced, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -90,7 +90,8 @@ def _worker(rank, world, port, n, dims, seed, chunks, q):
                 bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
         enc.eval()
         x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
-        sh = RowShards(n, world, rank, chunks=chunks)
+        bounds = RowShards.balanced_bounds(g.indptr, world) if balanced else None      # cut by work: uneven row ranges
+        sh = RowShards(n, world, rank, chunks=chunks, bounds=bounds)
         be = OracleBackend()
         from glnn_amd import dist as gdist
         gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
@@ -105,21 +106,25 @@ def _worker(rank, world, port, n, dims, seed, chunks, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,dims,chunks", [(1001, [12, 16, 16, 5], 1), (640, [8, 24, 6], 1), (1003, [8, 24, 24, 6], 3), (90, [6, 16, 5], 4)])
-def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims, chunks):
+@pytest.mark.parametrize("world,n,dims,chunks,balanced", [
+    (2, 1001, [12, 16, 16, 5], 1, False), (2, 640, [8, 24, 6], 1, False), (2, 1003, [8, 24, 24, 6], 3, False), (2, 90, [6, 16, 5], 4, False),
+    (2, 1001, [12, 16, 16, 5], 1, True), (4, 1003, [8, 24, 24, 6], 3, True), (4, 777, [8, 24, 6], 1, True), (4, 640, [12, 16, 16, 5], 2, False),
+    (8, 1001, [8, 24, 24, 6], 2, True), (8, 203, [6, 16, 5], 1, False)])
+def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced):
+    """world 2 / 4 / 8, equal and work-balanced (uneven) row ranges, plain and chunked-overlapped exchange."""
     sys.path.insert(0, ROOT)
     from oracle import teacher_oracle as to
     from graphgen import random_graph
     import torch.nn.functional as F
     from glnn_amd.models import SAGE
-    world, seed = 2, 5
+    seed = 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, chunks, balanced, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -155,8 +160,13 @@ def test_sharded_teacher_world2_gloo_equals_unsharded(n, dims, chunks):
         np.testing.assert_allclose(y, want[lo:hi], atol=1e-4, rtol=0)
         covered[lo:hi] = True
         assert stats["floats_received"] == stats["n_pad"] * per_node, (stats, per_node)
-        np.testing.assert_allclose(flat, np.full(10, 1.5))      # mean of 1 and 2
+        np.testing.assert_allclose(flat, np.full(10, (world + 1) / 2))      # mean of 1..world
     assert covered.all()
+    if balanced:        # the work-balanced cut really is uneven on this power-law graph, and evens out the edge counts
+        rows = sorted(hi - lo for _, lo, hi, *_ in res)
+        assert rows[0] < rows[-1]
+        nnz = [int(indptr[hi] - indptr[lo]) for _, lo, hi, *_ in res]
+        assert max(nnz) - min(nnz) <= 0.5 * max(nnz) + 250
 
 
 def _exchange_worker(rank, world, port, q):

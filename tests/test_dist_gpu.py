@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, dims, chunks, q):
+def _worker(rank, world, port, n, dims, chunks, balanced, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, n, dims, chunks, q):
                 bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
         model.eval()
         want = model.inference(FullNeighborLoader(g, 1024), x)
-        sh = RowShards(nn_, world, rank, chunks=chunks)
+        sh = RowShards(nn_, world, rank, chunks=chunks, bounds=RowShards.balanced_bounds(g.indptr, world) if balanced else None)
         with torch.no_grad():
             y = ShardedTeacher(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops).forward(x)
         err = float((y - want[sh.lo:sh.hi]).abs().max())
@@ -48,13 +48,14 @@ def _worker(rank, world, port, n, dims, chunks, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,chunks", [([128, 256, 256, 40], 1), ([100, 256, 256, 47], 4)])
-def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks):
+@pytest.mark.parametrize("dims,chunks,balanced", [([128, 256, 256, 40], 1, False), ([100, 256, 256, 47], 4, False), ([100, 256, 256, 47], 4, True),
+                                                  ([128, 256, 256, 40], 1, True)])
+def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks, balanced):
     world, n = 2, 9001
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, chunks, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, chunks, balanced, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -67,6 +68,65 @@ def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks):
         covered += hi - lo
         np.testing.assert_allclose(flat, np.full(8, 1.5))
     assert covered >= n - 2
+
+
+def _rccl_worker(port, q):
+    """ONE rank, backend "nccl" (= RCCL): the production transport branches of glnn_amd.dist -- the in-place
+    all_gather_into_tensor of a slot of the padded buffer, its async chunked form, the flat-gradient all_reduce, the
+    StatExchange hook -- executed for real on the GPU (a 1-rank communicator; FORCE_COLLECTIVES keeps the world == 1
+    short-cuts from skipping them).  Values must be unchanged: with one rank every collective is the identity."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from glnn_amd import data, ops
+        from glnn_amd import dist as gdist
+        from glnn_amd.graph import FullNeighborLoader
+        from glnn_amd.models import Model
+        gdist.FORCE_COLLECTIVES = True
+        torch.manual_seed(0)
+        g = data.make_graph("ogbn-arxiv", seed=0, device=dev, scale=0.05)
+        n = g.n_dst
+        errs = {}
+        for dims, chunks in (([100, 256, 256, 47], 4), ([128, 256, 256, 40], 1), ([64, 32, 16], 2)):
+            x = torch.randn(n, dims[0], device=dev)
+            model = Model(dict(model_name="SAGE", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                               dropout_ratio=0.5, norm_type="batch", device=dev))
+            model.eval()
+            want = model.inference(FullNeighborLoader(g, 1024), x)
+            sh = gdist.RowShards(n, 1, 0, chunks=chunks)
+            gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+            with torch.no_grad():
+                y = gdist.ShardedTeacher(model.encoder, g, sh, ops).forward(x)
+            torch.cuda.synchronize()
+            errs[(tuple(dims), chunks)] = (float((y - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+        flat = torch.arange(16, dtype=torch.float32, device=dev)
+        gdist.make_grad_sync(flat, 2, average=True)()            # "world 2" arithmetic over the 1-rank communicator: sum / 2
+        ex = gdist.StatExchange(1, 0, 8, dev)
+        ex.send[:24] = torch.arange(24, dtype=torch.float32, device=dev)
+        rc = ex.callback(None, ex.send.data_ptr(), ex.recv.data_ptr(), 24, None)
+        torch.cuda.synchronize()
+        q.put((errs, flat.cpu().numpy().copy(), rc, repr(ex.error), ex.recv[:24].cpu().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_branches_execute_on_one_rank():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    errs, flat, rc, err, recv = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for key, (e, ncoll) in errs.items():
+        assert e < 1e-4 and ncoll >= 1, (key, e, ncoll)
+    np.testing.assert_allclose(flat, np.arange(16) / 2)
+    assert rc == 0 and err == "None"
+    np.testing.assert_array_equal(recv, np.arange(24, dtype=np.float32))
 
 
 def _student_setup(dims, norm, dropout, dev, seed=3):
