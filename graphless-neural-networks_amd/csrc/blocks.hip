@@ -70,28 +70,41 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(V val, int64_t n, un
     if (w < wave) wave_off += s_wave[w];
     block_sum += s_wave[w];
   }
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
+    // decoupled look-back, 64 predecessors per round: lane i inspects workgroup j - i; the wave adds the aggregates up to
+    // the nearest published inclusive prefix (a single thread walking the status words one dependent load at a time cost
+    // 30-65 us on the 245-workgroup scans of a training batch)
     long long prefix = 0;
-    if (bid == 0) {
-      st_release(status, kStPrefix | (unsigned long long)block_sum);
-    } else {
-      st_release(status + bid, kStAgg | (unsigned long long)block_sum);
+    if (bid > 0) {
+      if (lane == 0) st_release(status + bid, kStAgg | (unsigned long long)block_sum);
       int j = bid - 1;
       while (true) {
-        const unsigned long long s = ld_acquire(status + j);
-        const unsigned long long state = s >> 62;
-        if (state < 2) {            // EMPTY: the predecessor has its ticket (it is resident) but has not published yet
+        const int idx = j - lane;
+        const unsigned long long sw = idx >= 0 ? ld_acquire(status + idx) : kStPrefix;      // before workgroup 0: prefix 0
+        const unsigned long long state = sw >> 62;
+        const unsigned long long empties = __ballot(state < 2), prefixes = __ballot(state == 3);
+        const int first_p = prefixes ? (__ffsll((unsigned long long)prefixes) - 1) : 64;
+        const unsigned long long window = first_p >= 63 ? ~0ull : ((1ull << (first_p + 1)) - 1);
+        if (empties & window) {        // a predecessor inside the window holds its ticket (it is resident) but has not published yet
           __builtin_amdgcn_s_sleep(1);
           continue;
         }
-        prefix += (long long)(s & kStMask);
-        if (state == 3) break;
-        --j;
+        unsigned long long v = lane <= first_p ? (sw & kStMask) : 0ull;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned lo = __shfl_xor((unsigned)(v & 0xFFFFFFFFull), off), hi = __shfl_xor((unsigned)(v >> 32), off);
+          v += ((unsigned long long)hi << 32) | lo;
+        }
+        prefix += (long long)v;
+        if (first_p < 64) break;
+        j -= 64;
       }
-      st_release(status + bid, kStPrefix | (unsigned long long)(prefix + block_sum));
     }
-    s_prefix = prefix;
-    if (bid == (int)gridDim.x - 1 && total) *total = prefix + block_sum;
+    if (lane == 0) {
+      st_release(status + bid, kStPrefix | (unsigned long long)(prefix + block_sum));
+      s_prefix = prefix;
+      if (bid == (int)gridDim.x - 1 && total) *total = prefix + block_sum;
+    }
   }
   __syncthreads();
   long long ex = s_prefix + wave_off + (inc - tsum);

@@ -68,6 +68,7 @@ struct SpmmArgs {
   float* out;
   int64_t ldo;
   int n_long_blocks;
+  int rows_per_block;           // rows a row-role workgroup pulls from its ticket (8 waves x 1..kRowsPerWave rows)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -190,7 +191,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += a.n_long_blocks) {
       if (threadIdx.x == 0) s_count = 0;
       __syncthreads();
-      const int64_t r = chunk * kBlock + threadIdx.x;
+      // chunk c owns the rows congruent to c modulo n_chunks (not a contiguous range): a degree-SORTED node order -- all
+      // hub rows at the front -- is dealt round-robin over the chunks and so over the long-row workgroups (a contiguous
+      // split put thousands of hub rows into a few workgroups: the D=47 layer ran 10.9 instead of 5.2 ms on such a graph)
+      const int64_t r = (int64_t)threadIdx.x * n_chunks + chunk;
       if (r < a.n_dst && (a.indptr[r + 1] - a.indptr[r]) > kLongRow) {
         const int slot = atomicAdd(&s_count, 1);
         s_rows[slot] = r;
@@ -222,13 +226,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
   if (threadIdx.x == 0) s_ticket = 0;
   __syncthreads();
   const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
-  const int64_t row_base = blk * (kWavesPerBlock * kRowsPerWave);
+  const int64_t row_base = blk * a.rows_per_block;
 #pragma unroll 1
   while (true) {
     int lr = 0;
     if (lane == 0) lr = atomicAdd(&s_ticket, 1);
     lr = __builtin_amdgcn_readfirstlane(lr);
-    if (lr >= kWavesPerBlock * kRowsPerWave) break;
+    if (lr >= a.rows_per_block) break;
     const int64_t v = row_base + lr;
     if (v >= a.n_dst) break;
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
@@ -487,7 +491,14 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     if (n_long < 1) n_long = 1;
     if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
     a.n_long_blocks = (int)n_long;
-    const int64_t rows_per_block = kWavesPerBlock * kRowsPerWave;
+    // rows per wave: 16 on whole graphs (amortises the workgroup's set-up; chosen by sweep), fewer on small inputs -- the
+    // blocks of a training batch have 0.5k-50k rows, and 16 dependent rows per wave left most of the 1024 SIMDs idle
+    // (80 us for a 7k-row block): keep >= ~2048 workgroups in flight
+    int64_t rpw = n_dst / (2048 * kWavesPerBlock);
+    if (rpw < 1) rpw = 1;
+    if (rpw > kRowsPerWave) rpw = kRowsPerWave;
+    const int64_t rows_per_block = kWavesPerBlock * rpw;
+    a.rows_per_block = (int)rows_per_block;
     const int64_t row_blocks = (n_dst + rows_per_block - 1) / rows_per_block;
     GLNN_REQUIRE(row_blocks + n_long < ((int64_t)1 << 31), "glnn_spmm_csr_f32: n_dst too large for one launch");
     const int grid = (int)(row_blocks + n_long);

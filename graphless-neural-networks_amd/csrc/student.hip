@@ -118,6 +118,7 @@ constexpr int kBnRows = 128;  // rows per chunk
 constexpr int kRowLanes = 4;
 constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
 constexpr int kUnroll = 8;
+constexpr int kManyChunks = 48;   // row chunks above which per-chunk partials are folded by a lane-split pass (> ~6k rows)
 
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
                                                         float* __restrict__ ws_mean, float* __restrict__ ws_m2) {
@@ -359,6 +360,31 @@ __global__ void chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int 
   out[col] = s;
 }
 
+// out[0:h] = sum_k ws1[k] (and out[h:2h] = sum_k ws2[k] when ws2 != NULL) with the column kernels' mapping: 64 columns x 4
+// partial lanes per workgroup, lane rl sums partials rl, rl+4, ... (8 independent loads in flight), the four lane sums are
+// folded in fixed order through LDS.  Used when a reduction has MANY row chunks (tens of thousands of rows: the hidden
+// activations of a sampled teacher batch) -- a single thread per column walking them is a chain of ~400 dependent adds.
+__global__ __launch_bounds__(256) void chunk_sum_lanes_kernel(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks,
+                                                              int h, float* __restrict__ out) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < h ? col : h - 1;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+  for (int k = rl; k < nchunks; k += kRowLanes) {
+    s1 += ws1[(int64_t)k * h + colc];
+    if (ws2) s2 += ws2[(int64_t)k * h + colc];
+  }
+  __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
+  sh1[rl][lc] = s1;
+  sh2[rl][lc] = s2;
+  __syncthreads();
+  if (rl == 0 && col < h) {
+    out[col] = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]);
+    if (ws2) out[h + col] = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
+  }
+}
+
 // send[0:h] = sum_k ws1[k], send[h:2h] = sum_k ws2[k]  (this rank's S1/S2, the 2h floats exchanged in the backward)
 __global__ void chunk_sum2_kernel(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks, int h,
                                   float* __restrict__ out) {
@@ -495,7 +521,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
-  const int64_t need = (int64_t)nchunks * h * ((gamma ? 2 : 0) + (dz_col_sum ? 1 : 0));
+  const bool prereduce = gamma && !g && nchunks > kManyChunks;     // many row chunks: fold S1/S2 once instead of in every workgroup
+  const int64_t need = (int64_t)nchunks * h * ((gamma ? 2 : 0) + (dz_col_sum ? 1 : 0)) + (prereduce ? 2ll * h : 0);
   GLNN_REQUIRE(need == 0 || (workspace && workspace_floats >= need), "glnn_bn_relu_bwd_f32: workspace needs >= %lld floats", (long long)need);
   BnBwdArgs a;
   a.da = da; a.ldda = ldda; a.z = z; a.ldz = ldz; a.rows = rows; a.h = h; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
@@ -504,7 +531,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
   if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
-  if (dz_col_sum) a.ws3 = w;
+  if (dz_col_sum) { a.ws3 = w; w += (int64_t)nchunks * h; }
+  float* totals = prereduce ? w : nullptr;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((h + 63) / 64, nchunks);
   a.p1 = a.ws1; a.p2 = a.ws2; a.nparts = nchunks; a.pstride = h; a.local_part = -1; a.rows_total = nullptr;
@@ -519,12 +547,20 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
       if (rx != GLNN_OK) return rx;
       a.p1 = g->recv; a.p2 = g->recv + h; a.nparts = g->world; a.pstride = 2ll * h; a.local_part = g->rank;
       a.rows_total = g->rows_out;
+    } else if (prereduce) {
+      hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, a.ws1, a.ws2, nchunks, h, totals);
+      a.p1 = totals; a.p2 = totals + h; a.nparts = 1; a.pstride = 0;
     }
     hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
   }
-  if (dz_col_sum) hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws3, nchunks, h, dz_col_sum);
+  if (dz_col_sum) {
+    if (nchunks > kManyChunks)
+      hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, a.ws3, (const float*)nullptr, nchunks, h, dz_col_sum);
+    else
+      hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws3, nchunks, h, dz_col_sum);
+  }
   return glnn::check_launch("glnn_bn_relu_bwd_f32");
 }
 
@@ -615,7 +651,10 @@ extern "C" int glnn_col_sum_f32(const float* x, int64_t ldx, int64_t rows, int h
                (long long)nchunks * h);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, x, ldx, rows, h, workspace);
-  hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, workspace, nchunks, h, out);
+  if (nchunks > kManyChunks)
+    hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, workspace, (const float*)nullptr, nchunks, h, out);
+  else
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, workspace, nchunks, h, out);
   return glnn::check_launch("glnn_col_sum_f32");
 }
 

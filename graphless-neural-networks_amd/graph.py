@@ -206,6 +206,7 @@ class NodeDataLoader:
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self._epoch = 0
         self._seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFF
+        self.prefetch, self._side = True, None
         # the whole-graph path of SAGE.inference is only valid when the loader sweeps EVERY node in id order
         if isinstance(sampler, MultiLayerFullNeighborSampler) and sampler.n_layers == 1 and not shuffle \
                 and self.nids.numel() == g.num_dst_nodes() and bool((self.nids.cpu() == torch.arange(g.num_dst_nodes())).all()):
@@ -233,20 +234,53 @@ class NodeDataLoader:
             block.gindices, block.dst_nodes = gidx, seeds       # the same edges with global source ids (TeacherEngine, layer 0)
         return input_nodes, block
 
+    def _batch(self, b, idx, fanouts):
+        dev = self.g.device
+        output_nodes = self.nids[idx].to(dev) if self.nids.device != dev else self.nids[idx.to(dev)]
+        seeds, blocks = output_nodes, []
+        for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
+            rng = (self._seed * 1000003 + self._epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
+            seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0))
+            blocks.insert(0, blk)
+        return seeds, output_nodes, blocks
+
     def __iter__(self):
+        """Batches are built ONE AHEAD on a side HIP stream: the sampler's kernels and its small host read-backs (edge / node
+        counts of every block) overlap the consumer's work on the current stream -- e.g. TeacherEngine's forward / backward of
+        the previous batch -- instead of draining it at every read-back (what the CPU workers of dgl's NodeDataLoader do
+        for the reference, here as stream-level concurrency on the GPU)."""
         self._epoch += 1
         n = self.nids.numel()
         order = torch.randperm(n) if self.shuffle else torch.arange(n)
-        dev = self.g.device
         fanouts = self.sampler.fanouts if isinstance(self.sampler, MultiLayerNeighborSampler) else [None] * self.sampler.n_layers
-        for b, s in enumerate(range(0, n, self.batch_size)):
-            idx = order[s:s + self.batch_size]
-            if self.drop_last and idx.numel() < self.batch_size:
-                break
-            output_nodes = self.nids[idx].to(dev)
-            seeds, blocks = output_nodes, []
-            for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
-                rng = (self._seed * 1000003 + self._epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
-                seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0))
-                blocks.insert(0, blk)
-            yield seeds, output_nodes, blocks
+        chunks = [order[s:s + self.batch_size] for s in range(0, n, self.batch_size)]
+        if self.drop_last and chunks and chunks[-1].numel() < self.batch_size:
+            chunks.pop()
+        if not self.g.indptr.is_cuda or not self.prefetch:
+            for b, idx in enumerate(chunks):
+                yield self._batch(b, idx, fanouts)
+            return
+        main = torch.cuda.current_stream(self.g.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.g.device)
+        side = self._side
+
+        side.wait_stream(main)          # ONCE: the graph / nids may have been produced on the consumer's stream; later builds
+                                        # depend on nothing the consumer queues, so they never wait for its kernels
+
+        def build(b):
+            with torch.cuda.stream(side):
+                batch = self._batch(b, chunks[b], fanouts)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return batch, ev
+
+        nxt = build(0) if chunks else None
+        for b in range(len(chunks)):
+            (input_nodes, output_nodes, blocks), ev = nxt
+            nxt = build(b + 1) if b + 1 < len(chunks) else None
+            main.wait_event(ev)
+            for t in [input_nodes, output_nodes] + [x for blk in blocks for x in (blk.indptr, blk.indices, blk.gindices, blk.dst_nodes)]:
+                if t is not None:
+                    t.record_stream(main)                    # allocated on the side stream, consumed on the main one
+            yield input_nodes, output_nodes, blocks

@@ -297,7 +297,7 @@ def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=N
         if dbeta is None:
             dbeta = torch.empty(h, dtype=torch.float32, device=z.device)
     if workspace is None and (gamma is not None or dz_col_sum is not None):
-        workspace = torch.empty(3 * ((rows + 127) // 128) * h, dtype=torch.float32, device=z.device)
+        workspace = torch.empty((3 * ((rows + 127) // 128) + 2) * h, dtype=torch.float32, device=z.device)
     rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
                                          _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
                                          _p(dz), _ld(dz), _p(dgamma), _p(dbeta), _p(dz_col_sum),

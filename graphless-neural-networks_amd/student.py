@@ -106,7 +106,7 @@ class StudentEngine:
         # workspaces
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
-        self.ws_bn = torch.empty(max(3 * n_chunks * hmax, 1024), **f32)
+        self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax, 1024), **f32)
         self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
         self.ws_loss = torch.empty(1024, **f32)

@@ -178,7 +178,7 @@ GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows
  *     dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); in place on da allowed.
  *     With gamma == NULL (norm_type "none") it is the plain ReLU backward dz = da*[z>0].
  *     dz_col_sum (optional) receives sum over rows of dz = the bias gradient of the Linear in front.
- *     workspace: >= ceil(rows/128)*h*(2 if gamma else 0 + 1 if dz_col_sum else 0) floats.
+ *     workspace: >= ceil(rows/128)*h*(2 if gamma else 0 + 1 if dz_col_sum else 0) + 2*h floats.
  *     drop_p > 0 first applies the Dropout backward da *= keep(row,col)/(1-drop_p) with the same
  *     (drop_seed) mask the forward operand transform used.
  * ------------------------------------------------------------------------------------------ */

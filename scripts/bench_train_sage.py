@@ -30,12 +30,12 @@ for i, b in enumerate(loader):
     if i == 49:
         break
 torch.cuda.synchronize(); t_s = (time.perf_counter() - t0) / 50
+from glnn_amd import teacher
 model.train()
+eng = teacher.get_engine(model, opt)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for input_nodes, output_nodes, blocks in batches:
-    logits = model(blocks, feats[input_nodes])
-    loss = crit(logits.log_softmax(1), labels[output_nodes])
-    opt.zero_grad(); loss.backward(); opt.step()
+    eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
 torch.cuda.synchronize(); t_c = (time.perf_counter() - t0) / 50
-print(f"per step: sampling + blocks {1e3 * t_s:.2f} ms, gather + fwd + bwd + Adam {1e3 * t_c:.2f} ms; "
+print(f"per step: sampling + blocks {1e3 * t_s:.2f} ms, fwd + loss + bwd + Adam (TeacherEngine) {1e3 * t_c:.2f} ms; "
       f"sources per batch {int(sum(b[0].numel() for b in batches) / 50)}", flush=True)

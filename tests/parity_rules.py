@@ -36,6 +36,7 @@ import re
 import numpy as np
 
 TOL = 1e-4
+NOISE_FACTOR = 4.0        # tolerances derived from the reference's own self-noise (fixture keys noise.*) use this multiple
 
 
 def is_gauge(g, key):
@@ -63,15 +64,12 @@ def check_final_state(g, sd, tol=TOL):
         affine = re.match(r"encoder\.norms\.\d+\.(weight|bias)", k)
         if ((m and int(m.group(1)) < L - 1) or affine) and g.norm == "batch" and g.wd == 0:
             assert d.mean() <= max(tol, 0.05 * g.lr) and d.max() <= 2 * g.lr, (k, d.mean(), d.max())
-        else:
-            assert d.max() <= tol, (k, d.max())
+        else:   # 1e-4, or 4x what the reference itself moves by under a one-ulp perturbation (MLP3w8 last layer: 1.5e-4)
+            assert d.max() <= max(tol, NOISE_FACTOR * float(g.z[f"noise.final.{k}"][0])), (k, d.max())
 
 
 def has_gauge(g):
     return g.norm == "batch" and g.wd == 0
-
-
-NOISE_FACTOR = 4.0
 
 
 def eval_tol(g):
