@@ -520,3 +520,65 @@ def test_full_size_xl_shard_properties():
     lo, hi = 5_000_000, 5_400_000
     part = ops.spmm(g.indptr[lo:hi + 1], g.indices, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x_self[lo:hi])
     assert torch.equal(part, out[lo:hi])
+
+
+# ------------------------------------------------------------------------------------------- driver loops
+@pytest.mark.parametrize("name", ["tran_nonorm", "tran_bn_wd", "ind_nonorm", "plain_mlp_tran"])
+def test_driver_loops_vs_reference_golden(name):
+    """The reference's own distill_run_transductive / distill_run_inductive / run_transductive (MLP branch) were run on small
+    gauge-free configs (tests/golden/make_driver_golden.py): epoch order, per-epoch evaluation rows, best-validation
+    snapshot + patience early stop, final evaluation of the restored state.  The mirror must stop at the same epoch, log the
+    same "Best valid model" line and return the same log-probs; it draws its permutations with torch.randperm after
+    set_seed(seed) exactly like the reference, so nothing is replayed."""
+    import os
+    from glnn_amd import train_and_eval as te
+    from glnn_amd import utils
+    from glnn_amd.models import Model
+    from golden_inputs import make_inputs, make_state
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "driver_loops.npz"))
+    cfg = lambda k: z[f"{name}.cfg.{k}"]
+    dims, norm, seed, n = [int(d) for d in cfg("dims")], str(cfg("norm")), int(cfg("seed")), int(cfg("n"))
+    feats, _, out_t, _ = make_inputs(seed, n, dims[0], dims[-1], 10)
+    w = np.random.RandomState(seed).standard_normal((dims[0], dims[-1])).astype(np.float32)
+    labels = (feats @ w).argmax(1).astype(np.int64)
+    perm = np.random.RandomState(seed + 1).permutation(n)
+    idx_train, idx_val, idx_test = (torch.from_numpy(perm[a:b].astype(np.int64)) for a, b in ((0, 120), (120, 200), (200, n)))
+    conf = dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.0,
+                norm_type=norm, device=DEV, seed=seed, batch_size=int(cfg("B")), lamb=float(cfg("lamb")), max_epoch=int(cfg("max_epoch")),
+                patience=int(cfg("patience")), eval_interval=1)
+    model = Model(conf)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in make_state(seed, dims, norm).items()})
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=float(cfg("wd")))
+    crit_l, crit_t = torch.nn.NLLLoss(), torch.nn.KLDivLoss(reduction="batchmean", log_target=True)
+    evaluator = utils.get_evaluator("cora")
+
+    class Log:
+        lines = []
+
+        def debug(self, m):
+            self.lines.append(m)
+
+        info = debug
+
+    logger, las = Log(), []
+    logger.lines = []
+    tf, tl, tt = torch.from_numpy(feats), torch.from_numpy(labels), torch.from_numpy(out_t)
+    kind = str(cfg("kind"))
+    if kind == "plain":
+        res = te.run_transductive(conf, model, None, tf, tl, (idx_train, idx_val, idx_test), crit_l, evaluator, opt, logger, las)
+    elif kind == "ind":
+        obs_tr, obs_va, obs_te, idx_obs, idx_ti = utils.graph_split(idx_train, idx_val, idx_test, 0.25, seed)
+        res = te.distill_run_inductive(conf, model, tf, tl, tt, (obs_tr, torch.cat([obs_tr, obs_va, obs_te]), obs_va, obs_te, idx_obs, idx_ti),
+                                       crit_l, crit_t, evaluator, opt, logger, las)
+    else:
+        res = te.distill_run_transductive(conf, model, tf, tl, tt, (idx_train, torch.cat([idx_train, idx_val, idx_test]), idx_val, idx_test),
+                                          crit_l, crit_t, evaluator, opt, logger, las)
+    want_las = z[f"{name}.loss_and_score"]
+    assert len(las) == len(want_las), (len(las), len(want_las))                      # stopped at the same epoch
+    np.testing.assert_allclose(np.asarray(las, np.float64), want_las, atol=2e-4, rtol=0)
+    assert logger.lines[-1] == str(z[f"{name}.last_log"])
+    np.testing.assert_allclose(np.asarray(res[1:], np.float64), z[f"{name}.scores"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(res[0].cpu().numpy(), z[f"{name}.out"], atol=2e-4, rtol=0)
+    for k, v in model.state_dict().items():
+        if v.ndim:
+            np.testing.assert_allclose(v.cpu().numpy(), z[f"{name}.final.{k}"], atol=2e-4, rtol=0, err_msg=k)
