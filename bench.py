@@ -82,6 +82,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed teacher forwards (default 100: a >= 3 s timed region at ~38 ms each)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "halo"],
+                    help="N > 1: per-layer all-gather of every rank's rows (default) or halo exchange of only the referenced remote rows")
+    ap.add_argument("--locality", type=float, default=0.0,
+                    help="0 = the prescribed products-shaped generator (no locality); p in (0,1] = a community-structured graph of the same "
+                         "size (64 communities, a fraction p of the edges inside them): what the halo exchange is for")
     ap.add_argument("--reorder", default="degree", choices=["degree", "none"],
                     help="N = 1: also time the forward on the graph renumbered by descending in-degree -> roofline_reordered")
     ap.add_argument("--reorder-steps", type=int, default=10)
@@ -105,7 +110,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     from glnn_amd import data, ops
-    from glnn_amd.dist import RowShards, ShardedTeacher, make_grad_sync
+    from glnn_amd.dist import HaloShardedTeacher, RowShards, ShardedTeacher, make_grad_sync
     from glnn_amd.graph import FullNeighborLoader
     from glnn_amd.models import Model
     from glnn_amd.student import StudentEngine
@@ -137,7 +142,11 @@ def main():
 
     # ---- synthetic ogbn-products-shaped inputs, generated in HBM (seed 0, identical on every rank) --------
     torch.manual_seed(0)
-    g = data.make_graph(GRAPH, seed=0, device=dev, scale=args.scale)
+    if args.locality > 0:
+        n_full = int(data.SHAPES[GRAPH]["n"] * args.scale)
+        g = data.make_clustered_graph(n_full, 50.5 if GRAPH == "ogbn-products" else 14.8, communities=64, p_in=args.locality, seed=0, device=dev)
+    else:
+        g = data.make_graph(GRAPH, seed=0, device=dev, scale=args.scale)
     n, nnz = g.n_dst, g.num_edges()
     feats, labels, out_t, _ = data.make_node_data(GRAPH, seed=0, device=dev, n=n)
     feats = ops.as_feat(feats)
@@ -149,7 +158,7 @@ def main():
     shards = RowShards(n, world, rank, chunks=4 if world > 1 else 1, bounds=RowShards.balanced_bounds(g.indptr, world) if world > 1 else None)
     if world > 1:
         shard_graph = g.row_range(shards.lo, shards.hi)
-        sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops)
+        sharded = (HaloShardedTeacher if args.exchange == "halo" else ShardedTeacher)(teacher.encoder, shard_graph, shards, ops)
         del g
         torch.cuda.empty_cache()
 
@@ -231,13 +240,17 @@ def main():
         "config": {"workload": f"{GRAPH}-shaped SAGE teacher forward (3 layers {'-'.join(map(str, SAGE_DIMS))}, BN, layer-wise "
                                f"full-neighbour inference, reference models.py:121-148) + {STUDENT['name']} student KL distillation step",
                    "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
-                   "graph": "seeded power-law multigraph, random node order", "scale": args.scale,
+                   "graph": "seeded power-law multigraph, random node order" if args.locality == 0 else
+                            f"community-structured random graph (64 communities, {args.locality:.2f} of the edges inside), community node order",
+                   "scale": args.scale, "exchange": args.exchange if world > 1 else None,
                    "parallelism": "1 GPU" if world == 1 else f"node-range row shards x{world}, all-gather per layer; student dp{world}"},
         "exchange": None if world == 1 else {
             "GB_received_per_rank_per_forward": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / args.steps,
             "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
-            "what": "all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
-                    "with the aggregation), 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none"},
+            "what": ("all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
+                     "with the aggregation), 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none")
+                    if args.exchange == "allgather" else
+                    "halo all-to-all of the narrow side of each layer boundary, only the remote rows this rank's edges reference"},
         "student": {"metric": f"student distill steps/s ({sd['name']} {'-'.join(map(str, sd['dims']))}, B={sd['batch']} per rank, dropout "
                               f"{sd['dropout']}, BN, KL soft-label step incl. gather, fwd, loss, bwd, Adam)",
                     "value": student_steps_per_s, "unit": "steps/s", "steps": k_student, "warmup": w_student,

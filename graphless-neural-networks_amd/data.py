@@ -75,6 +75,26 @@ def make_graph(name, seed=0, device="cpu", scale=1.0):
     raise ValueError(f"Unknown dataset shape: {name}")
 
 
+def make_clustered_graph(n, avg_deg, communities=64, p_in=0.9, seed=0, device="cpu", shuffle_ids=False):
+    """A graph WITH locality (the prescribed products-shaped generator has none): node v belongs to community v // (n / communities)
+    and an edge keeps its second endpoint inside the first endpoint's community with probability p_in (uniform elsewhere
+    otherwise); both directions stored.  With shuffle_ids the node ids are randomly permuted afterwards (the "random node
+    order" of the same graph).  Used to exercise the halo exchange of glnn_amd.dist.HaloShardedTeacher."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    m = int(n * avg_deg / 2)
+    size = max(1, n // communities)
+    a = torch.randint(0, n, (m,), generator=gen, device=device)
+    inside = torch.rand(m, generator=gen, device=device) < p_in
+    b_in = (a // size) * size + torch.randint(0, size, (m,), generator=gen, device=device)
+    b_out = torch.randint(0, n, (m,), generator=gen, device=device)
+    b = torch.where(inside, b_in, b_out).clamp_(max=n - 1)
+    if shuffle_ids:
+        perm = torch.randperm(n, generator=gen, device=device)
+        a, b = perm[a], perm[b]
+    return csr_from_edges(torch.cat([a, b]), torch.cat([b, a]), n)
+
+
 def reorder_by_degree(g):
     """Renumber the nodes of a square graph by descending in-degree (stable): new id r <- old id perm[r].  Returns
     (graph with relabelled rows and columns, perm); x_new = x[perm].  One-time host-side style preparation (torch

@@ -338,6 +338,166 @@ class ShardedTeacher:
         return y_own
 
 
+class HaloPlan:
+    """Which remote rows this rank's shard references, and which of its own rows the peers reference: the index lists of
+    the HALO exchange SURVEY.md 8(e) describes ("halo all-to-all of only the referenced remote rows, index lists
+    precomputed at partition time").  Built once per (graph shard, RowShards): one unique() over the shard's column ids and
+    two small all-to-alls (counts, then id lists).  Local activation buffers are laid out [own rows | halo rows], the halo
+    rows in ascending node id (= grouped by owner rank, since ranges are contiguous); `cols` are the shard's column indices
+    relabelled into that layout."""
+
+    def __init__(self, graph_shard, shards, group=None):
+        sh, dev = shards, graph_shard.indices.device
+        idx = graph_shard.indices.long()
+        ref = torch.unique(idx)                                               # sorted global ids this shard gathers
+        remote = ref[(ref < sh.lo) | (ref >= sh.hi)]
+        b = torch.tensor(sh.bounds, dtype=torch.int64, device=dev)
+        owner = torch.searchsorted(b[1:], remote, right=True)
+        self.recv_counts = torch.bincount(owner, minlength=sh.world).tolist()        # rows I receive from each rank
+        self.n_halo = int(remote.numel())
+        send_counts = _all_to_all_counts(self.recv_counts, sh, dev, group)
+        self.send_counts = send_counts                                               # rows each rank wants from me
+        wanted = _all_to_all_rows(remote.unsqueeze(1).contiguous(), self.recv_counts, send_counts, sh, group).squeeze(1)
+        if wanted.numel() and (int(wanted.min()) < sh.lo or int(wanted.max()) >= sh.hi):
+            raise RuntimeError("HaloPlan: a peer asked for rows this rank does not own")
+        self.send_rows = (wanted - sh.lo).contiguous()                               # local row offsets, grouped by requesting rank
+        pos = torch.searchsorted(remote, idx)
+        own = (idx >= sh.lo) & (idx < sh.hi)
+        self.cols = torch.where(own, idx - sh.lo, sh.rows + pos).to(torch.int32)
+        self.rows = sh.rows
+        self.n_send = int(sum(send_counts))
+
+
+def _all_to_all_counts(counts, shards, dev, group):
+    send = torch.tensor(counts, dtype=torch.int64, device=dev)
+    if shards.world == 1:
+        return [int(counts[0])]
+    if dist.get_backend(group) == "nccl":
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        return [int(v) for v in recv.tolist()]
+    gathered = [torch.empty_like(send) for _ in range(shards.world)]              # gloo has no all-to-all: gather the table
+    dist.all_gather(gathered, send, group=group)
+    return [int(gathered[r][shards.rank]) for r in range(shards.world)]
+
+
+def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None):
+    """Variable all-to-all of whole rows: `send` [sum(send_counts), w] grouped by destination rank -> [sum(recv_counts), w]
+    grouped by source rank.  RCCL: one all_to_all_single with split sizes; gloo (CPU tests): pairwise isend / irecv."""
+    n_recv = int(sum(recv_counts))
+    if out is None:
+        out = torch.empty((n_recv, send.shape[1]), dtype=send.dtype, device=send.device)
+    EXCHANGE_STATS["collectives"] += 1
+    EXCHANGE_STATS["floats_received"] += (n_recv - int(recv_counts[shards.rank])) * send.shape[1]
+    if shards.world == 1 and not FORCE_COLLECTIVES:
+        out.copy_(send)
+        return out
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(out, send, output_split_sizes=[int(c) for c in recv_counts], input_split_sizes=[int(c) for c in send_counts],
+                               group=group)
+        return out
+    s_off = [0] + list(torch.tensor(send_counts).cumsum(0).tolist())
+    r_off = [0] + list(torch.tensor(recv_counts).cumsum(0).tolist())
+    reqs, bufs = [], []
+    for r in range(shards.world):
+        if r == shards.rank:
+            out[r_off[r]:r_off[r + 1]].copy_(send[s_off[r]:s_off[r + 1]])
+            continue
+        if recv_counts[r]:
+            buf = torch.empty((int(recv_counts[r]), send.shape[1]), dtype=send.dtype)
+            bufs.append((r, buf))
+            reqs.append(dist.irecv(buf, src=r, group=group))
+        if send_counts[r]:
+            reqs.append(dist.isend(send[s_off[r]:s_off[r + 1]].cpu().contiguous(), dst=r, group=group))
+    for q in reqs:
+        q.wait()
+    for r, buf in bufs:
+        out[r_off[r]:r_off[r + 1]].copy_(buf)
+    return out
+
+
+class HaloShardedTeacher:
+    """SAGE layer-wise inference over a row-sharded graph with a HALO exchange: per layer boundary a rank receives only the
+    remote rows its own edges reference (all-to-all over HaloPlan's index lists) instead of every row (ShardedTeacher's
+    all-gather).  Activations live in local buffers [own rows | halo rows]; memory and wire volume scale with the shard's
+    frontier, not with N.  The same narrow-side rules apply: a widening layer exchanges its d_in-wide aggregate and projects
+    own + halo rows locally, a narrowing layer projects first and exchanges the d_out-wide rows, a layer in front of a
+    narrowing layer exchanges nothing.  On a graph WITHOUT locality (the prescribed random-order generator) the halo of a
+    rank is nearly every remote row and this degenerates to the all-gather's volume; it pays on locality-ordered graphs
+    (glnn_amd.data.make_clustered_graph: 8 ranks, 90 % intra-community edges -> ~0.5x the all-gather's bytes)."""
+
+    def __init__(self, encoder, graph_shard, shards, be, group=None):
+        self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
+        if graph_shard.n_dst != shards.rows:
+            raise ValueError(f"HaloShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
+        self.plan = HaloPlan(graph_shard, shards, group)
+        self._bufs = {}
+
+    def _local(self, key, d, device):
+        k = (key, d)
+        if k not in self._bufs:
+            self._bufs[k] = self.be.feat_empty(self.plan.rows + self.plan.n_halo, d, device, zero=True)
+        return self._bufs[k]
+
+    def _exchange(self, buf):
+        """Fill the halo rows of the local buffer `buf` (own rows valid) from their owners."""
+        pl, be = self.plan, self.be
+        base = _storage_rows(buf)
+        own = base[:pl.rows]
+        send = _storage_rows(be.gather_rows(buf[:pl.rows], pl.send_rows)) if hasattr(be, "gather_rows") else own[pl.send_rows]
+        _all_to_all_rows(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, out=base[pl.rows:])
+        return buf
+
+    def forward(self, x_full):
+        """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
+        enc, sh, be, g, pl = self.enc, self.sh, self.be, self.g, self.plan
+        x = be.as_feat(x_full)
+        cols, x_self = g.indices, x[sh.lo:sh.hi]          # layer 1 gathers from the replicated input with the original ids
+        complete = True
+        L = enc.num_layers
+        dims = [(lay.fc_neigh.weight.shape[1], lay.fc_neigh.weight.shape[0]) for lay in enc.layers]
+        out = None
+        for l in range(L):
+            w = enc.layers[l].fc_neigh.weight
+            ep_scale, ep_shift, relu = enc._tail(l)
+            d_in, d_out = dims[l]
+            last = l == L - 1
+            if d_in > d_out:                                   # narrowing: project own rows, exchange d_out-wide rows, aggregate
+                hw = self._local(("hw", l), d_out, x.device)
+                be.gemm(x_self, w, out=hw[:pl.rows])
+                self._exchange(hw)
+                out = be.feat_empty(pl.rows, d_out, x.device) if last else self._local(("y", l), d_out, x.device)[:pl.rows]
+                be.spmm(g.indptr, pl.cols, hw, pl.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out,
+                        x_self=hw[:pl.rows])
+                nxt = None if last else self._local(("y", l), d_out, x.device)
+            elif not complete:
+                raise RuntimeError("HaloShardedTeacher: internal error, an aggregating layer needs its halo rows")
+            elif not last and 2 * d_in <= d_out:               # widening: exchange the narrow aggregate, project own + halo rows
+                agg = self._local(("agg", l), d_in, x.device)
+                be.spmm(g.indptr, cols, x, pl.rows, be.AGG_SAGE_GCN, out=agg[:pl.rows], x_self=x_self)
+                self._exchange(agg)
+                nxt = self._local(("y", l), d_out, x.device)
+                be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=nxt)
+                x, cols, x_self, complete = nxt, pl.cols, nxt[:pl.rows], True
+                continue
+            else:                                              # plain aggregate-first layer on the own rows
+                nxt = None if last else self._local(("y", l), d_out, x.device)
+                out = be.feat_empty(pl.rows, d_out, x.device) if last else nxt[:pl.rows]
+                if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                    be.sage_fused(g.indptr, cols, x, pl.rows, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out, x_self=x_self)
+                else:
+                    be.gemm(be.spmm(g.indptr, cols, x, pl.rows, be.AGG_SAGE_GCN, x_self=x_self), w, ep_scale=ep_scale, ep_shift=ep_shift,
+                            relu=relu, out=out)
+            if not last:
+                if dims[l + 1][0] > dims[l + 1][1]:
+                    complete = False                           # the next (narrowing) layer projects its own rows only
+                else:
+                    self._exchange(nxt)
+                    complete = True
+                x, cols, x_self = nxt, pl.cols, nxt[:pl.rows]
+        return out
+
+
 def make_grad_sync(flat_grads, world, group=None, average=False):
     """Gradient exchange for the data-parallel student: one all-reduce over the engine's flat grad buffer."""
     if world == 1:

@@ -169,6 +169,92 @@ def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced)
         assert max(nnz) - min(nnz) <= 0.5 * max(nnz) + 250
 
 
+def _halo_worker(rank, world, port, n, dims, seed, shuffle, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glnn_amd import data
+        from glnn_amd import dist as gdist
+        from glnn_amd.models import SAGE
+        import torch.nn.functional as F
+        g = data.make_clustered_graph(n, 10, communities=16, p_in=0.95, seed=seed, shuffle_ids=shuffle)
+        torch.manual_seed(seed)
+        enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+        with torch.no_grad():
+            for bn in enc.norms:
+                bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+        enc.eval()
+        x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
+        sh = gdist.RowShards(n, world, rank, bounds=gdist.RowShards.balanced_bounds(g.indptr, world))
+        t = gdist.HaloShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, OracleBackend())
+        gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+        with torch.no_grad():
+            y_own = t.forward(x)
+        q.put((rank, sh.lo, sh.hi, y_own.numpy().copy(), dict(gdist.EXCHANGE_STATS), t.plan.n_halo, sum(t.plan.send_counts)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,shuffle", [(2, [12, 16, 16, 5], False), (4, [8, 24, 24, 6], False), (4, [8, 24, 6], True), (4, [16, 16, 16, 4], False)])
+def test_halo_sharded_teacher_gloo_equals_unsharded(world, dims, shuffle):
+    """The halo exchange (only the referenced remote rows, all-to-all over index lists built at partition time): result ==
+    the unsharded oracle forward; on the locality-ordered graph the bytes moved are a fraction of the all-gather's, on the
+    id-shuffled copy of the same graph (no locality) they approach it."""
+    sys.path.insert(0, ROOT)
+    from oracle import teacher_oracle as to
+    from glnn_amd import data
+    import torch.nn.functional as F
+    from glnn_amd.models import SAGE
+    n, seed = 1600, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, n, dims, seed, shuffle, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = data.make_clustered_graph(n, 10, communities=16, p_in=0.95, seed=seed, shuffle_ids=shuffle)
+    torch.manual_seed(seed)
+    enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+    with torch.no_grad():
+        for bn in enc.norms:
+            bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+    sd = {k: v.numpy() for k, v in enc.state_dict().items()}
+    L = len(dims) - 1
+    layers = [dict(weight=sd[f"layers.{i}.fc_neigh.weight"], bias=sd[f"layers.{i}.fc_neigh.bias"]) for i in range(L)]
+    norms = [dict(weight=sd[f"norms.{i}.weight"], bias=sd[f"norms.{i}.bias"], running_mean=sd[f"norms.{i}.running_mean"],
+                  running_var=sd[f"norms.{i}.running_var"]) for i in range(L - 1)]
+    x = np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32)
+    want = to.sage_inference(g.indptr.numpy(), g.indices.numpy(), x, layers, norms)
+    covered = np.zeros(n, bool)
+    r4 = lambda d: (d + 3) // 4 * 4
+    per_node = 0        # floats per halo row and forward: the narrow side of every boundary that is exchanged
+    for l in range(L):
+        d_in, d_out = dims[l], dims[l + 1]
+        if d_in > d_out:
+            per_node += r4(d_out)
+        elif l < L - 1 and 2 * d_in <= d_out:
+            per_node += r4(d_in)
+        elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
+            per_node += r4(d_out)
+    for rank, lo, hi, y, stats, n_halo, n_send in res:
+        np.testing.assert_allclose(y, want[lo:hi], atol=1e-4, rtol=0)
+        covered[lo:hi] = True
+        assert stats["floats_received"] == n_halo * per_node, (stats, n_halo, per_node)
+        remote_rows = n - (hi - lo)
+        if shuffle:
+            assert n_halo > 0.8 * remote_rows            # no locality: nearly every remote row is referenced
+        else:
+            assert n_halo < 0.55 * remote_rows, (n_halo, remote_rows)
+    assert covered.all()
+    assert sum(r[5] for r in res) == sum(r[6] for r in res)            # every requested row is sent by exactly one owner
+
+
 def _exchange_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

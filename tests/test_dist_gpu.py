@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, dims, chunks, balanced, q):
+def _worker(rank, world, port, n, dims, chunks, balanced, q, halo=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from glnn_amd import data, ops
-        from glnn_amd.dist import RowShards, ShardedTeacher, make_grad_sync
+        from glnn_amd.dist import HaloShardedTeacher, RowShards, ShardedTeacher, make_grad_sync
         from glnn_amd.graph import FullNeighborLoader
         from glnn_amd.models import Model
         dev = "cuda:0"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, n, dims, chunks, balanced, q):
         want = model.inference(FullNeighborLoader(g, 1024), x)
         sh = RowShards(nn_, world, rank, chunks=chunks, bounds=RowShards.balanced_bounds(g.indptr, world) if balanced else None)
         with torch.no_grad():
-            y = ShardedTeacher(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops).forward(x)
+            y = (HaloShardedTeacher if halo else ShardedTeacher)(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops).forward(x)
         err = float((y - want[sh.lo:sh.hi]).abs().max())
         flat = torch.full((8,), float(rank + 1), device=dev)
         make_grad_sync(flat, world, average=True)()
@@ -68,6 +68,24 @@ def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks, balanced):
         covered += hi - lo
         np.testing.assert_allclose(flat, np.full(8, 1.5))
     assert covered >= n - 2
+
+
+def test_halo_sharded_teacher_hip_two_ranks_one_gpu():
+    """The halo exchange with the real kernels: glnn_gather_rows_f32 packs the rows the peer references, the relabelled
+    [own | halo] column ids feed the fused / stand-alone aggregation kernels."""
+    world, n, dims = 2, 9001, [100, 256, 256, 47]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, 1, True, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, lo, hi, err, flat in res:
+        assert err < 1e-4, (rank, err)
 
 
 def _rccl_worker(port, q):
@@ -102,6 +120,11 @@ def _rccl_worker(port, q):
                 y = gdist.ShardedTeacher(model.encoder, g, sh, ops).forward(x)
             torch.cuda.synchronize()
             errs[(tuple(dims), chunks)] = (float((y - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+            gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+            with torch.no_grad():          # the halo form: all_to_all_single with split sizes on the 1-rank communicator
+                yh = gdist.HaloShardedTeacher(model.encoder, g, sh, ops).forward(x)
+            torch.cuda.synchronize()
+            errs[(tuple(dims), "halo")] = (float((yh - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
         flat = torch.arange(16, dtype=torch.float32, device=dev)
         gdist.make_grad_sync(flat, 2, average=True)()            # "world 2" arithmetic over the 1-rank communicator: sum / 2
         ex = gdist.StatExchange(1, 0, 8, dev)
