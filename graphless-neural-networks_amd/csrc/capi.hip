@@ -32,8 +32,9 @@ __global__ void move_rows_kernel(const float* __restrict__ x, int64_t ldx, const
 template <bool SCATTER>
 int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, int d, float* out, int64_t ldo,
               void* stream, const char* name) {
-  GLNN_REQUIRE(x && rows && out, "%s: null pointer", name);
   GLNN_REQUIRE(d >= 1 && n_rows >= 0, "%s: bad size", name);
+  if (n_rows == 0) return GLNN_OK;                      // nothing to move (empty tensors carry null pointers)
+  GLNN_REQUIRE(x && rows && out, "%s: null pointer", name);
   const int dpad = (d + 3) & ~3;
   GLNN_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= dpad && ldo >= dpad, "%s: leading dims must be multiples of 4 and >= %d", name, dpad);
   GLNN_REQUIRE(glnn::aligned16(x) && glnn::aligned16(out), "%s: 16-byte alignment required", name);
