@@ -48,6 +48,7 @@ SIGNATURES = {
 }
 
 MLP_MAX_LAYERS = 8
+MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
@@ -69,7 +70,7 @@ class MlpStepDesc(ctypes.Structure):
                  ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64), ("ws_loss", c_vp), ("ws_loss_floats", c_i64),
                  ("loss_out", c_vp), ("loss_accum", c_vp),
                  ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
-                 ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp)])
+                 ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp)])
 
 
 _lib = None

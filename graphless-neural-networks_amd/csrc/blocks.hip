@@ -30,11 +30,15 @@ constexpr int kScanTile = kScanThreads * kScanItems;
 // look-back status word: top 2 bits = state (01 = EMPTY, what the 0x7F memset leaves; 10 = aggregate; 11 = inclusive prefix)
 constexpr unsigned long long kStAgg = 2ull << 62, kStPrefix = 3ull << 62, kStMask = (1ull << 62) - 1;
 
+// The status word carries its own payload (state + value in ONE 64-bit word), so nothing else has to become visible with
+// it: relaxed agent-scope atomics (write-through / L2-bypassing accesses) are enough.  Release / acquire at agent scope
+// would write back / invalidate the XCD's whole L2 in every workgroup -- on this 8-XCD part that is what a device-scope
+// fence costs.
 __device__ __forceinline__ void st_release(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ld_acquire(unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out(i, exclusive prefix, value) for i in [0,n); *total = sum.  status: >= ceil(n/1024) words, ticket: 1 int, both 0x7F-filled.

@@ -63,12 +63,19 @@ struct BnGroup {
   float* recv;
   float* rows_out;   // device float: global row count of the step (written in the forward, read in the backward)
 };
+// `counters` (optional, device ints, all zero on entry, left zero on exit): with them the final fold of a two-stage reduction
+// is done by the last workgroup of the first stage instead of by a second launch (student.hip: last_workgroup()).
 int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps, float momentum,
              float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out, float* rstd_out,
-             float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream, const BnGroup* g);
+             float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream, const BnGroup* g,
+             int* counters = nullptr);
+int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels, const int64_t* label_rows,
+                 const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
+                 float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum, float* workspace, int64_t workspace_floats,
+                 void* stream, int* counter, float* col_sum);
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
-                void* stream, const BnGroup* g);
+                void* stream, const BnGroup* g, int* counters = nullptr);
 
 }  // namespace glnn

@@ -29,6 +29,8 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     grp = &grp_storage;
   }
 
+  // optional sync counters (zero on entry, left zero): two-stage reductions finish in their first launch (student.hip)
+  int* cnt = (d->sync_counters && grp == nullptr) ? d->sync_counters : nullptr;
   // ---- forward ----
   const float* src = feats;
   int64_t ld_src = ldx;
@@ -46,7 +48,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       if (d->batchnorm)
         GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                    d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
-                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp));
+                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
       a_scale = d->a_scale[l];
       a_shift = d->a_shift[l];
       src = out;
@@ -55,32 +57,35 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     }
   }
   // ---- loss + dlogits ----
-  GLNN_TRY(glnn_softmax_loss_f32(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
-                                 target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
-                                 nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream));
+  // with sync counters the loss kernel's last workgroup also finalises the loss and the last layer's bias gradient
+  const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
+  GLNN_TRY(glnn::softmax_loss(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
+                              target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
+                              nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
+                              cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr));
   // ---- backward ----
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
     if (l == 0) {
       GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], feats, ldx, idx, nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
-                                d->dims[0], L == 1 ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+                                d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
     GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                              p, seed, d->dims[l], d->gw[l], d->dims[l], l == L - 1 ? d->gb[l] : nullptr, d->ws_tn, d->ws_tn_floats,
-                              stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+                              p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
+                              d->ws_tn_floats, stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
     if (d->batchnorm) {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                  d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
-                                 d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp));
+                                 d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
     } else {
-      GLNN_TRY(glnn_bn_relu_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
-                                    nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
-                                    stream));
+      GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
+                                 stream, nullptr, cnt));
     }
     dz = d->dz;
     ld_dz = d->ld_dz;

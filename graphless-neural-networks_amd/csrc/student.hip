@@ -21,6 +21,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// "Last workgroup finishes the reduction": every workgroup publishes its partials, bumps a counter, and the one that sees
+// the final count folds all partials in fixed order -- the second (finalize) launch of a two-stage reduction disappears
+// (each launch costs ~5 us of device-side latency in the small-batch student step, whatever it computes).  The counter
+// must be 0 on entry and is reset by the last workgroup; callers that cannot guarantee that (the plain C entry points,
+// whose workspaces are uninitialised) pass NULL and get the two-launch form.
+// Cross-workgroup visibility WITHOUT a device-scope fence (which writes back / invalidates the XCD's whole L2 -- measured:
+// the fenced form made the MLP3w8 step 25 % SLOWER): the partials are published with relaxed agent-scope atomic stores
+// (write-through past the per-XCD L2) and read back by the last workgroup with relaxed agent-scope atomic loads;
+// __syncthreads() waits for the workgroup's stores to be acknowledged before thread 0 bumps the counter.
+__device__ __forceinline__ void st_part(float* p, float v, bool shared) {
+  if (shared) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ float ld_part(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool last_workgroup(int* counter, int total) {
+  __shared__ int s_last;
+  __syncthreads();                                   // every thread's partial stores have been acknowledged
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == total - 1);
+    if (s_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return s_last != 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // K4: one wavefront per row (c <= 64: one class per lane; larger c loops), 4 rows per workgroup.
 // ------------------------------------------------------------------------------------------
@@ -31,12 +59,15 @@ struct LossArgs {
   float scale;  // lamb / rows
   float* dz; int64_t ldg; float* logp; int64_t ldl;
   float* partial;  // [gridDim.x] per-block loss sums, or NULL (log_softmax only)
+  // fused finalize (counter != NULL): the last workgroup writes the loss (and, with col_sum != NULL and c <= 64, the
+  // column sums of dz = the bias gradient of the layer that produced the logits; col_partial [gridDim.x][64] scratch)
+  int* counter; float inv_rows; float* loss_out; float* loss_accum; float* col_sum; float* col_partial;
 };
 
 template <bool LOSS>
 __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float wave_loss = 0.f;
+  float wave_loss = 0.f, col_acc = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
     const float* zr = a.z + row * a.ldz;
     float mx = -INFINITY;
@@ -57,7 +88,9 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
         const float lp = zr[j] - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
         const float sm = expf(lp);
-        a.dz[row * a.ldg + j] = (sm - (j == y ? 1.f : 0.f)) * a.scale;
+        const float g = (sm - (j == y ? 1.f : 0.f)) * a.scale;
+        a.dz[row * a.ldg + j] = g;
+        col_acc += g;
         if (j == y) row_loss = -lp;
       }
       row_loss = wave_sum(row_loss);
@@ -74,16 +107,47 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
       for (int j = lane; j < a.c; j += 64) {
         const float lp = zr[j] - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
-        a.dz[row * a.ldg + j] = (expf(lp) * set - expf(tr[j])) * a.scale;
+        const float g = (expf(lp) * set - expf(tr[j])) * a.scale;
+        a.dz[row * a.ldg + j] = g;
+        col_acc += g;
       }
     }
     wave_loss += row_loss;
   }
   if (LOSS) {
     __shared__ float s[4];
+    __shared__ float sc[4][64];
     if (lane == 0) s[wave] = wave_loss;
+    sc[wave][lane] = col_acc;
     __syncthreads();
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (threadIdx.x == 0) st_part(&a.partial[blockIdx.x], (s[0] + s[1]) + (s[2] + s[3]), a.counter != nullptr);
+    if (!a.counter) return;
+    if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]), true);
+    if (!last_workgroup(a.counter, (int)gridDim.x)) return;
+    // ---- last workgroup: loss = sum of the per-workgroup partials / rows (fixed order); column sums of dz ----
+    __shared__ float red[256];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += ld_part(&a.partial[i]);
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float l = red[0] * a.inv_rows;
+      if (a.loss_out) a.loss_out[0] = l;
+      if (a.loss_accum) a.loss_accum[0] += l;
+    }
+    if (a.col_sum) {
+      float cs = 0.f;                                   // 4 partial lanes per column, folded in fixed order
+#pragma unroll 8
+      for (int k = wave; k < (int)gridDim.x; k += 4) cs += ld_part(&a.col_partial[(int64_t)k * 64 + lane]);
+      __syncthreads();
+      sc[wave][lane] = cs;
+      __syncthreads();
+      if (threadIdx.x < a.c) a.col_sum[threadIdx.x] = (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]);
+    }
   }
 }
 
@@ -120,8 +184,87 @@ constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
 constexpr int kUnroll = 8;
 constexpr int kManyChunks = 48;   // row chunks above which per-chunk partials are folded by a lane-split pass (> ~6k rows)
 
+struct BnFinArgs {
+  // partial k of column c:  mean = ws_mean[k*pstride + c], M2 = ws_m2[k*pstride + c], count = ws_cnt ? ws_cnt[k*pstride + c]
+  // : rows of chunk k.  (Local chunks: pstride = h, ws_cnt = NULL.  Gathered per-rank triples: pstride = 3h.)
+  const float* ws_cnt; const float* ws_mean; const float* ws_m2; int nparts; int64_t pstride; int64_t rows; int h;
+  // emit mode (emit_cnt != NULL): write the combined (count, mean, M2) and stop -- the per-rank triple that is exchanged
+  float* emit_cnt; float* emit_mean; float* emit_m2;
+  const float* gamma; const float* beta; float eps; float momentum;
+  float* running_mean; float* running_var; int64_t* nbt;
+  float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
+};
+
+__device__ __forceinline__ double part_count(const BnFinArgs& a, int k, int col) {
+  if (a.ws_cnt) return (double)a.ws_cnt[(int64_t)k * a.pstride + col];
+  int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
+  if (r1 > a.rows) r1 = a.rows;
+  return (double)(r1 - r0);
+}
+
+// One workgroup = 64 columns x 4 partial lanes (the column kernels' mapping): lane rl combines partials rl, rl+4, ... ; the
+// four lane results are combined in fixed order through LDS.  (A single thread per column walked the nparts partials as
+// one chain of dependent L2 round trips: 13-21 us for 32 partials.)
+template <bool COH>      // COH: the partials were published by other workgroups of THIS launch -> read them past the L2
+__device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colblock) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = colblock * 64 + lc;
+  const int colc = col < a.h ? col : a.h - 1;
+  if (colblock == 0 && threadIdx.x == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
+  __shared__ double sh_n[kRowLanes][64], sh_s[kRowLanes][64];
+  // combine of the partial (count, mean, M2) triples in double, fixed order, without a loop-carried divide:
+  //   N = sum n_k ;  mean = sum n_k*mean_k / N ;  M2 = sum [ M2_k + n_k*(mean_k - mean)^2 ]
+  double n = 0.0, sum = 0.0;
+#pragma unroll 4
+  for (int k = rl; k < a.nparts; k += kRowLanes) {
+    const double nb = part_count(a, k, colc);
+    n += nb;
+    sum += nb * (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]);
+  }
+  sh_n[rl][lc] = n;
+  sh_s[rl][lc] = sum;
+  __syncthreads();
+  n = (sh_n[0][lc] + sh_n[1][lc]) + (sh_n[2][lc] + sh_n[3][lc]);
+  const double mean = ((sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc])) / n;
+  __syncthreads();
+  double m2 = 0.0;
+#pragma unroll 4
+  for (int k = rl; k < a.nparts; k += kRowLanes) {
+    const double nb = part_count(a, k, colc);
+    const double dm = (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]) - mean;
+    m2 += (double)(COH ? ld_part(&a.ws_m2[(int64_t)k * a.pstride + colc]) : a.ws_m2[(int64_t)k * a.pstride + colc]) + nb * dm * dm;     // nb == 0: an empty slice contributes nothing
+  }
+  sh_s[rl][lc] = m2;
+  __syncthreads();
+  if (rl != 0 || col >= a.h) return;
+  m2 = (sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc]);
+  if (a.emit_cnt) {
+    a.emit_cnt[col] = (float)n;
+    a.emit_mean[col] = (float)mean;
+    a.emit_m2[col] = (float)m2;
+    return;
+  }
+  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
+  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
+  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
+  const float meanf = (float)mean;
+  const float rstd = 1.0f / sqrtf(var_b + a.eps);
+  if (a.mean_out) a.mean_out[col] = meanf;
+  if (a.rstd_out) a.rstd_out[col] = rstd;
+  const float g = a.gamma ? a.gamma[col] : 1.f, b = a.beta ? a.beta[col] : 0.f;
+  const float sc = g * rstd;
+  a.a_scale[col] = sc;
+  a.a_shift[col] = b - meanf * sc;
+  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
+  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_stage2(const BnFinArgs a) { bn_finalize_columns<false>(a, blockIdx.x); }
+
+// counters != NULL: the last row-chunk workgroup of a column block runs the stage-2 combine for its 64 columns itself.
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
-                                                        float* __restrict__ ws_mean, float* __restrict__ ws_m2) {
+                                                        float* __restrict__ ws_mean, float* __restrict__ ws_m2, const BnFinArgs fin,
+                                                        int* counters) {
   const int lc = threadIdx.x & 63;
   const int col = blockIdx.x * 64 + lc;
   const int colc = col < h ? col : h - 1;
@@ -156,83 +299,10 @@ __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__
   sh[rl][lc] = q;
   __syncthreads();
   if (rl == 0 && col < h) {
-    ws_mean[(int64_t)blockIdx.y * h + col] = mean;
-    ws_m2[(int64_t)blockIdx.y * h + col] = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
+    st_part(&ws_mean[(int64_t)blockIdx.y * h + col], mean, counters != nullptr);
+    st_part(&ws_m2[(int64_t)blockIdx.y * h + col], (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]), counters != nullptr);
   }
-}
-
-struct BnFinArgs {
-  // partial k of column c:  mean = ws_mean[k*pstride + c], M2 = ws_m2[k*pstride + c], count = ws_cnt ? ws_cnt[k*pstride + c]
-  // : rows of chunk k.  (Local chunks: pstride = h, ws_cnt = NULL.  Gathered per-rank triples: pstride = 3h.)
-  const float* ws_cnt; const float* ws_mean; const float* ws_m2; int nparts; int64_t pstride; int64_t rows; int h;
-  // emit mode (emit_cnt != NULL): write the combined (count, mean, M2) and stop -- the per-rank triple that is exchanged
-  float* emit_cnt; float* emit_mean; float* emit_m2;
-  const float* gamma; const float* beta; float eps; float momentum;
-  float* running_mean; float* running_var; int64_t* nbt;
-  float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
-};
-
-__device__ __forceinline__ double part_count(const BnFinArgs& a, int k, int col) {
-  if (a.ws_cnt) return (double)a.ws_cnt[(int64_t)k * a.pstride + col];
-  int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
-  if (r1 > a.rows) r1 = a.rows;
-  return (double)(r1 - r0);
-}
-
-// One workgroup = 64 columns x 4 partial lanes (the column kernels' mapping): lane rl combines partials rl, rl+4, ... ; the
-// four lane results are combined in fixed order through LDS.  (A single thread per column walked the nparts partials as
-// one chain of dependent L2 round trips: 13-21 us for 32 partials.)
-__global__ __launch_bounds__(256) void bn_stats_stage2(const BnFinArgs a) {
-  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lc;
-  const int colc = col < a.h ? col : a.h - 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
-  __shared__ double sh_n[kRowLanes][64], sh_s[kRowLanes][64];
-  // combine of the partial (count, mean, M2) triples in double, fixed order, without a loop-carried divide:
-  //   N = sum n_k ;  mean = sum n_k*mean_k / N ;  M2 = sum [ M2_k + n_k*(mean_k - mean)^2 ]
-  double n = 0.0, sum = 0.0;
-#pragma unroll 4
-  for (int k = rl; k < a.nparts; k += kRowLanes) {
-    const double nb = part_count(a, k, colc);
-    n += nb;
-    sum += nb * (double)a.ws_mean[(int64_t)k * a.pstride + colc];
-  }
-  sh_n[rl][lc] = n;
-  sh_s[rl][lc] = sum;
-  __syncthreads();
-  n = (sh_n[0][lc] + sh_n[1][lc]) + (sh_n[2][lc] + sh_n[3][lc]);
-  const double mean = ((sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc])) / n;
-  __syncthreads();
-  double m2 = 0.0;
-#pragma unroll 4
-  for (int k = rl; k < a.nparts; k += kRowLanes) {
-    const double nb = part_count(a, k, colc);
-    const double dm = (double)a.ws_mean[(int64_t)k * a.pstride + colc] - mean;
-    m2 += (double)a.ws_m2[(int64_t)k * a.pstride + colc] + nb * dm * dm;     // nb == 0: an empty slice contributes nothing
-  }
-  sh_s[rl][lc] = m2;
-  __syncthreads();
-  if (rl != 0 || col >= a.h) return;
-  m2 = (sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc]);
-  if (a.emit_cnt) {
-    a.emit_cnt[col] = (float)n;
-    a.emit_mean[col] = (float)mean;
-    a.emit_m2[col] = (float)m2;
-    return;
-  }
-  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
-  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
-  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
-  const float meanf = (float)mean;
-  const float rstd = 1.0f / sqrtf(var_b + a.eps);
-  if (a.mean_out) a.mean_out[col] = meanf;
-  if (a.rstd_out) a.rstd_out[col] = rstd;
-  const float g = a.gamma ? a.gamma[col] : 1.f, b = a.beta ? a.beta[col] : 0.f;
-  const float sc = g * rstd;
-  a.a_scale[col] = sc;
-  a.a_shift[col] = b - meanf * sc;
-  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
-  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
+  if (counters && last_workgroup(&counters[blockIdx.x], (int)gridDim.y)) bn_finalize_columns<true>(fin, blockIdx.x);
 }
 
 // BN / ReLU / dropout backward in three launches (was five + two for the bias gradient):
@@ -252,6 +322,7 @@ struct BnBwdArgs {
   // nchunks, h; batch split over ranks: the gathered per-rank sums).  dgamma/dbeta = the LOCAL sums: all partials
   // (local_part < 0) or partial `local_part` only.  rows_total: device float holding the global row count, or NULL.
   const float* p1; const float* p2; int nparts; int64_t pstride; int local_part; const float* rows_total;
+  int* counters; float* dz_col_sum;      // counters != NULL: the last row-chunk workgroup of a column block folds ws3 into dz_col_sum
 };
 
 template <bool BN>
@@ -346,7 +417,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
   if (a.ws3) {
     sh1[rl][lc] = sdz;
     __syncthreads();
-    if (rl == 0 && col < a.h) a.ws3[(int64_t)blockIdx.y * a.h + col] = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]);
+    if (rl == 0 && col < a.h) st_part(&a.ws3[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), a.counters != nullptr);
+    if (a.counters && last_workgroup(&a.counters[blockIdx.x], (int)gridDim.y)) {
+      float s = 0.f;                                    // lane-split fold of the per-chunk sums, fixed order
+#pragma unroll 8
+      for (int k = rl; k < a.nchunks; k += kRowLanes) s += ld_part(&a.ws3[(int64_t)k * a.h + colc]);
+      sh2[rl][lc] = s;
+      __syncthreads();
+      if (rl == 0 && col < a.h) a.dz_col_sum[col] = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
+    }
   }
   (void)sh2;
 }
@@ -429,28 +508,42 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
 
 }  // namespace
 
-extern "C" int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t rows, int c, int kind,
-                                     const int64_t* labels, const int64_t* label_rows, const float* target_logp,
-                                     int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
-                                     float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
-                                     float* workspace, int64_t workspace_floats, void* stream) {
+int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels,
+                       const int64_t* label_rows, const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb,
+                       float* dlogits, int64_t ldg, float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
+                       float* workspace, int64_t workspace_floats, void* stream, int* counter, float* col_sum) {
   GLNN_REQUIRE(logits && dlogits && workspace, "glnn_softmax_loss_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && c >= 1 && ldz >= c && ldg >= c, "glnn_softmax_loss_f32: bad sizes");
   GLNN_REQUIRE(kind == GLNN_LOSS_NLL || kind == GLNN_LOSS_KL, "glnn_softmax_loss_f32: unknown kind %d", kind);
   if (kind == GLNN_LOSS_NLL) GLNN_REQUIRE(labels, "glnn_softmax_loss_f32: NLL needs labels");
   if (kind == GLNN_LOSS_KL) GLNN_REQUIRE(target_logp && ldt >= c, "glnn_softmax_loss_f32: KL needs target_logp");
   GLNN_REQUIRE(!logprob_out || ldl >= c, "glnn_softmax_loss_f32: ldl too small");
+  GLNN_REQUIRE(!col_sum || (counter && c <= 64), "glnn_softmax_loss_f32: fused column sums need the counter and c <= 64");
   int64_t blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
-  GLNN_REQUIRE(workspace_floats >= blocks, "glnn_softmax_loss_f32: workspace needs >= %lld floats", (long long)blocks);
+  const int64_t cap = counter ? 256 : 1024;            // fused finalize: fewer, longer workgroups keep the last one's fold short
+  if (blocks > cap) blocks = cap;
+  const int64_t need = blocks * (col_sum ? 65 : 1);
+  GLNN_REQUIRE(workspace_floats >= need, "glnn_softmax_loss_f32: workspace needs >= %lld floats", (long long)need);
   LossArgs a;
   a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.kind = kind; a.labels = labels; a.label_rows = label_rows;
   a.t = target_logp; a.ldt = ldt; a.t_rows = target_rows; a.scale = lamb / (float)rows;
   a.dz = dlogits; a.ldg = ldg; a.logp = logprob_out; a.ldl = ldl; a.partial = workspace;
+  a.counter = counter; a.inv_rows = 1.0f / (float)rows; a.loss_out = loss_out; a.loss_accum = loss_accum;
+  a.col_sum = col_sum; a.col_partial = workspace + blocks;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum);
+  if (!counter)
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum);
   return glnn::check_launch("glnn_softmax_loss_f32");
+}
+
+extern "C" int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t rows, int c, int kind,
+                                     const int64_t* labels, const int64_t* label_rows, const float* target_logp,
+                                     int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
+                                     float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
+                                     float* workspace, int64_t workspace_floats, void* stream) {
+  return glnn::softmax_loss(logits, ldz, rows, c, kind, labels, label_rows, target_logp, ldt, target_rows, lamb, dlogits, ldg,
+                            logprob_out, ldl, loss_out, loss_accum, workspace, workspace_floats, stream, nullptr, nullptr);
 }
 
 extern "C" int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows, int c, float* out, int64_t ldo,
@@ -475,7 +568,7 @@ static int run_exchange(const glnn::BnGroup* g, int64_t floats, void* stream, co
 int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out,
                    float* rstd_out, float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats,
-                   void* stream, const glnn::BnGroup* g) {
+                   void* stream, const glnn::BnGroup* g, int* counters) {
   GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
@@ -483,12 +576,16 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* ws_mean = workspace;
   float* ws_m2 = workspace + (int64_t)nchunks * h;
-  hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2);
   BnFinArgs a = {};
   a.ws_mean = ws_mean; a.ws_m2 = ws_m2; a.nparts = nchunks; a.pstride = h; a.rows = rows; a.h = h; a.gamma = gamma; a.beta = beta;
   a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
   a.mean_out = mean_out; a.rstd_out = rstd_out; a.a_scale = a_scale_out; a.a_shift = a_shift_out;
   const dim3 fgrid((h + 63) / 64);
+  if (counters && !g) {     // one launch: the last row-chunk workgroup of every column block finishes the statistics
+    hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters);
+    return glnn::check_launch("glnn_bn_stats_f32");
+  }
+  hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr);
   if (g) {
     // this rank's (count, mean, M2) -> all-gather -> the same fixed-order combine over the rank triples
     BnFinArgs e = a;
@@ -516,7 +613,7 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
-                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g) {
+                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -528,6 +625,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.da = da; a.ldda = ldda; a.z = z; a.ldz = ldz; a.rows = rows; a.h = h; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
   a.a_scale = a_scale; a.a_shift = a_shift; a.dthr = glnn::drop_threshold(drop_p); a.dseed = drop_seed;
   a.dscale = 1.0f / (1.0f - drop_p); a.dz = dz; a.lddz = lddz; a.dgamma = dgamma; a.dbeta = dbeta; a.nchunks = nchunks;
+  a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
   if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
@@ -555,7 +653,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   } else {
     hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
   }
-  if (dz_col_sum) {
+  if (dz_col_sum && !a.counters) {
     if (nchunks > kManyChunks)
       hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, a.ws3, (const float*)nullptr, nchunks, h, dz_col_sum);
     else

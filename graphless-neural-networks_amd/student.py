@@ -20,6 +20,7 @@ The engine works IN PLACE on the `Model`'s own parameters/buffers and on the tor
 tensors (exp_avg / exp_avg_sq / step), so `state_dict()`, early-stopping snapshots
 (train_and_eval.py:588,596) and `optimizer.state_dict()` behave exactly as with the reference."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -109,7 +110,12 @@ class StudentEngine:
         self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax, 1024), **f32)
         self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
-        self.ws_loss = torch.empty(1024, **f32)
+        self.ws_loss = torch.empty(256 * 65 + 1024, **f32)
+        # fused finalizes (last workgroup folds the partials: 7 launches fewer per step): arxiv MLP 0.143 -> 0.136 ms, MLP3w4 0.193 ->
+        # 0.185, products MLP 0.229 -> 0.226, MLP3w8 1.196 -> 1.203 (interleaved A/B) -> only for the small, latency-bound steps
+        fused = os.environ.get("GLNN_STUDENT_FUSED_FINALIZE", "auto")
+        self.sync_counters = torch.zeros(_lib.MLP_COUNTERS, dtype=torch.int32, device=dev) \
+            if fused == "1" or (fused == "auto" and B * hmax <= (1 << 20)) else None
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -171,6 +177,8 @@ class StudentEngine:
         d.ws_gemm, d.ws_gemm_floats = ptr(self.ws_gemm), self.ws_gemm.numel()
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+        if self.sync_counters is not None and max(self.dims) <= 64 * (_lib.MLP_COUNTERS - 1):
+            d.sync_counters = ptr(self.sync_counters)
         return d
 
     # ------------------------------------------------------------------------------------------

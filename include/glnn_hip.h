@@ -231,6 +231,7 @@ GLNN_API int glnn_adam_step_f32(float* const* params, const float* const* grads,
  * The optimiser step is NOT included: call glnn_adam_step_f32 next (a gradient all-reduce may sit between).
  * ------------------------------------------------------------------------------------------ */
 #define GLNN_MLP_MAX_LAYERS 8
+#define GLNN_MLP_COUNTERS 1024   /* ints behind glnn_mlp_step_desc.sync_counters: one per 64-column block + one for the loss */
 
 /* Optional data-parallel hook (SURVEY.md 8e "Student"): when one batch is split over `world` ranks the
  * BatchNorm batch statistics must be taken over the WHOLE batch for the step to equal the single-GPU
@@ -294,6 +295,11 @@ typedef struct glnn_mlp_step_desc {
   float* sync_send;      /* >= 3 * max hidden floats */
   float* sync_recv;      /* >= world * 3 * max hidden floats */
   float* sync_rows;      /* 1 float: the global batch row count of the current step (written by the library) */
+  /* optional: GLNN_MLP_COUNTERS device ints, ZERO when first handed over (the library leaves them zero).  With them the
+   * BatchNorm statistics, the bias-gradient column sums and the loss finish inside their first launch (the last
+   * workgroup folds the partials) instead of in a second one: 7 launches fewer per 3-layer step.  ws_loss must then hold
+   * >= 256 * 65 floats for the last layer's bias gradient to ride along (label_dim <= 64).  NULL = two-launch forms. */
+  int32_t* sync_counters;
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,
