@@ -433,13 +433,13 @@ def cpu_baseline(sd, dev, scale, budget):
     to.sage_gcn_agg(ip, ix, x, threads=threads)                                    # page in / warm up
     t0 = time.perf_counter()
     reps = 0
-    while reps < 1 or time.perf_counter() - t0 < 10.0 * budget:
+    while reps < 1 or time.perf_counter() - t0 < 6.0 * budget:
         to.sage_inference(ip, ix, x, layers, norms, threads=threads)
         reps += 1
     t_teacher = (time.perf_counter() - t0) / reps
     t1 = time.perf_counter()
     areps = 0
-    while areps < 1 or time.perf_counter() - t1 < 3.0 * budget:
+    while areps < 1 or time.perf_counter() - t1 < 2.0 * budget:
         to.sage_gcn_agg(ip, ix, x, threads=threads)
         areps += 1
     t_agg = (time.perf_counter() - t1) / areps
@@ -450,7 +450,7 @@ def cpu_baseline(sd, dev, scale, budget):
     a @ xt
     t2 = time.perf_counter()
     sreps = 0
-    while sreps < 1 or time.perf_counter() - t2 < 3.0 * budget:
+    while sreps < 1 or time.perf_counter() - t2 < 2.0 * budget:
         a @ xt
         sreps += 1
     t_sparse = (time.perf_counter() - t2) / sreps
@@ -484,7 +484,7 @@ def cpu_baseline(sd, dev, scale, budget):
     step(0)
     t3 = time.perf_counter()
     steps = 0
-    while steps < 2 or time.perf_counter() - t3 < 8.0 * budget:
+    while steps < 2 or time.perf_counter() - t3 < 6.0 * budget:
         step(steps)
         steps += 1
     t_step = (time.perf_counter() - t3) / steps
