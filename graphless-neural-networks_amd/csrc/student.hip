@@ -182,6 +182,7 @@ constexpr int kBnRows = 128;  // rows per chunk
 constexpr int kRowLanes = 4;
 constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
 constexpr int kUnroll = 8;
+constexpr int kBnGroup = 64;      // partial triples per first-level group of the two-level statistics combine
 constexpr int kManyChunks = 48;   // row chunks above which per-chunk partials are folded by a lane-split pass (> ~6k rows)
 
 struct BnFinArgs {
@@ -190,6 +191,9 @@ struct BnFinArgs {
   const float* ws_cnt; const float* ws_mean; const float* ws_m2; int nparts; int64_t pstride; int64_t rows; int h;
   // emit mode (emit_cnt != NULL): write the combined (count, mean, M2) and stop -- the per-rank triple that is exchanged
   float* emit_cnt; float* emit_mean; float* emit_m2;
+  // group_len > 0 (emit mode only): workgroup (x, y) combines the partials [y*group_len, (y+1)*group_len) and emits triple y
+  // (row y of the emit arrays): the first level of a two-level combine for thousands of row chunks
+  int group_len;
   const float* gamma; const float* beta; float eps; float momentum;
   float* running_mean; float* running_var; int64_t* nbt;
   float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
@@ -211,12 +215,15 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
   const int col = colblock * 64 + lc;
   const int colc = col < a.h ? col : a.h - 1;
   if (colblock == 0 && threadIdx.x == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
+  const int p0 = a.group_len > 0 ? (int)blockIdx.y * a.group_len : 0;
+  const int p1 = a.group_len > 0 ? (p0 + a.group_len < a.nparts ? p0 + a.group_len : a.nparts) : a.nparts;
+  const int64_t eoff = a.group_len > 0 ? (int64_t)blockIdx.y * a.h : 0;
   __shared__ double sh_n[kRowLanes][64], sh_s[kRowLanes][64];
   // combine of the partial (count, mean, M2) triples in double, fixed order, without a loop-carried divide:
   //   N = sum n_k ;  mean = sum n_k*mean_k / N ;  M2 = sum [ M2_k + n_k*(mean_k - mean)^2 ]
   double n = 0.0, sum = 0.0;
 #pragma unroll 4
-  for (int k = rl; k < a.nparts; k += kRowLanes) {
+  for (int k = p0 + rl; k < p1; k += kRowLanes) {
     const double nb = part_count(a, k, colc);
     n += nb;
     sum += nb * (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]);
@@ -229,7 +236,7 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
   __syncthreads();
   double m2 = 0.0;
 #pragma unroll 4
-  for (int k = rl; k < a.nparts; k += kRowLanes) {
+  for (int k = p0 + rl; k < p1; k += kRowLanes) {
     const double nb = part_count(a, k, colc);
     const double dm = (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]) - mean;
     m2 += (double)(COH ? ld_part(&a.ws_m2[(int64_t)k * a.pstride + colc]) : a.ws_m2[(int64_t)k * a.pstride + colc]) + nb * dm * dm;     // nb == 0: an empty slice contributes nothing
@@ -239,9 +246,9 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
   if (rl != 0 || col >= a.h) return;
   m2 = (sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc]);
   if (a.emit_cnt) {
-    a.emit_cnt[col] = (float)n;
-    a.emit_mean[col] = (float)mean;
-    a.emit_m2[col] = (float)m2;
+    a.emit_cnt[eoff + col] = (float)n;
+    a.emit_mean[eoff + col] = (float)mean;
+    a.emit_m2[eoff + col] = (float)m2;
     return;
   }
   if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
@@ -443,16 +450,49 @@ __global__ void chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int 
 // partial lanes per workgroup, lane rl sums partials rl, rl+4, ... (8 independent loads in flight), the four lane sums are
 // folded in fixed order through LDS.  Used when a reduction has MANY row chunks (tens of thousands of rows: the hidden
 // activations of a sampled teacher batch) -- a single thread per column walking them is a chain of ~400 dependent adds.
-__global__ __launch_bounds__(256) void chunk_sum_lanes_kernel(const float* __restrict__ ws1, const float* __restrict__ ws2, int nchunks,
-                                                              int h, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void chunk_sum_lanes_kernel(float* __restrict__ ws1, float* __restrict__ ws2, int nchunks, int h,
+                                                              int slice, float* __restrict__ out) {
+  // blockIdx.y = slice of `slice` consecutive chunks; out == NULL: the slice's sum goes back into its FIRST chunk's slot (an
+  // in-place tree level: no other workgroup reads that slot), else into out[col] (+ out[h + col] for ws2).
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < h ? col : h - 1;
+  const int k0 = blockIdx.y * slice;
+  int k1 = k0 + slice;
+  if (k1 > nchunks) k1 = nchunks;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+  for (int k = k0 + rl; k < k1; k += kRowLanes) {
+    s1 += ws1[(int64_t)k * h + colc];
+    if (ws2) s2 += ws2[(int64_t)k * h + colc];
+  }
+  __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
+  sh1[rl][lc] = s1;
+  sh2[rl][lc] = s2;
+  __syncthreads();
+  if (rl == 0 && col < h) {
+    const float t1 = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), t2 = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
+    if (out) {
+      out[col] = t1;
+      if (ws2) out[h + col] = t2;
+    } else {
+      ws1[(int64_t)k0 * h + col] = t1;
+      if (ws2) ws2[(int64_t)k0 * h + col] = t2;
+    }
+  }
+}
+
+// strided view of the slice sums a tree level left behind: chunk k of the next level = slot k * slice of this one
+__global__ __launch_bounds__(256) void chunk_sum_strided_kernel(const float* __restrict__ ws1, const float* __restrict__ ws2, int nslices,
+                                                                int slice, int h, float* __restrict__ out) {
   const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lc;
   const int colc = col < h ? col : h - 1;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 8
-  for (int k = rl; k < nchunks; k += kRowLanes) {
-    s1 += ws1[(int64_t)k * h + colc];
-    if (ws2) s2 += ws2[(int64_t)k * h + colc];
+  for (int k = rl; k < nslices; k += kRowLanes) {
+    s1 += ws1[(int64_t)k * slice * h + colc];
+    if (ws2) s2 += ws2[(int64_t)k * slice * h + colc];
   }
   __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
   sh1[rl][lc] = s1;
@@ -462,6 +502,21 @@ __global__ __launch_bounds__(256) void chunk_sum_lanes_kernel(const float* __res
     out[col] = (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]);
     if (ws2) out[h + col] = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
   }
+}
+
+// out[0:h] = sum over the nchunks per-chunk partials of ws1 (and out[h:2h] of ws2): one lane-split pass, or -- for the
+// thousands of chunks of a 500k-row activation (products teacher training: a single pass walked ~1000 partials per lane,
+// 1 ms) -- an in-place tree level over slices of 64 chunks followed by the fold of the slice sums.  Fixed summation order.
+static void fold_chunks(float* ws1, float* ws2, int nchunks, int h, float* out, hipStream_t st) {
+  const dim3 cols((h + 63) / 64);
+  constexpr int kSlice = 64;
+  if (nchunks <= 4 * kSlice) {
+    hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3(cols.x, 1), dim3(256), 0, st, ws1, ws2, nchunks, h, nchunks, out);
+    return;
+  }
+  const int nslices = (nchunks + kSlice - 1) / kSlice;
+  hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3(cols.x, nslices), dim3(256), 0, st, ws1, ws2, nchunks, h, kSlice, (float*)nullptr);
+  hipLaunchKernelGGL(chunk_sum_strided_kernel, cols, dim3(256), 0, st, ws1, ws2, nslices, kSlice, h, out);
 }
 
 // send[0:h] = sum_k ws1[k], send[h:2h] = sum_k ws2[k]  (this rank's S1/S2, the 2h floats exchanged in the backward)
@@ -572,7 +627,8 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
   GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
-  GLNN_REQUIRE(workspace_floats >= 2ll * nchunks * h, "glnn_bn_stats_f32: workspace needs >= %lld floats", 2ll * nchunks * h);
+  const int64_t need_ws = 2ll * nchunks * h + (nchunks > 4 * kBnGroup ? 3ll * ((nchunks + kBnGroup - 1) / kBnGroup) * h : 0);
+  GLNN_REQUIRE(workspace_floats >= need_ws, "glnn_bn_stats_f32: workspace needs >= %lld floats", (long long)need_ws);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* ws_mean = workspace;
   float* ws_m2 = workspace + (int64_t)nchunks * h;
@@ -586,6 +642,16 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
     return glnn::check_launch("glnn_bn_stats_f32");
   }
   hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr);
+  if (!g && nchunks > 4 * kBnGroup) {
+    // thousands of row chunks (a 500k-row activation): combine groups of kBnGroup partial triples first (Chan's combine is
+    // associative), then the group triples -- a single level walked ~1000 partials per lane (0.35 ms)
+    const int ngroups = (nchunks + kBnGroup - 1) / kBnGroup;
+    float* grp = workspace + 2ll * nchunks * h;               // [3][ngroups][h]
+    BnFinArgs e = a;
+    e.emit_cnt = grp; e.emit_mean = grp + (int64_t)ngroups * h; e.emit_m2 = grp + 2ll * ngroups * h; e.group_len = kBnGroup;
+    hipLaunchKernelGGL(bn_stats_stage2, dim3(fgrid.x, ngroups), dim3(256), 0, st, e);
+    a.ws_cnt = e.emit_cnt; a.ws_mean = e.emit_mean; a.ws_m2 = e.emit_m2; a.nparts = ngroups; a.pstride = h;
+  }
   if (g) {
     // this rank's (count, mean, M2) -> all-gather -> the same fixed-order combine over the rank triples
     BnFinArgs e = a;
@@ -646,7 +712,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
       a.p1 = g->recv; a.p2 = g->recv + h; a.nparts = g->world; a.pstride = 2ll * h; a.local_part = g->rank;
       a.rows_total = g->rows_out;
     } else if (prereduce) {
-      hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, a.ws1, a.ws2, nchunks, h, totals);
+      fold_chunks(a.ws1, a.ws2, nchunks, h, totals, st);
       a.p1 = totals; a.p2 = totals + h; a.nparts = 1; a.pstride = 0;
     }
     hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
@@ -655,7 +721,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   }
   if (dz_col_sum && !a.counters) {
     if (nchunks > kManyChunks)
-      hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, a.ws3, (const float*)nullptr, nchunks, h, dz_col_sum);
+      fold_chunks(a.ws3, nullptr, nchunks, h, dz_col_sum, st);
     else
       hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws3, nchunks, h, dz_col_sum);
   }
@@ -750,7 +816,7 @@ extern "C" int glnn_col_sum_f32(const float* x, int64_t ldx, int64_t rows, int h
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(col_sum_partial_kernel, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, x, ldx, rows, h, workspace);
   if (nchunks > kManyChunks)
-    hipLaunchKernelGGL(chunk_sum_lanes_kernel, dim3((h + 63) / 64), dim3(256), 0, st, workspace, (const float*)nullptr, nchunks, h, out);
+    fold_chunks(workspace, nullptr, nchunks, h, out, st);
   else
     hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, st, workspace, nchunks, h, out);
   return glnn::check_launch("glnn_col_sum_f32");

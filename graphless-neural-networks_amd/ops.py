@@ -271,7 +271,8 @@ def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=
     if outs is None:
         outs = tuple(torch.empty(h, dtype=torch.float32, device=z.device) for _ in range(4))
     mean, rstd, a_scale, a_shift = outs
-    need = 2 * ((rows + 127) // 128) * h
+    nchunks = (rows + 127) // 128
+    need = 2 * nchunks * h + (3 * ((nchunks + 63) // 64) * h if nchunks > 256 else 0)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.float32, device=z.device)
     rc = _lib.lib().glnn_bn_stats_f32(_p(z), _ld(z), rows, h, _p(gamma), _p(beta), eps, momentum, _p(running_mean),

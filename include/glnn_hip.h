@@ -172,7 +172,8 @@ GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows
  *     eps 1e-5, momentum 0.1, biased batch variance for normalisation, unbiased for running_var).
  *   glnn_bn_stats_f32: from z [rows,h] computes a_scale = gamma*rstd, a_shift = beta - mean*a_scale
  *     (the operand transform the next glnn_gemm_f32 consumes), saves mean/rstd, and updates
- *     running_mean / running_var / num_batches_tracked in place.
+ *     running_mean / running_var / num_batches_tracked in place.  workspace: c = ceil(rows/128) row chunks ->
+ *     >= 2*c*h floats, plus 3*ceil(c/64)*h when c > 256 (two-level combine of the per-chunk statistics).
  *   glnn_bn_relu_bwd_f32: given da (grad wrt the post-ReLU activation) and z, computes
  *     dy = da * [z*a_scale+a_shift > 0], dgamma = sum dy*xhat, dbeta = sum dy and
  *     dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); in place on da allowed.

@@ -8,13 +8,17 @@ from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
 from glnn_amd.models import Model
 dev = "cuda:0"
 torch.manual_seed(0)
-g = data.make_graph("ogbn-arxiv", seed=0, device=dev)
+# reference train.conf.yaml:170-177 (arxiv: B=512, dropout 0.2, lr 0.01) / :196-204 (products: B=4096, dropout 0.5, lr 0.003)
+CFG = {"ogbn-arxiv": dict(f=128, c=40, B=512, p=0.2, lr=0.01, n_train=90941), "ogbn-products": dict(f=100, c=47, B=4096, p=0.5, lr=0.003, n_train=196615)}
+name = sys.argv[1] if len(sys.argv) > 1 else "ogbn-arxiv"
+c = CFG[name]
+g = data.make_graph(name, seed=0, device=dev)
 n = g.n_dst
-feats, labels, _, _ = data.make_node_data("ogbn-arxiv", seed=0, device=dev, n=n)
-model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=128, hidden_dim=256, label_dim=40, dropout_ratio=0.2, norm_type="batch", device=dev))
-opt = torch.optim.Adam(model.parameters(), lr=0.01)
-idx_train = torch.randperm(n)[:90941].to(dev)
-loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=True, drop_last=False)
+feats, labels, _, _ = data.make_node_data(name, seed=0, device=dev, n=n)
+model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=c["f"], hidden_dim=256, label_dim=c["c"], dropout_ratio=c["p"], norm_type="batch", device=dev))
+opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
+idx_train = torch.randperm(n)[:c["n_train"]].to(dev)
+loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=c["B"], shuffle=True, drop_last=False)
 crit = torch.nn.NLLLoss()
 for ep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -28,7 +32,7 @@ n_b = 0
 for b in loader:
     n_b += 1
     last = b
-    if n_b == 50:
+    if n_b == min(50, len(loader)):
         break
 torch.cuda.synchronize(); t_s = (time.perf_counter() - t0) / n_b
 from glnn_amd import teacher

@@ -295,7 +295,7 @@ def test_log_softmax():
 
 
 # ------------------------------------------------------------------------------------------- K5
-@pytest.mark.parametrize("rows,h", [(512, 256), (4096, 300), (100, 64), (129, 70)])
+@pytest.mark.parametrize("rows,h", [(512, 256), (4096, 300), (100, 64), (129, 70), (40000, 70), (7000, 256)])   # 40000 rows: two-level folds
 def test_bn_stats_and_backward_vs_oracle(rows, h):
     from glnn_amd import ops
     r = np.random.RandomState(rows)
