@@ -324,13 +324,14 @@ def test_bn_stats_and_backward_vs_oracle(rows, h):
     dz_w = gamma * cache["rstd"][0] * (dy - s1 / rows - xhat * (s2 / rows))
     dzsum = torch.empty(h, device=DEV)
     dz, dg, db = ops.bn_relu_bwd(dev(da), dev(z), dev(gamma), mean, rstd, a_sc, a_sh, dz_col_sum=dzsum)
-    np.testing.assert_allclose(dzsum.cpu().numpy(), dz_w.astype(np.float64).sum(0), atol=2e-4, rtol=0)
-    np.testing.assert_allclose(dg.cpu().numpy(), s2, atol=2e-4, rtol=1e-5)
-    np.testing.assert_allclose(db.cpu().numpy(), s1, atol=2e-4, rtol=1e-5)
+    # the column sums of dz are mathematically ZERO behind a BatchNorm: what is compared is fp32 summation noise, ~ rows * 1e-8
+    np.testing.assert_allclose(dzsum.cpu().numpy(), dz_w.astype(np.float64).sum(0), atol=2e-4 * max(1.0, rows / 4096), rtol=0)
+    np.testing.assert_allclose(dg.cpu().numpy(), s2, atol=2e-4 * max(1.0, rows / 4096), rtol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), s1, atol=2e-4 * max(1.0, rows / 4096), rtol=1e-5)
     np.testing.assert_allclose(dz.cpu().numpy(), dz_w, atol=TOL, rtol=0)
     dz2, _, _ = ops.bn_relu_bwd(dev(da), dev(z), dz_col_sum=dzsum)
     np.testing.assert_array_equal(dz2.cpu().numpy(), da * (z > 0))
-    np.testing.assert_allclose(dzsum.cpu().numpy(), (da * (z > 0)).astype(np.float64).sum(0), atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(dzsum.cpu().numpy(), (da * (z > 0)).astype(np.float64).sum(0), atol=2e-4 * max(1.0, rows / 4096), rtol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------- K6
