@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; 1.0 = the metric's config)")
     ap.add_argument("--student-steps-per-step", type=int, default=30, help="student steps timed per --steps unit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the sampled-block teacher-training object (N = 1)")
     ap.add_argument("--student-global-bn", action="store_true",
                     help="N > 1: take the student's BatchNorm batch statistics over the global (N x B rows) batch through the "
                          "exchange hook, i.e. exactly the single-GPU step on that batch (default: per-rank statistics)")
@@ -270,6 +271,10 @@ def main():
         if args.reorder != "none":
             result["roofline_reordered"] = reordered_leg(args, g, feats, teacher, FullNeighborLoader, ops, data)
 
+    # ---- sampled-block teacher TRAINING (SURVEY 8f rows 1+2; reference train_sage, train_and_eval.py:32-56) -- an extra object ----
+    if world == 1 and not args.no_train_leg:
+        result["teacher_training"] = teacher_training_leg(g, feats, labels, dev, data)
+
     # ---- CPU baseline on the host cores (oracle = 'port'; bounded sample) ---------------------------------
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, dev, min(CPU_SAMPLE_SCALE, args.scale), 1.0 if args.scale >= 1.0 else 0.1)
@@ -277,6 +282,39 @@ def main():
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def teacher_training_leg(g, feats, labels, dev, data):
+    """Epochs of the reference's train_sage on the bench graph with the reference's config for it (train.conf.yaml:170-177 /
+    196-204: fan-out 5,10,15; B=512 dropout 0.2 lr 0.01 on arxiv, B=4096 dropout 0.5 lr 0.003 on products): neighbour sampling
+    and block building on the device (one batch ahead on a side stream), forward + NLL + backward + Adam on TeacherEngine."""
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    prod = GRAPH == "ogbn-products"
+    bsz, p, lr = (4096, 0.5, 0.003) if prod else (512, 0.2, 0.01)
+    n = g.n_dst
+    n_train = max(bsz, int(n * (196615 / 2449029 if prod else 90941 / 169343)))
+    torch.manual_seed(0)
+    model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1], label_dim=SAGE_DIMS[-1],
+                       dropout_ratio=p, norm_type="batch", device=dev))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    idx_train = torch.randperm(n)[:n_train].to(dev)
+    loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=bsz, shuffle=True, drop_last=False)
+    crit = torch.nn.NLLLoss()
+    losses = [te.train_sage(model, loader, feats, labels, crit, opt)]            # warm-up epoch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    epochs = 3
+    for _ in range(epochs):
+        losses.append(te.train_sage(model, loader, feats, labels, crit, opt))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = epochs * len(loader)
+    return {"metric": f"sampled-block GraphSAGE training steps/s ({GRAPH}-shaped graph, fan-out 5,10,15, B={bsz}, dropout {p}, BN; "
+                      "sampling + block building + forward + NLL + backward + Adam, all on the device)",
+            "value": steps / dt, "unit": "steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "epoch_s": dt / epochs,
+            "train_nodes": n_train, "loss_first_last": [losses[0], losses[-1]]}
 
 
 def roofline_object(timing, nnz, n, with_traffic):

@@ -6,6 +6,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +35,8 @@ def test_bench_single_gpu_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert cb["aggregation_torch_sparse_csr_edges_per_s"] > 0 and cb["student_steps_per_s"] > 0 and "PyTorch CPU ops" in cb["student_kind"]
     assert out["student"]["value"] > 0
+    tt = out["teacher_training"]
+    assert tt["value"] > 0 and tt["unit"] == "steps/s" and all(np.isfinite(tt["loss_first_last"]))
     rr = out["roofline_reordered"]
     assert rr["order"].startswith("nodes renumbered") and rr["edges_per_s"] > 0 and rr["traffic"] is None
 
