@@ -322,22 +322,23 @@ def roofline_object(timing, nnz, n, with_traffic):
     torch.cuda.synchronize()
     per = {}
     for name, info, s, e in timing:
-        key = (name, info.get("d", info.get("n")), info.get("d_out", info.get("k")))
+        key = (name, info.get("d", info.get("n")), info.get("d_out", info.get("k")), info.get("d_chain", 0), info.get("d_written"))
         per.setdefault(key, []).append(s.elapsed_time(e))
     layers, tot_b, tot_ms = [], 0.0, 0.0
-    for (name, d, d_out), ms in per.items():
+    for (name, d, d_out, d_chain, d_written), ms in per.items():
         if name not in ("spmm", "sage_fused"):
             continue
         fused = name == "sage_fused"
-        b = alg_bytes(nnz, n, d, d_out if fused else None)
+        b = alg_bytes(nnz, n, d, (d_written if d_written is not None else d_out) if fused else None)     # bytes actually written per row
         avg = float(np.mean(ms))
-        layers.append({"kernel": (f"sage_fused_kernel<LPR={lanes_per_row(((d + 7) // 8) * 8)},U={SPMM_U}> (aggregate {d} wide + project to {d_out} on MFMA)"
+        layers.append({"kernel": (f"sage_fused_kernel<LPR={lanes_per_row(((d + 7) // 8) * 8)},U={SPMM_U}> (aggregate {d} wide + project to {d_out} on MFMA"
+                                  + (f", then to {d_chain} for the next layer: only those {d_written} floats per row are written)" if d_chain else ")")
                                   if fused else f"spmm_csr_kernel<LPR={lanes_per_row(d)},U={SPMM_U},SAGE_GCN>"),
                        "d": d, "avg_ms": avg, "alg_GB": b / 1e9, "GBps": b / avg / 1e6, "launches": len(ms),
                        "Gedges_per_s": nnz / avg / 1e6})
         tot_b += b
         tot_ms += avg
-    gemm_ms = sum(float(np.mean(ms)) for (name, _, _), ms in per.items() if name == "gemm")
+    gemm_ms = sum(float(np.mean(ms)) for (name, *_), ms in per.items() if name == "gemm")
     dom = max(layers, key=lambda r: r["avg_ms"])
     traffic = pmc_traffic(dom["kernel"].split(">")[0] + ">") if with_traffic else None
     return {

@@ -267,7 +267,10 @@ struct FusedArgs {
   const float* x_self; int64_t ld_self;
   const float* w_packed; int d_out; int kgroups;      // kgroups = ceil(d_in / 8)
   const float* ep_scale; const float* ep_shift; int relu;
-  float* out; int64_t ldo;
+  float* out; int64_t ldo;                              // may be NULL when the chained projection below is the only consumer
+  // optional chained projection: out2 = epi(...) @ W2^T for the NEXT layer when that layer projects first (in > out): the
+  // hidden rows go from the MFMA accumulators through LDS into a second MFMA pass and never reach HBM
+  const float* w2_packed; int d_out2; int kgroups2; float* out2; int64_t ldo2;
 };
 
 template <int LPR, int U, int RT>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains
@@ -348,57 +351,98 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
   // ---- phase B: [32*RT x K] (LDS) x W panel `wave` (packed, L2) on the MFMA -------------------------
   const int n_tiles = (a.d_out + 31) / 32;
   const int nt = wave;                                 // column panel of W
-  if (nt >= n_tiles) return;
+  const bool chain = a.w2_packed != nullptr;
+  if (nt >= n_tiles && !chain) return;
   const int li = lane & 31, kk = lane >> 5;
-  const float4* wp = reinterpret_cast<const float4*>(a.w_packed) + ((int64_t)nt * a.kgroups) * 64 + lane;
-  const float* ap = lds_a + li * lda + kk * 4;
   f32x16 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  constexpr int PF = 4;                      // B fragments in flight
-  float4 bq[PF];
+  if (nt < n_tiles) {
+    const float4* wp = reinterpret_cast<const float4*>(a.w_packed) + ((int64_t)nt * a.kgroups) * 64 + lane;
+    const float* ap = lds_a + li * lda + kk * 4;
+    constexpr int PF = 4;                      // B fragments in flight
+    float4 bq[PF];
 #pragma unroll
-  for (int q = 0; q < PF; ++q) bq[q] = (q < a.kgroups) ? wp[(int64_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int kg0 = 0; kg0 < a.kgroups; kg0 += PF) {
+    for (int q = 0; q < PF; ++q) bq[q] = (q < a.kgroups) ? wp[(int64_t)q * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kg0 = 0; kg0 < a.kgroups; kg0 += PF) {
 #pragma unroll
-    for (int q = 0; q < PF; ++q) {
-      const int kg = kg0 + q;
-      if (kg < a.kgroups) {
-        const float4 bv = bq[q];
-        const int nxt = kg + PF;
-        if (nxt < a.kgroups) bq[q] = wp[(int64_t)nxt * 64];
-        float4 av[RT];
+      for (int q = 0; q < PF; ++q) {
+        const int kg = kg0 + q;
+        if (kg < a.kgroups) {
+          const float4 bv = bq[q];
+          const int nxt = kg + PF;
+          if (nxt < a.kgroups) bq[q] = wp[(int64_t)nxt * 64];
+          float4 av[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) av[t] = *reinterpret_cast<const float4*>(ap + t * 32 * lda + kg * 8);
+          for (int t = 0; t < RT; ++t) av[t] = *reinterpret_cast<const float4*>(ap + t * 32 * lda + kg * 8);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv.x, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].x, bv.x, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv.y, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].y, bv.y, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv.z, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].z, bv.z, acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv.w, acc[t], 0, 0, 0);
+          for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t].w, bv.w, acc[t], 0, 0, 0);
+        }
       }
     }
   }
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) -----
   const int col = nt * 32 + li;
-  if (col < a.d_out) {
-    const float es = a.ep_scale ? a.ep_scale[col] : 1.f;
-    const float eh = a.ep_shift ? a.ep_shift[col] : 0.f;
+  const int ldh = a.kgroups2 * 8 + 4;                  // row stride of the hidden tile parked in LDS for the chained pass
+  if (chain) __syncthreads();                          // every wave is done reading the aggregate tile: the LDS is reused
+  if (nt < n_tiles) {
+    const bool col_ok2 = col < a.d_out;
+    const float es = (a.ep_scale && col_ok2) ? a.ep_scale[col] : 1.f;
+    const float eh = (a.ep_shift && col_ok2) ? a.ep_shift[col] : 0.f;
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (row < a.n_dst) {
-          float v = fmaf(acc[t][r], es, eh);
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[row * a.ldo + col] = v;
-        }
+        const int lr = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int64_t row = row0 + lr;
+        float v = fmaf(acc[t][r], es, eh);
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (!col_ok2) v = 0.f;
+        if (a.out && col_ok2 && row < a.n_dst) a.out[row * a.ldo + col] = v;
+        if (chain && col < a.kgroups2 * 8) lds_a[lr * ldh + col] = v;
       }
+  }
+  if (!chain) return;
+  __syncthreads();
+  // ---- phase C: [32*RT x d_out] hidden tile (LDS) x W2 panel `wave` on the MFMA -> out2 ----------------
+  const int n_tiles2 = (a.d_out2 + 31) / 32;
+  if (nt >= n_tiles2) return;
+  {
+    const float4* wp = reinterpret_cast<const float4*>(a.w2_packed) + ((int64_t)nt * a.kgroups2) * 64 + lane;
+    const float* ap = lds_a + li * ldh + kk * 4;
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int kg = 0; kg < a.kgroups2; ++kg) {
+      const float4 bv = wp[(int64_t)kg * 64];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const float4 av = *reinterpret_cast<const float4*>(ap + t * 32 * ldh + kg * 8);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+      }
+    }
+    const int col2 = nt * 32 + li;
+    if (col2 < a.d_out2) {
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+          if (row < a.n_dst) a.out2[row * a.ldo2 + col2] = acc[t][r];
+        }
+    }
   }
 }
 
@@ -554,13 +598,15 @@ extern "C" int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int 
 extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
                                    int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
                                    int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
-                                   int64_t ldo, void* stream) {
+                                   int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, void* stream) {
   if (n_dst == 0) return GLNN_OK;
-  GLNN_REQUIRE(indptr && x && x_self && w_packed && out, "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
+  GLNN_REQUIRE(indptr && x && x_self && w_packed && (out || w2_packed), "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
+  GLNN_REQUIRE(!w2_packed || (out2 && d_out2 >= 1 && d_out2 <= 256 && ldo2 >= d_out2 && glnn::aligned16(w2_packed)),
+               "glnn_sage_fused_f32: the chained projection needs out2 with ldo2 >= d_out2 in [1,256]");
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_sage_fused_f32: bad n_dst/n_src");
   GLNN_REQUIRE(d_in >= 1 && d_in <= 256 && d_out >= 1 && d_out <= 256, "glnn_sage_fused_f32: d_in and d_out must be in [1,256]");
   const int dpad = (d_in + 3) & ~3;
-  GLNN_REQUIRE(ldx % 4 == 0 && ldx >= dpad && ld_self % 4 == 0 && ld_self >= dpad && ldo >= d_out,
+  GLNN_REQUIRE(ldx % 4 == 0 && ldx >= dpad && ld_self % 4 == 0 && ld_self >= dpad && (!out || ldo >= d_out),
                "glnn_sage_fused_f32: leading dimensions (ldx, ld_self multiples of 4 and >= %d; ldo >= d_out)", dpad);
   GLNN_REQUIRE(glnn::aligned16(x) && glnn::aligned16(x_self) && glnn::aligned16(w_packed), "glnn_sage_fused_f32: 16-byte alignment required");
   if (n_dst == 0) return GLNN_OK;
@@ -568,12 +614,14 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.d_in = d_in; a.x_self = x_self;
   a.ld_self = ld_self; a.w_packed = w_packed; a.d_out = d_out; a.kgroups = (d_in + 7) / 8; a.ep_scale = ep_scale;
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
+  a.w2_packed = w2_packed; a.d_out2 = w2_packed ? d_out2 : 0; a.kgroups2 = w2_packed ? (d_out + 7) / 8 : 0; a.out2 = out2; a.ldo2 = ldo2;
   static const int rt_env = getenv("GLNN_FUSED_RT") ? atoi(getenv("GLNN_FUSED_RT")) : 0;   // tuning override (1 or 2)
   const int rt = rt_env ? rt_env : 1;
   const int rows_per_wg = 32 * rt;
   const int64_t blocks = (n_dst + rows_per_wg - 1) / rows_per_wg;
   GLNN_REQUIRE(blocks < ((int64_t)1 << 31), "glnn_sage_fused_f32: n_dst too large for one launch");
-  const size_t smem = sizeof(float) * rows_per_wg * (a.kgroups * 8 + 4);
+  const int kg_lds = a.kgroups2 > a.kgroups ? a.kgroups2 : a.kgroups;      // the hidden tile of the chained pass reuses the aggregate tile
+  const size_t smem = sizeof(float) * rows_per_wg * (kg_lds * 8 + 4);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int dv = dpad / 4;
   // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)

@@ -163,6 +163,8 @@ class SAGE(nn.Module):
                         h = _eval_tail(self, l, h)
         return h_list, h
 
+    CHAIN_NEXT_PROJECTION = True      # A/B switch of the chained projection in `inference`
+
     def _tail(self, l):
         """Fused eval tail of layer l: (ep_scale, ep_shift, relu) = BN(eval) o (+bias) o ReLU; dropout is a no-op."""
         bias = self.layers[l].fc_neigh.bias
@@ -188,11 +190,27 @@ class SAGE(nn.Module):
         whole_graph = whole_graph and getattr(dataloader, "graph", None) is not None     # loaders that do not sweep arange(N)
         with torch.no_grad():
             x = ops.as_feat(feats)
+            projected = None          # x @ W_l^T handed over by the previous (fused) layer when layer l projects first
             for l, layer in enumerate(self.layers):
                 ep_scale, ep_shift, relu = self._tail(l)
                 if whole_graph:
                     g = dataloader.graph
-                    y = layer(g, (x, x[: g.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                    n = g.num_dst_nodes()
+                    nxt = self.layers[l + 1] if l + 1 < self.num_layers else None
+                    if projected is not None:
+                        # the dense half of this layer already came out of the previous layer's kernel: aggregate + epilogue only
+                        y = ops.spmm(g.indptr, g.indices, projected, n, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                        projected = None
+                    elif nxt is not None and layer.fused_eligible() and nxt._in_feats > nxt._out_feats and nxt._out_feats <= 256 \
+                            and SAGE.CHAIN_NEXT_PROJECTION:
+                        # layer l aggregates first in the fused kernel and layer l+1 projects first: chain W_{l+1} behind the
+                        # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
+                        _, projected = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale,
+                                                      ep_shift=ep_shift, relu=relu, x_self=x[:n], w_next=nxt.fc_neigh.weight,
+                                                      want_out=False)
+                        y = x                                                    # (not read: the next layer consumes `projected`)
+                    else:
+                        y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
                 else:
                     d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
                     y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132

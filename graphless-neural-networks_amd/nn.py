@@ -32,6 +32,10 @@ class SAGEConv(nn.Module):
     def reset_parameters(self):
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=nn.init.calculate_gain("relu"))
 
+    def fused_eligible(self):
+        """Aggregate-first layers with d_in, d_out <= 256 run on the single-launch K1F kernel."""
+        return self._in_feats <= self._out_feats and self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256
+
     def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False):
         """out = fc_neigh((sum_{u->v} h[u] + h_dst[v]) / (deg(v)+1)).  ep_* / relu: optional fused tail
         (eval-mode BatchNorm + ReLU of the caller) used by SAGE.inference; bias is folded by the caller then."""

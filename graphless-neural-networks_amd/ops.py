@@ -141,9 +141,12 @@ def pack_weight(w):
     return wp
 
 
-def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None):
-    """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256)."""
-    _need_cuda(indptr, indices, x, w, ep_scale, ep_shift, out, x_self)
+def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
+               w_next=None, out_next=None, want_out=True):
+    """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256).
+    w_next [d_out2, d_out]: also returns (.. , out @ w_next.T) -- the projection of the NEXT layer when it projects first;
+    with want_out=False the hidden rows themselves are not written at all (returns (None, projected))."""
+    _need_cuda(indptr, indices, x, w, ep_scale, ep_shift, out, x_self, w_next, out_next)
     x = as_feat(x)
     x_self = x if x_self is None else as_feat(x_self)
     n_src, d_in = x.shape
@@ -152,14 +155,22 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
         raise ValueError("sage_fused: weight must be [d_out, d_in]")
     if w_packed is None:
         w_packed = pack_weight(w)
-    if out is None:
+    if out is None and (want_out or w_next is None):
         out = feat_empty(n_dst, d_out, x.device)
-    with _Timed("sage_fused", d=d_in, n_dst=n_dst, d_out=d_out):
+    w2p, d_out2 = None, 0
+    if w_next is not None:
+        if w_next.shape[1] != d_out:
+            raise ValueError("sage_fused: w_next must be [d_out2, d_out]")
+        w2p, d_out2 = pack_weight(w_next), w_next.shape[0]
+        if out_next is None:
+            out_next = feat_empty(n_dst, d_out2, x.device)
+    with _Timed("sage_fused", d=d_in, n_dst=n_dst, d_out=d_out, d_chain=d_out2, d_written=(d_out if out is not None else 0) + d_out2):
         rc = _lib.lib().glnn_sage_fused_f32(_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d_in, _p(x_self), _ld(x_self),
                                             _p(w_packed), d_out, _p(_vec(ep_scale, d_out, "ep_scale")),
-                                            _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out), _stream())
+                                            _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out) if out is not None else 0,
+                                            _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _stream())
     _lib.check(rc, "glnn_sage_fused_f32")
-    return out
+    return out if w_next is None else (out, out_next)
 
 
 DEG_RAW, DEG_RSQRT_CLAMP1, DEG_INV_PLUS1 = 0, 1, 2

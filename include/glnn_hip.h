@@ -84,11 +84,17 @@ GLNN_API int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, in
 GLNN_API int64_t glnn_packed_weight_floats(int d_out, int d_in);
 GLNN_API int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int d_in, float* w_packed,
                                   void* stream);
+/* Optional chained projection (w2_packed != NULL: W2 [d_out2, d_out] packed like W): additionally
+ *   out2[v,:] = out[v,:] @ W2^T   (no epilogue)
+ * i.e. the dense half of the NEXT layer when that layer projects first (in > out, models.py:138 on the last layer of the
+ * products / arxiv teachers): the hidden row goes from the MFMA accumulators through LDS into a second MFMA pass; with
+ * out == NULL it never reaches HBM at all. */
 GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
                                  int64_t n_src, const float* x, int64_t ldx, int d_in,
                                  const float* x_self, int64_t ld_self, const float* w_packed,
                                  int d_out, const float* ep_scale, const float* ep_shift, int relu,
-                                 float* out, int64_t ldo, void* stream);
+                                 float* out, int64_t ldo, const float* w2_packed, int d_out2,
+                                 float* out2, int64_t ldo2, void* stream);
 
 /* in_deg[v] = t(indptr[v+1]-indptr[v]); out_deg[u] = t(#edges with source u), as floats, t = `transform`:
  *   GLNN_DEG_RAW          the degree itself            g.in_degrees() / g.out_degrees()

@@ -110,6 +110,28 @@ def test_sage_fused_vs_oracle(n, d_in, d_out):
     np.testing.assert_allclose(plain.cpu().numpy(), to.linear(to.sage_gcn_agg(indptr, indices, x), w), atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("n,d_in,d_out,d2", [(3000, 256, 256, 47), (1001, 128, 256, 40), (500, 20, 32, 5), (333, 100, 200, 64), (70, 7, 9, 3)])
+def test_sage_fused_chained_projection_vs_oracle(n, d_in, d_out, d2):
+    """K1F with the NEXT layer's projection chained behind its epilogue (hidden rows never leave the workgroup):
+    out2 = relu(bn(agg @ W^T)) @ W2^T, with and without also writing the hidden rows."""
+    from glnn_amd import ops
+    indptr, indices = random_graph(n, 8, seed=d_in + d2, power=0.6, isolated=3, hub=500)
+    r = np.random.RandomState(d_out)
+    x = r.standard_normal((n, d_in)).astype(np.float32)
+    w = (r.standard_normal((d_out, d_in)) / np.sqrt(d_in)).astype(np.float32)
+    w2 = (r.standard_normal((d2, d_out)) / np.sqrt(d_out)).astype(np.float32)
+    sc, sh = r.uniform(.5, 1.5, d_out).astype(np.float32), r.uniform(-.5, .5, d_out).astype(np.float32)
+    agg = to.sage_gcn_agg(indptr, indices, x)
+    hid = np.maximum(to.linear(agg, w) * sc + sh, 0)
+    want2 = to.linear(hid, w2)
+    h, p2 = ops.sage_fused(dev(indptr), dev(indices), dev(x), n, dev(w), ep_scale=dev(sc), ep_shift=dev(sh), relu=True, w_next=dev(w2))
+    np.testing.assert_allclose(h.cpu().numpy(), hid, atol=TOL, rtol=1e-5)
+    np.testing.assert_allclose(p2.cpu().numpy(), want2, atol=TOL, rtol=1e-5)
+    none, p3 = ops.sage_fused(dev(indptr), dev(indices), dev(x), n, dev(w), ep_scale=dev(sc), ep_shift=dev(sh), relu=True, w_next=dev(w2),
+                              want_out=False)
+    assert none is None and torch.equal(p3, p2)
+
+
 def test_degrees():
     from glnn_amd import ops
     n = 1000
