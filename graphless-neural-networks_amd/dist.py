@@ -252,12 +252,14 @@ class ShardedTeacher:
                 xs = self._chunk_self(x, layout, c)
                 ip = g.indptr[off:off + nr + 1]
                 es, eh, rl = tail1
-                if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256:
-                    be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr], x_self=xs)
+                if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256 and d_out <= 256:
+                    # aggregate + project + tail + the NEXT layer's projection in one launch: layer l's rows never reach HBM
+                    be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
+                                  want_out=False)
                 else:
                     agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
                     be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
-                be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
+                    be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
         out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l + 1), d_out, x.device)
         for wk in works:
