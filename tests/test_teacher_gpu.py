@@ -391,3 +391,78 @@ def test_unsupported_teacher_configurations_raise():
                             torch.optim.Adam(cpu_model.parameters()))
     with pytest.raises(Exception):
         cpu_model(None, torch.randn(4, 8))                    # no CPU forward either
+
+
+def test_train_sage_step_with_dropout_matches_oracle_given_the_masks():
+    """Dropout 0.5 in the sampled-block step: the engine's counter-based masks (per hidden layer, keyed by the activation's
+    row / column) restated in numpy and fed to the oracle -> same loss and gradients."""
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    from oracle import student_oracle as so
+    from oracle.dropout_mask import keep_mask
+    z, batches = teacher_training()
+    dims = [int(d) for d in z["sage.dims"]]
+    feats, labels = z["sage.feats"], z["sage.labels"]
+    inp, outn, blks = batches[1]
+    p = 0.5
+    for norm in ("batch", "none"):
+        torch.manual_seed(4)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type=norm, device=DEV))
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sub_dict(z, f"sage.{norm}.init.").items()})
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=0.0)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        blocks = [_graph(ip, ix, ns) for ip, ix, ns in blks]
+        eng.step_sage(blocks, ops.as_feat(torch.from_numpy(feats).to(DEV)), torch.from_numpy(labels).to(DEV), torch.from_numpy(outn).to(DEV), 1.0,
+                      input_nodes=torch.from_numpy(inp).to(DEV))
+        masks = [keep_mask(len(blks[l][0]) - 1, dims[l + 1], p, eng._seed(l)).astype(np.float32) for l in range(2)]   # step_count == 1
+        assert all(abs(m.mean() - (1 - p)) < 0.1 for m in masks)
+        st = tt.TeacherState(sub_dict(z, f"sage.{norm}.init."), "sage", 3, norm)
+        logits, cache = tt.sage_forward(st, blks, feats[inp], masks=masks, p=p)
+        loss, dl = so.loss_and_dlogits(logits, labels[outn], "nll", 1.0)
+        assert abs(eng.loss_out.item() - float(loss)) < TOL
+        for (pname, prm), gr in zip(model.named_parameters(), tt.sage_backward(st, cache, dl, p=p)):
+            if norm == "batch" and pname.endswith("fc_neigh.bias") and not pname.startswith("encoder.layers.2"):
+                continue            # zero true gradient in front of a BatchNorm: both sides hold rounding noise
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=2e-5, rtol=1e-4, err_msg=f"{norm} {pname}")
+
+
+def test_full_size_products_training_epoch_properties():
+    """The reference's products teacher config at FULL size (reference train.conf.yaml:196-204: fan-out 5,10,15, B=4096,
+    dropout 0.5, BatchNorm, lr 0.003) on the 2.45 M-node / 124 M-edge products-shaped graph: block invariants on the biggest
+    blocks the path sees (hundreds of thousands of destinations), finite losses, BatchNorm / Adam counters in step."""
+    from glnn_amd import data
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    torch.manual_seed(0)
+    g = data.make_graph("ogbn-products", seed=0, device=DEV)
+    n = g.n_dst
+    feats, labels, _, _ = data.make_node_data("ogbn-products", seed=0, device=DEV, n=n)
+    idx_train = torch.randperm(n)[:40960].to(DEV)
+    loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=4096, shuffle=True, drop_last=False)
+    input_nodes, output_nodes, blocks = next(iter(loader))
+    assert len(output_nodes) == 4096 and blocks[2].num_dst_nodes() == 4096 and int(blocks[2].in_degrees().max()) <= 15
+    assert int(blocks[0].in_degrees().max()) <= 5 and blocks[0].num_src_nodes() == len(input_nodes) > 500_000
+    assert torch.equal(input_nodes[:4096], output_nodes)
+    assert int(torch.unique(input_nodes).numel()) == len(input_nodes)                       # a node appears once among the sources
+    assert torch.equal(input_nodes[blocks[0].indices.long()], blocks[0].gindices.long())
+    e = torch.randint(0, blocks[0].num_edges(), (2000,), device=DEV)                          # sampled edges are edges of the graph
+    dst_of = torch.searchsorted(blocks[0].indptr, e, right=True) - 1
+    v, u = input_nodes[dst_of], blocks[0].gindices[e].long()
+    lo, hi = g.indptr[v], g.indptr[v + 1]
+    hit = torch.zeros(2000, dtype=torch.bool, device=DEV)
+    for k in range(int((hi - lo).max())):
+        pos = (lo + k).clamp(max=g.num_edges() - 1)
+        hit |= (k < (hi - lo)) & (g.indices[pos].long() == u)
+    assert bool(hit.all())
+    model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=100, hidden_dim=256, label_dim=47, dropout_ratio=0.5, norm_type="batch",
+                       device=DEV))
+    opt = torch.optim.Adam(model.parameters(), lr=0.003)
+    l1 = te.train_sage(model, loader, feats, labels, torch.nn.NLLLoss(), opt)
+    l2 = te.train_sage(model, loader, feats, labels, torch.nn.NLLLoss(), opt)
+    assert np.isfinite(l1) and np.isfinite(l2) and 3.0 < l2 < 5.0            # ln(47) = 3.85: random labels cannot be learnt
+    assert int(model.encoder.norms[0].num_batches_tracked) == 20 and int(opt.state[next(model.parameters())]["step"]) == 20
+    assert all(torch.isfinite(p).all() for p in model.parameters())
