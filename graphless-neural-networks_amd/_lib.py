@@ -15,6 +15,7 @@ c_i64, c_int, c_f32, c_vp, c_u32 = ctypes.c_int64, ctypes.c_int, ctypes.c_float,
 SIGNATURES = {
     "glnn_abi_version": [],
     "glnn_device_info": [c_vp, c_vp, c_vp, c_int],
+    "glnn_struct_bytes": [c_int],
     "glnn_spmm_csr_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
                           c_int, c_vp, c_i64, c_vp],
     "glnn_packed_weight_floats": [c_int, c_int],
@@ -36,6 +37,7 @@ SIGNATURES = {
     "glnn_col_sum_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
+    "glnn_sage_fwd_bwd_f32": [c_vp, c_vp],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
@@ -73,6 +75,29 @@ class MlpStepDesc(ctypes.Structure):
                  ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp)])
 
 
+SAGE_MAX_LAYERS = 8
+
+
+class SageLayer(ctypes.Structure):
+    """glnn_sage_layer of include/glnn_hip.h (field for field)."""
+    _fields_ = ([("indptr", c_vp), ("indices", c_vp), ("n_dst", c_i64), ("n_src", c_i64), ("nnz", c_i64), ("self_rows", c_vp)] +
+                [(n, c_vp) for n in ("w", "b", "gw", "gb", "gamma", "beta", "ggamma", "gbeta", "running_mean", "running_var", "nbt",
+                                     "mean", "rstd", "a_scale", "a_shift")] +
+                [("agg", c_vp), ("ld_agg", c_i64), ("z", c_vp), ("ldz", c_i64), ("h", c_vp), ("ldh", c_i64),
+                 ("t_indptr", c_vp), ("t_indices", c_vp), ("inv_deg", c_vp), ("tr_ws", c_vp), ("tr_ws_bytes", c_i64), ("drop_seed", c_u32)])
+
+
+class SageStepDesc(ctypes.Structure):
+    """glnn_sage_step_desc of include/glnn_hip.h (field for field)."""
+    _fields_ = [("num_layers", ctypes.c_int32), ("batchnorm", ctypes.c_int32), ("dims", ctypes.c_int32 * (SAGE_MAX_LAYERS + 1)),
+                ("dropout_p", c_f32), ("bn_eps", c_f32), ("bn_momentum", c_f32), ("lamb", c_f32),
+                ("layer", SageLayer * SAGE_MAX_LAYERS),
+                ("x", c_vp), ("ldx", c_i64), ("x_rows", c_i64), ("labels", c_vp), ("label_rows", c_vp),
+                ("dlogits", c_vp), ("ld_dlogits", c_i64), ("dagg", c_vp), ("ld_dagg", c_i64), ("dh", c_vp), ("ld_dh", c_i64),
+                ("ws_bn", c_vp), ("ws_bn_floats", c_i64), ("ws_tn", c_vp), ("ws_tn_floats", c_i64), ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64),
+                ("ws_loss", c_vp), ("ws_loss_floats", c_i64), ("loss_out", c_vp), ("loss_accum", c_vp)]
+
+
 _lib = None
 
 
@@ -97,12 +122,17 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
         h.glnn_packed_weight_floats.restype = c_i64
+        h.glnn_struct_bytes.restype = c_i64
         h.glnn_block_workspace_bytes.restype = c_i64
         h.glnn_csr_transpose_workspace_bytes.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
         if h.glnn_abi_version() != ABI_VERSION:
             raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
+        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer)):
+            if h.glnn_struct_bytes(which) != ctypes.sizeof(mirror):
+                raise GlnnError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {h.glnn_struct_bytes(which)} in the library, "
+                                f"{ctypes.sizeof(mirror)} in this binding")
         _lib = h
     return _lib
 

@@ -53,6 +53,13 @@ extern "C" int glnn_abi_version(void) { return 3; }
 
 extern "C" const char* glnn_last_error(void) { return glnn::g_err; }
 
+extern "C" int64_t glnn_struct_bytes(int which) {
+  if (which == 0) return (int64_t)sizeof(glnn_mlp_step_desc);
+  if (which == 1) return (int64_t)sizeof(glnn_sage_step_desc);
+  if (which == 2) return (int64_t)sizeof(glnn_sage_layer);
+  return -1;
+}
+
 extern "C" int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int arch_buf_len) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return glnn::fail(GLNN_ERR_NO_DEVICE, "glnn_device_info: no HIP device");

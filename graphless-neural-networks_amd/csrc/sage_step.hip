@@ -1,0 +1,78 @@
+// One C call = forward + NLL + backward of a sampled-block GraphSAGE training step (reference train_and_eval.py:39-53:
+// model(blocks, feats[input_nodes]) -> log_softmax -> NLLLoss -> (loss*lamb).backward(); SAGE.forward models.py:101-119): the
+// launch sequence glnn_amd/teacher.py documents, issued from C++ so that the ~45 launches of a step cost one host round trip
+// (issued from Python they took ~0.7 ms of host time per step -- more than the 0.55 ms the GPU needs on the ogbn-arxiv config).
+// Every buffer is caller-owned (glnn_sage_step_desc); the optimiser step is NOT included: call glnn_adam_step_f32 next.
+#include "glnn_common.h"
+
+#define GLNN_TRY(expr)              \
+  do {                              \
+    const int rc_ = (expr);         \
+    if (rc_ != GLNN_OK) return rc_; \
+  } while (0)
+
+extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream) {
+  GLNN_REQUIRE(d && d->x && d->labels && d->dlogits && d->loss_out, "glnn_sage_fwd_bwd_f32: null pointer");
+  const int L = d->num_layers;
+  GLNN_REQUIRE(L >= 1 && L <= GLNN_SAGE_MAX_LAYERS, "glnn_sage_fwd_bwd_f32: num_layers=%d outside [1,%d]", L, GLNN_SAGE_MAX_LAYERS);
+  const float p = d->dropout_p;
+  for (int l = 0; l < L; ++l) {
+    const glnn_sage_layer& y = d->layer[l];
+    GLNN_REQUIRE(y.indptr && y.w && y.gw && y.agg && y.z && y.n_dst >= 1 && y.n_src >= y.n_dst,
+                 "glnn_sage_fwd_bwd_f32: layer %d: null pointer or bad block sizes", l);
+    GLNN_REQUIRE(l == 0 || y.n_src == d->layer[l - 1].n_dst, "glnn_sage_fwd_bwd_f32: block %d has %lld sources, block %d %lld destinations",
+                 l, (long long)y.n_src, l - 1, (long long)d->layer[l - 1].n_dst);
+    GLNN_REQUIRE(l == L - 1 || y.h, "glnn_sage_fwd_bwd_f32: hidden layer %d needs its activation buffer", l);
+    GLNN_REQUIRE(l == 0 || (y.t_indptr && y.t_indices && y.inv_deg && y.tr_ws), "glnn_sage_fwd_bwd_f32: layer %d needs the transpose buffers", l);
+  }
+  GLNN_REQUIRE(L == 1 || (d->dagg && d->dh), "glnn_sage_fwd_bwd_f32: backward scratch missing");
+
+  // ---- forward -----------------------------------------------------------------------------------------------------
+  for (int l = 0; l < L; ++l) {
+    const glnn_sage_layer& y = d->layer[l];
+    const int d_in = d->dims[l], d_out = d->dims[l + 1];
+    const float* src = l == 0 ? d->x : d->layer[l - 1].h;
+    const int64_t ld_src = l == 0 ? d->ldx : d->layer[l - 1].ldh;
+    const int64_t n_src = l == 0 ? d->x_rows : y.n_src;
+    // (sum_{u->v} h[u] + h_dst[v]) / (deg + 1); the outermost block may gather from the global matrix (self_rows)
+    GLNN_TRY(glnn_spmm_csr_f32(y.indptr, y.indices, y.n_dst, n_src, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, nullptr, src, ld_src,
+                               l == 0 ? y.self_rows : nullptr, nullptr, nullptr, 0, y.agg, y.ld_agg, stream));
+    GLNN_TRY(glnn_gemm_f32(y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_in, y.w, d_in, 0, d_out, nullptr, nullptr, y.b, 0,
+                           y.z, y.ldz, d->ws_gemm, d->ws_gemm_floats, stream));
+    if (l == L - 1) break;
+    if (d->batchnorm)
+      GLNN_TRY(glnn::bn_stats(y.z, y.ldz, y.n_dst, d_out, y.gamma, y.beta, d->bn_eps, d->bn_momentum, y.running_mean, y.running_var, y.nbt,
+                              y.mean, y.rstd, y.a_scale, y.a_shift, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+    GLNN_TRY(glnn_act_fwd_f32(y.z, y.ldz, y.n_dst, d_out, d->batchnorm ? y.a_scale : nullptr, d->batchnorm ? y.a_shift : nullptr, p,
+                              y.drop_seed, y.h, y.ldh, stream));
+  }
+  // ---- loss + dlogits (labels indexed by the batch's output nodes) ----------------------------------------------------
+  const glnn_sage_layer& top = d->layer[L - 1];
+  GLNN_TRY(glnn_softmax_loss_f32(top.z, top.ldz, top.n_dst, d->dims[L], GLNN_LOSS_NLL, d->labels, d->label_rows, nullptr, 0, nullptr, d->lamb,
+                                 d->dlogits, d->ld_dlogits, nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream));
+  // ---- backward --------------------------------------------------------------------------------------------------------
+  const float* dz = d->dlogits;
+  int64_t ld_dz = d->ld_dlogits;
+  for (int l = L - 1; l >= 0; --l) {
+    const glnn_sage_layer& y = d->layer[l];
+    const int d_in = d->dims[l], d_out = d->dims[l + 1];
+    // dW_l = dz^T agg (+ db for the last layer; hidden layers get it from the activation backward below)
+    GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in,
+                              l == L - 1 ? y.gb : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+    if (l == 0) break;                                     // the outermost block's input is feats: no gradient needed
+    // dagg = dz W ;  dh = (A^T + I_dst)(dagg / (deg + 1)) over the transposed block
+    GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_out, y.w, d_in, 1, d_in, nullptr, nullptr, nullptr, 0,
+                           d->dagg, d->ld_dagg, nullptr, 0, stream));
+    GLNN_TRY(glnn_csr_transpose(y.indptr, y.indices, y.n_dst, y.n_src, y.nnz, 1, y.t_indptr, y.t_indices, y.tr_ws, y.tr_ws_bytes, stream));
+    GLNN_TRY(glnn_degrees_f32(y.indptr, nullptr, y.n_dst, y.n_src, 0, GLNN_DEG_INV_PLUS1, y.inv_deg, nullptr, stream));
+    GLNN_TRY(glnn_spmm_csr_f32(y.t_indptr, y.t_indices, y.n_src, y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, nullptr, y.inv_deg, nullptr,
+                               0, nullptr, nullptr, nullptr, 0, d->dh, d->ld_dh, stream));
+    const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh
+    GLNN_TRY(glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, d->batchnorm ? prev.gamma : nullptr, prev.mean, prev.rstd,
+                               d->batchnorm ? prev.a_scale : nullptr, d->batchnorm ? prev.a_shift : nullptr, p, prev.drop_seed, d->dh,
+                               d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+    dz = d->dh;
+    ld_dz = d->ld_dh;
+  }
+  return GLNN_OK;
+}

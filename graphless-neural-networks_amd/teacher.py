@@ -27,11 +27,13 @@ synchronisation:
 
 The engine works IN PLACE on the Model's parameters / BatchNorm buffers and on the torch optimizer's state tensors, exactly
 like glnn_amd.student.StudentEngine, so state_dict(), early-stopping snapshots and optimizer.state_dict() keep working."""
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 from .autograd import graphconv_bwd, graphconv_fwd
 from .student import _mix32
 
@@ -152,49 +154,91 @@ class TeacherEngine:
     def step_sage(self, blocks, feats, labels, output_nodes, lamb=1.0, input_nodes=None):
         """One optimisation step on a batch of sampled blocks (blocks[0] outermost).  `feats` is the GLOBAL feature matrix:
         when blocks[0] carries global source ids (glnn_amd.graph.NodeDataLoader) its aggregation gathers from it directly,
-        otherwise feats[input_nodes] is gathered once (blocks that came from elsewhere)."""
+        otherwise feats[input_nodes] is gathered once (blocks that came from elsewhere).  The whole forward + loss + backward
+        is ONE C call (glnn_sage_fwd_bwd_f32, csrc/sage_step.hip) over buffers allocated here; Adam follows."""
         enc, L = self.enc, self.L
         ops._need_cuda(feats, labels, output_nodes, input_nodes)
         if len(blocks) != L:
             raise ValueError(f"TeacherEngine.step_sage: {len(blocks)} blocks for {L} layers")
+        if L > _lib.SAGE_MAX_LAYERS:
+            raise NotImplementedError(f"TeacherEngine: at most {_lib.SAGE_MAX_LAYERS} layers")
+        if labels.dtype != torch.int64 or output_nodes.dtype != torch.int64 or not output_nodes.is_contiguous():
+            raise ValueError("TeacherEngine.step_sage: labels / output_nodes must be int64 (output_nodes contiguous)")
         x = ops.as_feat(feats)
+        dev = self.dev
+        if blocks[0].gindices is None:
+            if input_nodes is None:
+                raise ValueError("TeacherEngine.step_sage: blocks without global ids need input_nodes")
+            x = ops.gather_rows(x, input_nodes)
+        for l in range(1, L):
+            if blocks[l].num_src_nodes() != blocks[l - 1].num_dst_nodes():
+                raise ValueError(f"TeacherEngine.step_sage: block {l} has {blocks[l].num_src_nodes()} sources, block {l - 1} "
+                                 f"{blocks[l - 1].num_dst_nodes()} destinations")
+        if x.shape[0] < (blocks[0].num_src_nodes() if blocks[0].gindices is None else 1):
+            raise ValueError("TeacherEngine.step_sage: the layer-0 source matrix is smaller than the outermost block")
         self.step_count += 1
-        saved, h = [], None
+        d = _lib.SageStepDesc()
+        dims = [enc.layers[0].fc_neigh.weight.shape[1]] + [lay.fc_neigh.weight.shape[0] for lay in enc.layers]
+        d.num_layers, d.batchnorm, d.dropout_p, d.lamb = L, 1 if self.bn else 0, self.p, float(lamb)
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        keep = []                                               # buffers of this step (alive until the call below is queued)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        max_rows, max_hidden = 1, 4
         for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):
+            y = d.layer[l]
+            n_dst, n_src, nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
+            glob = l == 0 and blk.gindices is not None
+            y.indptr, y.indices = ptr(blk.indptr), ptr(blk.gindices if glob else blk.indices)
+            y.n_dst, y.n_src, y.nnz = n_dst, n_src, nnz
+            y.self_rows = ptr(blk.dst_nodes) if glob else None
             w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
-            n_dst = blk.num_dst_nodes()
-            if l == 0 and blk.gindices is not None:
-                agg = ops.spmm(blk.indptr, blk.gindices, x, n_dst, ops.AGG_SAGE_GCN, x_self=x, self_rows=blk.dst_nodes)
-            else:
-                if l == 0:
-                    if input_nodes is None:
-                        raise ValueError("TeacherEngine.step_sage: blocks without global ids need input_nodes")
-                    h = ops.gather_rows(x, input_nodes)
-                if h.shape[0] != blk.num_src_nodes():
-                    raise ValueError(f"TeacherEngine.step_sage: layer {l} got {h.shape[0]} rows for a block with {blk.num_src_nodes()} sources")
-                agg = ops.spmm(blk.indptr, blk.indices, h, n_dst, ops.AGG_SAGE_GCN)
-            z = ops.gemm(agg, w, ep_shift=b)
+            y.w, y.b, y.gw, y.gb = ptr(w), ptr(b), ptr(self.grad(w)), ptr(self.grad(b))
+            agg, z = ops.feat_empty(n_dst, dims[l], dev), ops.feat_empty(n_dst, dims[l + 1], dev)
+            y.agg, y.ld_agg, y.z, y.ldz = ptr(agg), agg.stride(0), ptr(z), z.stride(0)
+            keep += [agg, z]
             if l != L - 1:
-                h, stats, seed = self._tail_fwd(l, z)
-                saved.append((agg, z, stats, seed))
-            else:
-                saved.append((agg, z, None, 0))
-        logits = saved[-1][1]
-        _, dz = ops.softmax_loss(logits, ops.LOSS_NLL, float(lamb), labels=labels, label_rows=output_nodes, loss_out=self.loss_out,
-                                 loss_accum=self.loss_accum, workspace=self.ws_loss)
-        for l in range(L - 1, -1, -1):
-            layer, blk = enc.layers[l], blocks[l]
-            w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
-            agg = saved[l][0]
-            # hidden layers get their bias gradient from the activation backward (column sums of dz) below
-            ops.gemm_tn(dz, agg, out=self.grad(w), col_sum_a=self.grad(b) if l == L - 1 else None)
-            if l == 0:
-                break
-            dagg = ops.gemm(dz, w, w_is_kn=True)
-            t = blk.transposed(add_self=True)
-            dh = ops.spmm(t.indptr, t.indices, dagg, blk.num_src_nodes(), ops.AGG_SUM, col_scale=blk.inv_deg_plus1())
-            _, z_prev, stats, seed = saved[l - 1]
-            dz = self._tail_bwd(l - 1, dh, z_prev, stats, seed, self.grad(enc.layers[l - 1].fc_neigh.bias))
+                h = ops.feat_empty(n_dst, dims[l + 1], dev)
+                y.h, y.ldh, y.drop_seed = ptr(h), h.stride(0), self._seed(l)
+                keep.append(h)
+                max_rows, max_hidden = max(max_rows, n_dst), max(max_hidden, dims[l + 1])
+                if self.bn:
+                    bn = enc.norms[l]
+                    d.bn_eps, d.bn_momentum = bn.eps, bn.momentum
+                    stats = [torch.empty(dims[l + 1], dtype=torch.float32, device=dev) for _ in range(4)]
+                    y.gamma, y.beta, y.ggamma, y.gbeta = ptr(bn.weight), ptr(bn.bias), ptr(self.grad(bn.weight)), ptr(self.grad(bn.bias))
+                    y.running_mean, y.running_var, y.nbt = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
+                    y.mean, y.rstd, y.a_scale, y.a_shift = (ptr(t) for t in stats)
+                    keep += stats
+            if l >= 1:
+                nnz_t = nnz + n_dst
+                t_indptr = torch.empty(n_src + 1, dtype=torch.int64, device=dev)
+                t_indices = torch.empty(max(nnz_t, 1), dtype=torch.int32, device=dev)
+                inv = torch.empty(n_dst, dtype=torch.float32, device=dev)
+                wsb = int(_lib.lib().glnn_csr_transpose_workspace_bytes(n_src, nnz_t))
+                tws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
+                y.t_indptr, y.t_indices, y.inv_deg, y.tr_ws, y.tr_ws_bytes = ptr(t_indptr), ptr(t_indices), ptr(inv), ptr(tws), tws.numel() * 8
+                keep += [t_indptr, t_indices, inv, tws]
+        d.x, d.ldx, d.x_rows = ptr(x), x.stride(0), x.shape[0]
+        d.labels, d.label_rows = ptr(labels), ptr(output_nodes)
+        n_out = blocks[-1].num_dst_nodes()
+        dlogits = ops.feat_empty(n_out, dims[-1], dev)
+        d.dlogits, d.ld_dlogits = ptr(dlogits), dlogits.stride(0)
+        if L > 1:
+            dagg = ops.feat_empty(max(b.num_dst_nodes() for b in blocks[1:]), max(dims[1:L]), dev)
+            dh = ops.feat_empty(max(b.num_src_nodes() for b in blocks[1:]), max(dims[1:L]), dev)
+            d.dagg, d.ld_dagg, d.dh, d.ld_dh = ptr(dagg), dagg.stride(0), ptr(dh), dh.stride(0)
+            keep += [dagg, dh]
+        nchunks = (max_rows + 127) // 128
+        ws_bn = torch.empty((3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024, dtype=torch.float32, device=dev)
+        ws_tn = torch.empty(64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims), dtype=torch.float32, device=dev)
+        ws_gemm = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+        d.ws_bn, d.ws_bn_floats, d.ws_tn, d.ws_tn_floats = ptr(ws_bn), ws_bn.numel(), ptr(ws_tn), ws_tn.numel()
+        d.ws_gemm, d.ws_gemm_floats, d.ws_loss, d.ws_loss_floats = ptr(ws_gemm), ws_gemm.numel(), ptr(self.ws_loss), self.ws_loss.numel()
+        d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+        keep += [dlogits, ws_bn, ws_tn, ws_gemm, x]
+        rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
+        _lib.check(rc, "glnn_sage_fwd_bwd_f32")
         self._adam()
 
     # ------------------------------------------------------------------------------------------ full-graph GCN

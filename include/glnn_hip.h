@@ -42,6 +42,9 @@ typedef enum {
 GLNN_API int glnn_abi_version(void);               /* bumped on any signature change */
 GLNN_API const char* glnn_last_error(void);        /* thread-local, never NULL */
 GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int arch_buf_len);
+/* sizeof of the descriptor structs below as THIS build sees them (0 = glnn_mlp_step_desc, 1 = glnn_sage_step_desc,
+ * 2 = glnn_sage_layer; -1 otherwise): lets a binding in another language check its mirror of the layout at load time. */
+GLNN_API int64_t glnn_struct_bytes(int which);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  CSR neighbour aggregation (SpMM with an implicit all-ones adjacency, multi-edges kept).
@@ -313,6 +316,51 @@ GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* f
                                   const int64_t* idx, int64_t m, int kind, const int64_t* labels,
                                   const float* target_logp, int64_t ldt, const int64_t* target_rows,
                                   float lamb, const uint32_t* drop_seeds, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The whole forward + NLL + backward of ONE sampled-block GraphSAGE training step in one call (reference
+ * train_and_eval.py:39-53 over SAGE.forward, models.py:101-119): per layer glnn_spmm_csr_f32 (SAGE_GCN) -> glnn_gemm_f32 ->
+ * glnn_bn_stats_f32 -> glnn_act_fwd_f32; glnn_softmax_loss_f32 with labels[label_rows[i]]; backward per layer
+ * glnn_gemm_tn_f32 -> glnn_gemm_f32 -> glnn_csr_transpose(add_self) + glnn_degrees_f32(1/(deg+1)) + glnn_spmm_csr_f32 (SUM
+ * over the transposed block) -> glnn_bn_relu_bwd_f32.  Every buffer is caller-owned:
+ *   layer[l].indptr/indices   block l (CSR over its destinations; layer[0] outermost), n_src of block l == n_dst of block l-1;
+ *                             layer[0] may carry GLOBAL column ids with self_rows[v] = global id of destination v, x = feats
+ *   w/b/gw/gb                 fc_neigh weight [dims[l+1], dims[l]] / bias and their gradients (contiguous)
+ *   gamma..a_shift            BatchNorm1d after hidden layer l (batchnorm != 0)
+ *   agg/z/h                   kept activations: aggregate [n_dst, dims[l]], pre-activation [n_dst, dims[l+1]] (z of the last
+ *                             layer = logits), hidden output [n_dst, dims[l+1]] (float4 rows: leading dims % 4 == 0)
+ *   t_indptr/t_indices/inv_deg/tr_ws  (l >= 1) outputs / workspace of the block's transpose (glnn_csr_transpose sizes)
+ *   dagg [max n_dst_l, max dims[l]], dh [max n_src_l, max dims[l]] (l >= 1)   backward scratch
+ * The optimiser step is NOT included: call glnn_adam_step_f32 next.
+ * ------------------------------------------------------------------------------------------ */
+#define GLNN_SAGE_MAX_LAYERS 8
+typedef struct glnn_sage_layer {
+  const int64_t* indptr; const int32_t* indices; int64_t n_dst, n_src, nnz;
+  const int64_t* self_rows;
+  float* w; float* b; float* gw; float* gb;
+  float* gamma; float* beta; float* ggamma; float* gbeta; float* running_mean; float* running_var; int64_t* nbt;
+  float* mean; float* rstd; float* a_scale; float* a_shift;
+  float* agg; int64_t ld_agg; float* z; int64_t ldz; float* h; int64_t ldh;
+  int64_t* t_indptr; int32_t* t_indices; float* inv_deg; void* tr_ws; int64_t tr_ws_bytes;
+  uint32_t drop_seed;
+} glnn_sage_layer;
+
+typedef struct glnn_sage_step_desc {
+  int32_t num_layers;
+  int32_t batchnorm;
+  int32_t dims[GLNN_SAGE_MAX_LAYERS + 1];
+  float dropout_p, bn_eps, bn_momentum, lamb;
+  glnn_sage_layer layer[GLNN_SAGE_MAX_LAYERS];
+  const float* x; int64_t ldx; int64_t x_rows;        /* source matrix of layer 0: feats (global ids) or the gathered batch features */
+  const int64_t* labels; const int64_t* label_rows;   /* labels[label_rows[i]] for destination i of the last block (label_rows NULL = i) */
+  float* dlogits; int64_t ld_dlogits;
+  float* dagg; int64_t ld_dagg; float* dh; int64_t ld_dh;
+  float* ws_bn; int64_t ws_bn_floats; float* ws_tn; int64_t ws_tn_floats; float* ws_gemm; int64_t ws_gemm_floats;
+  float* ws_loss; int64_t ws_loss_floats;
+  float* loss_out; float* loss_accum;
+} glnn_sage_step_desc;
+
+GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream);
 
 /* y = dropout(relu(z * a_scale + a_shift)) materialised (a_scale/a_shift NULL: plain ReLU): the `norms[l](h)` ->
  * `activation` -> `dropout` tail of a TRAINING-mode SAGE layer (reference models.py:113-117), whose output the next
