@@ -9,6 +9,9 @@ namespace {
 
 __device__ __forceinline__ uint32_t rng32(uint32_t seed, uint32_t a, uint32_t b) { return glnn::drop_hash(seed, a, b); }
 
+// F = compile-time bound of the fan-out (8 / 16 / 32 / 64): with every loop over the picked positions fully unrolled the
+// `picked` array stays in registers (a runtime-indexed int64[64] lived in scratch memory: 26-75 us per block of a training batch).
+template <int F>
 __global__ __launch_bounds__(256) void sample_neighbors_kernel(const int64_t* __restrict__ indptr,
                                                                const int32_t* __restrict__ indices,
                                                                const int64_t* __restrict__ seeds, int64_t n_seeds, int fanout,
@@ -26,17 +29,25 @@ __global__ __launch_bounds__(256) void sample_neighbors_kernel(const int64_t* __
     return;
   }
   // Floyd: for j = deg-fanout .. deg-1: t = U[0, j]; pick t unless already picked, then pick j
-  int64_t picked[64];
-  int np = 0;
-  for (int64_t j = deg - fanout; j < deg; ++j) {
-    const uint32_t r = rng32(seed, (uint32_t)i, (uint32_t)(j - (deg - fanout)));
-    int64_t t = (int64_t)(((uint64_t)r * (uint64_t)(j + 1)) >> 32);
-    bool dup = false;
-    for (int q = 0; q < np; ++q) dup |= (picked[q] == t);
-    if (dup) t = j;
-    picked[np++] = t;
+  int64_t picked[F];
+#pragma unroll
+  for (int s = 0; s < F; ++s) picked[s] = -1;
+  const int64_t base = deg - fanout;
+#pragma unroll
+  for (int s = 0; s < F; ++s) {
+    if (s < fanout) {
+      const int64_t j = base + s;
+      const uint32_t r = rng32(seed, (uint32_t)i, (uint32_t)s);
+      int64_t t = (int64_t)(((uint64_t)r * (uint64_t)(j + 1)) >> 32);
+      bool dup = false;
+#pragma unroll
+      for (int q = 0; q < F; ++q) dup |= (q < s) && (picked[q] == t);
+      picked[s] = dup ? j : t;
+    }
   }
-  for (int k = 0; k < fanout; ++k) dst[k] = indices[e0 + picked[k]];
+#pragma unroll
+  for (int s = 0; s < F; ++s)
+    if (s < fanout) dst[s] = indices[e0 + picked[s]];
   out_cnt[i] = fanout;
 }
 
@@ -47,7 +58,13 @@ extern "C" int glnn_sample_neighbors(const int64_t* indptr, const int32_t* indic
   GLNN_REQUIRE(indptr && indices && seeds && out_src && out_cnt, "glnn_sample_neighbors: null pointer");
   GLNN_REQUIRE(n_seeds >= 0 && fanout >= 1 && fanout <= 64, "glnn_sample_neighbors: fanout must be in [1,64]");
   if (n_seeds == 0) return GLNN_OK;
-  hipLaunchKernelGGL(sample_neighbors_kernel, dim3((unsigned)((n_seeds + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), indptr, indices, seeds, n_seeds, fanout, rng_seed, out_src, out_cnt);
+  const dim3 grid((unsigned)((n_seeds + 255) / 256));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define GLNN_SAMPLE(F_) hipLaunchKernelGGL((sample_neighbors_kernel<F_>), grid, dim3(256), 0, st, indptr, indices, seeds, n_seeds, fanout, rng_seed, out_src, out_cnt)
+  if (fanout <= 8) GLNN_SAMPLE(8);
+  else if (fanout <= 16) GLNN_SAMPLE(16);
+  else if (fanout <= 32) GLNN_SAMPLE(32);
+  else GLNN_SAMPLE(64);
+#undef GLNN_SAMPLE
   return glnn::check_launch("glnn_sample_neighbors");
 }
