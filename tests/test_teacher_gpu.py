@@ -466,3 +466,49 @@ def test_full_size_products_training_epoch_properties():
     assert np.isfinite(l1) and np.isfinite(l2) and 3.0 < l2 < 5.0            # ln(47) = 3.85: random labels cannot be learnt
     assert int(model.encoder.norms[0].num_batches_tracked) == 20 and int(opt.state[next(model.parameters())]["step"]) == 20
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_block_builder_and_loader_edge_cases():
+    """Empty and ragged inputs: no seeds, seeds without in-edges, a single seed, duplicate-free relabelling when every sampled
+    source is itself a seed, drop_last / short last batch, prefetch on and off giving the same batches."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
+    n = 500
+    indptr, indices = random_graph(n, 4, seed=1, isolated=40)
+    g = _graph(indptr, indices)
+    iso = torch.from_numpy(np.flatnonzero(np.diff(indptr) == 0)[:7].astype(np.int64)).to(DEV)
+    # seeds without any in-edge: an empty block whose sources are the seeds themselves
+    ip, ix, _, inp, nnz, n_src = ops.block_build(iso, g.indptr, g.indices, nnz_cap=0)
+    assert nnz == 0 and n_src == 7 and ip.tolist() == [0] * 8 and ix.numel() == 0 and torch.equal(inp, iso)
+    smp, cnt = ops.sample_neighbors(g.indptr, g.indices, iso, 5, 3)
+    ip, ix, _, inp, nnz, n_src = ops.block_build(iso, smp_src=smp, smp_cnt=cnt)
+    assert nnz == 0 and n_src == 7 and int(cnt.max()) == 0
+    # no seeds at all
+    none = torch.zeros(0, dtype=torch.int64, device=DEV)
+    ip, ix, _, inp, nnz, n_src = ops.block_build(none, g.indptr, g.indices, nnz_cap=0)
+    assert nnz == 0 and n_src == 0 and ip.tolist() == [0]
+    # a complete graph on 6 nodes as seeds: every source is a seed -> no extra input nodes
+    src = np.repeat(np.arange(6), 6); dst = np.tile(np.arange(6), 6)
+    from graphgen import csr_from_edges
+    kip, kix = csr_from_edges(src, dst, 6)
+    kg = _graph(kip, kix)
+    seeds = torch.tensor([3, 1, 5, 0, 2, 4], device=DEV)
+    ip, ix, _, inp, nnz, n_src = ops.block_build(seeds, kg.indptr, kg.indices, nnz_cap=36)
+    assert n_src == 6 and nnz == 36 and torch.equal(inp, seeds) and torch.equal(seeds[ix.long()], kg.indices.long()[
+        torch.cat([torch.arange(int(kg.indptr[v]), int(kg.indptr[v + 1])) for v in seeds.tolist()]).to(DEV)])
+    # loaders: short last batch / drop_last; the side-stream prefetch does not change what is produced
+    nids = torch.arange(10, 110)
+    for sampler in (MultiLayerNeighborSampler([3, 4]), MultiLayerFullNeighborSampler(2)):
+        batches = {}
+        for prefetch in (True, False):
+            loader = NodeDataLoader(g, nids, sampler, batch_size=32, shuffle=False, drop_last=False, seed=9)
+            loader.prefetch = prefetch
+            assert len(loader) == 4
+            batches[prefetch] = [(i.clone(), o.clone(), [b.indices.clone() for b in bl]) for i, o, bl in loader]
+            assert [len(o) for _, o, _ in batches[prefetch]] == [32, 32, 32, 4]
+        for (ia, oa, ba), (ib, ob, bb) in zip(batches[True], batches[False]):
+            assert torch.equal(ia, ib) and torch.equal(oa, ob) and all(torch.equal(x, y) for x, y in zip(ba, bb))
+        assert len(list(NodeDataLoader(g, nids, sampler, batch_size=32, drop_last=True))) == 3
+    # transposing an empty block
+    t = _graph(np.zeros(4, np.int64), np.zeros(0, np.int32), 9).transposed(add_self=True)
+    assert t.indptr.tolist() == [0, 1, 2, 3, 3, 3, 3, 3, 3, 3] and t.indices.tolist() == [0, 1, 2]
