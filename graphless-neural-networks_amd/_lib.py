@@ -54,7 +54,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
@@ -72,7 +72,8 @@ class MlpStepDesc(ctypes.Structure):
                  ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64), ("ws_loss", c_vp), ("ws_loss_floats", c_i64),
                  ("loss_out", c_vp), ("loss_accum", c_vp),
                  ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
-                 ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp)])
+                 ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp),
+                 ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS)])
 
 
 SAGE_MAX_LAYERS = 8

@@ -17,6 +17,7 @@
 // consume k pairs (t, 4+t).  Both operands use the same pairing, and a dot product does not care about
 // the order of its terms.  LDS rows are padded to 36 floats: conflict-free for ds_read_b128's 16-lane
 // groups (slot = 9*i mod 16 is a bijection on each group).
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -260,6 +261,54 @@ __device__ __forceinline__ float4 mask4(float4 v, int left) {   // keep elements
   return v;
 }
 
+// ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+template <int BMT, int BN, int MI, int NT>
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc)[MI][NT], int64_t m0, int n0, int wm, int wn, int li,
+                                           int kk) {
+  const bool full_tile = (m0 + BMT <= g.m) && (n0 + BN <= g.n);     // workgroup-uniform
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 32 + li;
+    const bool col_ok = col < g.n;
+    const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
+    const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int64_t rbase = m0 + wm * (BMT / 2) + i * 32 + 4 * kk;
+      float* cp = g.c + rbase * g.ldc + col;
+      float rs[16];
+      if (g.row_scale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int64_t rr = rbase + (r & 3) + 8 * (r >> 2);
+          if (rr > g.m - 1) rr = g.m - 1;
+          rs[r] = g.row_scale[rr];
+        }
+      }
+      if (full_tile) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r];
+          if (g.row_scale) v *= rs[r];
+          v = fmaf(v, es, eh);
+          if (g.relu) v = fmaxf(v, 0.f);
+          cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r];
+          if (g.row_scale) v *= rs[r];
+          v = fmaf(v, es, eh);
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (col_ok && rbase + ro < g.m) cp[(int64_t)ro * g.ldc] = v;
+        }
+      }
+    }
+  }
+}
+
 // BMT x BN block tile, 4 waves as 2 x 2: a wave owns (BMT/2) x (BN/2) = MI x NT MFMA blocks.  BMT = 64 (with BN = 64: one block per
 // wave) is the latency form for outputs of a few dozen tiles -- a B=512 student GEMM is 8 tiles of 128x128, i.e. 32 busy SIMDs
 // out of 1024 and a serial chain of 64 MFMAs per k-tile and wave; 64x64 tiles quarter that chain and quadruple the workgroups.
@@ -500,49 +549,269 @@ __global__ __launch_bounds__(256) void gemm_kernel_fast(const GemmArgs g) {
     return;
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const bool full_tile = (m0 + BMT <= g.m) && (n0 + BN <= g.n);     // workgroup-uniform
+  store_tile<BMT, BN, MI, NT>(g, acc, m0, n0, wm, wn, li, kk);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PIPE variant of the 128 x 128 x 32 kernels (plain operands, K a multiple of 32): the same tiles, k pairing and MFMA
+// order as gemm_kernel_fast / gemm_tn_kernel_t -- results are bit-identical -- but the steady-state loop is stated
+// instruction by instruction (asm volatile, hand-counted s_waitcnt) and contains NO vector-ALU work at all:
+//   * placement: hipcc treats the MFMA builtins as pure values and lets them float past sched_barrier, which left the 8
+//     ds_write_b128 of a k-tile back to back and its 8 global loads in one burst; here every 8th MFMA slot carries ONE
+//     {s_waitcnt vmcnt(7) -> ds_write_b128 -> buffer_load_dwordx4 into the same registers} piece, so a load has a whole
+//     k-tile (64 MFMAs of this wave) to arrive;
+//   * no VALU: a register-only MFMA loop on this part runs at 155 TF; with the GEMM's LDS/global instruction mix between the
+//     MFMAs 142-147 TF (experiments/mfma_mix.hip); every additional VALU instruction (64-bit address adds, k-tail selects)
+//     competes with the MFMAs for the SIMD's issue port.  Operands are therefore addressed through buffer descriptors
+//     (per-thread byte offsets fixed before the loop, the k-tile step in one SGPR), both LDS buffers through immediate
+//     offsets (loop unrolled by two k-tiles), and the k tail is not handled here at all (K % 32 != 0 takes gemm_kernel_fast).
+//   per k-group kg (16 MFMAs): m0 m1 m2 [piece 2kg] m3 m4 r m5 r m6 r m7 r m8 m9 [piece 2kg+1] m10 .. m15     (r = ds_read_b128 of
+//   group kg+1); in the last group the barrier follows m11, then the 4 reads of the next tile's first group, then m12..m15.
+// The compiler still allocates the registers.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#define GLNN_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_))
+#define GLNN_DS_READ(DST_, ADDR_, OFF_) \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_) : "memory")
+#define GLNN_DS_READ2ST64(DST_, ADDR_, OFF0_, OFF1_) \
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(DST_) : "v"(ADDR_), "n"(OFF0_), "n"(OFF1_) : "memory")
+#define GLNN_DS_WRITE(ADDR_, SRC_, OFF_) \
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(ADDR_), "v"(SRC_), "n"(OFF_) : "memory")
+#define GLNN_BLOAD(DST_, VOFF_, RSRC_, SOFF_) \
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(DST_) : "v"(VOFF_), "s"(RSRC_), "s"(SOFF_) : "memory")
+
+// raw buffer descriptor over [base, base + 2 GiB): stride 0, 32-bit data format; every offset used below is valid by construction
+__device__ __forceinline__ i32x4 make_rsrc(const float* base) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  i32x4 r;
+  r.x = (int)(uint32_t)b;
+  r.y = (int)(uint32_t)((b >> 32) & 0xFFFFu);
+  r.z = 0x7FFFFFFF;
+  r.w = 0x00020000;
+  return r;
+}
+
+// How a 128 x 32 operand tile lives in memory and in LDS:
+//   ROWK  rows = the output index, k contiguous (A of every forward GEMM, W[n,k]): LDS [row][k] padded to 36 floats, one
+//         ds_read_b128 per 32-row block and k-group (lane half kk takes k = 8 kg + 4 kk .. +3);
+//   KROW  rows = k, the output index contiguous (W[k,n] of the input-gradient GEMM, both operands of the weight-gradient
+//         GEMM): LDS [k][128] unpadded (a fragment read touches 32 consecutive floats of one k row), two
+//         ds_read2st64_b32 per block and k-group -- the same k per lane and MFMA as ROWK, without any transpose.
+enum { ROWK = 0, KROW = 1 };
+template <int STYLE> struct PipeOp;
+template <> struct PipeOp<ROWK> {
+  static constexpr int TILE = 128 * 36 * 4;      // bytes per LDS buffer
+  static constexpr int PIECE = 32 * 36 * 4;      // byte step between a thread's four staging pieces
+  static constexpr int READS = 2;                // DS reads per k-group (both 32-row blocks)
+  f32x4 q[2];
+};
+template <> struct PipeOp<KROW> {
+  static constexpr int TILE = 32 * 128 * 4;
+  static constexpr int PIECE = 8 * 128 * 4;
+  static constexpr int READS = 4;
+  f32x2 h[2][2];
+};
+
+// acc += A_tile . B_tile^T over nk k-tiles of 32 for ONE 128 x 128 output tile (4 waves as 2 x 2, 2 x 2 MFMA blocks each).
+//   a0 / b0   the tile's origin: ROWK -> element (first row, first k), KROW -> element (first k, first column)
+//   ext_a/b   valid rows (ROWK) / valid columns rounded up to 4 (KROW) from the origin: further ones are clamped (they only
+//             feed outputs that are never stored)
+template <int SA, int SB>
+__device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int64_t ext_a, const float* b0, int64_t ldb, int64_t ext_b,
+                                              int nk, f32x16 (&acc)[2][2]) {
+  using OA = PipeOp<SA>;
+  using OB = PipeOp<SB>;
+  constexpr int A_OFF = 0, B_OFF = 2 * OA::TILE;
+  constexpr int NRA = OA::READS, NR = OA::READS + OB::READS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kk = lane >> 5;
+
+  const i32x4 rsrc_a = make_rsrc(a0);
+  const i32x4 rsrc_b = make_rsrc(b0);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;       // the dynamic array is the kernel's only LDS object
+  uint32_t voff[8];                      // per-piece global byte offsets: 0..3 = A, 4..7 = B
+  uint32_t wr_a, wr_b;                   // LDS write bases (buffer 0)
+  uint32_t rd_a[2], rd_b[2];             // LDS fragment read bases (ROWK uses [0] only)
+  uint32_t step_a, step_b;               // global byte step per k-tile
+  auto setup = [&](auto style_, const int64_t ld, int64_t ext, int w, uint32_t lds_base, uint32_t* vo, uint32_t& wr, uint32_t (&rd)[2],
+                   uint32_t& step) {
+    constexpr int ST = decltype(style_)::value;
+    if constexpr (ST == ROWK) {
+      const int c4 = (tid & 7) * 4, r0 = tid >> 3;
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int col = n0 + wn * (BN / 2) + j * 32 + li;
-    const bool col_ok = col < g.n;
-    const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
-    const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int64_t rbase = m0 + wm * (BMT / 2) + i * 32 + 4 * kk;
-      float* cp = g.c + rbase * g.ldc + col;
-      float rs[16];
-      if (g.row_scale) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int64_t rr = rbase + (r & 3) + 8 * (r >> 2);
-          if (rr > g.m - 1) rr = g.m - 1;
-          rs[r] = g.row_scale[rr];
-        }
+      for (int q = 0; q < 4; ++q) {
+        int64_t r = r0 + 32 * q;
+        if (r > ext - 1) r = ext - 1;
+        vo[q] = (uint32_t)((r * ld + c4) * 4);
       }
-      if (full_tile) {
+      wr = lds_base + (uint32_t)((r0 * 36 + c4) * 4);
+      rd[0] = rd[1] = lds_base + (uint32_t)(((w * 64 + li) * 36 + kk * 4) * 4);
+      step = 32 * 4;
+    } else {
+      const int kr = tid >> 5;
+      int64_t n4 = (tid & 31) * 4;
+      if (n4 > ext - 4) n4 = ext - 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r];
-          if (g.row_scale) v *= rs[r];
-          v = fmaf(v, es, eh);
-          if (g.relu) v = fmaxf(v, 0.f);
-          cp[(int64_t)((r & 3) + 8 * (r >> 2)) * g.ldc] = v;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = (r & 3) + 8 * (r >> 2);
-          float v = acc[i][j][r];
-          if (g.row_scale) v *= rs[r];
-          v = fmaf(v, es, eh);
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (col_ok && rbase + ro < g.m) cp[(int64_t)ro * g.ldc] = v;
-        }
-      }
+      for (int q = 0; q < 4; ++q) vo[q] = (uint32_t)(((kr + 8 * q) * ld + n4) * 4);
+      wr = lds_base + (uint32_t)((kr * 128 + (tid & 31) * 4) * 4);
+      rd[0] = lds_base + (uint32_t)(((kk * 4) * 128 + w * 64 + li) * 4);
+      rd[1] = rd[0] + 32 * 4;
+      step = (uint32_t)(32 * ld * 4);
     }
+  };
+  setup(std::integral_constant<int, SA>{}, lda, ext_a, wm, lds0 + A_OFF, voff, wr_a, rd_a, step_a);
+  setup(std::integral_constant<int, SB>{}, ldb, ext_b, wn, lds0 + B_OFF, voff + 4, wr_b, rd_b, step_b);
+
+  f32x4 st[8];                           // the staged tile: one float4 per piece
+  auto tile_idx = [&](int kt) { return (uint32_t)(kt < nk ? kt : nk - 1); };   // tiles past the end re-read the last one (uniform: SALU)
+
+  // ---- prologue: tile 0 -> LDS buffer 0 ----
+  {
+    const uint32_t sa = 0, sb = 0;
+    static_for<8>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb;   // asm-only operands are not captured implicitly (clang)
+      if constexpr (p < 4) GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+      else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+    static_for<8>([&](auto p_) {
+      constexpr int p = decltype(p_)::value;
+      (void)wr_a; (void)wr_b; (void)st;
+      if constexpr (p < 4) GLNN_DS_WRITE(wr_a, st[p], p * OA::PIECE);
+      else GLNN_DS_WRITE(wr_b, st[p], (p - 4) * OB::PIECE);
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  PipeOp<SA> fa[2];                      // fragments, double-buffered by k-group parity
+  PipeOp<SB> fb[2];
+
+  // the DS reads of k-group KG out of LDS buffer BUF into fragment set PAR; R = 0 .. NR-1 selects one instruction
+  auto frag_read = [&](auto buf_, auto kg_, auto par_, auto r_) {
+    constexpr int BUF = decltype(buf_)::value, KG = decltype(kg_)::value, PAR = decltype(par_)::value, R = decltype(r_)::value;
+    (void)fa; (void)fb; (void)rd_a; (void)rd_b;
+    if constexpr (R < NRA) {
+      if constexpr (SA == ROWK) GLNN_DS_READ(fa[PAR].q[R], rd_a[0], BUF * OA::TILE + R * OA::PIECE + KG * 32);
+      else GLNN_DS_READ2ST64(fa[PAR].h[R / 2][R % 2], rd_a[R / 2], BUF * 64 + 2 * (KG * 8 + 2 * (R % 2)), BUF * 64 + 2 * (KG * 8 + 2 * (R % 2) + 1));
+    } else {
+      constexpr int Q = R - NRA;
+      if constexpr (SB == ROWK) GLNN_DS_READ(fb[PAR].q[Q], rd_b[0], BUF * OB::TILE + Q * OB::PIECE + KG * 32);
+      else GLNN_DS_READ2ST64(fb[PAR].h[Q / 2][Q % 2], rd_b[Q / 2], BUF * 64 + 2 * (KG * 8 + 2 * (Q % 2)), BUF * 64 + 2 * (KG * 8 + 2 * (Q % 2) + 1));
+    }
+  };
+
+  // one k-tile out of LDS buffer CUR; tile kt+1 goes registers -> buffer CUR^1, tile kt+2 global -> registers.
+  // PH = the wave's index in the workgroup staggers its two staging pieces per k-group (MFMA slots PH and PH+7): the barrier
+  // re-aligns the waves of a CU every k-tile, and waves handing a ds_write_b128 to the LDS store path in the same slot
+  // queue up behind each other (~13 cycles each).
+  auto ktile = [&](auto cur_, auto ph_, uint32_t sa, uint32_t sb) {
+    constexpr int CUR = decltype(cur_)::value, PH = decltype(ph_)::value;
+    static_for<64>([&](auto m_) {
+      constexpr int kg = decltype(m_)::value / 16, mm = decltype(m_)::value % 16;
+      constexpr int par = kg & 1;
+      (void)wr_a; (void)wr_b; (void)sa; (void)sb; (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)fa; (void)fb; (void)acc;
+      // ^ operands that appear only inside asm / discarded branches are not captured implicitly (clang)
+      if constexpr (mm == 0) {
+        // fragments of this group: issued >= 4 MFMAs ago; the previous group's second ds_write follows them only if its slot
+        // (PH + 7) lies behind the last read (slot 3 + NR)
+        if constexpr (kg == 0 || PH + 7 <= 3 + NR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      }
+      constexpr int t = mm / 4, i = (mm / 2) % 2, j = mm % 2;
+      if constexpr (SA == ROWK && SB == ROWK) GLNN_MFMA(acc[i][j], fa[par].q[i][t], fb[par].q[j][t]);
+      if constexpr (SA == ROWK && SB == KROW) GLNN_MFMA(acc[i][j], fa[par].q[i][t], fb[par].h[j][t / 2][t % 2]);
+      if constexpr (SA == KROW && SB == KROW) GLNN_MFMA(acc[i][j], fa[par].h[i][t / 2][t % 2], fb[par].h[j][t / 2][t % 2]);
+      if constexpr (SA == KROW && SB == ROWK) GLNN_MFMA(acc[i][j], fa[par].h[i][t / 2][t % 2], fb[par].q[j][t]);
+      if constexpr (mm == PH || mm == PH + 7) {
+        constexpr int p = 2 * kg + (mm == PH + 7 ? 1 : 0);
+        // piece p: the load issued one k-tile ago has 7 younger ones behind it
+        asm volatile("s_waitcnt vmcnt(7)" : "+v"(st[p]) : : "memory");
+        if constexpr (p < 4) {
+          GLNN_DS_WRITE(wr_a, st[p], (CUR ^ 1) * OA::TILE + p * OA::PIECE);
+          GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+        } else {
+          GLNN_DS_WRITE(wr_b, st[p], (CUR ^ 1) * OB::TILE + (p - 4) * OB::PIECE);
+          GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
+        }
+      }
+      if constexpr (kg < 3 && mm >= 4 && mm < 4 + NR)        // fragments of group kg+1 (other parity), one instruction per slot
+        frag_read(cur_, std::integral_constant<int, kg + 1>{}, std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, mm - 4>{});
+      if constexpr (kg == 3 && mm == 11) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_for<NR>([&](auto r_) {
+          frag_read(std::integral_constant<int, CUR ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_);
+        });
+      }
+    });
+  };
+  // everything that is in flight when the loop starts (tile 1, the first fragments) is issued inside the per-wave branch:
+  // values that cross the branch could be copied by the compiler, which cannot see that the asm loads have not landed yet
+  auto kloop = [&](auto ph_) {
+    {
+      const uint32_t sa = tile_idx(1) * step_a, sb = tile_idx(1) * step_b;
+      static_for<8>([&](auto p_) {
+        constexpr int p = decltype(p_)::value;
+        (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb;
+        if constexpr (p < 4) GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+        else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
+      });
+    }
+    static_for<NR>([&](auto r_) {
+      frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_);
+    });
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, ph_, tile_idx(kt + 2) * step_a, tile_idx(kt + 2) * step_b);
+      ktile(std::integral_constant<int, 1>{}, ph_, tile_idx(kt + 3) * step_a, tile_idx(kt + 3) * step_b);
+    }
+    if (kt < nk) ktile(std::integral_constant<int, 0>{}, ph_, tile_idx(kt + 2) * step_a, tile_idx(kt + 2) * step_b);
+    // drain: loads / fragment reads of the tiles past the end are in flight; the accumulators are read by VALU next (XDL
+    // write -> VALU read needs 18 wait states the compiler cannot see behind the asm)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  };
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // scalar: the four loops are selected by s_cbranch
+  if (wave_u == 0) kloop(std::integral_constant<int, 0>{});
+  else if (wave_u == 1) kloop(std::integral_constant<int, 1>{});
+  else if (wave_u == 2) kloop(std::integral_constant<int, 2>{});
+  else kloop(std::integral_constant<int, 3>{});
+}
+
+// GLNN_GEMM_PIPE=0 keeps every shape on the compiler-scheduled kernels (A/B runs, tests/test_kernels_gpu.py)
+inline bool pipe_enabled() {
+  const char* e = getenv("GLNN_GEMM_PIPE");      // read per call: the tests flip it inside one process
+  return !(e && e[0] == '0');
+}
+
+constexpr size_t pipe_lds_bytes(int sa, int sb) {
+  return 2 * (size_t)((sa == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE) + (sb == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE));
+}
+
+// C = epi(A . W^T) (B_KN = false, W [n,k]) or epi(A . W) (B_KN = true, W [k,n]): plain A, K % 32 == 0, no split-K
+template <bool B_KN>
+__global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 128;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (B_KN)
+    pipe_mainloop<ROWK, KROW>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + n0, g.ldb, ((g.n + 3) & ~3) - n0, g.k / BK, acc);
+  else
+    pipe_mainloop<ROWK, ROWK>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + (int64_t)n0 * g.ldb, g.ldb, g.n - n0, g.k / BK, acc);
+  store_tile<128, 128, 2, 2>(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -885,6 +1154,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
   }
 }
 
+// PIPE form of the 128 x 128 weight-gradient tile (see pipe_mainloop): both operands are k(m)-major, so both take the
+// KROW path -- no register transpose, no VALU in the loop.  Plain B, no gather, every split a whole number of k-tiles.
+__global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
+  const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128;
+  const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
+  int64_t mend = mbeg + g.rows_per_split;
+  if (mend > g.m) mend = g.m;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  pipe_mainloop<KROW, KROW>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
+                            ((g.nb + 3) & ~3) - j0, (int)((mend - mbeg) / BK), acc);
+  float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = j0 + wn * 64 + j * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
+      }
+  }
+}
+
 // sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
 __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
                                     int64_t ldc, int ka, int nb) {
@@ -976,20 +1277,32 @@ int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g
 #ifndef GLNN_GEMM_BKF
 #define GLNN_GEMM_BKF 32
 #endif
+#ifndef GLNN_GEMM_BMT
+#define GLNN_GEMM_BMT BM
+#endif
 template <int BN, bool B_KN>
 int launch_gemm(GemmArgs& g, bool fast, hipStream_t st) {
   constexpr int BKF = GLNN_GEMM_BKF;
+  constexpr int BMT = GLNN_GEMM_BMT;
   constexpr size_t smem_generic = sizeof(float) * 2 * (BM * LDS_K + (B_KN ? BK * (BN + 4) : BN * LDS_K));
-  constexpr size_t smem_fast = sizeof(float) * 2 * (BM * (BKF + 4) + (B_KN ? BKF * (BN + 4) : BN * (BKF + 4)));
+  constexpr size_t smem_fast = sizeof(float) * 2 * (BMT * (BKF + 4) + (B_KN ? BKF * (BN + 4) : BN * (BKF + 4)));
   static int cfg[4] = {1, 1, 1, 1};   // >0 = not configured yet
   if (!fast) {
     g.ksplits = 1; g.ktiles_per_split = (g.k + BK - 1) / BK;
     return launch_gemm_kernel(gemm_kernel_generic<BN, B_KN>, cfg[3], smem_generic, g, BN, st);
   }
+  if constexpr (BN == 128 && BMT == 128) {
+    // plain operands, whole k-tiles, no gather, and every byte offset inside the 2 GiB descriptor window
+    const bool window = B_KN ? (g.lda < (1 << 21) && (int64_t)g.k * g.ldb < (1 << 28)) : (g.lda < (1 << 21) && g.ldb < (1 << 21));
+    if (pipe_enabled() && !g.a_scale && g.ksplits == 1 && g.k % BK == 0 && !g.a_rows && window) {
+      static int cfg_pipe = 1;
+      return launch_gemm_kernel(gemm_kernel_pipe<B_KN>, cfg_pipe, pipe_lds_bytes(ROWK, B_KN ? KROW : ROWK), g, BN, st, 128);
+    }
+  }
   if (BKF != BK) g.ktiles_per_split *= BK / BKF;     // split bookkeeping is in units of the fast kernel's k-tiles
-  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st);
-  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st);
-  return launch_gemm_kernel(gemm_kernel_fast<BM, BN, B_KN, 2, BKF>, cfg[2], smem_fast, g, BN, st);
+  if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BMT, BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st, BMT);
+  if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BMT, BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st, BMT);
+  return launch_gemm_kernel(gemm_kernel_fast<BMT, BN, B_KN, 2, BKF>, cfg[2], smem_fast, g, BN, st, BMT);
 }
 
 // 64 x 64 tiles (one MFMA block per wave): the latency form for outputs of a few dozen tiles
@@ -1149,6 +1462,14 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
       else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 0, true>), 17, smem_s);
       else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 1, true>), 18, smem_s);
       else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 2, true>), 19, smem_s);
+    } else if (bnt == 128 && fast && pipe_enabled() && xf == 0 && !rows && g.m % BK == 0 && g.rows_per_split % BK == 0 &&
+               g.rows_per_split * (g.lda > g.ldb ? g.lda : g.ldb) < (1 << 28)) {
+      // plain operands, whole k-tiles in every split, byte offsets inside the 2 GiB descriptor windows
+      constexpr size_t smem_pipe = pipe_lds_bytes(KROW, KROW);
+      static int cfg_pipe = 1;
+      if (cfg_pipe > 0) cfg_pipe = set_smem(gemm_tn_kernel_pipe, smem_pipe);
+      if (cfg_pipe != GLNN_OK) return cfg_pipe;
+      hipLaunchKernelGGL(gemm_tn_kernel_pipe, grid, dim3(256), smem_pipe, st, g);
     } else if (bnt == 128) {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<128>), 0, smem128);
       else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 0, false>), 1, smem128t);

@@ -41,7 +41,8 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     const bool last = (l == L - 1);
     float* out = last ? d->logits : d->z[l];
     const int64_t ldo = last ? d->ld_logits : d->ldz[l];
-    GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, l > 0 ? p : 0.f, (l > 0 && p > 0.f) ? drop_seeds[l - 1] : 0u, m,
+    const bool recompute = l > 0 && a_scale != nullptr;     // the previous layer's tail evaluated in this GEMM's operand load
+    GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, recompute ? p : 0.f, (recompute && p > 0.f) ? drop_seeds[l - 1] : 0u, m,
                            d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
                            d->ws_gemm, d->ws_gemm_floats, stream));
     if (!last) {
@@ -49,11 +50,20 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
         GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                    d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
                                    d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
-      a_scale = d->a_scale[l];
-      a_shift = d->a_shift[l];
-      src = out;
-      ld_src = ldo;
       rows = nullptr;
+      if (d->act[l]) {       // the tail of hidden layer l materialised once: the next GEMM and the weight gradient read it plain
+        GLNN_REQUIRE(d->ld_act[l] >= ((d->dims[l + 1] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_act[%d] too small", l);
+        GLNN_TRY(glnn_act_fwd_f32(out, ldo, m, d->dims[l + 1], d->a_scale[l], d->a_shift[l], p, p > 0.f ? drop_seeds[l] : 0u,
+                                  d->act[l], d->ld_act[l], stream));
+        a_scale = a_shift = nullptr;
+        src = d->act[l];
+        ld_src = d->ld_act[l];
+      } else {
+        a_scale = d->a_scale[l];
+        a_shift = d->a_shift[l];
+        src = out;
+        ld_src = ldo;
+      }
     }
   }
   // ---- loss + dlogits ----
@@ -73,9 +83,14 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
-    GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                              p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
-                              d->ws_tn_floats, stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+    if (d->act[l - 1])
+      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
+                                d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
+                                d->ws_tn_floats, stream));
+    else
+      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
+                                p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
+                                d->ws_tn_floats, stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
     if (d->batchnorm) {

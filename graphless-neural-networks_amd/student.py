@@ -116,6 +116,15 @@ class StudentEngine:
         fused = os.environ.get("GLNN_STUDENT_FUSED_FINALIZE", "auto")
         self.sync_counters = torch.zeros(_lib.MLP_COUNTERS, dtype=torch.int32, device=dev) \
             if fused == "1" or (fused == "auto" and B * hmax <= (1 << 20)) else None
+        # the tail of hidden layer l (norm -> ReLU -> dropout) is either recomputed inside the operand loads of the next GEMM and
+        # of the weight gradient (nothing stored) or written once per step and read plain.  With dropout the recompute hashes
+        # every staged element in every workgroup that stages it (n_next / 128 times): MLP3w8 forward GEMM 316 vs 260 us + a
+        # 13 us pass, weight gradient 309 vs 277 us -> materialise when the next layer is wide and the batch large; small
+        # latency-bound steps keep the recompute (one launch fewer per hidden layer).
+        mat = os.environ.get("GLNN_STUDENT_MATERIALIZE_ACT", "auto")
+        self.act = [ops.feat_empty(B, self.dims[l + 1], dev)
+                    if mat == "1" or (mat == "auto" and self.p > 0 and self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)) else None
+                    for l in range(self.L - 1)]
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -161,6 +170,8 @@ class StudentEngine:
             mean, rstd, sc, sh = self.stats[l]
             d.mean[l], d.rstd[l], d.a_scale[l], d.a_shift[l] = ptr(mean), ptr(rstd), ptr(sc), ptr(sh)
             d.z[l], d.ldz[l] = ptr(self.z[l]), self.z[l].stride(0)
+            if self.act[l] is not None:
+                d.act[l], d.ld_act[l] = ptr(self.act[l]), self.act[l].stride(0)
             if self.bn:
                 bn = self.enc.norms[l]
                 if bn.momentum is None or not bn.affine or not bn.track_running_stats:

@@ -310,6 +310,13 @@ typedef struct glnn_mlp_step_desc {
    * workgroup folds the partials) instead of in a second one: 7 launches fewer per 3-layer step.  ws_loss must then hold
    * >= 256 * 65 floats for the last layer's bias gradient to ride along (label_dim <= 64).  NULL = two-launch forms. */
   int32_t* sync_counters;
+  /* optional, per hidden layer l: act[l] [max_batch, ld_act[l]] receives dropout(relu(norm(z[l]))) once per step
+   * (glnn_act_fwd_f32) and the next layer's forward and weight-gradient GEMMs read it as a plain operand.  NULL = that tail
+   * is recomputed inside their operand loads (nothing stored): cheaper for narrow layers and small batches; with dropout
+   * and a wide next layer the per-element mask hash, re-evaluated by every workgroup that stages the tile, costs more
+   * than one 8-byte-per-element pass (MLP3w8: 316 vs 260+13 us forward, 309 vs 277 us weight gradient). */
+  float* act[GLNN_MLP_MAX_LAYERS];
+  int64_t ld_act[GLNN_MLP_MAX_LAYERS];
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,

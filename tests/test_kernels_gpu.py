@@ -157,6 +157,40 @@ def test_gemm_vs_oracle(m, k, n, kn):
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
 
 
+@pytest.mark.parametrize("form,m,k,n", [("nt", 4096, 2048, 2048), ("nt", 300, 64, 200), ("nt", 129, 32, 129), ("nt", 1000, 96, 256),
+                                        ("kn", 4096, 2048, 2048), ("kn", 300, 64, 200), ("kn", 517, 160, 132), ("kn", 128, 32, 68),
+                                        ("tn", 4096, 2048, 2048), ("tn", 320, 200, 130), ("tn", 8192, 256, 256), ("tn", 64, 129, 257),
+                                        ("tn", 2080, 130, 100)])
+def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(form, m, k, n, monkeypatch):
+    """gemm_kernel_pipe / gemm_tn_kernel_pipe (hand-scheduled main loop, buffer loads, plain operands, K % 32 == 0) keep the tiles,
+    the k order and the MFMA order of gemm_kernel_fast / gemm_tn_kernel_t: same bits, ragged tiles, epilogues and splits included.
+    For "tn" (m, k, n) = (reduction rows, ka, nb)."""
+    from glnn_amd import ops
+    r = np.random.RandomState(m + k + n)
+    outs = []
+    if form == "tn":
+        a = ops.as_feat(dev((r.standard_normal((m, k)) / 8).astype(np.float32)))
+        b = ops.as_feat(dev(r.standard_normal((m, n)).astype(np.float32)))
+        want = a[:, :k].double().t() @ b[:, :n].double()
+    else:
+        a = ops.as_feat(dev(r.standard_normal((m, k)).astype(np.float32)))
+        w = dev((r.standard_normal((k, n) if form == "kn" else (n, k)) / np.sqrt(k)).astype(np.float32))
+        if form == "kn":
+            w = ops.as_feat(w)
+        rs, es, eh = (dev(r.uniform(0.5, 2, m).astype(np.float32)), dev(r.uniform(0.5, 1.5, n).astype(np.float32)),
+                      dev(r.standard_normal(n).astype(np.float32)))
+        ww = w[:, :n] if form == "kn" else w.t()
+        want = torch.relu((a[:, :k].double() @ ww.double()) * rs.double()[:, None] * es.double() + eh.double())
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_GEMM_PIPE", mode)
+        if form == "tn":
+            outs.append(ops.gemm_tn(a, b).clone())
+        else:
+            outs.append(ops.gemm(a, w, w_is_kn=(form == "kn"), row_scale=rs, ep_scale=es, ep_shift=eh, relu=True).clone())
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, (m if form == "tn" else k) / 512) ** 0.5, rtol=1e-5)
+
+
 def test_gemm_transpose_detecting():
     # A = I (padded) against an ASYMMETRIC B catches swapped C layouts
     from glnn_amd import ops

@@ -129,9 +129,12 @@ def test_dropout_mask_kernel_equals_numpy_restatement(rows, h, p, seed):
     assert np.array_equal(got, keep_mask(rows, h, p, seed))
 
 
-def test_training_step_with_dropout_matches_oracle_given_the_mask():
+@pytest.mark.parametrize("materialize", ["0", "1"])
+def test_training_step_with_dropout_matches_oracle_given_the_mask(materialize, monkeypatch):
+    """Both forms of a hidden layer's tail: recomputed inside the operand loads ("0") and written once by glnn_act_fwd_f32 ("1")."""
     from glnn_amd import ops
     from glnn_amd.student import StudentEngine
+    monkeypatch.setenv("GLNN_STUDENT_MATERIALIZE_ACT", materialize)
     g = Golden("bn_small")
     p = 0.4
     model, opt = _student(g, dropout=p)
@@ -158,6 +161,37 @@ def test_training_step_with_dropout_matches_oracle_given_the_mask():
     np.testing.assert_allclose(eng.logits[:bsz].cpu().numpy(), logits, atol=TOL, rtol=0)
     for (pname, prm), gr in zip(model.named_parameters(), grads):
         np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=TOL, rtol=1e-4, err_msg=pname)
+
+
+@pytest.mark.parametrize("dims,bsz,norm,p", [([100, 512, 512, 47], 4096, "batch", 0.2), ([24, 64, 64, 5], 300, "none", 0.5),
+                                             ([128, 1024, 1024, 40], 512, "batch", 0.5)])
+def test_materialised_activation_steps_equal_recomputed_ones_bit_for_bit(dims, bsz, norm, p, monkeypatch):
+    """glnn_mlp_step_desc.act: the stored tail and the one re-evaluated in the GEMM operand loads are the same fp32 expression
+    on the same counter-based mask, so three optimiser steps end in identical parameters, moments and running statistics."""
+    import copy
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    from glnn_amd.student import StudentEngine
+    torch.manual_seed(5)
+    base = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                      dropout_ratio=p, norm_type=norm, device=DEV))
+    x = ops.as_feat(torch.randn(2 * bsz, dims[0], device=DEV))
+    tgt = ops.as_feat(torch.log_softmax(torch.randn(2 * bsz, dims[-1], device=DEV), 1))
+    states = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_STUDENT_MATERIALIZE_ACT", mode)
+        model = copy.deepcopy(base)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+        eng = StudentEngine(model, opt, bsz)
+        assert all((a is not None) == (mode == "1") for a in eng.act)
+        for i in range(3):
+            eng.step(x, torch.arange(i * 7, i * 7 + bsz, device=DEV), ops.LOSS_KL, tgt, 1.0)
+        torch.cuda.synchronize()
+        states.append(([t.detach().clone() for t in model.state_dict().values()],
+                       [opt.state[q]["exp_avg"].clone() for q in model.parameters()], eng.loss_out.clone()))
+    for a, b in zip(states[0][0] + states[0][1] + [states[0][2]], states[1][0] + states[1][1] + [states[1][2]]):
+        assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------------------------------- teacher
