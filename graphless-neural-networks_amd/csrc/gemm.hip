@@ -708,10 +708,9 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     }
   };
 
-  // one k-tile out of LDS buffer CUR; tile kt+1 goes registers -> buffer CUR^1, tile kt+2 global -> registers.
-  // PH = the wave's index in the workgroup staggers its two staging pieces per k-group (MFMA slots PH and PH+7): the barrier
-  // re-aligns the waves of a CU every k-tile, and waves handing a ds_write_b128 to the LDS store path in the same slot
-  // queue up behind each other (~13 cycles each).
+  // one k-tile out of LDS buffer CUR; tile kt+1 goes registers -> buffer CUR^1, tile kt+2 global -> registers.  The two
+  // staging pieces of a k-group sit behind MFMA slots PH and PH+7 (giving every wave of the workgroup its own PH -- four copies
+  // of the loop -- so that the waves do not hand their ds_write_b128 to the LDS store path in the same slot measured equal).
   auto ktile = [&](auto cur_, auto ph_, uint32_t sa, uint32_t sb) {
     constexpr int CUR = decltype(cur_)::value, PH = decltype(ph_)::value;
     static_for<64>([&](auto m_) {
@@ -752,8 +751,8 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
       }
     });
   };
-  // everything that is in flight when the loop starts (tile 1, the first fragments) is issued inside the per-wave branch:
-  // values that cross the branch could be copied by the compiler, which cannot see that the asm loads have not landed yet
+  // everything that is in flight when the loop starts (tile 1, the first fragments) is issued right in front of it: the compiler
+  // cannot see that an asm load has not landed yet, so the loaded values must not cross a branch where it could copy them
   auto kloop = [&](auto ph_) {
     {
       const uint32_t sa = tile_idx(1) * step_a, sb = tile_idx(1) * step_b;
@@ -777,11 +776,7 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     // write -> VALU read needs 18 wait states the compiler cannot see behind the asm)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   };
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // scalar: the four loops are selected by s_cbranch
-  if (wave_u == 0) kloop(std::integral_constant<int, 0>{});
-  else if (wave_u == 1) kloop(std::integral_constant<int, 1>{});
-  else if (wave_u == 2) kloop(std::integral_constant<int, 2>{});
-  else kloop(std::integral_constant<int, 3>{});
+  kloop(std::integral_constant<int, 2>{});
 }
 
 // GLNN_GEMM_PIPE=0 keeps every shape on the compiler-scheduled kernels (A/B runs, tests/test_kernels_gpu.py)
