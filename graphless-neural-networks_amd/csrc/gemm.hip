@@ -583,13 +583,15 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define GLNN_BLOAD(DST_, VOFF_, RSRC_, SOFF_) \
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(DST_) : "v"(VOFF_), "s"(RSRC_), "s"(SOFF_) : "memory")
 
-// raw buffer descriptor over [base, base + 2 GiB): stride 0, 32-bit data format; every offset used below is valid by construction
-__device__ __forceinline__ i32x4 make_rsrc(const float* base) {
+// raw buffer descriptor over [base, base + bytes): stride 0, 32-bit data format.  A load whose offset (register + SGPR
+// step) reaches num_records returns 0 instead of touching memory: k rows past the end of a KROW operand (the last, partial
+// k-tile of a weight-gradient split; the prefetches past the last tile) need neither a clamp nor a mask.
+__device__ __forceinline__ i32x4 make_rsrc(const float* base, int64_t bytes) {
   const uint64_t b = reinterpret_cast<uint64_t>(base);
   i32x4 r;
   r.x = (int)(uint32_t)b;
   r.y = (int)(uint32_t)((b >> 32) & 0xFFFFu);
-  r.z = 0x7FFFFFFF;
+  r.z = (int)(bytes < 0 ? 0 : (bytes > 0x7FFFFFFF ? 0x7FFFFFFF : bytes));
   r.w = 0x00020000;
   return r;
 }
@@ -619,9 +621,11 @@ template <> struct PipeOp<KROW> {
 //   a0 / b0   the tile's origin: ROWK -> element (first row, first k), KROW -> element (first k, first column)
 //   ext_a/b   valid rows (ROWK) / valid columns rounded up to 4 (KROW) from the origin: further ones are clamped (they only
 //             feed outputs that are never stored)
+//   kext      k extent from the origin.  ROWK operands need kext == 32 nk (a k tail inside a row is not out of range);
+//             KROW operands may end inside the last k-tile: those rows lie behind the descriptor's end and read as 0
 template <int SA, int SB>
 __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int64_t ext_a, const float* b0, int64_t ldb, int64_t ext_b,
-                                              int nk, f32x16 (&acc)[2][2]) {
+                                              int64_t kext, int nk, f32x16 (&acc)[2][2]) {
   using OA = PipeOp<SA>;
   using OB = PipeOp<SB>;
   constexpr int A_OFF = 0, B_OFF = 2 * OA::TILE;
@@ -634,8 +638,8 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kk = lane >> 5;
 
-  const i32x4 rsrc_a = make_rsrc(a0);
-  const i32x4 rsrc_b = make_rsrc(b0);
+  const i32x4 rsrc_a = make_rsrc(a0, SA == ROWK ? ((ext_a - 1) * lda + kext) * 4 : ((kext - 1) * lda + ext_a) * 4);
+  const i32x4 rsrc_b = make_rsrc(b0, SB == ROWK ? ((ext_b - 1) * ldb + kext) * 4 : ((kext - 1) * ldb + ext_b) * 4);
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;       // the dynamic array is the kernel's only LDS object
   uint32_t voff[8];                      // per-piece global byte offsets: 0..3 = A, 4..7 = B
   uint32_t wr_a, wr_b;                   // LDS write bases (buffer 0)
@@ -671,7 +675,10 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   setup(std::integral_constant<int, SB>{}, ldb, ext_b, wn, lds0 + B_OFF, voff + 4, wr_b, rd_b, step_b);
 
   f32x4 st[8];                           // the staged tile: one float4 per piece
-  auto tile_idx = [&](int kt) { return (uint32_t)(kt < nk ? kt : nk - 1); };   // tiles past the end re-read the last one (uniform: SALU)
+  // SGPR offset of k-tile kt (uniform: SALU).  A tile past the end gets the descriptor's own size as offset: every lane is out of
+  // range and reads 0 without touching memory -- the prefetches behind the last tile, and the zero tile that pads an odd tile count
+  auto soff_a = [&](int kt) { return kt < nk ? (uint32_t)kt * step_a : (uint32_t)rsrc_a.z; };
+  auto soff_b = [&](int kt) { return kt < nk ? (uint32_t)kt * step_b : (uint32_t)rsrc_b.z; };
 
   // ---- prologue: tile 0 -> LDS buffer 0 ----
   {
@@ -755,7 +762,7 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   // cannot see that an asm load has not landed yet, so the loaded values must not cross a branch where it could copy them
   auto kloop = [&](auto ph_) {
     {
-      const uint32_t sa = tile_idx(1) * step_a, sb = tile_idx(1) * step_b;
+      const uint32_t sa = soff_a(1), sb = soff_b(1);
       static_for<8>([&](auto p_) {
         constexpr int p = decltype(p_)::value;
         (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb;
@@ -766,12 +773,12 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     static_for<NR>([&](auto r_) {
       frag_read(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, r_);
     });
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-      ktile(std::integral_constant<int, 0>{}, ph_, tile_idx(kt + 2) * step_a, tile_idx(kt + 2) * step_b);
-      ktile(std::integral_constant<int, 1>{}, ph_, tile_idx(kt + 3) * step_a, tile_idx(kt + 3) * step_b);
+    // always an even number of k-tiles (an odd count is padded with one all-zero tile): a separate tail after the loop is a
+    // control-flow join, where the compiler may copy the staged registers -- while their asm loads are still in flight
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(std::integral_constant<int, 0>{}, ph_, soff_a(kt + 2), soff_b(kt + 2));
+      ktile(std::integral_constant<int, 1>{}, ph_, soff_a(kt + 3), soff_b(kt + 3));
     }
-    if (kt < nk) ktile(std::integral_constant<int, 0>{}, ph_, tile_idx(kt + 2) * step_a, tile_idx(kt + 2) * step_b);
     // drain: loads / fragment reads of the tiles past the end are in flight; the accumulators are read by VALU next (XDL
     // write -> VALU read needs 18 wait states the compiler cannot see behind the asm)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -803,9 +810,9 @@ __global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (B_KN)
-    pipe_mainloop<ROWK, KROW>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + n0, g.ldb, ((g.n + 3) & ~3) - n0, g.k / BK, acc);
+    pipe_mainloop<ROWK, KROW>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + n0, g.ldb, ((g.n + 3) & ~3) - n0, g.k, g.k / BK, acc);
   else
-    pipe_mainloop<ROWK, ROWK>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + (int64_t)n0 * g.ldb, g.ldb, g.n - n0, g.k / BK, acc);
+    pipe_mainloop<ROWK, ROWK>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + (int64_t)n0 * g.ldb, g.ldb, g.n - n0, g.k, g.k / BK, acc);
   store_tile<128, 128, 2, 2>(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
 }
 
@@ -1166,7 +1173,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   pipe_mainloop<KROW, KROW>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
-                            ((g.nb + 3) & ~3) - j0, (int)((mend - mbeg) / BK), acc);
+                            ((g.nb + 3) & ~3) - j0, mend - mbeg, (int)((mend - mbeg + BK - 1) / BK), acc);
   float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1409,14 +1416,20 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;
   const bool fast = g.a_vec && g.b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
                     (!b_scale || (nb % 4 == 0 && glnn::aligned16(b_scale) && glnn::aligned16(b_shift)));
-  // latency regime (see gemm_kernel_fast): a few dozen output tiles -> 64 x 64 tiles, a quarter of the per-wave MFMA chain
-  const bool small = fast && gi * gj <= 64;
+  // the hand-scheduled 128 x 128 kernel: plain operands whose per-split byte offsets fit a 2 GiB descriptor window
+  const bool pipe_shape = fast && bnt == 128 && !b_scale && !b_rows && pipe_enabled() && (lda > ldb ? lda : ldb) < (1 << 20);
+  // latency regime (see gemm_kernel_fast): a few dozen output tiles -> 64 x 64 tiles, a quarter of the per-wave MFMA chain --
+  // unless the reduction is long enough for the pipelined kernel's deeper k-loop to pay (>= 2048 rows)
+  const bool small = fast && gi * gj <= 64 && !(pipe_shape && m >= 2048);
   if (small) { bnt = 64; gi = (ka + 63) / 64; gj = (nb + 63) / 64; }
   // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
   int splits = 1;
   const int64_t slab = (int64_t)ka * nb;
   const int64_t colsum_need = col_sum_a ? (int64_t)64 * ka : 0;
-  const int wg_target = small ? 1024 : 512;           // 64 x 64 tiles: four workgroups fit a CU, and a k-tile step is load-latency bound
+  // 64 x 64 tiles: four workgroups fit a CU, and a k-tile step is load-latency bound.  The pipelined kernel keeps its MFMA rate
+  // with ONE workgroup per CU, so it splits only up to 256 workgroups: half the slab traffic of 512 (MLP3w8's 2048 x 2048
+  // gradient needs no split and no fold at all: 245 -> 234 us; 60000 x 256 x 128: 97 -> 66 us; 1024 workgroups: 162 us)
+  const int wg_target = small ? 1024 : (pipe_shape ? 256 : 512);
   const int min_ktiles = small ? 2 : 4;
   if (workspace && gi * gj < wg_target) {
     splits = (wg_target + gi * gj - 1) / (gi * gj);
@@ -1432,6 +1445,7 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   g.rows_per_split = rps;
   splits = (int)((m + rps - 1) / rps);
   g.splits = splits;
+  const bool pipe_ok = pipe_shape && !small && rps * (lda > ldb ? lda : ldb) < (1 << 28);
   float* ws_partial = workspace ? workspace + colsum_need : nullptr;
   if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
   const int xf = !b_scale ? 0 : (g.drop_thr ? 2 : 1);
@@ -1457,9 +1471,8 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
       else if (xf == 0) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 0, true>), 17, smem_s);
       else if (xf == 1) GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 1, true>), 18, smem_s);
       else GLNN_TN_LAUNCH((gemm_tn_kernel_t<64, 64, 2, true>), 19, smem_s);
-    } else if (bnt == 128 && fast && pipe_enabled() && xf == 0 && !rows && g.m % BK == 0 && g.rows_per_split % BK == 0 &&
-               g.rows_per_split * (g.lda > g.ldb ? g.lda : g.ldb) < (1 << 28)) {
-      // plain operands, whole k-tiles in every split, byte offsets inside the 2 GiB descriptor windows
+    } else if (pipe_ok) {
+      // plain operands, byte offsets inside the 2 GiB descriptor windows; the last split may end inside a k-tile
       constexpr size_t smem_pipe = pipe_lds_bytes(KROW, KROW);
       static int cfg_pipe = 1;
       if (cfg_pipe > 0) cfg_pipe = set_smem(gemm_tn_kernel_pipe, smem_pipe);

@@ -65,3 +65,39 @@ def test_ops_refuse_cpu_tensors():
         ops.log_softmax(x)
     with pytest.raises(GlnnError):
         ops.spmm(torch.zeros(5, dtype=torch.int64), torch.zeros(1, dtype=torch.int32), x, 4, ops.AGG_SUM)
+
+
+def test_pipelined_gemm_loops_contain_no_vector_alu_and_no_register_copies(tmp_path):
+    """gemm_kernel_pipe / gemm_tn_kernel_pipe issue their operand loads from inline asm: the compiler does not know those loads are
+    in flight, so any register copy (or other VALU instruction) it placed between the prologue barrier and the final drain would
+    read registers that have not been written yet.  Checked on the ISA hipcc generates for gfx950 (also the performance contract:
+    no vector-ALU work between the MFMAs)."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graphless-neural-networks_amd", "csrc", "gemm.hip")
+    out = tmp_path / "gemm.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"-I{ROOT}/include",
+                    f"-I{ROOT}/graphless-neural-networks_amd/csrc", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*gemm_(?:tn_)?kernel_pipe[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 3, [k for k, _ in kernels]
+    for name, body in kernels:
+        lines = body.split("\n")
+        first_barrier = next(i for i, l in enumerate(lines) if "s_barrier" in l)
+        last_drain = max(i for i, l in enumerate(lines) if "s_nop 15" in l)
+        region = [l.split(";")[0].strip() for l in lines[first_barrier + 1:last_drain]]
+        assert sum("Loop Header" in l for l in lines) == 1
+        head = next(i for i, l in enumerate(lines) if "Loop Header" in l)
+        label = lines[head].split(":")[0].strip()
+        back = next(i for i, l in enumerate(lines) if i > head and "s_cbranch" in l and label in l)
+        loop = [l.split(";")[0].strip() for l in lines[head + 1:back]]
+        # inside the loop: no vector-ALU instruction on vector registers at all
+        valu = [l for l in loop if re.match(r"v_(?!mfma)", l) and re.search(r"\b[va]\[?\d", l)]
+        assert not valu, (name, valu[:5])
+        assert sum(l.startswith("v_mfma_f32_32x32x2") for l in loop) == 128      # two k-tiles per iteration
+        # around it (prologue barrier .. drain): no register-to-register copies
+        copies = [l for l in region if l.startswith(("v_mov", "v_accvgpr_read", "v_accvgpr_mov"))]
+        assert not copies, (name, copies[:5])

@@ -160,7 +160,9 @@ def test_gemm_vs_oracle(m, k, n, kn):
 @pytest.mark.parametrize("form,m,k,n", [("nt", 4096, 2048, 2048), ("nt", 300, 64, 200), ("nt", 129, 32, 129), ("nt", 1000, 96, 256),
                                         ("kn", 4096, 2048, 2048), ("kn", 300, 64, 200), ("kn", 517, 160, 132), ("kn", 128, 32, 68),
                                         ("tn", 4096, 2048, 2048), ("tn", 320, 200, 130), ("tn", 8192, 256, 256), ("tn", 64, 129, 257),
-                                        ("tn", 2080, 130, 100)])
+                                        ("tn", 2080, 130, 100), ("tn", 2077, 256, 256), ("tn", 60001, 256, 128), ("tn", 4096, 2048, 100),
+                                        ("tn", 2049, 129, 65), ("tn", 2064, 128, 128), ("tn", 2144, 130, 100), ("tn", 4128, 256, 256),
+                                        ("nt", 300, 96, 200), ("kn", 200, 32, 132), ("kn", 2100, 160, 256), ("nt", 5000, 224, 384)])
 def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(form, m, k, n, monkeypatch):
     """gemm_kernel_pipe / gemm_tn_kernel_pipe (hand-scheduled main loop, buffer loads, plain operands, K % 32 == 0) keep the tiles,
     the k order and the MFMA order of gemm_kernel_fast / gemm_tn_kernel_t: same bits, ragged tiles, epilogues and splits included.
@@ -187,7 +189,13 @@ def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(fo
             outs.append(ops.gemm_tn(a, b).clone())
         else:
             outs.append(ops.gemm(a, w, w_is_kn=(form == "kn"), row_scale=rs, ep_scale=es, ep_shift=eh, relu=True).clone())
-    assert torch.equal(outs[0], outs[1])
+    # the weight-gradient launcher picks other tiles / reduction splits for few-tile outputs over >= 2048 rows when the pipelined
+    # kernel is available: a different summation order across splits, so only closeness can be asked there
+    same_order = not (form == "tn" and m >= 2048 and ((k + 127) // 128) * ((n + 127) // 128) <= 64)
+    if same_order:
+        assert torch.equal(outs[0], outs[1])
+    else:
+        np.testing.assert_allclose(outs[1][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, m / 512) ** 0.5, rtol=1e-5)
     np.testing.assert_allclose(outs[0][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, (m if form == "tn" else k) / 512) ** 0.5, rtol=1e-5)
 
 
