@@ -73,7 +73,7 @@ class MlpStepDesc(ctypes.Structure):
                  ("loss_out", c_vp), ("loss_accum", c_vp),
                  ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
                  ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp),
-                 ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS)])
+                 ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS), ("xb", c_vp), ("ld_xb", c_i64)])
 
 
 SAGE_MAX_LAYERS = 8

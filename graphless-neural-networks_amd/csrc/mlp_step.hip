@@ -35,6 +35,14 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   const float* src = feats;
   int64_t ld_src = ldx;
   const int64_t* rows = idx;
+  const bool pregather = d->xb && idx;       // the batch rows copied once: layer 0's GEMMs read a plain operand
+  if (pregather) {
+    GLNN_REQUIRE(d->ld_xb >= ((d->dims[0] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_xb too small");
+    GLNN_TRY(glnn_gather_rows_f32(feats, ldx, idx, m, d->dims[0], d->xb, d->ld_xb, stream));
+    src = d->xb;
+    ld_src = d->ld_xb;
+    rows = nullptr;
+  }
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
   for (int l = 0; l < L; ++l) {
@@ -78,7 +86,8 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
     if (l == 0) {
-      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], feats, ldx, idx, nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
+      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
+                                nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
                                 d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
       break;
     }

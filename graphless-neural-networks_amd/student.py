@@ -125,6 +125,10 @@ class StudentEngine:
         self.act = [ops.feat_empty(B, self.dims[l + 1], dev)
                     if mat == "1" or (mat == "auto" and self.p > 0 and self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)) else None
                     for l in range(self.L - 1)]
+        # feats[idx] copied once per step when the batch is long enough for the first layer's weight gradient to take the
+        # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches keep the gather inside the operand loads
+        pg = os.environ.get("GLNN_STUDENT_PREGATHER", "auto")
+        self.xb = ops.feat_empty(B, self.dims[0], dev) if pg == "1" or (pg == "auto" and B >= 2048 and self.dims[0] > 64) else None
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -188,6 +192,8 @@ class StudentEngine:
         d.ws_gemm, d.ws_gemm_floats = ptr(self.ws_gemm), self.ws_gemm.numel()
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+        if self.xb is not None:
+            d.xb, d.ld_xb = ptr(self.xb), self.xb.stride(0)
         if self.sync_counters is not None and max(self.dims) <= 64 * (_lib.MLP_COUNTERS - 1):
             d.sync_counters = ptr(self.sync_counters)
         return d

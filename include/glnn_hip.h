@@ -317,6 +317,12 @@ typedef struct glnn_mlp_step_desc {
    * than one 8-byte-per-element pass (MLP3w8: 316 vs 260+13 us forward, 309 vs 277 us weight gradient). */
   float* act[GLNN_MLP_MAX_LAYERS];
   int64_t ld_act[GLNN_MLP_MAX_LAYERS];
+  /* optional: xb [max_batch, ld_xb] receives feats[idx] once per step (glnn_gather_rows_f32) and the first layer's forward and
+   * weight-gradient GEMMs read it as a plain operand -- the weight gradient then qualifies for the pipelined kernel
+   * (B=4096, 2048 x 100: 38 + 9 us gathered vs 29 us plain + a 4 us gather).  NULL (or idx == NULL) = rows gathered in the
+   * operand loads. */
+  float* xb;
+  int64_t ld_xb;
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,

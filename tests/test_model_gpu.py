@@ -135,6 +135,7 @@ def test_training_step_with_dropout_matches_oracle_given_the_mask(materialize, m
     from glnn_amd import ops
     from glnn_amd.student import StudentEngine
     monkeypatch.setenv("GLNN_STUDENT_MATERIALIZE_ACT", materialize)
+    monkeypatch.setenv("GLNN_STUDENT_PREGATHER", materialize)      # likewise feats[idx]: gathered in the operand loads / copied once
     g = Golden("bn_small")
     p = 0.4
     model, opt = _student(g, dropout=p)
