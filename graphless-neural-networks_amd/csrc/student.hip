@@ -742,24 +742,38 @@ extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* 
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
                                                       const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                       uint32_t thr, uint32_t seed, float dscale, float* __restrict__ y, int64_t ldy) {
+  constexpr int U = 4;                   // float4s in flight per thread: one per pass left the kernel at 2.9 TB/s (22 us for 2 x 32 MB)
   const int h4 = (h + 3) >> 2;
   const int64_t total = rows * h4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / h4;
-    const int c = (int)(i - r * h4) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(z + r * ldz + c);
-    float o[4] = {v.x, v.y, v.z, v.w};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += U * stride) {
+    float4 v[U];
+    int64_t r[U];
+    int c[U];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float x = 0.f;
-      if (c + t < h) {
-        x = a_scale ? fmaf(o[t], a_scale[c + t], a_shift[c + t]) : o[t];
-        x = fmaxf(x, 0.f);
-        if (thr) x = glnn::drop_keep(seed, thr, (uint32_t)r, (uint32_t)(c + t)) ? x * dscale : 0.f;
-      }
-      o[t] = x;                          // padding columns are written as zero
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      const int64_t ic = i < total ? i : i0;
+      r[u] = ic / h4;
+      c[u] = (int)(ic - r[u] * h4) * 4;
+      v[u] = *reinterpret_cast<const float4*>(z + r[u] * ldz + c[u]);
     }
-    *reinterpret_cast<float4*>(y + r * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * stride >= total) break;
+      float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float x = 0.f;
+        if (c[u] + t < h) {
+          x = a_scale ? fmaf(o[t], a_scale[c[u] + t], a_shift[c[u] + t]) : o[t];
+          x = fmaxf(x, 0.f);
+          if (thr) x = glnn::drop_keep(seed, thr, (uint32_t)r[u], (uint32_t)(c[u] + t)) ? x * dscale : 0.f;
+        }
+        o[t] = x;                          // padding columns are written as zero
+      }
+      *reinterpret_cast<float4*>(y + r[u] * ldy + c[u]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -781,7 +795,7 @@ extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h
   GLNN_REQUIRE((a_scale == nullptr) == (a_shift == nullptr), "glnn_act_fwd_f32: a_scale and a_shift go together");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_act_fwd_f32: drop_p must be in [0,1)");
   if (rows == 0) return GLNN_OK;
-  int64_t blocks = (rows * (hp / 4) + 255) / 256;
+  int64_t blocks = (rows * (hp / 4) + 4 * 256 - 1) / (4 * 256);      // four float4s per thread
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, ldz, rows, h, a_scale,
                      a_shift, glnn::drop_threshold(drop_p), drop_seed, 1.0f / (1.0f - drop_p), y, ldy);
