@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--student-steps-per-step", type=int, default=30, help="student steps timed per --steps unit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the sampled-block teacher-training object (N = 1)")
+    ap.add_argument("--no-grad-overlap", action="store_true",
+                    help="N > 1: one gradient all-reduce after the whole backward instead of starting the big layers' all-reduce "
+                         "from inside it (glnn_amd.dist.OverlappedGradSync)")
     ap.add_argument("--student-global-bn", action="store_true",
                     help="N > 1: take the student's BatchNorm batch statistics over the global (N x B rows) batch through the "
                          "exchange hook, i.e. exactly the single-GPU step on that batch (default: per-rank statistics)")
@@ -111,7 +114,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import torch.distributed as dist
     from glnn_amd import data, ops
-    from glnn_amd.dist import HaloShardedTeacher, RowShards, ShardedTeacher, make_grad_sync
+    from glnn_amd.dist import HaloShardedTeacher, OverlappedGradSync, RowShards, ShardedTeacher, make_grad_sync
     from glnn_amd.graph import FullNeighborLoader
     from glnn_amd.models import Model
     from glnn_amd.student import StudentEngine
@@ -205,7 +208,10 @@ def main():
     if world > 1 and args.student_global_bn:     # one N*B-row batch split over ranks, global BN statistics, summed gradients
         eng.enable_batch_split(world, rank)
     elif world > 1:   # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
-        eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
+        if args.no_grad_overlap:
+            eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
+        else:                                   # big weight gradients are all-reduced from inside the backward (grad_ready hook)
+            eng.overlap = OverlappedGradSync(eng, world, average=True)
     out_t = ops.as_feat(out_t)
     k_student = args.steps * args.student_steps_per_step
     w_student = max(args.warmup, 3)
@@ -259,6 +265,8 @@ def main():
                     "batchnorm": "global batch statistics (exchange hook)" if (world > 1 and args.student_global_bn)
                                  else "per-rank batch statistics",
                     "scaling": "weak",
+                    "gradient_exchange": None if world == 1 else ("one all-reduce after the backward" if args.no_grad_overlap and not args.student_global_bn
+                                                                  else "weight gradients >= 1 MB all-reduced from inside the backward (grad_ready hook), the rest after it"),
                     "gflop_per_step": 3 * 2 * sd["batch"] * sum(a * b for a, b in zip(sd["dims"][:-1], sd["dims"][1:])) / 1e9},
     }
     result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3      # per GPU

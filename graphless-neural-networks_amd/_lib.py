@@ -56,6 +56,7 @@ _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 ABI_VERSION = 4
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
+GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 
 
@@ -73,7 +74,8 @@ class MlpStepDesc(ctypes.Structure):
                  ("loss_out", c_vp), ("loss_accum", c_vp),
                  ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
                  ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp),
-                 ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS), ("xb", c_vp), ("ld_xb", c_i64)])
+                 ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS), ("xb", c_vp), ("ld_xb", c_i64),
+                 ("grad_ready", GRAD_READY_FN), ("grad_ready_ctx", c_vp)])
 
 
 SAGE_MAX_LAYERS = 8

@@ -89,6 +89,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
                                 nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
                                 d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+      if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, 0, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer 0)");
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
@@ -100,6 +101,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
                                 p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
                                 d->ws_tn_floats, stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
     if (d->batchnorm) {

@@ -142,7 +142,7 @@ class StudentEngine:
         is normalised by the global row count (`loss_scale_rows` is set per step by the caller or defaults to
         world * local rows), gradients are SUMMED over ranks -> the update equals the single-GPU step on the whole
         batch (tests/test_dist_gpu.py).  Dropout masks are drawn per rank."""
-        from .dist import StatExchange, make_grad_sync
+        from .dist import OverlappedGradSync, StatExchange
         if world <= 1:
             return
         hmax = max(self.dims[1:-1]) if self.L > 1 else 4
@@ -151,7 +151,7 @@ class StudentEngine:
         d.world, d.rank = world, rank
         d.exchange = self.exchange.callback
         d.sync_send, d.sync_recv, d.sync_rows = self.exchange.send.data_ptr(), self.exchange.recv.data_ptr(), self.exchange.rows.data_ptr()
-        self.grad_sync = make_grad_sync(self.flat_grads, world, group, average=False)
+        self.overlap = OverlappedGradSync(self, world, group, average=False)   # sets self.grad_sync and the desc hook
         self.batch_split_world = world
         self.base_seed = _mix32(self.base_seed ^ (0x9E3779B9 * (rank + 1)))      # independent dropout masks per rank
 
@@ -245,6 +245,10 @@ class StudentEngine:
         if rc != 0 and self.exchange is not None and self.exchange.error is not None:
             err, self.exchange.error = self.exchange.error, None
             raise RuntimeError("glnn_mlp_fwd_bwd_f32: the batch-statistics exchange failed") from err
+        overlap = getattr(self, "overlap", None)
+        if rc != 0 and overlap is not None and overlap.error is not None:
+            err, overlap.error = overlap.error, None
+            raise RuntimeError("glnn_mlp_fwd_bwd_f32: a gradient all-reduce started inside the backward failed") from err
         _lib.check(rc, "glnn_mlp_fwd_bwd_f32")
 
         # ---- (data-parallel) gradient exchange, then Adam ---------------------------------------

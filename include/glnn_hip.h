@@ -323,6 +323,13 @@ typedef struct glnn_mlp_step_desc {
    * operand loads. */
   float* xb;
   int64_t ld_xb;
+  /* optional data-parallel hook: called on the host right after the weight-gradient GEMM of `layer` has been enqueued, i.e.
+   * gw[layer] is complete in `stream` order while the rest of the backward (input gradient, BatchNorm backward, the layers
+   * in front) is still to be issued -- the host can start that layer's gradient all-reduce on its own stream and overlap
+   * it (glnn_amd.dist.OverlappedGradSync: MLP3w8's 16 MB hidden-layer gradient rides under ~0.35 ms of remaining backward).
+   * Return 0 on success.  NULL = no call. */
+  int (*grad_ready)(void* ctx, int layer, void* stream);
+  void* grad_ready_ctx;
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,

@@ -125,6 +125,32 @@ def _rccl_worker(port, q):
                 yh = gdist.HaloShardedTeacher(model.encoder, g, sh, ops).forward(x)
             torch.cuda.synchronize()
             errs[(tuple(dims), "halo")] = (float((yh - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+        # the gradient all-reduce started from inside the backward (grad_ready hook -> async RCCL all-reduce on the communicator's
+        # stream -> wait before Adam): with one rank every reduce is the identity, so the steps must equal the plain engine's
+        import copy
+        from glnn_amd.student import StudentEngine
+        torch.manual_seed(1)
+        base = Model(dict(model_name="MLP", num_layers=3, feat_dim=100, hidden_dim=512, label_dim=47, dropout_ratio=0.2,
+                          norm_type="batch", device=dev))
+        xs = ops.as_feat(torch.randn(4096, 100, device=dev))
+        tg = ops.as_feat(torch.log_softmax(torch.randn(4096, 47, device=dev), 1))
+        states, hook_calls, colls = [], 0, 0
+        for overlap in (False, True):
+            m2 = copy.deepcopy(base); m2.train()
+            o2 = torch.optim.Adam(m2.parameters(), lr=0.01)
+            eng = StudentEngine(m2, o2, 1024)
+            if overlap:
+                gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+                eng.overlap = gdist.OverlappedGradSync(eng, 1, average=True)
+                assert sorted(eng.overlap.big) == [1] and len(eng.overlap.rest) == 2          # the 512 x 512 gradient; before / after it
+            for i in range(3):
+                eng.step(xs, torch.arange(i * 5, i * 5 + 1024, device=dev), ops.LOSS_KL, tg, 1.0)
+            torch.cuda.synchronize()
+            if overlap:
+                hook_calls, colls = eng.overlap.calls, gdist.EXCHANGE_STATS["collectives"]
+            states.append([t.detach().clone() for t in m2.state_dict().values()])
+        overlap_equal = all(torch.equal(a, b) for a, b in zip(*states))
+        errs[("student-overlap", "hooks")] = (0.0 if (overlap_equal and hook_calls == 9) else 1.0, colls // 3)   # 3 collectives per step
         flat = torch.arange(16, dtype=torch.float32, device=dev)
         gdist.make_grad_sync(flat, 2, average=True)()            # "world 2" arithmetic over the 1-rank communicator: sum / 2
         ex = gdist.StatExchange(1, 0, 8, dev)
