@@ -543,14 +543,14 @@ class OverlappedGradSync:
             pos = hi
         if pos < flat.numel():
             self.rest.append(flat[pos:])
-        self.works, self.error, self.calls = [], None, 0
+        self.works, self.error, self.calls, self.collectives = [], None, 0, 0
         self.callback = _lib.GRAD_READY_FN(self._hook)
         engine.desc.grad_ready = self.callback
         engine.grad_sync = self.finish
 
     def _reduce(self, t, async_op):
         if FORCE_COLLECTIVES or self.world > 1:
-            EXCHANGE_STATS["collectives"] += 1
+            self.collectives += 1                       # (not EXCHANGE_STATS: that is the teacher's feature exchange)
             if self.average and dist.get_backend(self.group) == "nccl":
                 return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)

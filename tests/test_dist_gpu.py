@@ -140,14 +140,13 @@ def _rccl_worker(port, q):
             o2 = torch.optim.Adam(m2.parameters(), lr=0.01)
             eng = StudentEngine(m2, o2, 1024)
             if overlap:
-                gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
                 eng.overlap = gdist.OverlappedGradSync(eng, 1, average=True)
                 assert sorted(eng.overlap.big) == [1] and len(eng.overlap.rest) == 2          # the 512 x 512 gradient; before / after it
             for i in range(3):
                 eng.step(xs, torch.arange(i * 5, i * 5 + 1024, device=dev), ops.LOSS_KL, tg, 1.0)
             torch.cuda.synchronize()
             if overlap:
-                hook_calls, colls = eng.overlap.calls, gdist.EXCHANGE_STATS["collectives"]
+                hook_calls, colls = eng.overlap.calls, eng.overlap.collectives
             states.append([t.detach().clone() for t in m2.state_dict().values()])
         overlap_equal = all(torch.equal(a, b) for a, b in zip(*states))
         errs[("student-overlap", "hooks")] = (0.0 if (overlap_equal and hook_calls == 9) else 1.0, colls // 3)   # 3 collectives per step
