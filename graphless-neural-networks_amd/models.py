@@ -92,16 +92,27 @@ class MLP(nn.Module):
                 h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
         return h_list, h
 
-    def _forward_hip_eval(self, feats):
-        """Eval-mode chain: each Linear is one glnn_gemm_f32; BN(eval)+ReLU of layer l are folded into the
-        operand load of layer l+1 (dropout is the identity in eval mode), so h_list holds the raw Linear outputs
-        exactly as the reference returns them."""
+    def _forward_hip_eval(self, feats, want_hidden=True):
+        """Eval-mode chain: each Linear is one glnn_gemm_f32 (dropout is the identity in eval mode).
+        want_hidden (what `MLP.forward` returns: h_list = the raw Linear outputs, reference models.py:44-53): BN(eval)+ReLU of
+        layer l are folded into the OPERAND LOAD of layer l+1, so z_l is stored exactly as the reference returns it.
+        Otherwise (Model.forward / inference / evaluate: only the logits are used) they go into the EPILOGUE of layer l itself,
+        relu((x W^T) s + (b s + t)): the next GEMM then reads a plain operand and takes the pipelined kernel -- the 2048-wide
+        middle layer of MLP3w8 over millions of rows is the whole cost of evaluating / serving the student."""
         h = ops.as_feat(feats)
         h_list = []
         a_scale = a_shift = None
         for l, layer in enumerate(self.layers):
-            z = ops.gemm(h, layer.weight, a_scale=a_scale, a_shift=a_shift, ep_shift=layer.bias)
-            if l != self.num_layers - 1:
+            last = l == self.num_layers - 1
+            if want_hidden or last:
+                z = ops.gemm(h, layer.weight, a_scale=a_scale, a_shift=a_shift, ep_shift=layer.bias)
+            else:
+                if self.norm_type == "batch":
+                    s, t = _bn_eval_fold(self.norms[l], layer.bias)      # BN_eval(x + bias) = x s + t
+                    z = ops.gemm(h, layer.weight, ep_scale=s, ep_shift=t, relu=True)
+                else:
+                    z = ops.gemm(h, layer.weight, ep_shift=layer.bias, relu=True)
+            if not last and want_hidden:
                 h_list.append(z)
                 if self.norm_type == "batch":
                     a_scale, a_shift = _bn_eval_fold(self.norms[l], None)
@@ -289,6 +300,11 @@ class Model(nn.Module):
     def forward(self, data, feats):
         """data: a graph `g`, a list of blocks, or None for MLPs."""
         if "MLP" in self.model_name:
+            if not self.encoder.training:           # logits only: the hidden Linear outputs need not be kept raw
+                _need_hip(feats, "MLP.forward")
+                _check_tail(self.encoder)
+                with torch.no_grad():
+                    return self.encoder._forward_hip_eval(feats, want_hidden=False)[1]
             return self.encoder(feats)[1]
         return self.encoder(data, feats)[1]
 

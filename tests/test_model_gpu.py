@@ -119,6 +119,35 @@ def test_eval_forward_at_identical_state_vs_oracle():
         np.testing.assert_allclose(got_z.cpu().numpy(), want_z, atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("norm", ["batch", "none"])
+def test_eval_chain_logits_only_form_equals_the_form_that_keeps_hidden_outputs(norm):
+    """Model.forward in eval mode folds BN(eval)+ReLU into the producing GEMM's epilogue (next GEMM reads a plain operand);
+    MLP.forward / forward_fitnet keep the raw hidden Linear outputs and fold them into the next operand load: same logits."""
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    torch.manual_seed(2)
+    model = Model(dict(model_name="MLP", num_layers=3, feat_dim=100, hidden_dim=256, label_dim=47, dropout_ratio=0.3, norm_type=norm, device=DEV))
+    with torch.no_grad():
+        for bn in model.encoder.norms:
+            bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    model.eval()
+    x = ops.as_feat(torch.randn(3001, 100, device=DEV))
+    a = model(None, x)
+    h_list, b = model.forward_fitnet(None, x)
+    assert len(h_list) == 2 and a.shape == b.shape == (3001, 47)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=1e-5)
+    # and against plain torch ops on the same parameters
+    enc = model.encoder
+    h = x[:, :100]
+    for l, layer in enumerate(enc.layers):
+        h = torch.nn.functional.linear(h, layer.weight, layer.bias)
+        if l < 2:
+            if norm == "batch":
+                h = torch.nn.functional.batch_norm(h, enc.norms[l].running_mean, enc.norms[l].running_var, enc.norms[l].weight, enc.norms[l].bias, False, 0.1, enc.norms[l].eps)
+            h = torch.relu(h)
+    np.testing.assert_allclose(a.cpu().numpy(), h.detach().cpu().numpy(), atol=TOL, rtol=1e-4)
+
+
 @pytest.mark.parametrize("rows,h,p,seed", [(32, 48, 0.4, 0x00C0FFEE), (4096, 2048, 0.2, 12345), (513, 257, 0.5, 0xFFFFFFFF), (1, 1, 0.9, 7)])
 def test_dropout_mask_kernel_equals_numpy_restatement(rows, h, p, seed):
     """glnn_dropout_mask_u8 (what every fused kernel evaluates on the fly) == oracle/dropout_mask.py, bit for bit: the
