@@ -147,8 +147,22 @@ __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ in
   return acc;
 }
 
+// per-column epilogue constants of a lane's four columns, fetched ONCE per wave: inside finish_row they were eight 4-byte loads
+// per output row that the compiler could not hoist past the stores
+struct EpCols { float s[4], h[4]; };
+__device__ __forceinline__ EpCols load_ep_cols(const SpmmArgs& a, int col4) {
+  EpCols e;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bool ok = col4 + t < a.d;
+    e.s[t] = (a.ep_scale && ok) ? a.ep_scale[col4 + t] : 1.f;
+    e.h[t] = (a.ep_shift && ok) ? a.ep_shift[col4 + t] : 0.f;
+  }
+  return e;
+}
+
 template <int MODE>
-__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4) {
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep) {
   float4 y;
   if (MODE == GLNN_AGG_SAGE_GCN) {
     const int64_t sr = a.self_rows ? a.self_rows[v] : v;
@@ -164,8 +178,8 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
   for (int t = 0; t < 4; ++t) {
     const int c = col4 + t;
     if (c < a.d) {
-      if (a.ep_scale) yy[t] *= a.ep_scale[c];
-      if (a.ep_shift) yy[t] += a.ep_shift[c];
+      if (a.ep_scale) yy[t] *= ep.s[t];
+      if (a.ep_shift) yy[t] += ep.h[t];
       if (a.relu) yy[t] = fmaxf(yy[t], 0.f);
     } else {
       yy[t] = 0.f;  // padding columns are written as zero
@@ -181,6 +195,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
   const int c = lane % LPR;
   const int col4 = c * 4;
   const bool col_ok = col4 < a.d;
+  const EpCols ep = load_ep_cols(a, col_ok ? col4 : 0);
 
   if ((int)blockIdx.x < a.n_long_blocks) {
     // ---- long-row role: scan a strided share of the rows, whole workgroup per long row ----
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
           float4 t = s_part[0][lane];
 #pragma unroll
           for (int w = 1; w < kWavesPerBlock; ++w) t = add4(t, s_part[w][lane]);
-          finish_row<MODE>(a, v, e1 - e0, t, col4);
+          finish_row<MODE>(a, v, e1 - e0, t, col4, ep);
         }
         __syncthreads();
       }
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
     const int64_t deg = e1 - e0;
     if (deg > kLongRow) continue;
     float4 acc = wave_gather_sum<LPR, U, CS>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane);
-    if (lane < LPR && col_ok) finish_row<MODE>(a, v, deg, acc, col4);
+    if (lane < LPR && col_ok) finish_row<MODE>(a, v, deg, acc, col4, ep);
   }
 }
 
