@@ -256,6 +256,7 @@ __global__ void block_empty_counts_kernel(int64_t* counts, int64_t* indptr, int6
 struct TrArgs {
   const int64_t* indptr; const int32_t* indices; int64_t n_dst, n_src, nnz; int add_self;
   int64_t* t_indptr; int32_t* t_indices; int32_t* tmp; int* cursor;
+  int cursor_base;      // what the count pass starts from: 0x7F7F7F7F when the cursors were filled by the workspace's ONE memset
 };
 
 __global__ __launch_bounds__(256) void tr_count_kernel(const TrArgs a) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void tr_count_kernel(const TrArgs a) {
 }
 struct TrCount {
   TrArgs a;
-  __device__ int operator()(int64_t u) const { return a.cursor[u] + ((a.add_self && u < a.n_dst) ? 1 : 0); }
+  __device__ int operator()(int64_t u) const { return a.cursor[u] - a.cursor_base + ((a.add_self && u < a.n_dst) ? 1 : 0); }
 };
 struct TrWrite {
   TrArgs a;
@@ -418,8 +419,13 @@ extern "C" int glnn_csr_transpose(const int64_t* indptr, const int32_t* indices,
   TrArgs a;
   a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.n_src = n_src; a.nnz = nnz; a.add_self = add_self;
   a.t_indptr = t_indptr; a.t_indices = t_indices; a.cursor = cursor; a.tmp = cursor + n_src;
-  if (hipMemsetAsync(workspace, 0x7F, (size_t)(b * 8 + 16), st) != hipSuccess ||
-      hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)n_src, st) != hipSuccess)
+  // scan status / ticket / per-source counters in ONE fill: the counters start at 0x7F7F7F7F and the scan subtracts it (the write
+  // half of the scan re-bases them to 0 / 1 for the fill pass anyway); a second memset is one more ~5 us launch per block
+  // per training step.  Degrees that could carry 0x7F7F7F7F + count past INT_MAX keep the separate zero fill.
+  const bool one_fill = nnz_out < (1 << 23);
+  a.cursor_base = one_fill ? 0x7F7F7F7F : 0;
+  if (hipMemsetAsync(workspace, 0x7F, (size_t)(b * 8 + 16) + (one_fill ? sizeof(int) * (size_t)n_src : 0), st) != hipSuccess ||
+      (!one_fill && hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)n_src, st) != hipSuccess))
     return glnn::fail(GLNN_ERR_HIP, "glnn_csr_transpose: memset failed");
   if (nnz > 0) {
     int64_t blocks = (nnz + 255) / 256;
