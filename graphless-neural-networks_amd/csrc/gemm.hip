@@ -1189,6 +1189,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
 }
 
 // sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
+// Many splits (the weight gradient over tens of thousands of rows: 64 slabs of a 256 x 256 output): one thread per float4 walking
+// all slabs keeps a quarter of the CUs busy with 64 dependent-looking loads each (16.8 MB in 16.6 us).  Here a workgroup owns 64
+// float4 columns x 4 slab lanes; lane j sums the slabs j, j+4, ... (fixed order), the four lane sums are folded in fixed order
+// through LDS: all CUs busy, 16 loads per thread.
+__global__ __launch_bounds__(256) void split_reduce_lanes_kernel(const float* __restrict__ ws, int64_t slab, int splits,
+                                                                 float* __restrict__ c, int64_t ldc, int ka, int nb) {
+  const int64_t total4 = ((int64_t)ka * nb) >> 2;
+  const int nb4 = nb >> 2;
+  const int lc = threadIdx.x & 63, kl = threadIdx.x >> 6;
+  __shared__ float4 sh[4][64];
+  for (int64_t i0 = (int64_t)blockIdx.x * 64; i0 < total4; i0 += (int64_t)gridDim.x * 64) {
+    const int64_t i = i0 + lc;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4) {
+#pragma unroll 4
+      for (int k = kl; k < splits; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    sh[kl][lc] = s;
+    __syncthreads();
+    if (kl == 0 && i < total4) {
+      const float4 a = sh[0][lc], b = sh[1][lc], d = sh[2][lc], e = sh[3][lc];
+      const int64_t r = i / nb4, cc = (i - r * nb4) * 4;
+      *reinterpret_cast<float4*>(c + r * ldc + cc) =
+          make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, int splits, float* __restrict__ c,
                                     int64_t ldc, int ka, int nb) {
   const int64_t total = (int64_t)ka * nb;
@@ -1500,9 +1532,15 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   int rc = glnn::check_launch("glnn_gemm_tn_f32");
   if (rc != GLNN_OK) return rc;
   if (splits > 1) {
-    int blocks = (int)((slab + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_partial, slab, splits, c, ldc, ka, nb);
+    if (splits >= 16 && ((nb | ldc | slab) & 3) == 0 && glnn::aligned16(ws_partial) && glnn::aligned16(c)) {
+      int64_t blocks = ((slab >> 2) + 63) / 64;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(split_reduce_lanes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ws_partial, slab, splits, c, ldc, ka, nb);
+    } else {
+      int blocks = (int)((slab + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_partial, slab, splits, c, ldc, ka, nb);
+    }
     rc = glnn::check_launch("glnn_gemm_tn_f32(reduce)");
     if (rc != GLNN_OK) return rc;
   }
