@@ -1,3 +1,4 @@
+"""Rate of glnn_act_fwd_f32 (plain ReLU / BN+ReLU / +dropout) next to torch.relu and a copy (development aid)."""
 import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from glnn_amd import ops
