@@ -5,6 +5,7 @@
 //   K6  fused multi-tensor Adam, torch.optim.Adam semantics (reference train_student.py:275-277)
 // All reductions are tree/fixed-order (no float atomics): results are run-to-run deterministic.
 #include <cmath>
+#include <cstdlib>
 
 #include "glnn_common.h"
 
@@ -437,6 +438,96 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
   (void)sh2;
 }
 
+// BN / ReLU / dropout backward in ONE launch, for grids small enough to be co-resident (<= 256 workgroups: the latency-bound
+// B = 512 ... 4096 students, where bn_bwd_partial + bn_bwd_apply were two ~7-9 us launches over half a megabyte): every workgroup
+// keeps its 128 x 64 tile of z and dy in registers, publishes its partial sums (write-through stores), bumps the column block's
+// arrival counter and WAITS until all row chunks of that column block have arrived; then the same fixed-order sums and the same
+// per-element arithmetic as the two-launch form follow -- bit-identical results.  The arrival counter is counters[512 + column
+// block]; the fold counter of the bias gradient stays counters[column block]; the last workgroup through the fold resets both.
+__global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < a.h ? col : a.h - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > a.rows) r1 = a.rows;
+  const float mu = a.mean[colc], rs = a.rstd[colc], sc = a.a_scale[colc], sf = a.a_shift[colc], g = a.gamma[colc];
+  float zz[kRowsPerLane], dy[kRowsPerLane];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {
+    float dd[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const int64_t rc = r < r1 ? r : r0;
+      zz[i0 + u] = a.z[rc * a.ldz + colc];
+      dd[u] = a.da[rc * a.ldda + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const float d = r < r1 ? bn_dy<true>(a, zz[i0 + u], dd[u], r, colc, sc, sf) : 0.f;
+      dy[i0 + u] = d;
+      s1 += d;
+      s2 = fmaf(d, (zz[i0 + u] - mu) * rs, s2);
+    }
+  }
+  __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
+  __shared__ int s_go;
+  sh1[rl][lc] = s1;
+  sh2[rl][lc] = s2;
+  __syncthreads();
+  if (rl == 0 && col < a.h) {
+    st_part(&a.ws1[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), true);
+    st_part(&a.ws2[(int64_t)blockIdx.y * a.h + col], (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]), true);
+  }
+  __syncthreads();                                     // the partial stores of this workgroup have been acknowledged
+  if (threadIdx.x == 0) {
+    int* arrive = &a.counters[512 + blockIdx.x];
+    __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.y) __builtin_amdgcn_s_sleep(1);
+    s_go = 1;
+  }
+  __syncthreads();
+  (void)s_go;
+  // every row lane sums the same partials in the same order -> identical S1/S2 everywhere (as bn_bwd_apply)
+  float S1 = 0.f, S2 = 0.f;
+  for (int k = 0; k < a.nchunks; ++k) {
+    S1 += ld_part(&a.ws1[(int64_t)k * a.h + colc]);
+    S2 += ld_part(&a.ws2[(int64_t)k * a.h + colc]);
+  }
+  if (blockIdx.y == 0 && rl == 0 && col < a.h) {
+    a.dbeta[col] = S1;
+    a.dgamma[col] = S2;
+  }
+  const float inv_b = 1.0f / (float)a.rows;
+  const float c1 = S1 * inv_b, c2 = S2 * inv_b, grs = g * rs;
+  float sdz = 0.f;
+#pragma unroll
+  for (int i = 0; i < kRowsPerLane; ++i) {
+    const int64_t r = r0 + rl + 4 * i;
+    if (r < r1) {
+      const float out = grs * (dy[i] - c1 - (zz[i] - mu) * rs * c2);
+      if (col < a.h) a.dz[r * a.lddz + col] = out;
+      sdz += out;
+    }
+  }
+  __syncthreads();
+  sh1[rl][lc] = sdz;
+  __syncthreads();
+  if (rl == 0 && col < a.h) st_part(&a.ws3[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), true);
+  if (last_workgroup(&a.counters[blockIdx.x], (int)gridDim.y)) {
+    if (threadIdx.x == 0) __hip_atomic_store(&a.counters[512 + blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float s = 0.f;                                      // lane-split fold of the per-chunk sums, fixed order (as bn_bwd_apply)
+#pragma unroll 8
+    for (int k = rl; k < a.nchunks; k += kRowLanes) s += ld_part(&a.ws3[(int64_t)k * a.h + colc]);
+    sh2[rl][lc] = s;
+    __syncthreads();
+    if (rl == 0 && col < a.h) a.dz_col_sum[col] = (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]);
+  }
+}
+
 __global__ void chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int h, float* __restrict__ out) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= h) return;
@@ -700,6 +791,13 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((h + 63) / 64, nchunks);
   a.p1 = a.ws1; a.p2 = a.ws2; a.nparts = nchunks; a.pstride = h; a.local_part = -1; a.rows_total = nullptr;
+  const char* ol = getenv("GLNN_BN_BWD_ONE_LAUNCH");          // "0": keep partial + apply as two launches (A/B runs, tests)
+  const bool one_launch = !(ol && ol[0] == '0');
+  if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= 256 && grid.x <= 256) {
+    GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
+    hipLaunchKernelGGL(bn_bwd_fused, grid, dim3(256), 0, st, a);     // co-resident grid: partial -> wait -> apply in one launch
+    return glnn::check_launch("glnn_bn_relu_bwd_f32");
+  }
   if (gamma) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);

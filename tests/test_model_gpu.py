@@ -227,6 +227,39 @@ def test_materialised_activation_steps_equal_recomputed_ones_bit_for_bit(dims, b
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("dims,bsz,p", [([128, 256, 256, 40], 512, 0.2), ([100, 256, 256, 47], 4096, 0.5), ([24, 64, 64, 5], 300, 0.0),
+                                        ([128, 1024, 1024, 40], 512, 0.5)])
+def test_one_launch_batchnorm_backward_equals_the_two_launch_form_bit_for_bit(dims, bsz, p, monkeypatch):
+    """bn_bwd_fused (partial sums -> wait for the column block's other row chunks -> apply, one launch for co-resident grids)
+    performs the sums and the per-element arithmetic of bn_bwd_partial + bn_bwd_apply in the same order: three optimiser steps
+    end in identical parameters, moments, running statistics and loss.  Run twice in a row: the counters must come back to 0."""
+    import copy
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    from glnn_amd.student import StudentEngine
+    torch.manual_seed(9)
+    base = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                      dropout_ratio=p, norm_type="batch", device=DEV))
+    x = ops.as_feat(torch.randn(2 * bsz, dims[0], device=DEV))
+    tgt = ops.as_feat(torch.log_softmax(torch.randn(2 * bsz, dims[-1], device=DEV), 1))
+    states = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_BN_BWD_ONE_LAUNCH", mode)
+        model = copy.deepcopy(base)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+        eng = StudentEngine(model, opt, bsz)
+        assert eng.sync_counters is not None
+        for i in range(3):
+            eng.step(x, torch.arange(i * 7, i * 7 + bsz, device=DEV), ops.LOSS_KL, tgt, 1.0)
+        torch.cuda.synchronize()
+        assert int(eng.sync_counters.abs().sum()) == 0
+        states.append(([t.detach().clone() for t in model.state_dict().values()],
+                       [opt.state[q]["exp_avg"].clone() for q in model.parameters()], eng.loss_out.clone()))
+    for a, b in zip(states[0][0] + states[0][1] + [states[0][2]], states[1][0] + states[1][1] + [states[1][2]]):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------- teacher
 def _sage_model(dims, norm, seed):
     from glnn_amd.models import Model
