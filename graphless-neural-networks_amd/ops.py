@@ -39,7 +39,16 @@ class _Timed:
             _TIMING.append((self.name, self.info, self.s, e))
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a C pointer.  torch.cuda.current_stream() builds a Stream object and
+    resolves the device through several Python layers (~8 us per call: 50 us of host time per sampled batch); the raw getter
+    torch itself uses for its compiled kernels returns the same handle in well under a microsecond."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
