@@ -71,6 +71,18 @@ def check_supported(model, criterion, optimizer):
                            "selects the CPU: pass --device 0)")
 
 
+class _Arena:
+    """Bump allocator over one device buffer (base None: sizing pass); 256-byte granules keep every sub-buffer float4-aligned."""
+
+    def __init__(self, base):
+        self.base, self.off = base, 0
+
+    def take(self, nbytes):
+        p = None if self.base is None else self.base + self.off
+        self.off += (int(nbytes) + 255) // 256 * 256
+        return p
+
+
 class TeacherEngine:
     def __init__(self, model, optimizer):
         self.model, self.enc, self.opt = model, model.encoder, optimizer
@@ -182,10 +194,43 @@ class TeacherEngine:
         d.num_layers, d.batchnorm, d.dropout_p, d.lamb = L, 1 if self.bn else 0, self.p, float(lamb)
         for i, v in enumerate(dims):
             d.dims[i] = v
-        keep = []                                               # buffers of this step (alive until the call below is queued)
+        # Every buffer of the step is scratch that only the C call touches, so they are carved as raw pointers out of ONE arena
+        # (52 torch.empty calls per step cost ~80 us of host time -- the sampled-block loop is bound by the host, not the GPU).
+        # Two passes over the same layout code: the first sizes the arena, the second hands out the pointers.
+        r4 = lambda c: (c + 3) // 4 * 4
         ptr = lambda t: None if t is None else t.data_ptr()
-        max_rows, max_hidden = 1, 4
-        for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):
+
+        def layout(A):
+            max_rows, max_hidden = 1, 4
+            for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):
+                y = d.layer[l]
+                n_dst, n_src, nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
+                y.agg, y.ld_agg = A.take(4 * n_dst * r4(dims[l])), r4(dims[l])
+                y.z, y.ldz = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
+                if l != L - 1:
+                    y.h, y.ldh = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
+                    max_rows, max_hidden = max(max_rows, n_dst), max(max_hidden, dims[l + 1])
+                    if self.bn:
+                        y.mean, y.rstd, y.a_scale, y.a_shift = (A.take(4 * dims[l + 1]) for _ in range(4))
+                if l >= 1:
+                    nnz_t = nnz + n_dst
+                    wsb = int(_lib.lib().glnn_csr_transpose_workspace_bytes(n_src, nnz_t))
+                    y.t_indptr, y.t_indices, y.inv_deg = A.take(8 * (n_src + 1)), A.take(4 * max(nnz_t, 1)), A.take(4 * n_dst)
+                    y.tr_ws, y.tr_ws_bytes = A.take(wsb), (wsb + 7) // 8 * 8
+            n_out = blocks[-1].num_dst_nodes()
+            d.dlogits, d.ld_dlogits = A.take(4 * n_out * r4(dims[-1])), r4(dims[-1])
+            if L > 1:
+                wd = r4(max(dims[1:L]))
+                d.dagg, d.ld_dagg = A.take(4 * max(b.num_dst_nodes() for b in blocks[1:]) * wd), wd
+                d.dh, d.ld_dh = A.take(4 * max(b.num_src_nodes() for b in blocks[1:]) * wd), wd
+            nchunks = (max_rows + 127) // 128
+            d.ws_bn_floats = (3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024
+            d.ws_tn_floats = 64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims)
+            d.ws_gemm_floats = 1 << 20
+            d.ws_bn, d.ws_tn, d.ws_gemm = A.take(4 * d.ws_bn_floats), A.take(4 * d.ws_tn_floats), A.take(4 * d.ws_gemm_floats)
+            return A.off
+
+        for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):       # everything that is not scratch
             y = d.layer[l]
             n_dst, n_src, nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
             glob = l == 0 and blk.gindices is not None
@@ -194,49 +239,21 @@ class TeacherEngine:
             y.self_rows = ptr(blk.dst_nodes) if glob else None
             w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
             y.w, y.b, y.gw, y.gb = ptr(w), ptr(b), ptr(self.grad(w)), ptr(self.grad(b))
-            agg, z = ops.feat_empty(n_dst, dims[l], dev), ops.feat_empty(n_dst, dims[l + 1], dev)
-            y.agg, y.ld_agg, y.z, y.ldz = ptr(agg), agg.stride(0), ptr(z), z.stride(0)
-            keep += [agg, z]
             if l != L - 1:
-                h = ops.feat_empty(n_dst, dims[l + 1], dev)
-                y.h, y.ldh, y.drop_seed = ptr(h), h.stride(0), self._seed(l)
-                keep.append(h)
-                max_rows, max_hidden = max(max_rows, n_dst), max(max_hidden, dims[l + 1])
+                y.drop_seed = self._seed(l)
                 if self.bn:
                     bn = enc.norms[l]
                     d.bn_eps, d.bn_momentum = bn.eps, bn.momentum
-                    stats = [torch.empty(dims[l + 1], dtype=torch.float32, device=dev) for _ in range(4)]
                     y.gamma, y.beta, y.ggamma, y.gbeta = ptr(bn.weight), ptr(bn.bias), ptr(self.grad(bn.weight)), ptr(self.grad(bn.bias))
                     y.running_mean, y.running_var, y.nbt = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
-                    y.mean, y.rstd, y.a_scale, y.a_shift = (ptr(t) for t in stats)
-                    keep += stats
-            if l >= 1:
-                nnz_t = nnz + n_dst
-                t_indptr = torch.empty(n_src + 1, dtype=torch.int64, device=dev)
-                t_indices = torch.empty(max(nnz_t, 1), dtype=torch.int32, device=dev)
-                inv = torch.empty(n_dst, dtype=torch.float32, device=dev)
-                wsb = int(_lib.lib().glnn_csr_transpose_workspace_bytes(n_src, nnz_t))
-                tws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
-                y.t_indptr, y.t_indices, y.inv_deg, y.tr_ws, y.tr_ws_bytes = ptr(t_indptr), ptr(t_indices), ptr(inv), ptr(tws), tws.numel() * 8
-                keep += [t_indptr, t_indices, inv, tws]
+        total = layout(_Arena(None))
+        arena = torch.empty(total + 256, dtype=torch.uint8, device=dev)
+        layout(_Arena((arena.data_ptr() + 255) // 256 * 256))
         d.x, d.ldx, d.x_rows = ptr(x), x.stride(0), x.shape[0]
         d.labels, d.label_rows = ptr(labels), ptr(output_nodes)
-        n_out = blocks[-1].num_dst_nodes()
-        dlogits = ops.feat_empty(n_out, dims[-1], dev)
-        d.dlogits, d.ld_dlogits = ptr(dlogits), dlogits.stride(0)
-        if L > 1:
-            dagg = ops.feat_empty(max(b.num_dst_nodes() for b in blocks[1:]), max(dims[1:L]), dev)
-            dh = ops.feat_empty(max(b.num_src_nodes() for b in blocks[1:]), max(dims[1:L]), dev)
-            d.dagg, d.ld_dagg, d.dh, d.ld_dh = ptr(dagg), dagg.stride(0), ptr(dh), dh.stride(0)
-            keep += [dagg, dh]
-        nchunks = (max_rows + 127) // 128
-        ws_bn = torch.empty((3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024, dtype=torch.float32, device=dev)
-        ws_tn = torch.empty(64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims), dtype=torch.float32, device=dev)
-        ws_gemm = torch.empty(1 << 20, dtype=torch.float32, device=dev)
-        d.ws_bn, d.ws_bn_floats, d.ws_tn, d.ws_tn_floats = ptr(ws_bn), ws_bn.numel(), ptr(ws_tn), ws_tn.numel()
-        d.ws_gemm, d.ws_gemm_floats, d.ws_loss, d.ws_loss_floats = ptr(ws_gemm), ws_gemm.numel(), ptr(self.ws_loss), self.ws_loss.numel()
+        d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
-        keep += [dlogits, ws_bn, ws_tn, ws_gemm, x]
+        keep = [arena, x]                                       # alive until the call below is queued (same-stream reuse is ordered)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         _lib.check(rc, "glnn_sage_fwd_bwd_f32")
         self._adam()
