@@ -1,3 +1,4 @@
+"""cProfile of the host side of the sampled-block loader alone (arxiv config) -- development aid."""
 import os, sys, time, cProfile, pstats, io
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
