@@ -29,8 +29,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // whose workspaces are uninitialised) pass NULL and get the two-launch form.
 // Cross-workgroup visibility WITHOUT a device-scope fence (which writes back / invalidates the XCD's whole L2 -- measured:
 // the fenced form made the MLP3w8 step 25 % SLOWER): the partials are published with relaxed agent-scope atomic stores
-// (write-through past the per-XCD L2) and read back by the last workgroup with relaxed agent-scope atomic loads;
-// __syncthreads() waits for the workgroup's stores to be acknowledged before thread 0 bumps the counter.
+// (write-through past the per-XCD L2) and read back by the last workgroup with relaxed agent-scope atomic loads.
+// ORDER: a relaxed store followed by __syncthreads() is NOT enough -- the workgroup-scope fence of the barrier does not
+// wait for the write-through (the gfx950 ISA had `global_store_dword ... sc1; s_barrier; global_atomic_add` with no
+// s_waitcnt vmcnt(0) in between), so another XCD could see the final count before the partials.  Every storing wave
+// therefore drains its own vector-memory queue (publish_drain) before the barrier in front of the counter update;
+// tests/test_capi_symbols.py asserts the s_waitcnt vmcnt(0) on the generated ISA.
 __device__ __forceinline__ void st_part(float* p, float v, bool shared) {
   if (shared) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *p = v;
@@ -38,9 +42,12 @@ __device__ __forceinline__ void st_part(float* p, float v, bool shared) {
 __device__ __forceinline__ float ld_part(const float* p) {
   return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// all of this wave's global stores (incl. the write-through partials) have been acknowledged by the memory system
+__device__ __forceinline__ void publish_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bool last_workgroup(int* counter, int total) {
   __shared__ int s_last;
-  __syncthreads();                                   // every thread's partial stores have been acknowledged
+  publish_drain();                                   // this wave's partial stores have been acknowledged ...
+  __syncthreads();                                   // ... and so have every other wave's of the workgroup
   if (threadIdx.x == 0) {
     const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (prev == total - 1);
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
     st_part(&a.ws1[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), true);
     st_part(&a.ws2[(int64_t)blockIdx.y * a.h + col], (sh2[0][lc] + sh2[1][lc]) + (sh2[2][lc] + sh2[3][lc]), true);
   }
+  publish_drain();
   __syncthreads();                                     // the partial stores of this workgroup have been acknowledged
   if (threadIdx.x == 0) {
     int* arrive = &a.counters[512 + blockIdx.x];
@@ -767,6 +775,28 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
                         rstd_out, a_scale_out, a_shift_out, workspace, workspace_floats, stream, nullptr);
 }
 
+// bn_bwd_fused WAITS inside an ordinary launch: every workgroup of its grid must be resident at once or the waiting ones
+// starve the rest (a hang).  Limit = HALF of what the current device can hold of this kernel (occupancy x CUs, queried once
+// per device: a CPX/QPX partition exposes 32/64 CUs, and concurrent kernels -- the RCCL kernels of an overlapped gradient
+// exchange -- may hold CUs), never more than 256; larger grids keep the two-launch form.
+static int fused_grid_limit() {
+  static int limit[64];
+  static bool known[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!known[dev]) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    int lim = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bn_bwd_fused, 256, 0) == hipSuccess &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      lim = per_cu * prop.multiProcessorCount / 2;
+    limit[dev] = lim > 256 ? 256 : lim;
+    known[dev] = true;
+  }
+  return limit[dev];
+}
+
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
@@ -793,7 +823,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.p1 = a.ws1; a.p2 = a.ws2; a.nparts = nchunks; a.pstride = h; a.local_part = -1; a.rows_total = nullptr;
   const char* ol = getenv("GLNN_BN_BWD_ONE_LAUNCH");          // "0": keep partial + apply as two launches (A/B runs, tests)
   const bool one_launch = !(ol && ol[0] == '0');
-  if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= 256 && grid.x <= 256) {
+  if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= fused_grid_limit() && grid.x <= 256) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     hipLaunchKernelGGL(bn_bwd_fused, grid, dim3(256), 0, st, a);     // co-resident grid: partial -> wait -> apply in one launch
     return glnn::check_launch("glnn_bn_relu_bwd_f32");

@@ -279,8 +279,11 @@ class NodeDataLoader:
         for b in range(len(chunks)):
             (input_nodes, output_nodes, blocks), ev = nxt
             nxt = build(b + 1) if b + 1 < len(chunks) else None
-            main.wait_event(ev)
+            # the consumer's stream is asked for at EVERY hand-over: a caller that steps inside its own `with torch.cuda.stream(...)`
+            # gets the batch ordered on (and kept alive for) the stream it is actually running on, not the one __iter__ started on
+            cur = torch.cuda.current_stream(self.g.device)
+            cur.wait_event(ev)
             for t in [input_nodes, output_nodes] + [x for blk in blocks for x in (blk.indptr, blk.indices, blk.gindices, blk.dst_nodes)]:
                 if t is not None:
-                    t.record_stream(main)                    # allocated on the side stream, consumed on the main one
+                    t.record_stream(cur)                     # allocated on the side stream, consumed on the current one
             yield input_nodes, output_nodes, blocks

@@ -242,6 +242,12 @@ class StudentEngine:
             ops._p(target) if kind == ops.LOSS_NLL else None,
             ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
             ops._p(trow), float(lamb), self._seed_arr, ops._stream())
+        if rc != 0:
+            # a step that aborted midway: Adam's bias correction and the dropout seeds must not advance, and the arrival / fold
+            # counters of the one-launch reductions may be left non-zero (the next launch would skip its wait and read stale partials)
+            self.step_count -= 1
+            if self.sync_counters is not None:
+                self.sync_counters.zero_()
         if rc != 0 and self.exchange is not None and self.exchange.error is not None:
             err, self.exchange.error = self.exchange.error, None
             raise RuntimeError("glnn_mlp_fwd_bwd_f32: the batch-statistics exchange failed") from err

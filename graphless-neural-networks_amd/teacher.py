@@ -226,7 +226,8 @@ class TeacherEngine:
             nchunks = (max_rows + 127) // 128
             d.ws_bn_floats = (3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024
             d.ws_tn_floats = 64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims)
-            d.ws_gemm_floats = 1 << 20
+            # split-K slabs, sized as StudentEngine does; the GEMM only splits outputs of < 256 tiles, i.e. <= 512 slabs of 128 x 128
+            d.ws_gemm_floats = min(max(16 * max(b.num_dst_nodes() for b in blocks) * min(dims[1:]), 1 << 20), 512 * 128 * 128)
             d.ws_bn, d.ws_tn, d.ws_gemm = A.take(4 * d.ws_bn_floats), A.take(4 * d.ws_tn_floats), A.take(4 * d.ws_gemm_floats)
             return A.off
 
@@ -255,6 +256,8 @@ class TeacherEngine:
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
         keep = [arena, x]                                       # alive until the call below is queued (same-stream reuse is ordered)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
+        if rc != 0:
+            self.step_count -= 1          # the step never happened: Adam's bias correction and the dropout seeds stay where they were
         _lib.check(rc, "glnn_sage_fwd_bwd_f32")
         self._adam()
 
@@ -268,6 +271,15 @@ class TeacherEngine:
                                "(dgl GraphConv semantics; add self-loops or set allow_zero_in_degree).")
         n = g.num_dst_nodes()
         self.step_count += 1
+        try:
+            self._step_gcn_body(g, feats, labels, idx_train, lamb, n)
+        except Exception:
+            self.step_count -= 1          # the step never happened (see step_sage)
+            raise
+        self._adam()
+
+    def _step_gcn_body(self, g, feats, labels, idx_train, lamb, n):
+        enc, L, p = self.enc, self.L, self.p
         a = ops.as_feat(feats)
         saved = []
         for l, layer in enumerate(enc.layers):
@@ -292,7 +304,6 @@ class TeacherEngine:
                 break
             _, _, y_prev, seed_prev = saved[l - 1]        # dropout backward, then the ReLU inside conv l-1 (y > 0 <=> z > 0)
             dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, drop_p=p, drop_seed=seed_prev, dz_col_sum=self.grad(enc.layers[l - 1].bias))
-        self._adam()
 
 
 def get_engine(model, optimizer):

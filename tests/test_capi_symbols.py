@@ -101,3 +101,39 @@ def test_pipelined_gemm_loops_contain_no_vector_alu_and_no_register_copies(tmp_p
         # around it (prologue barrier .. drain): no register-to-register copies
         copies = [l for l in region if l.startswith(("v_mov", "v_accvgpr_read", "v_accvgpr_mov"))]
         assert not copies, (name, copies[:5])
+
+
+def test_cross_workgroup_publishes_drain_their_stores_before_the_counter_update(tmp_path):
+    """last_workgroup / bn_bwd_fused (csrc/student.hip) publish partial sums with write-through stores and then bump an arrival
+    counter that workgroups on OTHER XCDs read.  A barrier alone does not wait for the write-through on gfx950 (the ISA used to be
+    `global_store_dword ... sc1; s_barrier; global_atomic_add`), so every storing wave must drain its vector-memory queue first.
+    Checked on the generated ISA: in every kernel, walking back from each counter atomic to the last write-through store before it
+    crosses an `s_waitcnt vmcnt(0)` (every basic-block path is inspected textually: the store and the waitcnt are emitted in
+    straight-line order in front of the barrier)."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graphless-neural-networks_amd", "csrc", "student.hip")
+    out = tmp_path / "student.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", f"-I{ROOT}/include",
+                    f"-I{ROOT}/graphless-neural-networks_amd/csrc", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    checked = 0
+    for name, body in kernels:
+        lines = [l.split(";")[0].strip() for l in body.split("\n")]
+        atomics = [i for i, l in enumerate(lines) if l.startswith("global_atomic_add")]
+        stores = [i for i, l in enumerate(lines) if l.startswith("global_store") and "sc1" in l]
+        if not atomics or not stores:
+            continue
+        for a in atomics:
+            before = [s for s in stores if s < a]
+            if not before:
+                continue
+            region = lines[before[-1] + 1:a]
+            assert any(re.match(r"s_waitcnt\s+vmcnt\(0\)", l) for l in region), (name, region[:12])
+            assert any(l.startswith("s_barrier") for l in region), name
+            checked += 1
+    assert checked >= 4, checked      # loss, bn statistics, bn backward (partial / fused), column sums
