@@ -143,10 +143,17 @@ class ShardedTeacher:
     arrival order.  The gathered activations then live in a chunk-major row order ([chunk][rank][rows]); the next
     layer reads them through a column-index array relabelled once at construction -- no data is ever re-packed."""
 
-    def __init__(self, encoder, graph_shard, shards, be, group=None):
+    def __init__(self, encoder, graph_shard, shards, be, group=None, widening_exchange="narrow"):
+        """widening_exchange: what a widening layer (2*d_in <= d_out: products layer 1, 100 -> 256) puts on the wire --
+        "narrow": its d_in-wide aggregate, every rank then projects ALL rows itself (least bytes, replicated GEMM);
+        "wide":   its d_out-wide output of the fused aggregate+project kernel on the own rows only (no replicated work,
+                  d_out/d_in times the bytes).  Both are chunked and overlapped when shards.chunks > 1; results are identical."""
         self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
         if graph_shard.n_dst != shards.rows:
             raise ValueError(f"ShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
+        if widening_exchange not in ("narrow", "wide"):
+            raise ValueError("ShardedTeacher: widening_exchange must be 'narrow' or 'wide'")
+        self.widening_exchange = widening_exchange
         self._bufs = {}
         self._col_cache = {}
 
@@ -229,6 +236,34 @@ class ShardedTeacher:
             be.gemm(agg[c * span:(c + 1) * span], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[c * span:(c + 1) * span])
         return y
 
+    def _plain_layer_overlapped(self, l, x, layout, w, tail):
+        """Aggregate-first layer whose d_out-wide OUTPUT is exchanged, chunks > 1 ("wide" exchange of a widening layer): the own
+        rows go through the fused aggregate + project kernel chunk by chunk, each chunk's all-gather is issued asynchronously
+        as soon as the chunk is queued.  Returns the chunk-major gathered buffer (every rank's rows)."""
+        be, g, sh = self.be, self.g, self.sh
+        ep_scale, ep_shift, relu = tail
+        d_in, d_out = w.shape[1], w.shape[0]
+        y = self._full_buffer(("ycm", l), d_out, x.device)       # chunk-major [C][P][cr]
+        base = _storage_rows(y)
+        span = sh.world * sh.cr
+        idx = self._cols(layout)
+        works = []
+        for c in range(sh.chunks):
+            off, nr = sh.chunk_rows(c)
+            p0 = (c * sh.world + sh.rank) * sh.cr
+            if nr > 0:
+                ip = g.indptr[off:off + nr + 1]
+                xs = self._chunk_self(x, layout, c)
+                if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                    be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs)
+                else:
+                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
+                    be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+        for wk in works:
+            wk()
+        return y
+
     def _plain_then_narrow_overlapped(self, l, x, layout):
         """Aggregate-first layer l followed by a narrowing layer l+1, chunks > 1: the own rows of layer l are produced
         chunk by chunk, each chunk is projected with W_{l+1} at once (layer l+1 projects first) and the all-gather of
@@ -301,7 +336,12 @@ class ShardedTeacher:
                         out=out, x_self=hw[sh.slot:sh.slot + sh.rows])
             elif not complete:
                 raise RuntimeError("ShardedTeacher: internal error, an aggregating layer needs every node's input row")
-            elif multi and not last and 2 * d_in <= d_out:
+            elif multi and not last and 2 * d_in <= d_out and self.widening_exchange == "wide" and sh.chunks > 1 and not next_narrow:
+                x = self._plain_layer_overlapped(l, x, layout, w, tail)       # exchange the wide output, chunked + overlapped
+                layout, y_own = "cm", None
+                l += 1
+                continue
+            elif multi and not last and 2 * d_in <= d_out and self.widening_exchange == "narrow":
                 # widening layer (products layer 1: 100 -> 256): exchange the NARROW aggregate and let every rank
                 # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
                 # instead of 2.5 GB on products) for the price of a replicated [N, d_in] x [d_in, d_out] GEMM.

@@ -225,10 +225,11 @@ class SAGE(nn.Module):
                 else:
                     d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
                     y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132
+                    wp = ops.pack_weight(layer.fc_neigh.weight) if layer.fused_eligible() else None     # once per layer, not per chunk
                     for input_nodes, output_nodes, blocks in dataloader:
                         block = blocks[0].int().to(x.device)
                         h = ops.gather_rows(x, input_nodes)                              # feats[input_nodes]
-                        h = layer(block, (h, h[: block.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                        h = layer(block, (h, h[: block.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, w_packed=wp)
                         ops.scatter_rows(h, output_nodes, y)                             # y[output_nodes] = h
                 x = y
             return x

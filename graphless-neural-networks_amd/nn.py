@@ -36,9 +36,11 @@ class SAGEConv(nn.Module):
         """Aggregate-first layers with d_in, d_out <= 256 run on the single-launch K1F kernel."""
         return self._in_feats <= self._out_feats and self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256
 
-    def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False):
+    def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False, w_packed=None):
         """out = fc_neigh((sum_{u->v} h[u] + h_dst[v]) / (deg(v)+1)).  ep_* / relu: optional fused tail
-        (eval-mode BatchNorm + ReLU of the caller) used by SAGE.inference; bias is folded by the caller then."""
+        (eval-mode BatchNorm + ReLU of the caller) used by SAGE.inference; bias is folded by the caller then.
+        w_packed: ops.pack_weight(fc_neigh.weight) of a caller that sweeps many blocks with the same weights (the chunked
+        inference loop packs once per layer instead of once per chunk)."""
         h_src, h_dst = feat if isinstance(feat, tuple) else (feat, feat)
         n_dst = graph.num_dst_nodes()
         if h_dst.shape[0] != n_dst:
@@ -58,7 +60,7 @@ class SAGEConv(nn.Module):
         if self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256:
             # aggregation + projection + epilogue in one launch: the aggregated rows never reach HBM
             return ops.sage_fused(graph.indptr, graph.indices, h_src, n_dst, w, ep_scale=ep_scale, ep_shift=shift, relu=relu,
-                                  x_self=h_dst)
+                                  x_self=h_dst, w_packed=w_packed)
         agg = ops.spmm(graph.indptr, graph.indices, h_src, n_dst, ops.AGG_SAGE_GCN)
         return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu)
 

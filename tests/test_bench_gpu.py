@@ -39,6 +39,12 @@ def test_bench_single_gpu_line():
     assert tt["value"] > 0 and tt["unit"] == "steps/s" and all(np.isfinite(tt["loss_first_last"]))
     rr = out["roofline_reordered"]
     assert rr["order"].startswith("nodes renumbered") and rr["edges_per_s"] > 0 and rr["traffic"] is None
+    # the timed output checks itself: fused + chained + project-first forward == stand-alone aggregation + GEMM, aggregate-first
+    assert out["verified"] is True and out["verify"]["max_abs_diff_vs_unfused_aggregate_first"] <= 1e-4
+    assert out["verify"]["layer1_conservation_rel_err_fp64"] < 1e-5 and out["rccl_ranks"] == 1
+    assert cb["student_threads_best"] >= 1 and len(cb["student_thread_sweep"]) >= 1 and cb["teacher_reps"] >= 3
+    rc = out["roofline_clustered"]
+    assert rc["edges_per_s"] > 0 and "communities" in rc["graph"]
 
 
 @pytest.mark.parametrize("extra", [[], ["--student-global-bn"]])
@@ -55,3 +61,19 @@ def test_bench_two_ranks_driver_launch_line(extra):
     assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * 148 < 0.15 * 4e-9 * n_pad * 148, ex
     assert ex["collectives_per_forward"] == 8
     assert ("global" in out["student"]["batchnorm"]) == bool(extra)
+
+
+@pytest.mark.parametrize("l1", ["narrow", "wide"])
+def test_bench_self_launches_its_ranks(l1):
+    """`python bench.py --gpus 2` with NO launcher: bench.py spawns the two ranks itself (it used to run one rank and
+    print n_gpus 1); both layer-1 exchange variants; the sharded output verifies against the unsharded forward."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1", "--layer1-exchange", l1],
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+    assert [d["rank"] for d in out["devices"]] == [0, 1]
+    assert out["verified"] is True and out["verify"]["max_abs_diff_vs_unsharded"] <= 1e-4
+    assert out["config"]["layer1_exchange"] == l1
+    n_pad = -(-out["config"]["nodes"] // 8) * 8
+    per_node = 148 if l1 == "narrow" else 256 + 48
+    ex = out["exchange"]
+    assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * per_node < 0.15 * 4e-9 * n_pad * per_node, ex

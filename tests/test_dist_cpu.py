@@ -70,7 +70,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, dims, seed, chunks, balanced, q):
+def _worker(rank, world, port, n, dims, seed, chunks, balanced, widening, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -96,7 +96,7 @@ def _worker(rank, world, port, n, dims, seed, chunks, balanced, q):
         from glnn_amd import dist as gdist
         gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
         with torch.no_grad():
-            y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be).forward(x)
+            y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, widening_exchange=widening).forward(x)
         stats = dict(gdist.EXCHANGE_STATS, n_pad=sh.n_pad)
         # DP gradient exchange
         flat = torch.full((10,), float(rank + 1))
@@ -106,12 +106,16 @@ def _worker(rank, world, port, n, dims, seed, chunks, balanced, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,dims,chunks,balanced", [
-    (2, 1001, [12, 16, 16, 5], 1, False), (2, 640, [8, 24, 6], 1, False), (2, 1003, [8, 24, 24, 6], 3, False), (2, 90, [6, 16, 5], 4, False),
-    (2, 1001, [12, 16, 16, 5], 1, True), (4, 1003, [8, 24, 24, 6], 3, True), (4, 777, [8, 24, 6], 1, True), (4, 640, [12, 16, 16, 5], 2, False),
-    (8, 1001, [8, 24, 24, 6], 2, True), (8, 203, [6, 16, 5], 1, False)])
-def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced):
-    """world 2 / 4 / 8, equal and work-balanced (uneven) row ranges, plain and chunked-overlapped exchange."""
+@pytest.mark.parametrize("world,n,dims,chunks,balanced,widening", [
+    (2, 1001, [12, 16, 16, 5], 1, False, "narrow"), (2, 640, [8, 24, 6], 1, False, "narrow"), (2, 1003, [8, 24, 24, 6], 3, False, "narrow"),
+    (2, 90, [6, 16, 5], 4, False, "narrow"), (2, 1001, [12, 16, 16, 5], 1, True, "narrow"), (4, 1003, [8, 24, 24, 6], 3, True, "narrow"),
+    (4, 777, [8, 24, 6], 1, True, "narrow"), (4, 640, [12, 16, 16, 5], 2, False, "narrow"), (8, 1001, [8, 24, 24, 6], 2, True, "narrow"),
+    (8, 203, [6, 16, 5], 1, False, "narrow"),
+    (2, 1003, [8, 24, 24, 6], 3, False, "wide"), (2, 1003, [8, 24, 24, 6], 1, True, "wide"), (4, 1003, [8, 24, 24, 6], 4, True, "wide"),
+    (2, 90, [6, 16, 5], 4, False, "wide")])
+def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced, widening):
+    """world 2 / 4 / 8, equal and work-balanced (uneven) row ranges, plain and chunked-overlapped exchange; a widening layer
+    exchanging its narrow aggregate (replicated projection) or its wide output (bench.py --layer1-exchange)."""
     sys.path.insert(0, ROOT)
     from oracle import teacher_oracle as to
     from graphgen import random_graph
@@ -121,7 +125,7 @@ def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, chunks, balanced, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, seed, chunks, balanced, widening, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -152,7 +156,7 @@ def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced)
         d_in, d_out = dims[l], dims[l + 1]
         if d_in > d_out:
             per_node += r4(d_out)
-        elif l < L - 1 and 2 * d_in <= d_out:
+        elif l < L - 1 and 2 * d_in <= d_out and widening == "narrow":
             per_node += r4(d_in)
         elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
             per_node += r4(d_out)

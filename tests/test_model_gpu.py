@@ -577,6 +577,62 @@ def test_full_size_arxiv_teacher_forward_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
 
 
+def test_full_size_products_teacher_forward_vs_oracle():
+    """The HEADLINE kernel at the HEADLINE size (BASELINE configs[3], what bench.py times): the ogbn-products-shaped graph at
+    scale 1.0 (2,449,029 nodes, 123,718,280 in-edges, power-law with ~17k-degree hubs), SAGE 100-256-256-47 + BatchNorm,
+    `Model.inference` through exactly the launches of the bench -- sage_fused_kernel<32> (100 -> 256), sage_fused_kernel<64> with
+    the chained 256 -> 47 projection (76,532 tiles, > 128-degree rows through the 8-wave deferred path, the LDS ticket under real
+    contention), spmm_csr_kernel<16> (47 wide) -- vs the CPU oracle (OpenMP) on identical inputs: max |diff| <= 1e-4.
+    (reference models.py:121-148; the oracle aggregates first in every layer as dgl 0.6.1 does, the HIP path projects the
+    last layer first.)  Then, at the same size: fused == unfused (stand-alone aggregation + GEMM) for both fused layers, and
+    the fp64 conservation identity of the 256-wide aggregation."""
+    from glnn_amd import data, ops
+    from glnn_amd.graph import FullNeighborLoader
+    g = data.make_graph("ogbn-products", seed=0, device=DEV)
+    n = g.n_dst
+    assert n == 2449029 and g.num_edges() == 123718280
+    assert int(g.in_degrees().max()) > 4096            # the hub rows exist
+    x = np.random.RandomState(0).standard_normal((n, 100)).astype(np.float32)
+    model, layers, norms = _sage_model([100, 256, 256, 47], "batch", seed=5)
+    xd = torch.from_numpy(x).to(DEV)
+    loader = FullNeighborLoader(g, 4096)
+    got = model.inference(loader, xd)
+    assert got.shape == (n, 47)
+    gc = g.to("cpu")
+    want = to.sage_inference(gc.indptr.numpy(), gc.indices.numpy(), x, layers, norms, threads=to.max_threads())
+    got_h = got.cpu().numpy()
+    err = np.abs(got_h - want)
+    assert np.isfinite(got_h).all()
+    assert float(err.max()) <= TOL, (float(err.max()), int(np.argmax(err.max(1))))
+    # the same forward without the chained projection and without the fused kernel: same numbers to rounding
+    enc = model.encoder
+    l0, l1, l2 = enc.layers
+    s0, h0, _ = enc._tail(0)
+    s1, h1, _ = enc._tail(1)
+    xf = ops.as_feat(xd)
+    y0_f = ops.sage_fused(g.indptr, g.indices, xf, n, l0.fc_neigh.weight, ep_scale=s0, ep_shift=h0, relu=True)
+    agg0 = ops.spmm(g.indptr, g.indices, xf, n, ops.AGG_SAGE_GCN)
+    y0_u = ops.gemm(agg0, l0.fc_neigh.weight, ep_scale=s0, ep_shift=h0, relu=True)
+    assert float((y0_f - y0_u).abs().max()) <= 2e-5
+    del agg0, y0_u
+    y1_f, p2_f = ops.sage_fused(g.indptr, g.indices, y0_f, n, l1.fc_neigh.weight, ep_scale=s1, ep_shift=h1, relu=True,
+                                w_next=l2.fc_neigh.weight)
+    agg1 = ops.spmm(g.indptr, g.indices, y0_f, n, ops.AGG_SAGE_GCN)
+    # conservation on the 256-wide aggregation (fp64): sum_v (deg_v + 1) * mean_v == sum_u (outdeg_u + 1) * y0[u]
+    deg, outdeg = g.in_degrees().double(), g.out_degrees().double()
+    lhs = ((deg + 1).unsqueeze(1) * agg1[:, :256].double()).sum(0)
+    rhs = ((outdeg + 1).unsqueeze(1) * y0_f[:, :256].double()).sum(0)
+    assert float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1)) < 1e-5
+    y1_u = ops.gemm(agg1, l1.fc_neigh.weight, ep_scale=s1, ep_shift=h1, relu=True)
+    assert float((y1_f - y1_u).abs().max()) <= 2e-5
+    p2_u = ops.gemm(y1_u, l2.fc_neigh.weight)
+    assert float((p2_f[:, :47] - p2_u[:, :47]).abs().max()) <= 5e-5
+    # chained-only form (hidden rows never written: what SAGE.inference launches) == the form that also writes them, bit for bit
+    _, p2_c = ops.sage_fused(g.indptr, g.indices, y0_f, n, l1.fc_neigh.weight, ep_scale=s1, ep_shift=h1, relu=True,
+                             w_next=l2.fc_neigh.weight, want_out=False)
+    assert torch.equal(p2_c[:, :47], p2_f[:, :47])
+
+
 def test_full_size_xl_shard_properties():
     """BASELINE configs[4] at FULL size on one GPU: one rank's shard of the 100 M-node / 2 B-edge graph = 12.5 M destination
     rows with 250 M in-edges whose sources are drawn over ALL 100 M nodes, gathering from the replicated 100 M x 128 fp32
