@@ -306,6 +306,7 @@ def main():
     if world == 1 and timing:
         full = GRAPH == "ogbn-products" and args.scale == 1.0
         result["roofline"] = roofline_object(timing, nnz, n, with_traffic=full)
+        result["roofline"].update(hbm_estimate(result["roofline"], g))
         if args.reorder != "none":
             result["roofline_reordered"] = reordered_leg(args, g, feats, teacher, FullNeighborLoader, ops, data)
 
@@ -455,6 +456,27 @@ def roofline_object(timing, nnz, n, with_traffic):
                 + ("" if GRAPH == "ogbn-products" else "; the feature matrix fits the 256 MB Infinity Cache at this shape, so the "
                    "rate is a cache rate and the HBM fraction is not meaningful (SURVEY 8d)"),
     }
+
+
+def hbm_estimate(rf, g):
+    """How much of the dominant launch's fabric traffic can the 256 MiB Infinity Cache have served?  rocprofv3 exposes no MALL
+    hit counter on gfx950 (scripts/pmc_l2.sh lists what exists: the L2's fabric-side request counters count hits and misses of
+    the memory-side cache alike), so the HBM bytes are BRACKETED: upper = every fabric request came from HBM (= `traffic`, or
+    the algorithmic bytes when no PMC constant applies); lower = an ideal cache that pins the hottest source rows -- as many
+    rows by out-degree as fit 256 MiB -- and serves every gather of them."""
+    d = int(rf["kernel"].rsplit("D=", 1)[1].rstrip(")"))
+    row_bytes = -(-4 * d // 128) * 128                      # a gathered row in whole 128-byte lines
+    n, nnz = g.n_dst, g.num_edges()
+    k = min(n, (256 << 20) // row_bytes)
+    outdeg = g.out_degrees()
+    hot = float(torch.topk(outdeg, k).values.double().sum() / max(1, nnz))
+    upper = rf["traffic"] if rf.get("traffic") else rf["algorithmic_bytes_per_launch"]
+    lower = upper - hot * nnz * row_bytes
+    sec = rf["avg_launch_ms"] / 1e3
+    return {"hbm_bytes_estimated": {"upper": upper, "lower": lower, "infinity_cache_hit_bound": hot, "hot_rows": k,
+                                    "frac_of_peak_upper": upper / sec / (HBM_PEAK_GBS * 1e9), "frac_of_peak_lower": lower / sec / (HBM_PEAK_GBS * 1e9),
+                                    "how": "no MALL hit counter on gfx950: upper = all fabric traffic from HBM; lower = the hottest source rows "
+                                           "that fit 256 MiB (by out-degree) pinned in the Infinity Cache, every gather of them a hit"}}
 
 
 def reordered_leg(args, g, feats, teacher, FullNeighborLoader, ops, data):
