@@ -9,7 +9,7 @@ def short(name):
     m = re.search(r"(spmm_csr_kernel|sage_fused_kernel|spmm_gpr_kernel)<(\d+), (\d+)", name)
     if m:
         return f"{m.group(1)}<LPR={m.group(2)},U={m.group(3)}" + (">" if m.group(1) == "sage_fused_kernel" else ",SAGE_GCN>")
-    if "elementwise" in name and "copy" in name.lower():
+    if "move_rows_kernel" in name:
         return "copy"
     return None
 
@@ -39,7 +39,7 @@ for k, cs in vals.items():
         e["fabric_write_bytes"] = 64 * m.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (m["TCC_EA0_WRREQ_sum"] - m.get("TCC_EA0_WRREQ_64B_sum", 0))
     res[k] = e
 if "copy" in res and "fabric_read_bytes_by_size" in res["copy"]:
-    true = 4.0 * (1 << 30)
+    true = 4.0 * (1 << 30) + 8.0 * (1 << 22)          # the matrix + the int64 row ids
     res["copy"]["known_bytes_read"] = true
     res["copy"]["calibration_read_ratio"] = res["copy"]["fabric_read_bytes_by_size"] / true
     if "fabric_write_bytes" in res["copy"]:

@@ -275,6 +275,43 @@ def run_case(name, cfg):
     out["noise.eval_out"] = np.asarray([d.max().item(), d.mean().item()], np.float64)
     out["noise.eval_loss"] = np.float64(abs(loss_e - loss_e2))
 
+    # ---- an ABSOLUTE anchor for the post-training outputs: the same passes (same permutations, same initial state, same masks)
+    # through the reference in float64.  |ref_fp32 - ref_fp64| is how far fp32 rounding alone moves the reference's own result;
+    # tests/parity_rules.py holds an implementation to |impl - ref_fp64| <= 2 x that distance (max and mean), which -- unlike a
+    # multiple of the fp32 self-noise -- cannot be met by a subtly biased implementation whose bias exceeds the rounding scale.
+    model64 = ref_models.Model(conf).double()
+    model64.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd0.items()})
+    if p_drop > 0:
+        model64.encoder.dropout = MaskDropout(p_drop, cfg["drop_base_seed"], L - 1)
+    opt64 = torch.optim.Adam(model64.parameters(), lr=cfg["lr"], weight_decay=cfg["wd"])
+    replay = iter(perms)
+    losses64 = []
+
+    class Rec64(Rec):
+        def __call__(self, o, y):
+            l = self.crit(o, y)
+            losses64.append(float(l.item()))
+            return l
+
+    tf64, tt64 = tf.double(), tt.double()
+    torch.randperm = lambda *a, **k: torch.from_numpy(next(replay).astype(np.int64))
+    try:
+        for _ in range(cfg["epochs"]):
+            ref_te.train_mini_batch(model64, tf64[til], labels_l, cfg["B"], Rec64(criterion_l), opt64, cfg["lamb"])
+            ref_te.train_mini_batch(model64, tf64, tt64, cfg["B"], Rec64(criterion_t), opt64, 1 - cfg["lamb"])
+    finally:
+        torch.randperm = real_randperm
+    o64, loss_e64, score_e64 = ref_te.evaluate_mini_batch(model64, tf64, tl, criterion_l, cfg["B"], evaluator)
+    o64n = o64.numpy()
+    out["f64.eval_out"] = o64n.copy() if cfg["full"] else np.asarray(o64n, np.float64).ravel()[::_stride[0]].copy()
+    out["f64.eval_loss"] = np.float64(loss_e64)
+    out["f64.eval_score"] = np.float64(score_e64)
+    out["f64.step_losses"] = np.asarray(losses64, np.float64)
+    d64 = (o_all.double() - o64).abs()
+    out["f64.dist_eval_out"] = np.asarray([d64.max().item(), d64.mean().item()], np.float64)      # |ref_fp32 - ref_fp64|: max, mean
+    out["f64.dist_eval_loss"] = np.float64(abs(loss_e - loss_e64))
+    out["f64.dist_step_losses"] = np.float64(np.abs(np.asarray(losses64) - np.asarray(step_losses)).max())
+
     # ---- config + (small cases) inputs
     for k in ("B", "n", "n_l", "lamb", "lr", "wd", "epochs", "seed"):
         out[f"cfg.{k}"] = np.float64(cfg[k])

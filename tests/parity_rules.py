@@ -18,7 +18,10 @@ makes a few weight entries whose true gradient is ~0 wander by a fraction of lr.
     (measured numpy-oracle vs reference, MLP3w4 after 4 steps: gamma_0 mean 6e-5, max 5e-4 = lr/20) -- the
     per-step losses, which see all of it, still agree to 1e-4;
   * gauge entries are skipped when weight_decay == 0, and held to 1e-4 otherwise;
-  * EVAL-mode outputs after training: the bar comes from the REFERENCE ITSELF.  Every fixture stores `noise.*`:
+  * EVAL-mode outputs after training (round 3): anchored in the reference's FLOAT64 run -- check_eval_out() below; the
+    paragraph that follows is the round-2 rule (4 x self-noise), kept for the `noise.*` keys it explains, which still bound
+    the trained STATE entries.
+  * (round 2) EVAL-mode outputs after training: the bar comes from the REFERENCE ITSELF.  Every fixture stores `noise.*`:
     what two runs of the reference's own train_mini_batch / evaluate_mini_batch disagree by when the initial
     weights of one are moved by a single fp32 ulp (tests/golden/make_student_golden.py).  Without the gauge
     freedom that is ~3e-6 (bn_small, nonorm_fullbatch, dropout case) and eval_tol() is the 1e-4 bar.  In the
@@ -72,18 +75,35 @@ def has_gauge(g):
     return g.norm == "batch" and g.wd == 0
 
 
+ANCHOR_FACTOR = 2.0       # post-training outputs: |impl - ref_fp64| <= 2 x |ref_fp32 - ref_fp64|
+
+
+def check_eval_out(g, out):
+    """Eval-mode log-probs AFTER training (round 3): anchored in the reference's own FLOAT64 run of the same passes (fixture
+    keys f64.*, tests/golden/make_student_golden.py).  |ref_fp32 - ref_fp64| is how far fp32 rounding alone moves the
+    reference; an implementation must stay within 2 x that distance of the fp64 result, max and mean (never tighter than the
+    1e-4 bar).  Round 2 used 4 x the reference's one-ulp self-noise -- 0.14 for MLP3w8; the anchor is 0.018 there, and a
+    biased implementation cannot hide inside it unless its bias is below the rounding scale itself.
+    (MLP3w4: anchor 2.8e-2 vs 1.6e-2 before -- fp32 is simply that far from fp64 on this config.)"""
+    d = np.abs(g.view(np.asarray(out)).astype(np.float64) - np.asarray(g.z["f64.eval_out"], np.float64))
+    dist = g.z["f64.dist_eval_out"]
+    tol_max, tol_mean = max(TOL, ANCHOR_FACTOR * float(dist[0])), max(TOL / 5, ANCHOR_FACTOR * float(dist[1]))
+    assert d.max() <= tol_max, ("eval max", d.max(), tol_max)
+    assert d.mean() <= tol_mean, ("eval mean", d.mean(), tol_mean)
+
+
 def eval_tol(g):
-    """max-abs tolerance of eval-mode log-probs AFTER training: the 1e-4 bar, or 4x the reference's own
-    one-ulp self-noise where that is larger (the gauge configs)."""
-    return max(TOL, NOISE_FACTOR * float(g.z["noise.eval_out"][0]))
+    """max-abs distance allowed between an implementation's eval log-probs and the reference's FP32 ones after training: both
+    lie within their anchors of the fp64 result, so (1 + ANCHOR_FACTOR) x |ref_fp32 - ref_fp64|, never below 1e-4."""
+    return max(TOL, (1.0 + ANCHOR_FACTOR) * float(g.z["f64.dist_eval_out"][0]))
 
 
 def eval_mean_tol(g):
-    return max(TOL / 5, NOISE_FACTOR * float(g.z["noise.eval_out"][1]))
+    return max(TOL / 5, (1.0 + ANCHOR_FACTOR) * float(g.z["f64.dist_eval_out"][1]))
 
 
 def eval_loss_tol(g):
-    return max(TOL, NOISE_FACTOR * float(g.z["noise.eval_loss"]), eval_mean_tol(g))
+    return max(TOL, ANCHOR_FACTOR * float(g.z["f64.dist_eval_loss"]), eval_mean_tol(g))
 
 
 def moment_tols(g, pname):

@@ -57,7 +57,7 @@ def test_group_per_row_aggregation_kernel_vs_oracle(d, mode, monkeypatch):
     else:
         want = to.spmm_sum(indptr, indices, x)
         got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SUM)
-    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0 if mode == "sage" else 1e-5)    # (unnormalised sums of 2500 terms)
     if mode == "sage":
         bias = np.random.RandomState(1).standard_normal(d).astype(np.float32)
         got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN, ep_shift=dev(bias), relu=True)
@@ -74,7 +74,7 @@ def test_group_per_row_aggregation_kernel_vs_oracle(d, mode, monkeypatch):
     ref = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN if mode == "sage" else ops.AGG_SUM)
     monkeypatch.setenv("GLNN_SPMM_GPR", "1")
     again = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN if mode == "sage" else ops.AGG_SUM)
-    assert float((ref - again).abs().max()) <= 2e-5
+    assert float((ref - again).abs().max() / ref.abs().max().clamp(min=1)) <= 2e-5
 
 
 def test_spmm_known_answers_on_gpu():

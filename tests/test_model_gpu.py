@@ -9,7 +9,7 @@ from golden_inputs import CASES, Golden
 from graphgen import random_graph
 from oracle import student_oracle as so
 from oracle import teacher_oracle as to
-from parity_rules import check_final_state, eval_loss_tol, eval_mean_tol, eval_tol, has_gauge
+from parity_rules import check_eval_out, check_final_state, eval_loss_tol, eval_mean_tol, eval_tol, has_gauge
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -94,6 +94,7 @@ def test_distill_passes_vs_reference_golden(name, monkeypatch):
     check_final_state(g, {k: v.cpu().numpy() for k, v in model.state_dict().items()})
     evaluator = lambda o, y: o.argmax(1).eq(y).float().mean().item()
     out, loss_e, score_e = te.evaluate_mini_batch(model, feats, labels, criterion_l, g.B, evaluator)
+    check_eval_out(g, out.cpu().numpy())                     # |impl - ref_fp64| <= 2 x |ref_fp32 - ref_fp64| (tests/parity_rules.py)
     np.testing.assert_allclose(g.view(out.cpu().numpy()), g.z["eval_out"], atol=eval_tol(g), rtol=0)
     assert np.abs(g.view(out.cpu().numpy()) - g.z["eval_out"]).mean() <= eval_mean_tol(g)
     assert abs(loss_e - float(g.z["eval_loss"])) < eval_loss_tol(g)

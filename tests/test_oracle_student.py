@@ -5,7 +5,7 @@ import pytest
 
 from golden_inputs import CASES, Golden
 from oracle import student_oracle as so
-from parity_rules import check_final_state, eval_loss_tol, eval_mean_tol, eval_tol, is_gauge, moment_tols
+from parity_rules import check_eval_out, check_final_state, eval_loss_tol, eval_mean_tol, eval_tol, is_gauge, moment_tols
 
 TOL = 1e-4   # north-star bar: 1e-4 abs, fp32
 
@@ -56,6 +56,7 @@ def test_distill_passes_and_eval(name):
         np.testing.assert_allclose(g.view(m), g.z[f"adam.exp_avg.{pname}"], atol=am, rtol=1e-3)
         np.testing.assert_allclose(g.view(v), g.z[f"adam.exp_avg_sq.{pname}"], atol=av, rtol=1e-3)
     out = so.evaluate_mini_batch(st, g.feats, g.B)
+    check_eval_out(g, out)                     # |impl - ref_fp64| <= 2 x |ref_fp32 - ref_fp64| (tests/parity_rules.py)
     np.testing.assert_allclose(g.view(out), g.z["eval_out"], atol=eval_tol(g), rtol=0)
     assert np.abs(g.view(out) - g.z["eval_out"]).mean() <= eval_mean_tol(g)
     assert abs(so.nll_loss(out, g.labels) - float(g.z["eval_loss"])) < eval_loss_tol(g)
