@@ -75,16 +75,20 @@ def has_gauge(g):
     return g.norm == "batch" and g.wd == 0
 
 
-ANCHOR_FACTOR = 2.0       # post-training outputs: |impl - ref_fp64| <= 2 x |ref_fp32 - ref_fp64|
+# post-training outputs: |impl - ref_fp64| <= 3 x |ref_fp32 - ref_fp64|.  Two correct fp32 implementations sit at independent
+# draws of the same rounding noise from the fp64 result, so their distances differ by a factor: the numpy oracle's distance is
+# 0.16-2.02 x the reference's over the seven fixtures (max: 0.22-1.20 x; mean: 0.16-2.02 x, the 2.02 on MLP3w8) -- a factor of
+# 2 (VERDICT r2's suggestion) fails the oracle itself by 1 % there, 3 holds with margin
+ANCHOR_FACTOR = 3.0
 
 
 def check_eval_out(g, out):
     """Eval-mode log-probs AFTER training (round 3): anchored in the reference's own FLOAT64 run of the same passes (fixture
     keys f64.*, tests/golden/make_student_golden.py).  |ref_fp32 - ref_fp64| is how far fp32 rounding alone moves the
-    reference; an implementation must stay within 2 x that distance of the fp64 result, max and mean (never tighter than the
-    1e-4 bar).  Round 2 used 4 x the reference's one-ulp self-noise -- 0.14 for MLP3w8; the anchor is 0.018 there, and a
-    biased implementation cannot hide inside it unless its bias is below the rounding scale itself.
-    (MLP3w4: anchor 2.8e-2 vs 1.6e-2 before -- fp32 is simply that far from fp64 on this config.)"""
+    reference; an implementation must stay within 3 x that distance of the fp64 result, max and mean (never tighter than the
+    1e-4 bar).  Round 2 used 4 x the reference's one-ulp self-noise -- 0.14 for MLP3w8; the anchor is 0.028 there, and a
+    biased implementation cannot hide inside it unless its bias is at the rounding scale itself.
+    (MLP3w4: anchor 4.2e-2 vs 1.6e-2 before -- fp32 is simply that far from fp64 on this config.)"""
     d = np.abs(g.view(np.asarray(out)).astype(np.float64) - np.asarray(g.z["f64.eval_out"], np.float64))
     dist = g.z["f64.dist_eval_out"]
     tol_max, tol_mean = max(TOL, ANCHOR_FACTOR * float(dist[0])), max(TOL / 5, ANCHOR_FACTOR * float(dist[1]))
