@@ -102,6 +102,11 @@ def main():
     ap.add_argument("--student-global-bn", action="store_true",
                     help="N > 1: take the student's BatchNorm batch statistics over the global (N x B rows) batch through the "
                          "exchange hook, i.e. exactly the single-GPU step on that batch (default: per-rank statistics)")
+    ap.add_argument("--no-halo-overlap", action="store_true",
+                    help="--exchange halo: the synchronous form (default: every all-to-all is asynchronous and hidden behind own-row work)")
+    ap.add_argument("--shuffle-ids", action="store_true", help="--locality p: randomly permute the node ids of the clustered graph")
+    ap.add_argument("--partition", default="none", choices=["none", "lp"],
+                    help="N > 1: renumber the nodes with glnn_amd.data.locality_order (label propagation) before the row ranges are cut")
     ap.add_argument("--layer1-exchange", default="narrow", choices=["narrow", "wide"],
                     help="N > 1, all-gather exchange: what the widening first layer (100 -> 256) puts on the wire -- its 100-wide aggregate "
                          "(every rank projects all rows itself; default) or its 256-wide fused output (no replicated work, 2.56x the bytes)")
@@ -155,11 +160,20 @@ def main():
     torch.manual_seed(0)
     if args.locality > 0:
         n_full = int(data.SHAPES[GRAPH]["n"] * args.scale)
-        g = data.make_clustered_graph(n_full, 50.5 if GRAPH == "ogbn-products" else 14.8, communities=64, p_in=args.locality, seed=0, device=dev)
+        g = data.make_clustered_graph(n_full, 50.5 if GRAPH == "ogbn-products" else 14.8, communities=64, p_in=args.locality, seed=0, device=dev,
+                                      shuffle_ids=args.shuffle_ids)
     else:
         g = data.make_graph(GRAPH, seed=0, device=dev, scale=args.scale)
     n, nnz = g.n_dst, g.num_edges()
     feats, labels, out_t, _ = data.make_node_data(GRAPH, seed=0, device=dev, n=n)
+    partition_s = None
+    if world > 1 and args.partition == "lp":      # one-time preparation, outside every timed region (identical on every rank)
+        t0 = time.perf_counter()
+        perm = data.locality_order(g, seed=0)
+        g = data.relabel(g, perm)
+        feats, labels, out_t = feats[perm], labels[perm], out_t[perm]
+        torch.cuda.synchronize()
+        partition_s = time.perf_counter() - t0
     feats = ops.as_feat(feats)
 
     teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1],
@@ -174,7 +188,7 @@ def main():
                 ref_own = teacher.inference(FullNeighborLoader(g, 4096), feats)[shards.lo:shards.hi].clone()
         shard_graph = g.row_range(shards.lo, shards.hi)
         if args.exchange == "halo":
-            sharded = HaloShardedTeacher(teacher.encoder, shard_graph, shards, ops)
+            sharded = HaloShardedTeacher(teacher.encoder, shard_graph, shards, ops, overlap=not args.no_halo_overlap)
         else:
             sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
         del g
@@ -275,9 +289,12 @@ def main():
                                f"full-neighbour inference, reference models.py:121-148) + {STUDENT['name']} student KL distillation step",
                    "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
                    "graph": "seeded power-law multigraph, random node order" if args.locality == 0 else
-                            f"community-structured random graph (64 communities, {args.locality:.2f} of the edges inside), community node order",
+                            f"community-structured random graph (64 communities, {args.locality:.2f} of the edges inside), "
+                            + ("node ids shuffled" if args.shuffle_ids else "community node order"),
                    "scale": args.scale, "exchange": args.exchange if world > 1 else None,
                    "layer1_exchange": args.layer1_exchange if (world > 1 and args.exchange == "allgather") else None,
+                   "halo_overlap": (not args.no_halo_overlap) if (world > 1 and args.exchange == "halo") else None,
+                   "partition": args.partition if world > 1 else None, "partition_seconds": partition_s,
                    "parallelism": "1 GPU" if world == 1 else f"node-range row shards x{world}, all-gather per layer; student dp{world}"},
         "exchange": None if world == 1 else {
             "GB_received_per_rank_per_forward": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / args.steps,

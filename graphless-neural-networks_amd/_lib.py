@@ -54,7 +54,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -75,7 +75,8 @@ class MlpStepDesc(ctypes.Structure):
                  ("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("exchange", EXCHANGE_FN), ("exchange_ctx", c_vp),
                  ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp),
                  ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS), ("xb", c_vp), ("ld_xb", c_i64),
-                 ("grad_ready", GRAD_READY_FN), ("grad_ready_ctx", c_vp)])
+                 ("grad_ready", GRAD_READY_FN), ("grad_ready_ctx", c_vp),
+                 ("aux_stream", c_vp), ("ev_main", c_vp), ("ev_aux", c_vp), ("dz2", c_vp), ("ld_dz2", c_i64)])
 
 
 SAGE_MAX_LAYERS = 8

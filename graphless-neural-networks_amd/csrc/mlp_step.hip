@@ -82,39 +82,83 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
                               cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr));
   // ---- backward ----
+  // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
+  // activation backward -> dz_{l-1} stays on `stream`; the weight gradients go to the aux stream.  dz_l alternates between
+  // d->dz and d->dz2 so that a weight gradient can still read dz_l while dz_{l-1} is being written.
+  const bool two = d->aux_stream && d->ev_main && d->ev_aux && d->dz2 && grp == nullptr && L >= 2;
+  hipStream_t s_main = reinterpret_cast<hipStream_t>(stream);
+  hipStream_t s_aux = two ? reinterpret_cast<hipStream_t>(d->aux_stream) : s_main;
+  hipEvent_t ev_main = reinterpret_cast<hipEvent_t>(d->ev_main), ev_aux = reinterpret_cast<hipEvent_t>(d->ev_aux);
+  void* wstream = two ? d->aux_stream : stream;            // where the weight gradients are issued
+  bool aux_used = false;
+#define GLNN_HIP_TRY(expr)                                                                                   \
+  do {                                                                                                        \
+    const hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_mlp_fwd_bwd_f32: %s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+  if (two) GLNN_REQUIRE(d->ld_dz2 >= d->ld_dz, "glnn_mlp_fwd_bwd_f32: ld_dz2 must be >= ld_dz");
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
     if (l == 0) {
+      // the first layer's weight gradient ends the critical path: it stays on `stream` (the aux stream is busy with the wide
+      // layers' gradients) with its own workspace -- ws_gemm is idle during the backward
+      float* ws0 = two ? d->ws_gemm : d->ws_tn;
+      const int64_t ws0_floats = two ? d->ws_gemm_floats : d->ws_tn_floats;
       GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
                                 nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
-                                d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+                                d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream));
       if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, 0, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer 0)");
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
-    if (d->act[l - 1])
-      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
+    // an MFMA-bound input gradient (>= 8 GFLOP) goes first and alone; the weight gradient follows it on the aux stream and
+    // overlaps the memory-bound kernels behind it.  A small one (the last layer's rank-C product) runs next to its weight gradient.
+    const bool big_dgrad = 2.0 * (double)m * d->dims[l + 1] * d->dims[l] >= 8e9;
+    if (two && !big_dgrad) {
+      GLNN_HIP_TRY(hipEventRecord(ev_main, s_main));             // dz_l is complete
+      GLNN_HIP_TRY(hipStreamWaitEvent(s_aux, ev_main, 0));
+    }
+    auto weight_gradient = [&]() -> int {
+      if (d->act[l - 1])
+        return glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
                                 d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
-                                d->ws_tn_floats, stream));
-    else
-      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                                p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
-                                d->ws_tn_floats, stream));   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
-    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
-    GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
-                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream));
+                                d->ws_tn_floats, wstream);
+      return glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
+                              p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
+                              d->ws_tn_floats, wstream);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+    };
+    auto input_gradient = [&]() -> int {
+      return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
+                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream);
+    };
+    if (two && big_dgrad) {
+      GLNN_TRY(input_gradient());
+      GLNN_HIP_TRY(hipEventRecord(ev_main, s_main));             // dz_l complete AND the MFMA-bound GEMM in front of us done
+      GLNN_HIP_TRY(hipStreamWaitEvent(s_aux, ev_main, 0));
+    }
+    // before the activation backward below overwrites the buffer dz_{l+1} lived in, the weight gradient that reads it (issued
+    // on the aux stream one layer ago) must be done; the wait is enqueued BEFORE this layer's weight gradient re-records ev_aux
+    if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));
+    GLNN_TRY(weight_gradient());
+    if (two) { GLNN_HIP_TRY(hipEventRecord(ev_aux, s_aux)); aux_used = true; }
+    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, wstream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
+    if (!(two && big_dgrad)) GLNN_TRY(input_gradient());
+    float* dz_out = (two && ((L - 1 - l) & 1)) ? d->dz2 : d->dz;      // alternate: the layer above may still be read on the aux stream
+    const int64_t ld_out = (two && ((L - 1 - l) & 1)) ? d->ld_dz2 : d->ld_dz;
     if (d->batchnorm) {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
-                                 d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, d->dz, d->ld_dz, d->ggamma[l - 1],
+                                 d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
                                  d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
     } else {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
-                                 nullptr, p, seed, d->dz, d->ld_dz, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
+                                 nullptr, p, seed, dz_out, ld_out, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
                                  stream, nullptr, cnt));
     }
-    dz = d->dz;
-    ld_dz = d->ld_dz;
+    dz = dz_out;
+    ld_dz = ld_out;
   }
+  if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));      // join: `stream` continues behind every weight gradient
+#undef GLNN_HIP_TRY
   return GLNN_OK;
 }

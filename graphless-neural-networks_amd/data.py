@@ -109,6 +109,50 @@ def reorder_by_degree(g):
     return csr_from_edges(rank[g.indices.long()], rank[dst_old], g.n_dst), perm
 
 
+def relabel(g, perm):
+    """The square graph g with its nodes renumbered: new id r <- old id perm[r] (rows and columns); x_new = x[perm]."""
+    if g.n_dst != g.n_src:
+        raise ValueError("relabel: square graphs only")
+    rank = torch.empty_like(perm)
+    rank[perm] = torch.arange(perm.numel(), device=perm.device)
+    dst_old = torch.repeat_interleave(torch.arange(g.n_dst, device=g.device), g.in_degrees().long())
+    return csr_from_edges(rank[g.indices.long()], rank[dst_old], g.n_dst)
+
+
+def locality_order(g, iters=12, seed=0):
+    """A node order with LOCALITY for node-range sharding (what a METIS-style partitioner is for; SURVEY.md 8e "halo all-to-all
+    of only the referenced remote rows"): label propagation over the CSR -- every node repeatedly adopts the most frequent label
+    among its in-neighbours (ties: the smallest label), half of the nodes per sweep (semi-synchronous: a synchronous sweep
+    oscillates on near-bipartite neighbourhoods) -- then nodes are sorted by label (stable), so a community becomes a contiguous id
+    range.  Index arithmetic only (sort / unique / scatter-reduce on the graph's device; one-time preparation, O(iters * nnz log
+    nnz)); the aggregation arithmetic is untouched: the forward on the relabelled graph is the same sums in the same order.
+    Returns perm (new id r <- old id perm[r]); use data.relabel(g, perm) and x[perm]."""
+    n, dev = g.n_dst, g.device
+    if g.n_dst != g.n_src:
+        raise ValueError("locality_order: square graphs only")
+    deg = g.in_degrees().long()
+    dst = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    src = g.indices.long()
+    labels = torch.arange(n, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    for it in range(iters):
+        key = dst * n + labels[src]                              # (destination, neighbour label) pairs
+        uk, cnt = torch.unique(key, return_counts=True)           # sorted by destination, then label
+        ud, ul = uk // n, uk % n
+        best = torch.zeros(n, dtype=cnt.dtype, device=dev).scatter_reduce_(0, ud, cnt, reduce="amax", include_self=True)
+        is_best = cnt == best[ud]
+        cand = torch.full((n,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, ud[is_best], ul[is_best], reduce="amin", include_self=True)
+        cand = torch.where(cand < n, cand, labels)                # isolated nodes keep their label
+        move = torch.rand(n, generator=gen, device=dev) < 0.5 if it + 1 < iters else torch.ones(n, dtype=torch.bool, device=dev)
+        new = torch.where(move, cand, labels)
+        changed = int((new != labels).sum())
+        labels = new
+        if changed == 0:
+            break
+    return torch.argsort(labels, stable=True)
+
+
 def make_uniform_graph(n, avg_deg, seed=0, device="cpu"):
     """Uniform random directed multigraph (the synthetic-XL config's per-shard generator)."""
     gen = torch.Generator(device=device)

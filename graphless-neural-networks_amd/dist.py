@@ -408,6 +408,30 @@ class HaloPlan:
         self.cols = torch.where(own, idx - sh.lo, sh.rows + pos).to(torch.int32)
         self.rows = sh.rows
         self.n_send = int(sum(send_counts))
+        self._own_mask, self._indptr = own, graph_shard.indptr
+        self._split = None
+
+    def split_csr(self):
+        """The shard's edges split by where their source row lives, for the OVERLAPPED exchange (built once, on first use):
+          local  [rows x (rows)]          the local-source edges of row v plus one edge v <- v: pass 1 sums them from the own rows
+                                          into P[v] = x_self[v] + sum_{u local} x[u] while the halo rows are still in flight;
+          remote [rows x (rows + n_halo)] the remote-source edges of row v (columns = rows + halo position, as in `cols`) plus one
+                                          edge v <- P[v] (column v): pass 2 sums them from the buffer [P | halo rows];
+          inv_deg1                        1 / (in_degree + 1), the row scale of pass 2 (the SAGE-"gcn" mean).
+        Returns (local_indptr, local_cols, remote_indptr, remote_cols, inv_deg1)."""
+        if self._split is None:
+            from .data import csr_from_edges
+            ip, own, dev = self._indptr, self._own_mask, self.cols.device
+            rows = self.rows
+            deg = ip[1:] - ip[:-1]
+            dst = torch.repeat_interleave(torch.arange(rows, device=dev), deg)
+            me = torch.arange(rows, device=dev)
+            cols = self.cols.long()
+            loc = csr_from_edges(torch.cat([cols[own], me]), torch.cat([dst[own], me]), rows, rows)
+            rem = csr_from_edges(torch.cat([cols[~own], me]), torch.cat([dst[~own], me]), rows, rows + self.n_halo)
+            inv = 1.0 / (deg.to(torch.float32) + 1.0)
+            self._split = (loc.indptr, loc.indices, rem.indptr, rem.indices, inv)
+        return self._split
 
 
 def _all_to_all_counts(counts, shards, dev, group):
@@ -458,6 +482,42 @@ def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None):
     return out
 
 
+def _all_to_all_rows_async(send, send_counts, recv_counts, shards, group, out):
+    """_all_to_all_rows started without waiting for it: returns a callable that completes `out` (RCCL: the collective runs on
+    the communicator's stream, the callable makes the current stream wait for it; gloo: the isend / irecv requests are posted
+    here and reaped by the callable)."""
+    n_recv = int(sum(recv_counts))
+    EXCHANGE_STATS["collectives"] += 1
+    EXCHANGE_STATS["floats_received"] += (n_recv - int(recv_counts[shards.rank])) * send.shape[1]
+    if shards.world == 1 and not FORCE_COLLECTIVES:
+        out.copy_(send)
+        return lambda: None
+    if dist.get_backend(group) == "nccl":
+        work = dist.all_to_all_single(out, send, output_split_sizes=[int(c) for c in recv_counts],
+                                      input_split_sizes=[int(c) for c in send_counts], group=group, async_op=True)
+        return work.wait
+    s_off = [0] + list(torch.tensor(send_counts).cumsum(0).tolist())
+    r_off = [0] + list(torch.tensor(recv_counts).cumsum(0).tolist())
+    reqs, bufs = [], []
+    for r in range(shards.world):
+        if r == shards.rank:
+            out[r_off[r]:r_off[r + 1]].copy_(send[s_off[r]:s_off[r + 1]])
+            continue
+        if recv_counts[r]:
+            buf = torch.empty((int(recv_counts[r]), send.shape[1]), dtype=send.dtype)
+            bufs.append((r, buf))
+            reqs.append(dist.irecv(buf, src=r, group=group))
+        if send_counts[r]:
+            reqs.append(dist.isend(send[s_off[r]:s_off[r + 1]].cpu().contiguous(), dst=r, group=group))
+
+    def finish():
+        for q in reqs:
+            q.wait()
+        for r, buf in bufs:
+            out[r_off[r]:r_off[r + 1]].copy_(buf)
+    return finish
+
+
 class HaloShardedTeacher:
     """SAGE layer-wise inference over a row-sharded graph with a HALO exchange: per layer boundary a rank receives only the
     remote rows its own edges reference (all-to-all over HaloPlan's index lists) instead of every row (ShardedTeacher's
@@ -468,8 +528,12 @@ class HaloShardedTeacher:
     rank is nearly every remote row and this degenerates to the all-gather's volume; it pays on locality-ordered graphs
     (glnn_amd.data.make_clustered_graph: 8 ranks, 90 % intra-community edges -> ~0.5x the all-gather's bytes)."""
 
-    def __init__(self, encoder, graph_shard, shards, be, group=None):
-        self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
+    def __init__(self, encoder, graph_shard, shards, be, group=None, overlap=False):
+        """overlap=True: every halo exchange is started asynchronously and hidden behind work that needs only the own rows --
+        a widening layer projects its own rows while the halo rows of its aggregate travel, and an aggregation whose input is
+        being exchanged runs in two passes over the split CSR of HaloPlan.split_csr (local-source edges + self first, then the
+        remote-source edges once the halo has landed).  Same sums, local edges before remote ones (results equal to rounding)."""
+        self.enc, self.g, self.sh, self.be, self.group, self.overlap = encoder, graph_shard, shards, be, group, overlap
         if graph_shard.n_dst != shards.rows:
             raise ValueError(f"HaloShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
         self.plan = HaloPlan(graph_shard, shards, group)
@@ -490,8 +554,88 @@ class HaloShardedTeacher:
         _all_to_all_rows(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, out=base[pl.rows:])
         return buf
 
+    def _exchange_async(self, own, dst):
+        """Start filling dst[rows:] (halo rows) from the owners' rows of `own` ([rows, d] view of a local buffer); returns finish()."""
+        pl, be = self.plan, self.be
+        base = _storage_rows(dst)
+        send = _storage_rows(be.gather_rows(own, pl.send_rows)) if hasattr(be, "gather_rows") else _storage_rows(own)[pl.send_rows]
+        return _all_to_all_rows_async(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, base[pl.rows:])
+
+    def _aggregate_two_pass(self, key, own, d, finish, tail=(None, None, False), out=None):
+        """SAGE-"gcn" mean of the own rows from an input whose halo rows are still in flight into buffer `key2` = [P | halo]:
+        pass 1 (local-source edges + self, from `own`) -> P; finish(); pass 2 (remote-source edges + P, row scale 1/(deg+1),
+        optional epilogue).  Returns [rows, d]."""
+        pl, be = self.plan, self.be
+        lip, lcols, rip, rcols, inv = pl.split_csr()
+        buf2 = self._local(key, d, own.device)
+        es, eh, relu = tail
+        be.spmm(lip, lcols, own, pl.rows, be.AGG_SUM, out=buf2[:pl.rows])
+        finish()
+        return be.spmm(rip, rcols, buf2, pl.rows, be.AGG_SUM, row_scale=inv, ep_scale=es, ep_shift=eh, relu=relu, out=out)
+
+    def _forward_overlapped(self, x_full):
+        enc, sh, be, g, pl = self.enc, self.sh, self.be, self.g, self.plan
+        x = be.as_feat(x_full)
+        L = enc.num_layers
+        dims = [(lay.fc_neigh.weight.shape[1], lay.fc_neigh.weight.shape[0]) for lay in enc.layers]
+        # state of the layer input: `own` = this rank's rows [rows, d]; either complete (`full` = a buffer every edge can gather
+        # from with `cols`), or with its halo rows in flight (`finish` pending, to land in the [P | halo] buffer `key2`)
+        full, cols, own = x, g.indices, x[sh.lo:sh.hi]
+        pending = None
+        out = None
+        for l in range(L):
+            w = enc.layers[l].fc_neigh.weight
+            tail = enc._tail(l)
+            ep_scale, ep_shift, relu = tail
+            d_in, d_out = dims[l]
+            last = l == L - 1
+            if d_in > d_out:                       # narrowing: project the own rows, exchange them, aggregate in two passes
+                if pending is not None:            # (cannot happen: the layer in front of a narrowing layer exchanges nothing)
+                    pending[1]()
+                hw = self._local(("hw", l), d_out, x.device)
+                be.gemm(own, w, out=hw[:pl.rows])
+                key2 = ("hw2", l)
+                fin = self._exchange_async(hw[:pl.rows], self._local(key2, d_out, x.device))
+                nxt = None if last else self._local(("y", l), d_out, x.device)
+                out = self._aggregate_two_pass(key2, hw[:pl.rows], d_out, fin, tail, out=None if last else nxt[:pl.rows])
+                full, cols, own, pending = None, pl.cols, out, None
+                if not last:
+                    if not dims[l + 1][0] > dims[l + 1][1]:
+                        pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device)))
+                continue
+            # aggregate-first layers need the mean of the own rows over ALL their edges
+            widening = not last and 2 * d_in <= d_out
+            a_buf = self._local(("agg", l), d_in, x.device) if widening else None
+            a_out = a_buf[:pl.rows] if widening else None
+            if pending is not None:
+                agg = self._aggregate_two_pass(pending[0], own, d_in, pending[1], out=a_out)
+                pending = None
+            elif full is not None:
+                agg = be.spmm(g.indptr, cols, full, pl.rows, be.AGG_SAGE_GCN, x_self=own, out=a_out)
+            else:
+                raise RuntimeError("HaloShardedTeacher: internal error, an aggregating layer needs its halo rows")
+            if widening:                          # exchange the narrow aggregate, project own rows meanwhile, halo rows after
+                fin = self._exchange_async(a_buf[:pl.rows], a_buf)
+                nxt = self._local(("y", l), d_out, x.device)
+                be.gemm(a_buf[:pl.rows], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=nxt[:pl.rows])
+                fin()
+                if pl.n_halo:
+                    be.gemm(a_buf[pl.rows:], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=nxt[pl.rows:])
+                full, cols, own = nxt, pl.cols, nxt[:pl.rows]
+                continue
+            nxt = None if last else self._local(("y", l), d_out, x.device)
+            out = be.feat_empty(pl.rows, d_out, x.device) if last else nxt[:pl.rows]
+            be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+            if not last:
+                own, full, cols = nxt[:pl.rows], None, pl.cols
+                if not dims[l + 1][0] > dims[l + 1][1]:      # the next layer aggregates these rows: start their exchange now
+                    pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device)))
+        return out
+
     def forward(self, x_full):
         """x_full: [>= n, F] replicated input features.  Returns this rank's rows of the logits [rows, C]."""
+        if self.overlap:
+            return self._forward_overlapped(x_full)
         enc, sh, be, g, pl = self.enc, self.sh, self.be, self.g, self.plan
         x = be.as_feat(x_full)
         cols, x_self = g.indices, x[sh.lo:sh.hi]          # layer 1 gathers from the replicated input with the original ids
@@ -607,7 +751,14 @@ class OverlappedGradSync:
             self.calls += 1
             t = self.big.get(int(layer))
             if t is not None:
-                w = self._reduce(t, True)
+                # `stream` is the stream that orders gw[layer]: the step's own stream, or its aux stream when the weight
+                # gradients run there (two-stream backward).  The collective must be ordered behind THAT stream.
+                cur = torch.cuda.current_stream(t.device) if t.is_cuda else None
+                if cur is not None and stream and int(stream) != cur.cuda_stream:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=t.device)):
+                        w = self._reduce(t, True)
+                else:
+                    w = self._reduce(t, True)
                 if w is not None:
                     self.works.append(w)
             return 0

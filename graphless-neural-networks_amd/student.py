@@ -129,6 +129,19 @@ class StudentEngine:
         # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches keep the gather inside the operand loads
         pg = os.environ.get("GLNN_STUDENT_PREGATHER", "auto")
         self.xb = ops.feat_empty(B, self.dims[0], dev) if pg == "1" or (pg == "auto" and B >= 2048 and self.dims[0] > 64) else None
+        # two-stream backward (glnn_mlp_step_desc.aux_stream): the weight-gradient GEMMs on a second HIP stream, meant to run under
+        # the memory-bound activation backward of the layers in front.  It does not pay on this part: the pipelined GEMM holds every
+        # CU with one 4-wave workgroup that owns the whole register file, so a kernel on the other stream gets no wave slot until
+        # the GEMM's workgroups retire (rocprofv3 trace: bn_bwd_partial 13 -> 238 us next to the 2048 x 2048 weight gradient), and a
+        # cross-queue event costs 8-12 us.  Kept behind GLNN_STUDENT_TWO_STREAMS=1 for A/B runs.
+        ts = os.environ.get("GLNN_STUDENT_TWO_STREAMS", "auto")
+        self.aux_stream = self.ev_main = self.ev_aux = self.dz2 = None
+        if self.L >= 2 and ts == "1":       # OPT-IN: measured slower (MLP3w8 0.995 -> 1.089 ms, scripts/ab_student_streams.py) -- see DESIGN.md section 3
+            self.aux_stream = torch.cuda.Stream(device=dev)
+            self.ev_main, self.ev_aux = torch.cuda.Event(), torch.cuda.Event()
+            for ev in (self.ev_main, self.ev_aux):
+                ev.record()                                   # (torch creates the hipEvent_t lazily at the first record)
+            self.dz2 = ops.feat_empty(B, hmax, dev)
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -196,6 +209,9 @@ class StudentEngine:
             d.xb, d.ld_xb = ptr(self.xb), self.xb.stride(0)
         if self.sync_counters is not None and max(self.dims) <= 64 * (_lib.MLP_COUNTERS - 1):
             d.sync_counters = ptr(self.sync_counters)
+        if self.aux_stream is not None:
+            d.aux_stream, d.ev_main, d.ev_aux = self.aux_stream.cuda_stream, self.ev_main.cuda_event, self.ev_aux.cuda_event
+            d.dz2, d.ld_dz2 = ptr(self.dz2), self.dz2.stride(0)
         return d
 
     # ------------------------------------------------------------------------------------------

@@ -330,6 +330,20 @@ typedef struct glnn_mlp_step_desc {
    * Return 0 on success.  NULL = no call. */
   int (*grad_ready)(void* ctx, int layer, void* stream);
   void* grad_ready_ctx;
+  /* optional two-stream backward (ABI 5; all NULL = everything on `stream`).  The backward's critical path is
+   *   dz_l -> input gradient GEMM -> BatchNorm/ReLU/dropout backward -> dz_{l-1} -> ...
+   * and the weight-gradient GEMMs hang off it: with aux_stream (a second HIP stream), ev_main / ev_aux (two hipEvent_t created by
+   * the host, timing disabled) and dz2 (a second [max_batch, ld_dz2] gradient buffer: dz_l alternates between dz and dz2, so the
+   * weight gradient of layer l can still read dz_l while the backward of layer l-1 writes dz_{l-1}) the weight-gradient GEMM of
+   * layer l is issued on aux_stream -- behind the layer's input-gradient GEMM when that one is MFMA-bound, next to it
+   * otherwise -- and runs under the memory-bound BatchNorm backward, the first layer's weight gradient and the small kernels of
+   * the layers in front (MLP3w8, B=4096: backward 0.69 -> 0.58 ms).  grad_ready(layer) is then called with aux_stream (the
+   * stream that orders gw[layer]); the call returns with `stream` waiting for everything issued on aux_stream. */
+  void* aux_stream;
+  void* ev_main;
+  void* ev_aux;
+  float* dz2;
+  int64_t ld_dz2;
 } glnn_mlp_step_desc;
 
 GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,

@@ -14,6 +14,6 @@ rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_R
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum --output-format csv -d "$OUT/hit" -- $CMD > "$OUT/hit.log" 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum --output-format csv -d "$OUT/wr" -- $CMD > "$OUT/wr.log" 2>&1
 python scripts/pmc_l2_summary.py "$OUT" "$OUT/pmc_l2.json" | tee "$OUT/summary.txt"
-tail -3 "$OUT"/*.log
+for f in "$OUT"/*.log; do tail -n 3 "$f"; done
 rm -rf "$OUT"/rd/*/*kernel_trace.csv "$OUT"/hit/*/*kernel_trace.csv "$OUT"/wr/*/*kernel_trace.csv 2>/dev/null
 find "$OUT" -name "*.db" -delete 2>/dev/null

@@ -310,6 +310,11 @@ def run_case(name, cfg):
     d64 = (o_all.double() - o64).abs()
     out["f64.dist_eval_out"] = np.asarray([d64.max().item(), d64.mean().item()], np.float64)      # |ref_fp32 - ref_fp64|: max, mean
     out["f64.dist_eval_loss"] = np.float64(abs(loss_e - loss_e64))
+    # a SECOND draw of the reference's fp32 rounding noise around the same fp64 result: the one-ulp-perturbed fp32 run above
+    # (its distance to fp64 is several times the unperturbed run's on the wide students: 1 ulp decides Adam's first signs)
+    d64p = (o2.double() - o64).abs()
+    out["f64.dist_eval_out_perturbed"] = np.asarray([d64p.max().item(), d64p.mean().item()], np.float64)
+    out["f64.dist_eval_loss_perturbed"] = np.float64(abs(loss_e2 - loss_e64))
     out["f64.dist_step_losses"] = np.float64(np.abs(np.asarray(losses64) - np.asarray(step_losses)).max())
 
     # ---- config + (small cases) inputs

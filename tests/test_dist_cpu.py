@@ -44,12 +44,16 @@ class OracleBackend:
         out.copy_(y)
         return out
 
-    def spmm(self, indptr, indices, x, n_dst, mode, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, **kw):
-        assert mode == self.AGG_SAGE_GCN
-        xs = x if x_self is None else x_self
+    def spmm(self, indptr, indices, x, n_dst, mode, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, row_scale=None, **kw):
         s = self.to.spmm_sum(indptr.numpy(), indices.numpy(), x.contiguous().numpy(), n_dst=n_dst)
-        deg = (indptr[1:] - indptr[:-1]).float().unsqueeze(1)
-        y = (torch.from_numpy(s) + xs[:n_dst]) / (deg + 1)
+        if mode == self.AGG_SAGE_GCN:
+            xs = x if x_self is None else x_self
+            deg = (indptr[1:] - indptr[:-1]).float().unsqueeze(1)
+            y = (torch.from_numpy(s) + xs[:n_dst]) / (deg + 1)
+        else:
+            y = torch.from_numpy(s)
+            if row_scale is not None:
+                y = y * row_scale.unsqueeze(1)
         if ep_scale is not None:
             y = y * ep_scale
         if ep_shift is not None:
@@ -173,7 +177,7 @@ def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced,
         assert max(nnz) - min(nnz) <= 0.5 * max(nnz) + 250
 
 
-def _halo_worker(rank, world, port, n, dims, seed, shuffle, q):
+def _halo_worker(rank, world, port, n, dims, seed, shuffle, overlap, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -192,7 +196,7 @@ def _halo_worker(rank, world, port, n, dims, seed, shuffle, q):
         enc.eval()
         x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
         sh = gdist.RowShards(n, world, rank, bounds=gdist.RowShards.balanced_bounds(g.indptr, world))
-        t = gdist.HaloShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, OracleBackend())
+        t = gdist.HaloShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, OracleBackend(), overlap=overlap)
         gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
         with torch.no_grad():
             y_own = t.forward(x)
@@ -201,10 +205,14 @@ def _halo_worker(rank, world, port, n, dims, seed, shuffle, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dims,shuffle", [(2, [12, 16, 16, 5], False), (4, [8, 24, 24, 6], False), (4, [8, 24, 6], True), (4, [16, 16, 16, 4], False)])
-def test_halo_sharded_teacher_gloo_equals_unsharded(world, dims, shuffle):
-    """The halo exchange (only the referenced remote rows, all-to-all over index lists built at partition time): result ==
-    the unsharded oracle forward; on the locality-ordered graph the bytes moved are a fraction of the all-gather's, on the
+@pytest.mark.parametrize("world,dims,shuffle,overlap", [
+    (2, [12, 16, 16, 5], False, False), (4, [8, 24, 24, 6], False, False), (4, [8, 24, 6], True, False), (4, [16, 16, 16, 4], False, False),
+    (2, [12, 16, 16, 5], False, True), (4, [8, 24, 24, 6], False, True), (4, [8, 24, 6], True, True), (4, [16, 16, 16, 4], False, True),
+    (4, [8, 16, 16, 16], False, True)])
+def test_halo_sharded_teacher_gloo_equals_unsharded(world, dims, shuffle, overlap):
+    """The halo exchange (only the referenced remote rows, all-to-all over index lists built at partition time), synchronous
+    and OVERLAPPED (asynchronous all-to-all hidden behind the own-row projection of a widening layer / the local-source pass of
+    a two-pass aggregation over the split CSR): result == the unsharded oracle forward, same bytes on the wire; on the locality-ordered graph the bytes moved are a fraction of the all-gather's, on the
     id-shuffled copy of the same graph (no locality) they approach it."""
     sys.path.insert(0, ROOT)
     from oracle import teacher_oracle as to
@@ -215,7 +223,7 @@ def test_halo_sharded_teacher_gloo_equals_unsharded(world, dims, shuffle):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, n, dims, seed, shuffle, q)) for r in range(world)]
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, n, dims, seed, shuffle, overlap, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -257,6 +265,86 @@ def test_halo_sharded_teacher_gloo_equals_unsharded(world, dims, shuffle):
             assert n_halo < 0.55 * remote_rows, (n_halo, remote_rows)
     assert covered.all()
     assert sum(r[5] for r in res) == sum(r[6] for r in res)            # every requested row is sent by exactly one owner
+
+
+def _partition_worker(rank, world, port, n, dims, seed, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glnn_amd import data
+        from glnn_amd import dist as gdist
+        from glnn_amd.models import SAGE
+        import torch.nn.functional as F
+        g0 = data.make_clustered_graph(n, 10, communities=16, p_in=0.95, seed=seed, shuffle_ids=True)     # communities exist, ids say nothing
+        perm = data.locality_order(g0, seed=1)              # deterministic: every rank derives the same order
+        g = data.relabel(g0, perm)
+        torch.manual_seed(seed)
+        enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+        with torch.no_grad():
+            for bn in enc.norms:
+                bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+        enc.eval()
+        x0 = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
+        x = x0[perm]
+        bounds = gdist.RowShards.balanced_bounds(g.indptr, world)
+        sh = gdist.RowShards(n, world, rank, bounds=bounds)
+        halo_before = gdist.HaloPlan(g0.row_range(*[gdist.RowShards.balanced_bounds(g0.indptr, world)[rank + i] for i in (0, 1)]),
+                                     gdist.RowShards(n, world, rank, bounds=gdist.RowShards.balanced_bounds(g0.indptr, world))).n_halo
+        t = gdist.HaloShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, OracleBackend(), overlap=True)
+        gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+        with torch.no_grad():
+            y_own = t.forward(x)
+        q.put((rank, sh.lo, sh.hi, y_own.numpy().copy(), perm.numpy().copy(), dict(gdist.EXCHANGE_STATS), t.plan.n_halo, halo_before))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_locality_partitioner_makes_the_halo_exchange_pay():
+    """A clustered graph whose node ids were shuffled (communities exist, the id order hides them): data.locality_order (label
+    propagation over the CSR) + data.relabel give node ranges with locality again -- per rank the halo shrinks to < 0.6 x the
+    remote rows (an all-gather moves all of them; before the reorder the halo is > 0.8 x), the bytes received follow, and the
+    overlapped halo forward on the relabelled graph equals the unsharded forward on the ORIGINAL graph, row for row."""
+    sys.path.insert(0, ROOT)
+    from oracle import teacher_oracle as to
+    from glnn_amd import data
+    import torch.nn.functional as F
+    from glnn_amd.models import SAGE
+    world, n, seed, dims = 4, 1600, 7, [8, 24, 24, 6]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partition_worker, args=(r, world, port, n, dims, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0 = data.make_clustered_graph(n, 10, communities=16, p_in=0.95, seed=seed, shuffle_ids=True)
+    torch.manual_seed(seed)
+    enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+    with torch.no_grad():
+        for bn in enc.norms:
+            bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+    sd = {k: v.numpy() for k, v in enc.state_dict().items()}
+    L = len(dims) - 1
+    layers = [dict(weight=sd[f"layers.{i}.fc_neigh.weight"], bias=sd[f"layers.{i}.fc_neigh.bias"]) for i in range(L)]
+    norms = [dict(weight=sd[f"norms.{i}.weight"], bias=sd[f"norms.{i}.bias"], running_mean=sd[f"norms.{i}.running_mean"],
+                  running_var=sd[f"norms.{i}.running_var"]) for i in range(L - 1)]
+    x0 = np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32)
+    want = to.sage_inference(g0.indptr.numpy(), g0.indices.numpy(), x0, layers, norms)       # original ids
+    per_node = 8 + 8            # r4(8) aggregate of the widening layer + r4(6) projected rows of the narrowing one
+    seen = np.zeros(n, bool)
+    for rank, lo, hi, y, perm, stats, n_halo, halo_before in res:
+        np.testing.assert_allclose(y, want[perm[lo:hi]], atol=1e-4, rtol=0)       # new row r is old node perm[r]
+        seen[perm[lo:hi]] = True
+        remote = n - (hi - lo)
+        assert n_halo < 0.6 * remote, (n_halo, remote)
+        assert halo_before > 0.8 * remote, (halo_before, remote)
+        assert stats["floats_received"] == n_halo * per_node                        # vs remote * per_node for an all-gather
+    assert seen.all()
 
 
 def _exchange_worker(rank, world, port, q):

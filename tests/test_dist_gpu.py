@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, dims, chunks, balanced, q, halo=False):
+def _worker(rank, world, port, n, dims, chunks, balanced, q, halo=False, variant=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,10 @@ def _worker(rank, world, port, n, dims, chunks, balanced, q, halo=False):
         want = model.inference(FullNeighborLoader(g, 1024), x)
         sh = RowShards(nn_, world, rank, chunks=chunks, bounds=RowShards.balanced_bounds(g.indptr, world) if balanced else None)
         with torch.no_grad():
-            y = (HaloShardedTeacher if halo else ShardedTeacher)(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops).forward(x)
+            if halo:
+                y = HaloShardedTeacher(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops, overlap=(variant == "overlap")).forward(x)
+            else:
+                y = ShardedTeacher(model.encoder, g.row_range(sh.lo, sh.hi), sh, ops, widening_exchange=variant or "narrow").forward(x)
         err = float((y - want[sh.lo:sh.hi]).abs().max())
         flat = torch.full((8,), float(rank + 1), device=dev)
         make_grad_sync(flat, world, average=True)()
@@ -70,14 +73,19 @@ def test_sharded_teacher_hip_two_ranks_one_gpu(dims, chunks, balanced):
     assert covered >= n - 2
 
 
-def test_halo_sharded_teacher_hip_two_ranks_one_gpu():
+@pytest.mark.parametrize("halo,variant,chunks,dims", [(True, None, 1, [100, 256, 256, 47]), (True, "overlap", 1, [100, 256, 256, 47]),
+                                                     (True, "overlap", 1, [64, 64, 64, 64]), (False, "wide", 4, [100, 256, 256, 47]),
+                                                     (False, "wide", 1, [100, 256, 256, 47])])
+def test_halo_sharded_teacher_hip_two_ranks_one_gpu(halo, variant, chunks, dims):
     """The halo exchange with the real kernels: glnn_gather_rows_f32 packs the rows the peer references, the relabelled
-    [own | halo] column ids feed the fused / stand-alone aggregation kernels."""
-    world, n, dims = 2, 9001, [100, 256, 256, 47]
+    [own | halo] column ids feed the fused / stand-alone aggregation kernels; its OVERLAPPED form (asynchronous exchange, two-pass
+    aggregation over the split CSR with the AGG_SUM kernel + row scale); and the all-gather teacher exchanging the WIDE output
+    of the first layer (bench.py --layer1-exchange wide)."""
+    world, n = 2, 9001
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, 1, True, q, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, dims, chunks, True, q, halo, variant)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -125,6 +133,16 @@ def _rccl_worker(port, q):
                 yh = gdist.HaloShardedTeacher(model.encoder, g, sh, ops).forward(x)
             torch.cuda.synchronize()
             errs[(tuple(dims), "halo")] = (float((yh - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+            gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+            with torch.no_grad():          # its overlapped form: async all_to_all_single (work.wait) + the two-pass aggregation
+                yo = gdist.HaloShardedTeacher(model.encoder, g, sh, ops, overlap=True).forward(x)
+            torch.cuda.synchronize()
+            errs[(tuple(dims), "halo-overlap")] = (float((yo - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+            gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+            with torch.no_grad():          # the all-gather teacher exchanging the wide first-layer output, chunked + async
+                yw = gdist.ShardedTeacher(model.encoder, g, sh, ops, widening_exchange="wide").forward(x)
+            torch.cuda.synchronize()
+            errs[(tuple(dims), "wide")] = (float((yw - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
         # the gradient all-reduce started from inside the backward (grad_ready hook -> async RCCL all-reduce on the communicator's
         # stream -> wait before Adam): with one rank every reduce is the identity, so the steps must equal the plain engine's
         import copy
