@@ -39,6 +39,13 @@ SIGNATURES = {
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
     "glnn_sage_fwd_bwd_f32": [c_vp, c_vp],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
+    "glnn_norm_drop_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64, c_vp],
+    "glnn_bn_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64,
+                        c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_layernorm_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_int, c_f32, c_u32, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "glnn_layernorm_bwd_workspace_floats": [c_i64, c_int],
+    "glnn_layernorm_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64,
+                               c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_dropout_mask_u8": [c_i64, c_int, c_f32, c_u32, c_vp, c_vp],
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
     "glnn_block_workspace_bytes": [c_i64, c_i64],
@@ -129,6 +136,7 @@ def lib():
         h.glnn_struct_bytes.restype = c_i64
         h.glnn_block_workspace_bytes.restype = c_i64
         h.glnn_csr_transpose_workspace_bytes.restype = c_i64
+        h.glnn_layernorm_bwd_workspace_floats.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
         if h.glnn_abi_version() != ABI_VERSION:

@@ -131,8 +131,16 @@ class _NormActDropFn(torch.autograd.Function):
     reference's training-mode forwards (models.py:48-52, 113-117)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, bn, p, seed):
+    def forward(ctx, z, gamma, beta, bn, p, seed, relu=True):
         z = ops.as_feat(z.detach())
+        ctx.relu = relu
+        ctx.layer_norm = isinstance(bn, torch.nn.LayerNorm)
+        if ctx.layer_norm:
+            y, mean, rstd = ops.layernorm_fwd(z, None if gamma is None else gamma.detach(), None if beta is None else beta.detach(),
+                                              eps=bn.eps, relu=relu, drop_p=p, drop_seed=seed)
+            ctx.save_for_backward(z, mean, rstd, *(t.detach() for t in (gamma, beta) if t is not None))
+            ctx.has_bn, ctx.p, ctx.seed, ctx.affine = False, p, seed, gamma is not None
+            return y
         if bn is not None:
             mean, rstd, a_scale, a_shift = ops.bn_stats(z, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var,
                                                         bn.num_batches_tracked, eps=bn.eps, momentum=bn.momentum)
@@ -141,28 +149,35 @@ class _NormActDropFn(torch.autograd.Function):
             a_scale = a_shift = None
             ctx.save_for_backward(z)
         ctx.has_bn, ctx.p, ctx.seed = bn is not None, p, seed
-        return ops.act_fwd(z, a_scale, a_shift, drop_p=p, drop_seed=seed)
+        return ops.act_fwd(z, a_scale, a_shift, drop_p=p, drop_seed=seed, relu=relu)
 
     @staticmethod
     def backward(ctx, dy):
         dy = ops.as_feat(dy.contiguous())
+        if ctx.layer_norm:
+            z, mean, rstd, *aff = ctx.saved_tensors
+            gamma, beta = (aff + [None, None])[:2] if ctx.affine else (None, None)
+            dz, dgamma, dbeta = ops.layernorm_bwd(dy, z, gamma, beta, mean, rstd, relu=ctx.relu, drop_p=ctx.p, drop_seed=ctx.seed)
+            return dz, dgamma, dbeta, None, None, None, None
         if ctx.has_bn:
             z, gamma, mean, rstd, a_scale, a_shift = ctx.saved_tensors
-            dz, dgamma, dbeta = ops.bn_relu_bwd(dy, z, gamma, mean, rstd, a_scale, a_shift, drop_p=ctx.p, drop_seed=ctx.seed)
-            return dz, dgamma, dbeta, None, None, None
+            dz, dgamma, dbeta = ops.bn_relu_bwd(dy, z, gamma, mean, rstd, a_scale, a_shift, drop_p=ctx.p, drop_seed=ctx.seed, relu=ctx.relu)
+            return dz, dgamma, dbeta, None, None, None, None
         (z,) = ctx.saved_tensors
-        dz, _, _ = ops.bn_relu_bwd(dy, z, drop_p=ctx.p, drop_seed=ctx.seed)
-        return dz, None, None, None, None, None
+        dz, _, _ = ops.bn_relu_bwd(dy, z, drop_p=ctx.p, drop_seed=ctx.seed, relu=ctx.relu)
+        return dz, None, None, None, None, None, None
 
 
 _drop_counter = [0]
 
 
-def norm_act_drop(z, bn, p):
-    """Training-mode tail of a hidden layer.  bn: nn.BatchNorm1d (reference defaults) or None; p: dropout probability.
+def norm_act_drop(z, bn, p, relu=True):
+    """Training-mode tail of a hidden layer: norm -> ReLU -> dropout (MLP / SAGE, reference models.py:48-52, 113-117) or, with
+    relu=False, norm -> dropout (GCN, models.py:195-198: the ReLU sits inside the GraphConv).  bn: nn.BatchNorm1d (reference
+    defaults), nn.LayerNorm, or None; p: dropout probability.
     The dropout stream is counter-based: seed = hash(torch.initial_seed(), call counter)."""
     _drop_counter[0] += 1
     seed = (int(torch.initial_seed()) * 0x9E3779B1 + _drop_counter[0] * 0x85EBCA77) & 0xFFFFFFFF if p > 0 else 0
     if bn is not None:
-        return _NormActDropFn.apply(z, bn.weight, bn.bias, bn, float(p), seed)
-    return _NormActDropFn.apply(z, None, None, None, float(p), seed)
+        return _NormActDropFn.apply(z, bn.weight, bn.bias, bn, float(p), seed, relu)
+    return _NormActDropFn.apply(z, None, None, None, float(p), seed, relu)

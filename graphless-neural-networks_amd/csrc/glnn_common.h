@@ -76,6 +76,6 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
-                void* stream, const BnGroup* g, int* counters = nullptr);
+                void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1);
 
 }  // namespace glnn

@@ -22,7 +22,9 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
 
   glnn::BnGroup grp_storage;
   const glnn::BnGroup* grp = nullptr;
-  if (d->world > 1 && d->batchnorm) {
+  GLNN_REQUIRE(d->batchnorm >= 0 && d->batchnorm <= 2, "glnn_mlp_fwd_bwd_f32: batchnorm must be 0 (no norm), 1 (BatchNorm1d) or 2 (LayerNorm)");
+  const bool layernorm = d->batchnorm == 2;          // per-row statistics: nothing to exchange when a batch is split over ranks
+  if (d->world > 1 && d->batchnorm == 1) {
     GLNN_REQUIRE(d->exchange && d->sync_send && d->sync_recv && d->sync_rows && d->rank >= 0 && d->rank < d->world,
                  "glnn_mlp_fwd_bwd_f32: world=%d needs the exchange hook, sync buffers and a valid rank", d->world);
     grp_storage = {d->world, d->rank, d->exchange, d->exchange_ctx, d->sync_send, d->sync_recv, d->sync_rows};
@@ -53,7 +55,17 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, recompute ? p : 0.f, (recompute && p > 0.f) ? drop_seeds[l - 1] : 0u, m,
                            d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
                            d->ws_gemm, d->ws_gemm_floats, stream));
-    if (!last) {
+    if (!last && layernorm) {
+      // LayerNorm -> ReLU -> dropout in one row-wise pass; the tail is always materialised (per-row statistics cannot ride in a
+      // GEMM operand transform); mean[l] / rstd[l] hold the per-ROW statistics (max_batch floats each) for the backward
+      GLNN_REQUIRE(d->act[l] && d->ld_act[l] >= ((d->dims[l + 1] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: LayerNorm needs act[%d]", l);
+      GLNN_TRY(glnn_layernorm_fwd_f32(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, 1, p, p > 0.f ? drop_seeds[l] : 0u,
+                                      d->act[l], d->ld_act[l], d->mean[l], d->rstd[l], stream));
+      rows = nullptr;
+      a_scale = a_shift = nullptr;
+      src = d->act[l];
+      ld_src = d->ld_act[l];
+    } else if (!last) {
       if (d->batchnorm)
         GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                    d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
@@ -146,7 +158,11 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     if (!(two && big_dgrad)) GLNN_TRY(input_gradient());
     float* dz_out = (two && ((L - 1 - l) & 1)) ? d->dz2 : d->dz;      // alternate: the layer above may still be read on the aux stream
     const int64_t ld_out = (two && ((L - 1 - l) & 1)) ? d->ld_dz2 : d->ld_dz;
-    if (d->batchnorm) {
+    if (layernorm) {
+      GLNN_TRY(glnn_layernorm_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->beta[l - 1],
+                                      d->mean[l - 1], d->rstd[l - 1], 1, p, seed, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1],
+                                      d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream));
+    } else if (d->batchnorm) {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                  d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
                                  d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));

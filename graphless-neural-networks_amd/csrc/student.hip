@@ -338,12 +338,13 @@ struct BnBwdArgs {
   // (local_part < 0) or partial `local_part` only.  rows_total: device float holding the global row count, or NULL.
   const float* p1; const float* p2; int nparts; int64_t pstride; int local_part; const float* rows_total;
   int* counters; float* dz_col_sum;      // counters != NULL: the last row-chunk workgroup of a column block folds ws3 into dz_col_sum
+  int relu;                              // 1: the ReLU sits behind the norm (MLP / SAGE tails); 0: no ReLU in this tail (GCN: norm -> dropout)
 };
 
 template <bool BN>
 __device__ __forceinline__ float bn_dy(const BnBwdArgs& a, float zz, float dav, int64_t r, int col, float sc, float sf) {
   if (a.dthr) dav = glnn::drop_keep(a.dseed, a.dthr, (uint32_t)r, (uint32_t)col) ? dav * a.dscale : 0.f;
-  return (BN ? fmaf(zz, sc, sf) : zz) > 0.f ? dav : 0.f;
+  return (!a.relu || (BN ? fmaf(zz, sc, sf) : zz) > 0.f) ? dav : 0.f;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_partial(const BnBwdArgs a) {
@@ -800,7 +801,7 @@ static int fused_grid_limit() {
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
-                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters) {
+                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -813,6 +814,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.a_scale = a_scale; a.a_shift = a_shift; a.dthr = glnn::drop_threshold(drop_p); a.dseed = drop_seed;
   a.dscale = 1.0f / (1.0f - drop_p); a.dz = dz; a.lddz = lddz; a.dgamma = dgamma; a.dbeta = dbeta; a.nchunks = nchunks;
   a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
+  a.relu = relu ? 1 : 0;
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
   if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
@@ -865,12 +867,22 @@ extern "C" int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* 
                            dbeta, dz_col_sum, workspace, workspace_floats, stream, nullptr);
 }
 
+// the same with the tail's ReLU optional: relu = 0 is the backward of  norm -> dropout  (GCN.forward, reference models.py:189-199,
+// where the ReLU sits INSIDE the GraphConv in front of the norm and is differentiated separately)
+extern "C" int glnn_bn_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
+                               const float* mean, const float* rstd, const float* a_scale, const float* a_shift, int relu, float drop_p,
+                               uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
+                               float* workspace, int64_t workspace_floats, void* stream) {
+  return glnn::bn_relu_bwd(da, ldda, z, ldz, rows, h, gamma, mean, rstd, a_scale, a_shift, drop_p, drop_seed, dz, lddz, dgamma,
+                           dbeta, dz_col_sum, workspace, workspace_floats, stream, nullptr, nullptr, relu);
+}
+
 // y = dropout(relu(z * a_scale + a_shift)): the materialised form of the operand transform the GEMM loaders apply on the
 // fly, for consumers that GATHER the activation (the next SAGE layer's aggregation over a sampled block).
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
                                                       const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                       uint32_t thr, uint32_t seed, float dscale, float* __restrict__ y, int64_t ldy,
-                                                      bool vec_cols) {
+                                                      bool vec_cols, bool relu) {
   constexpr int U = 4;                   // float4s in flight per thread: one per pass left the kernel at 2.9 TB/s (22 us for 2 x 32 MB)
   const int h4 = (h + 3) >> 2;
   const int64_t total = rows * h4;
@@ -909,7 +921,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
         float x = 0.f;
         if (c[u] + t < h) {
           x = a_scale ? fmaf(o[t], sc[t], sf[t]) : o[t];
-          x = fmaxf(x, 0.f);
+          if (relu) x = fmaxf(x, 0.f);
           if (thr) x = glnn::drop_keep(seed, thr, (uint32_t)r[u], (uint32_t)(c[u] + t)) ? x * dscale : 0.f;
         }
         o[t] = x;                          // padding columns are written as zero
@@ -927,8 +939,8 @@ __global__ void dropout_mask_kernel(int64_t rows, int h, uint32_t thr, uint32_t 
   }
 }
 
-extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale, const float* a_shift,
-                                float drop_p, uint32_t drop_seed, float* y, int64_t ldy, void* stream) {
+static int act_fwd_impl(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale, const float* a_shift, int relu,
+                        float drop_p, uint32_t drop_seed, float* y, int64_t ldy, void* stream) {
   GLNN_REQUIRE(z && y, "glnn_act_fwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 0 && h >= 1, "glnn_act_fwd_f32: bad sizes");
   const int64_t hp = (h + 3) & ~3;
@@ -941,8 +953,20 @@ extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, ldz, rows, h, a_scale,
                      a_shift, glnn::drop_threshold(drop_p), drop_seed, 1.0f / (1.0f - drop_p), y, ldy,
-                     a_scale == nullptr || (glnn::aligned16(a_scale) && glnn::aligned16(a_shift)));
+                     a_scale == nullptr || (glnn::aligned16(a_scale) && glnn::aligned16(a_shift)), relu != 0);
   return glnn::check_launch("glnn_act_fwd_f32");
+}
+
+extern "C" int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale, const float* a_shift,
+                                float drop_p, uint32_t drop_seed, float* y, int64_t ldy, void* stream) {
+  return act_fwd_impl(z, ldz, rows, h, a_scale, a_shift, 1, drop_p, drop_seed, y, ldy, stream);
+}
+
+// y = dropout(relu?(z * a_scale + a_shift)): glnn_act_fwd_f32 with the ReLU optional (relu = 0: the norm -> dropout tail of
+// GCN.forward, reference models.py:189-199)
+extern "C" int glnn_norm_drop_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale, const float* a_shift,
+                                      int relu, float drop_p, uint32_t drop_seed, float* y, int64_t ldy, void* stream) {
+  return act_fwd_impl(z, ldz, rows, h, a_scale, a_shift, relu, drop_p, drop_seed, y, ldy, stream);
 }
 
 // column sums of a [rows, h] matrix: per-128-row-chunk partials (4 row lanes x 64 columns per workgroup), then the fixed-order

@@ -30,24 +30,34 @@ def _need_hip(x, what):
 
 
 def _check_tail(module):
-    """The hidden-layer tails implemented on HIP: BatchNorm1d with the reference's defaults or no norm, ReLU, dropout."""
-    if module.norm_type not in ("none", "batch"):
-        raise NotImplementedError("norm_type 'layer' (used by the reference only for the BGNN house_class dataset, which is outside "
-                                  "the MI355X hot-path scope) has no HIP kernel")
+    """The hidden-layer tails implemented on HIP: BatchNorm1d / LayerNorm with the reference's defaults or no norm, ReLU, dropout."""
+    if module.norm_type not in ("none", "batch", "layer"):
+        raise NotImplementedError(f"norm_type {module.norm_type!r}: the reference builds 'none', 'batch' or 'layer' (models.py:28-31)")
     act = getattr(module, "activation", F.relu)
     if act is not F.relu and getattr(act, "__name__", "") != "relu":
         raise NotImplementedError("only ReLU hidden activations (what the reference constructs, models.py:371,381)")
     for bn in module.norms:
-        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+        if isinstance(bn, nn.LayerNorm):
+            if not bn.elementwise_affine or len(bn.normalized_shape) != 1:
+                raise NotImplementedError("nn.LayerNorm(hidden_dim) with the reference's defaults (elementwise affine)")
+        elif not (bn.affine and bn.track_running_stats and bn.momentum is not None):
             raise NotImplementedError("BatchNorm1d with the reference's defaults (affine, running stats, momentum 0.1)")
 
 
-def _eval_tail(module, l, z):
-    """Eval-mode `norms[l] -> relu -> dropout` of a hidden layer on a materialised z: one glnn_act_fwd_f32."""
+def _norm_of(module, l):
+    return module.norms[l] if module.norm_type != "none" else None
+
+
+def _eval_tail(module, l, z, relu=True):
+    """Eval-mode `norms[l] -> relu -> dropout` of a hidden layer on a materialised z (relu=False: GCN's `norms[l] -> dropout`):
+    one glnn_act_fwd_f32 / glnn_norm_drop_fwd_f32 / glnn_layernorm_fwd_f32."""
     if module.norm_type == "batch":
         a_scale, a_shift = _bn_eval_fold(module.norms[l], None)
-        return ops.act_fwd(z, a_scale, a_shift)
-    return ops.act_fwd(z)
+        return ops.act_fwd(z, a_scale, a_shift, relu=relu)
+    if module.norm_type == "layer":
+        ln = module.norms[l]
+        return ops.layernorm_fwd(z, ln.weight.detach(), ln.bias.detach(), eps=ln.eps, relu=relu, want_stats=False)[0]
+    return ops.act_fwd(z) if relu else z
 
 
 class MLP(nn.Module):
@@ -89,7 +99,7 @@ class MLP(nn.Module):
             if l != self.num_layers - 1:
                 h_list.append(h)
                 # norm -> relu -> dropout as one differentiable HIP op (same module state: running stats, affine)
-                h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
+                h = norm_act_drop(h, _norm_of(self, l), self.dropout.p)
         return h_list, h
 
     def _forward_hip_eval(self, feats, want_hidden=True):
@@ -102,6 +112,15 @@ class MLP(nn.Module):
         h = ops.as_feat(feats)
         h_list = []
         a_scale = a_shift = None
+        if self.norm_type == "layer":          # per-ROW statistics cannot ride in a GEMM's per-column operand transform / epilogue
+            for l, layer in enumerate(self.layers):
+                z = ops.gemm(h, layer.weight, ep_shift=layer.bias)
+                if l != self.num_layers - 1:
+                    if want_hidden:
+                        h_list.append(z)
+                    z = _eval_tail(self, l, z)
+                h = z
+            return h_list, h
         for l, layer in enumerate(self.layers):
             last = l == self.num_layers - 1
             if want_hidden or last:
@@ -165,7 +184,7 @@ class SAGE(nn.Module):
                 h = layer(block, (h, h_dst))
                 if l != self.num_layers - 1:
                     h_list.append(h)
-                    h = norm_act_drop(h, self.norms[l] if self.norm_type == "batch" else None, self.dropout.p)
+                    h = norm_act_drop(h, _norm_of(self, l), self.dropout.p)
             else:
                 with torch.no_grad():
                     h = layer(block, (h, h_dst))
@@ -188,7 +207,8 @@ class SAGE(nn.Module):
             return s, sh, True
         if self.norm_type == "none":
             return None, bias, True
-        raise NotImplementedError("SAGE.inference fast path: norm_type 'layer' is not used by the hot-path configs")
+        raise NotImplementedError("SAGE._tail: LayerNorm has per-row statistics and cannot be folded into a kernel epilogue "
+                                  "(SAGE.inference applies it as its own pass; the sharded teachers do not support it)")
 
     def inference(self, dataloader, feats, whole_graph=True):
         """Layer-wise full-neighbour inference (reference models.py:121-148).
@@ -202,8 +222,10 @@ class SAGE(nn.Module):
         with torch.no_grad():
             x = ops.as_feat(feats)
             projected = None          # x @ W_l^T handed over by the previous (fused) layer when layer l projects first
+            ln = self.norm_type == "layer"
             for l, layer in enumerate(self.layers):
-                ep_scale, ep_shift, relu = self._tail(l)
+                post_ln = ln and l != self.num_layers - 1      # LayerNorm -> ReLU as a pass of its own behind the conv (+ bias)
+                ep_scale, ep_shift, relu = (None, layer.fc_neigh.bias, False) if post_ln else self._tail(l)
                 if whole_graph:
                     g = dataloader.graph
                     n = g.num_dst_nodes()
@@ -213,7 +235,7 @@ class SAGE(nn.Module):
                         y = ops.spmm(g.indptr, g.indices, projected, n, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
                         projected = None
                     elif nxt is not None and layer.fused_eligible() and nxt._in_feats > nxt._out_feats and nxt._out_feats <= 256 \
-                            and SAGE.CHAIN_NEXT_PROJECTION:
+                            and SAGE.CHAIN_NEXT_PROJECTION and not post_ln:
                         # layer l aggregates first in the fused kernel and layer l+1 projects first: chain W_{l+1} behind the
                         # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
                         _, projected = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale,
@@ -230,7 +252,11 @@ class SAGE(nn.Module):
                         block = blocks[0].int().to(x.device)
                         h = ops.gather_rows(x, input_nodes)                              # feats[input_nodes]
                         h = layer(block, (h, h[: block.num_dst_nodes()]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, w_packed=wp)
+                        if post_ln:
+                            h = _eval_tail(self, l, h)
                         ops.scatter_rows(h, output_nodes, y)                             # y[output_nodes] = h
+                if post_ln and whole_graph:
+                    y = _eval_tail(self, l, y)
                 x = y
             return x
 
@@ -262,19 +288,22 @@ class GCN(nn.Module):
             self.norms.append(nn.LayerNorm(hidden_dim))
 
     def forward(self, g, feats):
-        """reference models.py:189-199: GraphConv (ReLU inside the conv on hidden layers) -> norm -> dropout."""
+        """reference models.py:189-199: GraphConv (ReLU inside the conv on hidden layers) -> norms[l] -> dropout (NO ReLU behind
+        the norm).  train.conf.yaml's cora-style sections use norm_type none, pokec / penn94 GCN use batch."""
         _need_hip(feats, "GCN.forward")
-        if self.norm_type != "none":
-            raise NotImplementedError("GCN with a norm layer: every GCN section of the reference's train.conf.yaml uses "
-                                      "norm_type 'none'; BatchNorm/LayerNorm after a GraphConv has no HIP path")
+        _check_tail(self)
         h = feats
         h_list = []
         for l, layer in enumerate(self.layers):
             h = layer(g, h)
             if l != self.num_layers - 1:
                 h_list.append(h)
-                if self.training and self.dropout.p > 0:
-                    h = norm_act_drop(h, None, self.dropout.p)        # h >= 0 already: relu is the identity here
+                if self.training:
+                    if self.norm_type != "none" or self.dropout.p > 0:
+                        h = norm_act_drop(h, _norm_of(self, l), self.dropout.p, relu=False)
+                elif self.norm_type != "none":
+                    with torch.no_grad():
+                        h = _eval_tail(self, l, h, relu=False)
         return h_list, h
 
 

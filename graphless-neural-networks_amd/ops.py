@@ -303,8 +303,9 @@ def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=
 
 
 def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=None, dz=None, dgamma=None,
-                dbeta=None, workspace=None, drop_p=0.0, drop_seed=0, dz_col_sum=None):
-    """K5 glnn_bn_relu_bwd_f32.  Returns (dz, dgamma, dbeta); gamma=None => plain ReLU backward.
+                dbeta=None, workspace=None, drop_p=0.0, drop_seed=0, dz_col_sum=None, relu=True):
+    """K5 glnn_bn_relu_bwd_f32 (relu=False: glnn_bn_bwd_f32, the norm -> dropout tail of GCN.forward).  Returns (dz, dgamma,
+    dbeta); gamma=None => plain ReLU (+ dropout) backward.
     dz_col_sum: optional [h] output = column sums of dz (the bias gradient of the Linear in front)."""
     _need_cuda(da, z, gamma, mean, rstd, a_scale, a_shift, dz, dgamma, dbeta, workspace)
     _mat(da, "bn_relu_bwd da")
@@ -319,11 +320,52 @@ def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=N
             dbeta = torch.empty(h, dtype=torch.float32, device=z.device)
     if workspace is None and (gamma is not None or dz_col_sum is not None):
         workspace = torch.empty((3 * ((rows + 127) // 128) + 2) * h, dtype=torch.float32, device=z.device)
-    rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
-                                         _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
-                                         _p(dz), _ld(dz), _p(dgamma), _p(dbeta), _p(dz_col_sum),
-                                         _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
+    if relu:
+        rc = _lib.lib().glnn_bn_relu_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
+                                             _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF,
+                                             _p(dz), _ld(dz), _p(dgamma), _p(dbeta), _p(dz_col_sum),
+                                             _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
+    else:
+        rc = _lib.lib().glnn_bn_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(gamma), _p(mean), _p(rstd),
+                                        _p(a_scale), _p(a_shift), 0, float(drop_p), int(drop_seed) & 0xFFFFFFFF,
+                                        _p(dz), _ld(dz), _p(dgamma), _p(dbeta), _p(dz_col_sum),
+                                        _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
     _lib.check(rc, "glnn_bn_relu_bwd_f32")
+    return dz, dgamma, dbeta
+
+
+def layernorm_fwd(z, gamma=None, beta=None, eps=1e-5, relu=True, drop_p=0.0, drop_seed=0, out=None, want_stats=True):
+    """glnn_layernorm_fwd_f32: out = dropout(relu?(LayerNorm(z))); returns (out, mean_row, rstd_row) (stats None if not wanted)."""
+    _need_cuda(z, gamma, beta, out)
+    z = as_feat(z)
+    rows, h = z.shape
+    if out is None:
+        out = feat_empty(rows, h, z.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=z.device) if want_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=z.device) if want_stats else None
+    rc = _lib.lib().glnn_layernorm_fwd_f32(_p(z), _ld(z), rows, h, _p(_vec(gamma, h, "gamma")), _p(_vec(beta, h, "beta")), float(eps),
+                                           1 if relu else 0, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(out), _ld(out), _p(mean),
+                                           _p(rstd), _stream())
+    _lib.check(rc, "glnn_layernorm_fwd_f32")
+    return out, mean, rstd
+
+
+def layernorm_bwd(da, z, gamma, beta, mean, rstd, relu=True, drop_p=0.0, drop_seed=0, dz=None, dz_col_sum=None, want_param_grads=True):
+    """glnn_layernorm_bwd_f32.  Returns (dz, dgamma, dbeta)."""
+    _need_cuda(da, z, gamma, beta, mean, rstd, dz, dz_col_sum)
+    da, z = as_feat(da), as_feat(z)
+    rows, h = z.shape
+    if dz is None:
+        dz = feat_empty(rows, h, z.device)
+    dgamma = torch.empty(h, dtype=torch.float32, device=z.device) if (want_param_grads and gamma is not None) else None
+    dbeta = torch.empty(h, dtype=torch.float32, device=z.device) if dgamma is not None else None
+    ws = None
+    if dgamma is not None or dz_col_sum is not None:
+        ws = torch.empty(_lib.lib().glnn_layernorm_bwd_workspace_floats(rows, h), dtype=torch.float32, device=z.device)
+    rc = _lib.lib().glnn_layernorm_bwd_f32(_p(da), _ld(da), _p(z), _ld(z), rows, h, _p(_vec(gamma, h, "gamma")), _p(_vec(beta, h, "beta")),
+                                           _p(mean), _p(rstd), 1 if relu else 0, float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(dz), _ld(dz),
+                                           _p(dgamma), _p(dbeta), _p(dz_col_sum), _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _lib.check(rc, "glnn_layernorm_bwd_f32")
     return dz, dgamma, dbeta
 
 
@@ -363,15 +405,20 @@ def adam_step(table, lr, step, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-
     _lib.check(rc, "glnn_adam_step_f32")
 
 
-def act_fwd(z, a_scale=None, a_shift=None, drop_p=0.0, drop_seed=0, out=None):
-    """glnn_act_fwd_f32: out = dropout(relu(z * a_scale + a_shift)) (plain ReLU without a_scale/a_shift)."""
+def act_fwd(z, a_scale=None, a_shift=None, drop_p=0.0, drop_seed=0, out=None, relu=True):
+    """glnn_act_fwd_f32: out = dropout(relu(z * a_scale + a_shift)) (plain ReLU without a_scale/a_shift); relu=False:
+    glnn_norm_drop_fwd_f32, the same without the ReLU (GCN's norm -> dropout tail)."""
     _need_cuda(z, a_scale, a_shift, out)
     _mat(z, "act_fwd z")
     rows, h = z.shape
     if out is None:
         out = feat_empty(rows, h, z.device)
-    rc = _lib.lib().glnn_act_fwd_f32(_p(z), _ld(z), rows, h, _p(_vec(a_scale, h, "a_scale")), _p(_vec(a_shift, h, "a_shift")),
-                                     float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(out), _ld(out), _stream())
+    if relu:
+        rc = _lib.lib().glnn_act_fwd_f32(_p(z), _ld(z), rows, h, _p(_vec(a_scale, h, "a_scale")), _p(_vec(a_shift, h, "a_shift")),
+                                         float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(out), _ld(out), _stream())
+    else:
+        rc = _lib.lib().glnn_norm_drop_fwd_f32(_p(z), _ld(z), rows, h, _p(_vec(a_scale, h, "a_scale")), _p(_vec(a_shift, h, "a_shift")), 0,
+                                               float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(out), _ld(out), _stream())
     _lib.check(rc, "glnn_act_fwd_f32")
     return out
 

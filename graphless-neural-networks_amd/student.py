@@ -44,8 +44,8 @@ class StudentEngine:
         `self.flat_grads`, see glnn_amd.dist.make_grad_sync).  loss_scale_rows: the GLOBAL batch size when
         the batch is split over ranks (the loss mean and dlogits are taken over it)."""
         enc = model.encoder
-        if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch"):
-            raise NotImplementedError("StudentEngine: MLP students with norm_type none|batch (the hot-path configs)")
+        if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch", "layer"):
+            raise NotImplementedError("StudentEngine: MLP students with norm_type none|batch|layer (reference models.py:28-31)")
         if type(optimizer) is not torch.optim.Adam:
             raise NotImplementedError("StudentEngine: the reference uses torch.optim.Adam (train_student.py:275)")
         grp = optimizer.param_groups
@@ -54,6 +54,7 @@ class StudentEngine:
         self.model, self.enc, self.opt = model, enc, optimizer
         self.L = enc.num_layers
         self.bn = enc.norm_type == "batch"
+        self.ln = enc.norm_type == "layer"          # per-row statistics; the tail is always materialised (glnn_layernorm_fwd_f32)
         self.p = float(enc.dropout.p)
         self.W = [l.weight for l in enc.layers]
         self.b = [l.bias for l in enc.layers]
@@ -77,6 +78,8 @@ class StudentEngine:
             h = self.dims[l + 1]
             if self.bn:
                 self.stats.append(tuple(torch.empty(h, **f32) for _ in range(4)))
+            elif self.ln:            # per-ROW mean / rstd
+                self.stats.append((torch.empty(B, **f32), torch.empty(B, **f32), None, None))
             else:
                 self.stats.append((None, None, torch.ones(h, **f32), torch.zeros(h, **f32)))
         # parameters in torch order (model.parameters()): layers.{i}.weight, .bias ..., norms.{i}.weight, .bias ...
@@ -107,7 +110,7 @@ class StudentEngine:
         # workspaces
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
-        self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax, 1024), **f32)
+        self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax, 1024, _lib.lib().glnn_layernorm_bwd_workspace_floats(B, hmax) if self.ln else 0), **f32)
         self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
         self.ws_loss = torch.empty(256 * 65 + 1024, **f32)
@@ -123,7 +126,7 @@ class StudentEngine:
         # latency-bound steps keep the recompute (one launch fewer per hidden layer).
         mat = os.environ.get("GLNN_STUDENT_MATERIALIZE_ACT", "auto")
         self.act = [ops.feat_empty(B, self.dims[l + 1], dev)
-                    if mat == "1" or (mat == "auto" and self.p > 0 and self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)) else None
+                    if self.ln or mat == "1" or (mat == "auto" and self.p > 0 and self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)) else None
                     for l in range(self.L - 1)]
         # feats[idx] copied once per step when the batch is long enough for the first layer's weight gradient to take the
         # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches keep the gather inside the operand loads
@@ -173,7 +176,7 @@ class StudentEngine:
         L = self.L
         if L > _lib.MLP_MAX_LAYERS:
             raise NotImplementedError(f"StudentEngine: at most {_lib.MLP_MAX_LAYERS} layers")
-        d.num_layers, d.batchnorm, d.dropout_p, d.max_batch = L, 1 if self.bn else 0, self.p, self.B
+        d.num_layers, d.batchnorm, d.dropout_p, d.max_batch = L, 1 if self.bn else (2 if self.ln else 0), self.p, self.B
         for i, v in enumerate(self.dims):
             d.dims[i] = v
         ptr = lambda t: None if t is None else t.data_ptr()
@@ -197,6 +200,13 @@ class StudentEngine:
                 d.gamma[l], d.beta[l] = ptr(bn.weight), ptr(bn.bias)
                 d.ggamma[l], d.gbeta[l] = ptr(self._grad(bn.weight)), ptr(self._grad(bn.bias))
                 d.running_mean[l], d.running_var[l], d.nbt[l] = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
+            elif self.ln:
+                ln = self.enc.norms[l]
+                if not isinstance(ln, nn.LayerNorm) or not ln.elementwise_affine or len(ln.normalized_shape) != 1:
+                    raise NotImplementedError("StudentEngine: nn.LayerNorm(hidden_dim) with the reference's defaults")
+                d.bn_eps = ln.eps
+                d.gamma[l], d.beta[l] = ptr(ln.weight), ptr(ln.bias)
+                d.ggamma[l], d.gbeta[l] = ptr(self._grad(ln.weight)), ptr(self._grad(ln.bias))
         d.logits, d.ld_logits = ptr(self.logits), self.logits.stride(0)
         d.dlogits, d.ld_dlogits = ptr(self.dlogits), self.dlogits.stride(0)
         d.da, d.ld_da, d.dz, d.ld_dz = ptr(self.da), self.da.stride(0), ptr(self.dz), self.dz.stride(0)
@@ -310,15 +320,18 @@ def student_supported(model, criterion, optimizer, feats=None, labels=None):
         raise NotImplementedError("student step: the criterion must be nn.NLLLoss() or nn.KLDivLoss(reduction='batchmean', "
                                   "log_target=True) (reference train_student.py:278-279)")
     enc = model.encoder
-    if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch"):
-        raise NotImplementedError("student step: MLP students with norm_type none|batch (the hot-path configs)")
+    if "MLP" not in model.model_name or enc.norm_type not in ("none", "batch", "layer"):
+        raise NotImplementedError("student step: MLP students with norm_type none|batch|layer (reference models.py:28-31)")
     if enc.num_layers > _lib.MLP_MAX_LAYERS:
         raise NotImplementedError(f"student step: at most {_lib.MLP_MAX_LAYERS} layers")
     grp = optimizer.param_groups
     if type(optimizer) is not torch.optim.Adam or len(grp) != 1 or grp[0].get("amsgrad") or grp[0].get("maximize"):
         raise NotImplementedError("student step: torch.optim.Adam with one param group, no amsgrad/maximize (train_student.py:275-277)")
     for bn in enc.norms:
-        if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        if isinstance(bn, nn.LayerNorm):
+            if not bn.elementwise_affine or len(bn.normalized_shape) != 1:
+                raise NotImplementedError("student step: nn.LayerNorm(hidden_dim) with the reference's defaults")
+        elif bn.momentum is None or not bn.affine or not bn.track_running_stats:
             raise NotImplementedError("student step: BatchNorm1d with the reference's defaults")
     if next(model.parameters()).device.type != "cuda":
         raise RuntimeError("student step: the model must be on the GPU (HIP path only; pass --device 0, the reference's default "

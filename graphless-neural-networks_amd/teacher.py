@@ -58,13 +58,16 @@ def check_supported(model, criterion, optimizer):
         if enc.norm_type not in ("none", "batch") or not _is_relu(enc.activation):
             raise NotImplementedError("TeacherEngine: SAGE with norm_type none|batch and ReLU (the reference's configs)")
     else:
-        if enc.norm_type != "none":
-            raise NotImplementedError("TeacherEngine: GCN with norm_type 'none' (every GCN section of train.conf.yaml)")
+        if enc.norm_type not in ("none", "batch", "layer"):      # train.conf.yaml: cora-style GCN none, pokec / penn94 GCN batch
+            raise NotImplementedError("TeacherEngine: GCN with norm_type none|batch|layer")
         for lay in enc.layers[:-1]:
             if not _is_relu(lay._activation):
                 raise NotImplementedError("TeacherEngine: GraphConv(activation=F.relu) on hidden layers (models.py:170-187)")
     for bn in enc.norms:
-        if bn.momentum is None or not bn.affine or not bn.track_running_stats:
+        if isinstance(bn, nn.LayerNorm):
+            if not bn.elementwise_affine or len(bn.normalized_shape) != 1:
+                raise NotImplementedError("TeacherEngine: nn.LayerNorm(hidden_dim) with the reference's defaults")
+        elif bn.momentum is None or not bn.affine or not bn.track_running_stats:
             raise NotImplementedError("TeacherEngine: BatchNorm1d with the reference's defaults")
     if next(model.parameters()).device.type != "cuda":
         raise RuntimeError("TeacherEngine needs the model on the GPU (HIP path only; the reference's --device -1 default "
@@ -282,13 +285,25 @@ class TeacherEngine:
         enc, L, p = self.enc, self.L, self.p
         a = ops.as_feat(feats)
         saved = []
+        norm_kind = enc.norm_type
         for l, layer in enumerate(enc.layers):
             last = l == L - 1
             y, mid, first = graphconv_fwd(g, a, layer.weight, layer.bias, relu=not last)
             seed = self._seed(l)
-            saved.append((mid, first, y, seed))
-            if not last:
-                a = ops.act_fwd(y, drop_p=p, drop_seed=seed) if p > 0 else y       # y >= 0 already (ReLU inside the conv)
+            stats = None
+            if not last:      # reference models.py:195-198: norms[l] -> dropout, NO ReLU behind the norm (it sits inside the conv)
+                if norm_kind == "batch":
+                    bn = enc.norms[l]
+                    stats = ops.bn_stats(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, eps=bn.eps,
+                                         momentum=bn.momentum)
+                    a = ops.act_fwd(y, stats[2], stats[3], drop_p=p, drop_seed=seed, relu=False)
+                elif norm_kind == "layer":
+                    ln = enc.norms[l]
+                    a, mu, rs = ops.layernorm_fwd(y, ln.weight, ln.bias, eps=ln.eps, relu=False, drop_p=p, drop_seed=seed)
+                    stats = (mu, rs)
+                else:
+                    a = ops.act_fwd(y, drop_p=p, drop_seed=seed) if p > 0 else y       # y >= 0 already (ReLU inside the conv)
+            saved.append((mid, first, y, seed, stats))
         logits = saved[-1][2]
         logits_tr = ops.gather_rows(logits, idx_train)                            # out[idx_train] (train_and_eval.py:22)
         _, dl = ops.softmax_loss(logits_tr, ops.LOSS_NLL, float(lamb), labels=labels, label_rows=idx_train, loss_out=self.loss_out,
@@ -298,12 +313,25 @@ class TeacherEngine:
         ops.col_sum(dz, out=self.grad(enc.layers[-1].bias))
         for l in range(L - 1, -1, -1):
             layer = enc.layers[l]
-            mid, first, _, _ = saved[l]
+            mid, first, _, _, _ = saved[l]
             da = graphconv_bwd(g, dz, mid, first, layer.weight, self.grad(layer.weight), want_da=l > 0)
             if l == 0:
                 break
-            _, _, y_prev, seed_prev = saved[l - 1]        # dropout backward, then the ReLU inside conv l-1 (y > 0 <=> z > 0)
-            dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, drop_p=p, drop_seed=seed_prev, dz_col_sum=self.grad(enc.layers[l - 1].bias))
+            _, _, y_prev, seed_prev, stats = saved[l - 1]
+            if norm_kind == "batch":       # dropout + norm backward (no ReLU in this tail) -> grad wrt the conv's output y
+                bn = enc.norms[l - 1]
+                mean, rstd, a_sc, a_sh = stats
+                ops.bn_relu_bwd(da, y_prev, bn.weight, mean, rstd, a_sc, a_sh, dz=da, dgamma=self.grad(bn.weight), dbeta=self.grad(bn.bias),
+                                drop_p=p, drop_seed=seed_prev, relu=False)
+                dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, dz_col_sum=self.grad(enc.layers[l - 1].bias))     # the ReLU inside conv l-1
+            elif norm_kind == "layer":
+                ln = enc.norms[l - 1]
+                _, dg, db = ops.layernorm_bwd(da, y_prev, ln.weight, ln.bias, stats[0], stats[1], relu=False, drop_p=p, drop_seed=seed_prev, dz=da)
+                self.grad(ln.weight).copy_(dg)
+                self.grad(ln.bias).copy_(db)
+                dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, dz_col_sum=self.grad(enc.layers[l - 1].bias))
+            else:                          # dropout backward, then the ReLU inside conv l-1 (y > 0 <=> z > 0)
+                dz, _, _ = ops.bn_relu_bwd(da, y_prev, dz=da, drop_p=p, drop_seed=seed_prev, dz_col_sum=self.grad(enc.layers[l - 1].bias))
 
 
 def get_engine(model, optimizer):

@@ -256,7 +256,8 @@ typedef int (*glnn_exchange_fn)(void* ctx, const float* send, float* recv, int64
 
 typedef struct glnn_mlp_step_desc {
   int32_t num_layers;
-  int32_t batchnorm;
+  int32_t batchnorm;      /* hidden-layer norm: 0 none, 1 nn.BatchNorm1d, 2 nn.LayerNorm (ABI 5: gamma/beta = its affine, bn_eps = its eps,
+                           * mean[l]/rstd[l] = max_batch floats of per-ROW statistics, act[l] required, a_scale/a_shift/running_* unused) */
   int32_t dims[GLNN_MLP_MAX_LAYERS + 1];
   float dropout_p;
   float bn_eps;
@@ -403,6 +404,38 @@ GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream
 GLNN_API int glnn_act_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale,
                               const float* a_shift, float drop_p, uint32_t drop_seed, float* y, int64_t ldy,
                               void* stream);
+
+/* glnn_act_fwd_f32 / glnn_bn_relu_bwd_f32 with the tail's ReLU optional (ABI 5).  relu = 0 is the hidden-layer tail of the
+ * reference's GCN (models.py:189-199: GraphConv(activation=relu) -> norms[l] -> dropout -- the ReLU sits inside the conv, IN
+ * FRONT of the norm; train.conf.yaml's pokec / penn94 GCN sections use norm_type batch): y = dropout(z * a_scale + a_shift),
+ * and the backward gates nothing by the sign of the normalised value. */
+GLNN_API int glnn_norm_drop_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* a_scale,
+                                    const float* a_shift, int relu, float drop_p, uint32_t drop_seed, float* y,
+                                    int64_t ldy, void* stream);
+GLNN_API int glnn_bn_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
+                             const float* gamma, const float* mean, const float* rstd, const float* a_scale,
+                             const float* a_shift, int relu, float drop_p, uint32_t drop_seed, float* dz,
+                             int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                             int64_t workspace_floats, void* stream);
+
+/* nn.LayerNorm(hidden) as a hidden-layer tail (reference models.py:28-31, 87-90, 174-186; train.conf.yaml uses norm_type
+ * "layer" for the house_class MLP):
+ *   forward   y = dropout(relu?(xhat * gamma + beta)),  xhat = (z - mean_row) * rstd_row,  rstd = 1/sqrt(biased var + eps);
+ *             mean_out / rstd_out [rows] (optional) are what the backward needs; gamma/beta NULL = no affine.
+ *   backward  dy = da * keep/(1-p) * [relu ? xhat*gamma+beta > 0 : 1];  dgamma = sum_rows dy*xhat, dbeta = sum_rows dy;
+ *             dz = rstd * (dy*gamma - mean_cols(dy*gamma) - xhat * mean_cols(dy*gamma*xhat));  dz_col_sum (optional) = sum_rows dz
+ *             = the bias gradient of the Linear in front.  workspace >= glnn_layernorm_bwd_workspace_floats(rows, h) floats when
+ *             any column sum is requested; h <= 4096.  In place on da allowed (dz == da).
+ * Rows are float4 rows (leading dimensions % 4 == 0, >= round4(h), 16-byte aligned); padding columns of y / dz = 0. */
+GLNN_API int glnn_layernorm_fwd_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
+                                    const float* beta, float eps, int relu, float drop_p, uint32_t drop_seed,
+                                    float* y, int64_t ldy, float* mean_out, float* rstd_out, void* stream);
+GLNN_API int64_t glnn_layernorm_bwd_workspace_floats(int64_t rows, int h);
+GLNN_API int glnn_layernorm_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h,
+                                    const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                    int relu, float drop_p, uint32_t drop_seed, float* dz, int64_t lddz,
+                                    float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                                    int64_t workspace_floats, void* stream);
 
 /* The dropout keep-mask the kernels above evaluate on the fly (nn.Dropout, reference models.py:52):
  * mask[r*h + c] = 1 if element (r,c) is kept under (drop_p, drop_seed).  torch's Philox stream cannot

@@ -63,6 +63,11 @@ def make_state(seed, dims, norm):
         bound = 1.0 / np.sqrt(dims[i])
         sd[f"encoder.layers.{i}.weight"] = rs.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(np.float32)
         sd[f"encoder.layers.{i}.bias"] = rs.uniform(-bound, bound, (dims[i + 1],)).astype(np.float32)
+    if norm == "layer":
+        for i in range(L - 1):
+            h = dims[i + 1]
+            sd[f"encoder.norms.{i}.weight"] = rs.uniform(0.5, 1.5, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.bias"] = rs.uniform(-0.2, 0.2, (h,)).astype(np.float32)
     if norm == "batch":
         for i in range(L - 1):
             h = dims[i + 1]
@@ -86,6 +91,10 @@ CASES = {
     "mlp3w8": dict(dims=[100, 2048, 2048, 47], norm="batch", B=4096, n=8192, n_l=4100, lamb=0.0, lr=0.01, wd=0.0, epochs=1, full=False, seed=6, stride=211),
     # dropout > 0 with the keep-mask applied OUTSIDE: the reference's nn.Dropout is swapped for a multiply by the
     # counter-based mask of libglnn_hip.so (restated in numpy: oracle/dropout_mask.py), seeds as StudentEngine derives them
+    # nn.LayerNorm tails (reference models.py:30-31; train.conf.yaml:257-264 house_class MLP: 3 x 512, norm_type layer, dropout 0,
+    # weight_decay 0): a small full-detail case with weight decay and the house_class shape (its batch is the whole training set)
+    "ln_small": dict(dims=[24, 48, 48, 10], norm="layer", B=32, n=200, n_l=70, lamb=0.3, lr=0.01, wd=5e-4, epochs=2, full=True, seed=8),
+    "ln_house_dims": dict(dims=[16, 512, 512, 5], norm="layer", B=512, n=1536, n_l=600, lamb=0.0, lr=0.01, wd=0.0, epochs=1, full=False, seed=9),
     "bn_small_dropout": dict(dims=[24, 48, 48, 10], norm="batch", B=32, n=200, n_l=70, lamb=0.3, lr=0.01, wd=5e-4, epochs=2, full=True, seed=7,
                              dropout=0.4, drop_base_seed=0x00C0FFEE),
 }

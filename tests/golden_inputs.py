@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["bn_small", "nonorm_fullbatch", "arxiv_dims", "products_dims_narrow", "mlp3w4", "mlp3w8", "bn_small_dropout"]
+CASES = ["bn_small", "nonorm_fullbatch", "arxiv_dims", "products_dims_narrow", "mlp3w4", "mlp3w8", "bn_small_dropout", "ln_small",
+         "ln_house_dims"]
 
 
 def make_inputs(seed, n, f, c, n_l):
@@ -27,6 +28,11 @@ def make_state(seed, dims, norm):
         bound = 1.0 / np.sqrt(dims[i])
         sd[f"encoder.layers.{i}.weight"] = rs.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(np.float32)
         sd[f"encoder.layers.{i}.bias"] = rs.uniform(-bound, bound, (dims[i + 1],)).astype(np.float32)
+    if norm == "layer":
+        for i in range(L - 1):
+            h = dims[i + 1]
+            sd[f"encoder.norms.{i}.weight"] = rs.uniform(0.5, 1.5, (h,)).astype(np.float32)
+            sd[f"encoder.norms.{i}.bias"] = rs.uniform(-0.2, 0.2, (h,)).astype(np.float32)
     if norm == "batch":
         for i in range(L - 1):
             h = dims[i + 1]
@@ -60,7 +66,7 @@ class Golden:
                 assert np.array_equal(z[f"init.{k}"], v)
         self.perms = [z[f"perm_{i}"].astype(np.int64) for i in range(int(z["num_perms"]))]
         self.param_names = [f"encoder.layers.{i}.{s}" for i in range(len(self.dims) - 1) for s in ("weight", "bias")]
-        if self.norm == "batch":
+        if self.norm in ("batch", "layer"):
             self.param_names += [f"encoder.norms.{i}.{s}" for i in range(len(self.dims) - 2) for s in ("weight", "bias")]
 
     def masks(self, step, rows):

@@ -436,6 +436,73 @@ def test_bn_stats_and_backward_vs_oracle(rows, h):
     np.testing.assert_allclose(dzsum.cpu().numpy(), (da * (z > 0)).astype(np.float64).sum(0), atol=2e-4 * max(1.0, rows / 4096), rtol=1e-5)
 
 
+@pytest.mark.parametrize("rows,h,relu,p", [(100, 48, True, 0.0), (513, 512, True, 0.3), (64, 2048, True, 0.0), (33, 2500, False, 0.2),
+                                           (40, 70, False, 0.0), (1000, 1, True, 0.0), (7, 4096, True, 0.5)])
+def test_layernorm_forward_and_backward_vs_torch(rows, h, relu, p):
+    """glnn_layernorm_fwd_f32 / glnn_layernorm_bwd_f32 = dropout(relu?(nn.LayerNorm(h)(z))) and its backward (reference
+    models.py:30-31, 48-52), against torch.nn.functional.layer_norm in float64 with THIS library's dropout mask as an input:
+    odd widths, rows held in registers (<= 2048 columns) and re-read (wider), one / two / four column quads per backward thread,
+    ragged last row chunk, the column sums (dgamma, dbeta, bias gradient) and in-place dz == da."""
+    import torch.nn.functional as F
+    from glnn_amd import ops
+    r = np.random.RandomState(rows + h)
+    z = torch.from_numpy((r.standard_normal((rows, h)) * 1.5 + r.standard_normal((rows, 1))).astype(np.float32))
+    gamma = torch.from_numpy(r.uniform(.5, 1.5, h).astype(np.float32))
+    beta = torch.from_numpy((r.standard_normal(h) * .3).astype(np.float32))
+    da = torch.from_numpy(r.standard_normal((rows, h)).astype(np.float32))
+    seed = 4242
+    keep = ops.dropout_mask(rows, h, p, seed, DEV).cpu().double() if p > 0 else torch.ones(rows, h, dtype=torch.float64)
+    zd, gd, bd = z.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    y_ref = F.layer_norm(zd, (h,), gd, bd, 1e-5)
+    if relu:
+        y_ref = F.relu(y_ref)
+    y_ref = y_ref * keep / (1.0 - p)
+    y_ref.backward(da.double())
+    y, mean, rstd = ops.layernorm_fwd(dev(z.numpy()), dev(gamma.numpy()), dev(beta.numpy()), relu=relu, drop_p=p, drop_seed=seed)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(mean.cpu().numpy(), z.double().mean(1).numpy(), atol=1e-5, rtol=0)
+    if y.stride(0) > h:
+        base = torch.as_strided(y, (rows, y.stride(0)), (y.stride(0), 1))
+        assert float(base[:, h:].abs().max()) == 0.0
+    dzsum = torch.empty(h, device=DEV)
+    dz, dg, db = ops.layernorm_bwd(dev(da.numpy()), dev(z.numpy()), dev(gamma.numpy()), dev(beta.numpy()), mean, rstd, relu=relu, drop_p=p,
+                                   drop_seed=seed, dz_col_sum=dzsum)
+    scale = max(1.0, float(zd.grad.abs().max()))
+    np.testing.assert_allclose(dz.cpu().numpy(), zd.grad.numpy(), atol=5e-5 * scale, rtol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gd.grad.numpy(), atol=2e-4 * max(1.0, rows / 512), rtol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), atol=2e-4 * max(1.0, rows / 512), rtol=1e-4)
+    np.testing.assert_allclose(dzsum.cpu().numpy(), zd.grad.sum(0).numpy(), atol=2e-4 * max(1.0, rows / 512) * scale, rtol=1e-4)
+    buf = ops.as_feat(dev(da.numpy()))
+    dz2, _, _ = ops.layernorm_bwd(buf, dev(z.numpy()), dev(gamma.numpy()), dev(beta.numpy()), mean, rstd, relu=relu, drop_p=p, drop_seed=seed,
+                                  dz=buf, want_param_grads=False)
+    assert torch.equal(dz2, dz)
+
+
+def test_norm_tail_without_relu_forward_and_backward():
+    """glnn_norm_drop_fwd_f32 / glnn_bn_bwd_f32 with relu = 0: y = dropout(BatchNorm_train(z)) (GCN's norm -> dropout tail) and its
+    backward vs torch in float64 (this library's dropout mask as an input)."""
+    import torch.nn.functional as F
+    from glnn_amd import ops
+    rows, h, p, seed = 700, 96, 0.4, 99
+    r = np.random.RandomState(5)
+    z = torch.from_numpy((r.standard_normal((rows, h)) * 2 + 1).astype(np.float32))
+    gamma, beta = torch.from_numpy(r.uniform(.5, 1.5, h).astype(np.float32)), torch.from_numpy(r.standard_normal(h).astype(np.float32))
+    da = torch.from_numpy(r.standard_normal((rows, h)).astype(np.float32))
+    keep = ops.dropout_mask(rows, h, p, seed, DEV).cpu().double()
+    zd, gd, bd = z.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    y_ref = F.batch_norm(zd, None, None, gd, bd, True, 0.1, 1e-5) * keep / (1 - p)
+    y_ref.backward(da.double())
+    mean, rstd, a_sc, a_sh = ops.bn_stats(dev(z.numpy()), dev(gamma.numpy()), dev(beta.numpy()), torch.zeros(h, device=DEV), torch.ones(h, device=DEV),
+                                          torch.zeros(1, dtype=torch.int64, device=DEV))
+    y = ops.act_fwd(dev(z.numpy()), a_sc, a_sh, drop_p=p, drop_seed=seed, relu=False)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    assert float(y.min()) < 0        # no ReLU
+    dz, dg, db = ops.bn_relu_bwd(dev(da.numpy()), dev(z.numpy()), dev(gamma.numpy()), mean, rstd, a_sc, a_sh, drop_p=p, drop_seed=seed, relu=False)
+    np.testing.assert_allclose(dz.cpu().numpy(), zd.grad.numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(dg.cpu().numpy(), gd.grad.numpy(), atol=5e-4, rtol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), atol=5e-4, rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------- K6
 @pytest.mark.parametrize("wd", [0.0, 5e-4])
 def test_adam_vs_oracle(wd):

@@ -467,7 +467,7 @@ def test_full_size_products_properties():
 
 
 # ------------------------------------------------------------------------------------------- sampler
-@pytest.mark.parametrize("norm", ["batch", "none"])
+@pytest.mark.parametrize("norm", ["batch", "none", "layer"])
 def test_training_mode_forward_under_autograd_matches_torch_ops(norm):
     """MLP.forward in TRAINING mode under torch autograd (callers that differentiate Model.forward themselves): Linear,
     norm -> ReLU -> dropout run as differentiable HIP ops (glnn_amd.autograd).  With dropout 0 outputs, gradients and the
@@ -496,6 +496,9 @@ def test_training_mode_forward_under_autograd_matches_torch_ops(norm):
                 bn = enc.norms[l]
                 h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, True, bn.momentum, bn.eps)
                 bn.num_batches_tracked += 1
+            elif norm == "layer":
+                ln = enc.norms[l]
+                h = F.layer_norm(h, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
             h = F.relu(h)
     F.nll_loss(h.log_softmax(1), y).backward()
     np.testing.assert_allclose(out_f.detach().cpu().numpy(), h.detach().cpu().numpy(), atol=TOL, rtol=0)
@@ -505,6 +508,133 @@ def test_training_mode_forward_under_autograd_matches_torch_ops(norm):
         np.testing.assert_allclose(pf.grad.cpu().numpy(), pp.grad.cpu().numpy(), atol=2e-5, rtol=1e-3, err_msg=k)
     for (k, bf), (_, bp) in zip(fused.named_buffers(), plain.named_buffers()):
         np.testing.assert_allclose(bf.cpu().numpy(), bp.cpu().numpy(), atol=1e-5, rtol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("norm", ["batch", "layer", "none"])
+def test_gcn_with_norm_layers_training_step_and_eval_vs_dense_torch(norm):
+    """GCN.forward with a norm behind the GraphConv (reference models.py:189-199: conv(relu inside) -> norms[l] -> dropout, NO ReLU
+    behind the norm; train.conf.yaml's pokec / penn94 GCN sections use norm_type batch): the reference's full-graph `train` step
+    (train_and_eval.py:12-29) on TeacherEngine.step_gcn and the eval forward, against the same model written with dense torch
+    ops in this test (D^-1/2 A D^-1/2 as a dense matrix, F.batch_norm / F.layer_norm, torch.optim.Adam)."""
+    import copy
+    import torch.nn.functional as F
+    from glnn_amd import train_and_eval as te
+    from glnn_amd.graph import CSRGraph
+    from glnn_amd.models import Model
+    n, dims = 700, [20, 32, 32, 5]
+    indptr, indices = random_graph(n, 6, seed=11, power=0.5, symmetric=True, self_loops=True)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    a = torch.zeros(n, n, dtype=torch.float64)
+    for v in range(n):
+        for e in range(indptr[v], indptr[v + 1]):
+            a[v, indices[e]] += 1
+    dinv_in, dinv_out = a.sum(1).clamp(min=1).pow(-0.5), a.sum(0).clamp(min=1).pow(-0.5)
+    a_hat = (dinv_in[:, None] * a * dinv_out[None, :]).float().to(DEV)
+    torch.manual_seed(3)
+    x = torch.randn(n, dims[0], device=DEV)
+    y = torch.randint(0, dims[-1], (n,), device=DEV)
+    idx_train = torch.arange(0, n, 3, device=DEV)
+    model = Model(dict(model_name="GCN", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.0,
+                       norm_type=norm, device=DEV))
+    with torch.no_grad():
+        for nm in model.encoder.norms:
+            nm.weight.uniform_(.5, 1.5); nm.bias.uniform_(-.2, .2)
+    plain = copy.deepcopy(model)
+
+    def dense_forward(m, training):
+        h = x
+        enc = m.encoder
+        for l, layer in enumerate(enc.layers):
+            h = a_hat @ (h @ layer.weight) + layer.bias
+            if l != len(enc.layers) - 1:
+                h = F.relu(h)
+                if norm == "batch":
+                    bn = enc.norms[l]
+                    h = F.batch_norm(h, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+                    if training:
+                        bn.num_batches_tracked += 1
+                elif norm == "layer":
+                    ln = enc.norms[l]
+                    h = F.layer_norm(h, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+        return h
+
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    opt_p = torch.optim.Adam(plain.parameters(), lr=0.01, weight_decay=5e-4)
+    crit = torch.nn.NLLLoss()
+    for step in range(3):
+        loss = te.train(model, g, x, y, crit, opt, idx_train)
+        plain.train()
+        out = dense_forward(plain, True).log_softmax(1)
+        lp = crit(out[idx_train], y[idx_train])
+        opt_p.zero_grad(); lp.backward(); opt_p.step()
+        assert abs(loss - lp.item()) < TOL, (step, loss, lp.item())
+    for (k, pf), (_, pp) in zip(model.named_parameters(), plain.named_parameters()):
+        if norm == "batch" and k.endswith(".bias") and ".norms." not in k and not k.startswith("encoder.layers.2"):
+            continue      # a conv bias in front of ReLU -> BatchNorm is NOT a pure gauge (the ReLU sits between), but keep the rule uniform
+        np.testing.assert_allclose(pf.detach().cpu().numpy(), pp.detach().cpu().numpy(), atol=2e-4, rtol=0, err_msg=k)
+    for (k, bf), (_, bp) in zip(model.named_buffers(), plain.named_buffers()):
+        np.testing.assert_allclose(bf.cpu().numpy(), bp.cpu().numpy(), atol=1e-5, rtol=1e-5, err_msg=k)
+    model.eval(); plain.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(g, x).cpu().numpy(), dense_forward(plain, False).cpu().numpy(), atol=2e-4, rtol=0)
+    # the autograd surface (callers that differentiate GCN.forward themselves) agrees with the engine's first-step gradients
+    m2 = copy.deepcopy(plain); m3 = copy.deepcopy(plain)
+    m2.train(); m3.train()
+    crit(m2(g, x).log_softmax(1)[idx_train], y[idx_train]).backward()
+    crit(dense_forward(m3, True).log_softmax(1)[idx_train], y[idx_train]).backward()
+    for (k, pf), (_, pp) in zip(m2.named_parameters(), m3.named_parameters()):
+        np.testing.assert_allclose(pf.grad.cpu().numpy(), pp.grad.cpu().numpy(), atol=2e-5, rtol=1e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("dims", [[16, 64, 64, 5], [40, 300, 7]])
+def test_sage_with_layernorm_inference_and_block_forward_vs_torch(dims):
+    """SAGE with norm_type 'layer' (reference models.py:87-90): layer-wise inference (whole graph and chunked) and the
+    training-mode block forward under autograd vs the same model with the aggregation as a dense matrix and F.layer_norm."""
+    import copy
+    import torch.nn.functional as F
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    from glnn_amd.models import Model
+    n = 900
+    indptr, indices = random_graph(n, 7, seed=5, power=0.5, isolated=4)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    a = torch.zeros(n, n)
+    for v in range(n):
+        for e in range(indptr[v], indptr[v + 1]):
+            a[v, indices[e]] += 1
+    a = ((a + torch.eye(n)) / (a.sum(1, keepdim=True) + 1)).to(DEV)          # SAGE-"gcn" mean incl. the self row
+    torch.manual_seed(1)
+    L = len(dims) - 1
+    model = Model(dict(model_name="SAGE", num_layers=L, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.0,
+                       norm_type="layer", device=DEV))
+    with torch.no_grad():
+        for nm in model.encoder.norms:
+            nm.weight.uniform_(.5, 1.5); nm.bias.uniform_(-.2, .2)
+    x = torch.randn(n, dims[0], device=DEV)
+
+    def dense(m):
+        h = x
+        for l, layer in enumerate(m.encoder.layers):
+            h = F.linear(a @ h, layer.fc_neigh.weight, layer.fc_neigh.bias)
+            if l != L - 1:
+                ln = m.encoder.norms[l]
+                h = F.relu(F.layer_norm(h, ln.normalized_shape, ln.weight, ln.bias, ln.eps))
+        return h
+
+    model.eval()
+    with torch.no_grad():
+        want = dense(model).cpu().numpy()
+    loader = FullNeighborLoader(g, 256)
+    np.testing.assert_allclose(model.inference(loader, x).cpu().numpy(), want, atol=TOL, rtol=0)
+    np.testing.assert_allclose(model.encoder.inference(loader, x, whole_graph=False).cpu().numpy(), want, atol=TOL, rtol=0)
+    m2, m3 = copy.deepcopy(model), copy.deepcopy(model)
+    m2.train(); m3.train()
+    out2 = m2([g] * L, x)
+    out2.pow(2).sum().backward()
+    out3 = dense(m3)
+    out3.pow(2).sum().backward()
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out3.detach().cpu().numpy(), atol=TOL, rtol=0)
+    for (k, pf), (_, pp) in zip(m2.named_parameters(), m3.named_parameters()):
+        np.testing.assert_allclose(pf.grad.cpu().numpy(), pp.grad.cpu().numpy(), atol=2e-3, rtol=1e-3, err_msg=k)
 
 
 def test_neighbor_sampler_and_blocks():
