@@ -186,6 +186,31 @@ def main():
     out.update({"gcn.indptr": ip2, "gcn.indices": ix2, "gcn.feats": feats2, "gcn.labels": labels2, "gcn.idx_train": idx_train,
                 "gcn.dims": np.asarray(dims2)})
 
+    # ---- train (full-graph GCN) WITH a norm layer (round 3): reference models.py:189-199 puts norms[l] BEHIND the GraphConv's ReLU
+    # and applies no ReLU after it; train.conf.yaml:206-213, 231-238 (pokec / penn94 GCN) use norm_type batch, weight_decay 0.001
+    for tag, norm in (("gcnbn", "batch"), ("gcnln", "layer")):
+        dims3 = [60, 16, 16, 5]
+        torch.manual_seed(7 if norm == "batch" else 8)
+        conf3 = dict(model_name="GCN", num_layers=3, feat_dim=dims3[0], hidden_dim=dims3[1], label_dim=dims3[-1], dropout_ratio=0.0,
+                     norm_type=norm, device="cpu")
+        gcn3 = ref_models.Model(conf3)
+        with torch.no_grad():
+            for nm in gcn3.encoder.norms:
+                nm.weight.uniform_(0.5, 1.5)
+                nm.bias.uniform_(-0.2, 0.2)
+        opt3 = torch.optim.Adam(gcn3.parameters(), lr=0.01, weight_decay=1e-3)
+        for k, v in gcn3.state_dict().items():
+            out[f"{tag}.init.{k}"] = v.numpy().copy()
+        losses3 = [ref_te.train(gcn3, g2, torch.from_numpy(feats2), torch.from_numpy(labels2), nn.NLLLoss(), opt3, torch.from_numpy(idx_train))
+                   for _ in range(5)]
+        out[f"{tag}.losses"] = np.asarray(losses3)
+        for k, v in gcn3.state_dict().items():
+            out[f"{tag}.final.{k}"] = v.numpy().copy()
+        gcn3.eval()
+        with torch.no_grad():
+            out[f"{tag}.eval_logits"] = gcn3(g2, torch.from_numpy(feats2)).numpy().copy()
+        out[f"{tag}.dims"] = np.asarray(dims3)
+
     path = os.path.join(HERE, "teacher_training.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes; sage epoch losses",

@@ -238,6 +238,32 @@ def test_train_gcn_vs_reference_golden():
         np.testing.assert_allclose(v.cpu().numpy(), z[f"gcn.final.{k}"], atol=TOL, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("tag,norm", [("gcnbn", "batch"), ("gcnln", "layer")])
+def test_train_gcn_with_norm_layer_vs_reference_golden(tag, norm):
+    """GCN with a norm layer (round 3): five steps of the reference's own `train` (train_and_eval.py:12-29) over `GCN.forward`
+    (models.py:189-199: GraphConv(relu) -> norms[l] -> dropout, no ReLU behind the norm) with nn.BatchNorm1d / nn.LayerNorm, Adam
+    with weight_decay 0.001 (the pokec / penn94 GCN sections of train.conf.yaml) -- per-step losses, final parameters and
+    BatchNorm buffers, and the eval-mode logits of the trained model, against TeacherEngine.step_gcn / GCN.forward."""
+    from glnn_amd import train_and_eval as te
+    z, _ = teacher_training()
+    dims = [int(d) for d in z[f"{tag}.dims"]]
+    model, opt = _teacher("GCN", dims, norm, sub_dict(z, f"{tag}.init."), 1e-3)
+    g = _graph(z["gcn.indptr"], z["gcn.indices"])
+    feats, labels = torch.from_numpy(z["gcn.feats"]).to(DEV), torch.from_numpy(z["gcn.labels"]).to(DEV)
+    idx_train = torch.from_numpy(z["gcn.idx_train"]).to(DEV)
+    losses = [te.train(model, g, feats, labels, torch.nn.NLLLoss(), opt, idx_train) for _ in range(5)]
+    np.testing.assert_allclose(losses, z[f"{tag}.losses"], atol=TOL, rtol=0)
+    for k, v in model.state_dict().items():
+        want = z[f"{tag}.final.{k}"]
+        if v.dim() == 0:
+            assert int(v) == int(want), k
+        else:
+            np.testing.assert_allclose(v.cpu().numpy(), want, atol=2e-4, rtol=0, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(g, feats).cpu().numpy(), z[f"{tag}.eval_logits"], atol=5e-4, rtol=0)
+
+
 def test_gcn_step_both_weight_orders_and_dropout_vs_oracle():
     """GraphConv aggregates first when in <= out and multiplies first when in > out (dgl): a 12->20->20->5 GCN takes both
     branches in one step; then the same with dropout 0.5, the oracle fed with the kernels' own keep-masks."""
