@@ -848,8 +848,9 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   a.ld_self = ld_self; a.w_packed = w_packed; a.d_out = d_out; a.kgroups = (d_in + 7) / 8; a.ep_scale = ep_scale;
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
   a.w2_packed = w2_packed; a.d_out2 = w2_packed ? d_out2 : 0; a.kgroups2 = w2_packed ? (d_out + 7) / 8 : 0; a.out2 = out2; a.ldo2 = ldo2;
-  static const int rt_env = getenv("GLNN_FUSED_RT") ? atoi(getenv("GLNN_FUSED_RT")) : 0;   // tuning override (1 or 2)
-  const int rt = rt_env ? rt_env : 1;
+  // one 32-row sub-tile per workgroup (RT = 1).  RT = 2 (64-row tiles, every W fragment load feeding two MFMA chains) was measured
+  // 1.5x slower in round 1 -- big workgroups drain badly -- and its instantiations were removed in round 3
+  constexpr int rt = 1;
   const int rows_per_wg = 32 * rt;
   const int64_t blocks = (n_dst + rows_per_wg - 1) / rows_per_wg;
   GLNN_REQUIRE(blocks < ((int64_t)1 << 31), "glnn_sage_fused_f32: n_dst too large for one launch");
@@ -859,15 +860,8 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   const int dv = dpad / 4;
   // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)
   const int kv = a.kgroups * 2;      // float4 per padded row
-  static int configured = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_fused_kernel<64, GLNN_FUSED_U, 2>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 0 : -1;
-  if (configured != 0) return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fused_f32: cannot raise the dynamic LDS limit");
 #define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
-  if (rt == 2) {
-    if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 2); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 2); else GLNN_FUSED_LAUNCH(64, 2);
-  } else {
-    if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 1); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 1); else GLNN_FUSED_LAUNCH(64, 1);
-  }
+  if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 1); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 1); else GLNN_FUSED_LAUNCH(64, 1);
 #undef GLNN_FUSED_LAUNCH
   return glnn::check_launch("glnn_sage_fused_f32");
 }
