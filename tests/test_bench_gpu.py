@@ -77,3 +77,15 @@ def test_bench_self_launches_its_ranks(l1):
     per_node = 148 if l1 == "narrow" else 256 + 48
     ex = out["exchange"]
     assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * per_node < 0.15 * 4e-9 * n_pad * per_node, ex
+
+
+def test_bench_halo_exchange_with_partitioner_two_ranks():
+    """bench.py --exchange halo on a clustered graph whose ids were shuffled, re-partitioned by label propagation (--partition lp),
+    overlapped exchange: the sharded output verifies against the unsharded forward on the relabelled graph, and the halo moves
+    fewer bytes than an all-gather of the same rows would (n_pad * 148 floats per rank and forward)."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1", "--exchange", "halo",
+                "--locality", "0.95", "--shuffle-ids", "--partition", "lp"], env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["verified"] is True and out["config"]["partition"] == "lp" and out["config"]["halo_overlap"] is True
+    assert out["config"]["partition_seconds"] > 0
+    full = 4e-9 * out["config"]["nodes"] * 148 / 2          # what one rank would receive from the other under the all-gather
+    assert out["exchange"]["GB_received_per_rank_per_forward"] < 0.8 * full, (out["exchange"], full)
