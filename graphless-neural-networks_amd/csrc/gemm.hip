@@ -967,7 +967,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
 // Thread map: tid -> (rg: rows 4rg..4rg+3 of the 32-row k-tile, cg: columns 4cg..4cg+3), interleaved (below).
 // ---------------------------------------------------------------------------------------------
 template <int BMT, int BNT, int XF, bool ROWS>
-__global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
+__device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx, const int by, const int bz) {
   constexpr int MI = BMT / 64;
   constexpr int NT = BNT / 64;
   constexpr int A_TILE = BMT * LDS_K, B_TILE = BNT * LDS_K;
@@ -977,8 +977,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
-  const int i0 = blockIdx.x * BMT, j0 = blockIdx.y * BNT;
-  const int64_t mbeg = (int64_t)blockIdx.z * g.rows_per_split;
+  const int i0 = bx * BMT, j0 = by * BNT;
+  const int64_t mbeg = (int64_t)bz * g.rows_per_split;
   int64_t mend = mbeg + g.rows_per_split;
   if (mend > g.m) mend = g.m;
 
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
     mfma_range(fa[(G - 1) & 1], fb[(G - 1) & 1], MG / 2, MG);
   }
 
-  float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
+  float* cbase = g.c + (g.splits > 1 ? (int64_t)bz * g.ka * g.ldc : 0);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = j0 + wn * (BNT / 2) + j * 32 + li;
@@ -1153,6 +1153,42 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
         const int row = i0 + wm * (BMT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
       }
+  }
+}
+
+template <int BMT, int BNT, int XF, bool ROWS>
+__global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
+  gemm_tn_tile_t<BMT, BNT, XF, ROWS>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// ONE launch for several independent weight gradients (the deferred dW_l of a small-batch student step, mlp_step.hip): the blocks of
+// every problem's (gi, gj, splits) grid are laid end to end; a block finds its problem and runs the SAME 64 x 64 tile code with that
+// problem's arguments -- bit-identical partials, three launches and three dependent-latency chains fewer per step.
+constexpr int kTnMultiMax = 4;
+struct TnMultiArgs {
+  GemmTnArgs g[kTnMultiMax];
+  int start[kTnMultiMax + 1];             // first block of every problem
+  int gi[kTnMultiMax], gj[kTnMultiMax];
+  int xf[kTnMultiMax], rows[kTnMultiMax];
+  int n;
+};
+__global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const TnMultiArgs mm) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kTnMultiMax; ++q)
+    if (q < mm.n && (int)blockIdx.x >= mm.start[q]) p = q;
+  const int local = (int)blockIdx.x - mm.start[p];
+  const int bx = local % mm.gi[p], by = (local / mm.gi[p]) % mm.gj[p], bz = local / (mm.gi[p] * mm.gj[p]);
+  const GemmTnArgs& g = mm.g[p];
+  const int xf = mm.xf[p];
+  if (mm.rows[p]) {
+    if (xf == 0) gemm_tn_tile_t<64, 64, 0, true>(g, bx, by, bz);
+    else if (xf == 1) gemm_tn_tile_t<64, 64, 1, true>(g, bx, by, bz);
+    else gemm_tn_tile_t<64, 64, 2, true>(g, bx, by, bz);
+  } else {
+    if (xf == 0) gemm_tn_tile_t<64, 64, 0, false>(g, bx, by, bz);
+    else if (xf == 1) gemm_tn_tile_t<64, 64, 1, false>(g, bx, by, bz);
+    else gemm_tn_tile_t<64, 64, 2, false>(g, bx, by, bz);
   }
 }
 
@@ -1428,6 +1464,132 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   if (n > 64) return b_layout ? launch_gemm<128, true>(g, fast, st) : launch_gemm<128, false>(g, fast, st);
   return b_layout ? launch_gemm<64, true>(g, fast, st) : launch_gemm<64, false>(g, fast, st);
 }
+
+// ---- several independent weight gradients in ONE gemm launch + ONE fold launch (see gemm_tn_multi_kernel) -------------------
+struct FoldMultiArgs {
+  const float* ws[kTnMultiMax]; int64_t slab[kTnMultiMax]; int splits[kTnMultiMax];
+  float* c[kTnMultiMax]; int64_t ldc[kTnMultiMax]; int ka[kTnMultiMax], nb[kTnMultiMax];
+  int start[kTnMultiMax + 1]; int n;
+};
+// split_reduce_kernel for every problem with more than one split: the same sums in the same order (k = 0, 1, 2, ...)
+__global__ void split_reduce_multi_kernel(const FoldMultiArgs fm) {
+  int p = 0;
+#pragma unroll
+  for (int q = 1; q < kTnMultiMax; ++q)
+    if (q < fm.n && (int)blockIdx.x >= fm.start[q]) p = q;
+  const int64_t b0 = (int)blockIdx.x - fm.start[p], nblk = fm.start[p + 1] - fm.start[p];
+  const float* ws = fm.ws[p];
+  float* c = fm.c[p];
+  const int64_t slab = fm.slab[p], ldc = fm.ldc[p];
+  const int splits = fm.splits[p], ka = fm.ka[p], nb = fm.nb[p];
+  const int64_t total = (int64_t)ka * nb;
+  if (((nb | ldc | slab) & 3) == 0 && glnn::aligned16(ws) && glnn::aligned16(c)) {
+    const int64_t total4 = total >> 2;
+    const int nb4 = nb >> 2;
+    for (int64_t i = b0 * blockDim.x + threadIdx.x; i < total4; i += nblk * blockDim.x) {
+      float4 s = *reinterpret_cast<const float4*>(ws + 4 * i);
+      for (int k = 1; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t r = i / nb4, cc = (i - r * nb4) * 4;
+      *reinterpret_cast<float4*>(c + r * ldc + cc) = s;
+    }
+    return;
+  }
+  for (int64_t i = b0 * blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
+    const int64_t r = i / nb, cc = i - r * nb;
+    c[r * ldc + cc] = s;
+  }
+}
+
+// The plan glnn_gemm_tn_f32 makes for a "small" problem (64 x 64 tiles, the reduction split until ~1024 workgroups exist), or false
+// if the problem would not take that path there.  `avail` = workspace floats the split slabs may use.
+static bool tn_small_plan(int64_t m, int ka, int nb, int64_t lda, int64_t ldb, const float* a, const float* b, const float* b_scale,
+                          const float* b_shift, const int64_t* b_rows, int64_t avail, int* gi, int* gj, int* splits, int64_t* rps) {
+  const bool a_vec = (lda % 4 == 0) && glnn::aligned16(a), b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
+  const bool fast = a_vec && b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
+                    (!b_scale || (nb % 4 == 0 && glnn::aligned16(b_scale) && glnn::aligned16(b_shift)));
+  const int bnt = nb > 64 ? 128 : 64;
+  const int gi0 = (ka + BM - 1) / BM, gj0 = (nb + bnt - 1) / bnt;
+  const bool pipe_shape = fast && bnt == 128 && !b_scale && !b_rows && pipe_enabled() && (lda > ldb ? lda : ldb) < (1 << 20);
+  if (!(fast && gi0 * gj0 <= 64 && !(pipe_shape && m >= 2048))) return false;
+  *gi = (ka + 63) / 64; *gj = (nb + 63) / 64;
+  int sp = 1;
+  const int64_t slab = (int64_t)ka * nb;
+  if (*gi * *gj < 1024) {
+    sp = (1024 + *gi * *gj - 1) / (*gi * *gj);
+    const int64_t max_by_rows = (m + 2 * BK - 1) / (2 * BK);
+    if (sp > max_by_rows) sp = (int)max_by_rows;
+    if ((int64_t)sp * slab > avail) sp = (int)(avail / slab);
+    if (sp < 1) sp = 1;
+  }
+  int64_t r = (m + sp - 1) / sp;
+  r = (r + BK - 1) / BK * BK;
+  *rps = r;
+  *splits = (int)((m + r - 1) / r);
+  return true;
+}
+
+namespace glnn {
+// n <= 4 independent products c_p = a_p^T . b'_p (the arguments of glnn_gemm_tn_f32, no col_sum_a) as ONE gemm launch and ONE fold
+// launch.  Returns GLNN_ERR_UNSUPPORTED without launching anything when a problem would not take the 64 x 64 path of
+// glnn_gemm_tn_f32 or the slabs do not fit the workspace: the caller then issues the products one by one.  Results are bit-identical
+// to the one-by-one form (same tile code, same split plan computed against the same workspace size, same fold order).
+int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspace_floats, void* stream) {
+  if (n < 1 || n > kTnMultiMax || !workspace) return GLNN_ERR_UNSUPPORTED;
+  TnMultiArgs mm;
+  FoldMultiArgs fm;
+  mm.n = n; fm.n = 0;
+  int64_t ws_off = 0;
+  int blocks = 0, fblocks = 0;
+  for (int p = 0; p < n; ++p) {
+    const TnProblem& q = pr[p];
+    if (!(q.a && q.b && q.c) || q.m < 1 || q.ka < 1 || q.nb < 1 || q.lda < q.ka || q.ldb < q.nb || q.ldc < q.nb) return GLNN_ERR_UNSUPPORTED;
+    if ((q.b_scale == nullptr) != (q.b_shift == nullptr) || q.drop_p < 0.f || q.drop_p >= 1.f || (q.drop_p > 0.f && !q.b_scale)) return GLNN_ERR_UNSUPPORTED;
+    int gi, gj, sp; int64_t rps;
+    if (!tn_small_plan(q.m, q.ka, q.nb, q.lda, q.ldb, q.a, q.b, q.b_scale, q.b_shift, q.b_rows, workspace_floats, &gi, &gj, &sp, &rps))
+      return GLNN_ERR_UNSUPPORTED;
+    GemmTnArgs& g = mm.g[p];
+    g.drop_thr = glnn::drop_threshold(q.drop_p); g.drop_seed = q.drop_seed; g.drop_scale = 1.0f / (1.0f - q.drop_p);
+    g.a = q.a; g.lda = q.lda; g.m = q.m; g.ka = q.ka; g.b = q.b; g.ldb = q.ldb; g.b_rows = q.b_rows; g.b_scale = q.b_scale; g.b_shift = q.b_shift;
+    g.nb = q.nb; g.a_vec = 1; g.b_vec = 1; g.splits = sp; g.rows_per_split = rps;
+    const int64_t slab = (int64_t)q.ka * q.nb;
+    if (sp > 1) {
+      ws_off = (ws_off + 3) & ~(int64_t)3;
+      if (ws_off + (int64_t)sp * slab > workspace_floats) return GLNN_ERR_UNSUPPORTED;
+      g.c = workspace + ws_off; g.ldc = q.nb;
+      const int f = fm.n++;
+      fm.ws[f] = g.c; fm.slab[f] = slab; fm.splits[f] = sp; fm.c[f] = q.c; fm.ldc[f] = q.ldc; fm.ka[f] = q.ka; fm.nb[f] = q.nb;
+      int fb = (int)((slab + 255) / 256);
+      if (fb > 2048) fb = 2048;
+      fm.start[f] = fblocks; fblocks += fb; fm.start[f + 1] = fblocks;
+      ws_off += (int64_t)sp * slab;
+    } else {
+      g.c = q.c; g.ldc = q.ldc;
+    }
+    mm.start[p] = blocks; mm.gi[p] = gi; mm.gj[p] = gj;
+    mm.xf[p] = !q.b_scale ? 0 : (g.drop_thr ? 2 : 1);
+    mm.rows[p] = q.b_rows ? 1 : 0;
+    blocks += gi * gj * sp;
+    mm.start[p + 1] = blocks;
+  }
+  for (int p = n; p < kTnMultiMax; ++p) { mm.start[p + 1] = blocks; mm.gi[p] = mm.gj[p] = 1; mm.xf[p] = mm.rows[p] = 0; }
+  constexpr size_t smem_s = sizeof(float) * 2 * (64 * LDS_K + 64 * LDS_K);
+  static int cfg = 1;
+  if (cfg > 0) cfg = set_smem(gemm_tn_multi_kernel, smem_s);
+  if (cfg != GLNN_OK) return cfg;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3(blocks), dim3(256), smem_s, st, mm);
+  int rc = glnn::check_launch("glnn_gemm_tn_f32(batch)");
+  if (rc != GLNN_OK || fm.n == 0) return rc;
+  for (int f = fm.n; f < kTnMultiMax; ++f) fm.start[f + 1] = fblocks;
+  hipLaunchKernelGGL(split_reduce_multi_kernel, dim3(fblocks), dim3(256), 0, st, fm);
+  return glnn::check_launch("glnn_gemm_tn_f32(batch fold)");
+}
+}  // namespace glnn
 
 extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                                 const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,

@@ -78,4 +78,12 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
                 void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1);
 
+// gemm.hip: several independent weight gradients (arguments as glnn_gemm_tn_f32, no column sums) in one gemm + one fold launch;
+// GLNN_ERR_UNSUPPORTED (nothing launched) when a problem does not qualify -- see gemm_tn_batch
+struct TnProblem {
+  const float* a; int64_t lda; int64_t m; int ka; const float* b; int64_t ldb; const int64_t* b_rows; const float* b_scale;
+  const float* b_shift; float drop_p; uint32_t drop_seed; int nb; float* c; int64_t ldc;
+};
+int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream);
+
 }  // namespace glnn

@@ -145,6 +145,8 @@ class StudentEngine:
             for ev in (self.ev_main, self.ev_aux):
                 ev.record()                                   # (torch creates the hipEvent_t lazily at the first record)
             self.dz2 = ops.feat_empty(B, hmax, dev)
+        if self.dz2 is None and self.sync_counters is not None and self.L <= 3:
+            self.dz2 = ops.feat_empty(B, hmax, dev)      # small steps defer their weight gradients to ONE batched launch (mlp_step.hip): dz_l must outlive the loop
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
@@ -221,6 +223,7 @@ class StudentEngine:
             d.sync_counters = ptr(self.sync_counters)
         if self.aux_stream is not None:
             d.aux_stream, d.ev_main, d.ev_aux = self.aux_stream.cuda_stream, self.ev_main.cuda_event, self.ev_aux.cuda_event
+        if self.dz2 is not None:
             d.dz2, d.ld_dz2 = ptr(self.dz2), self.dz2.stride(0)
         return d
 
