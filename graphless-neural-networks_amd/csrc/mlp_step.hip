@@ -166,8 +166,11 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
                               d->ws_tn_floats, wstream);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
     };
     auto input_gradient = [&]() -> int {
+      // ws_gemm is idle during the backward (two-stream form: the first layer's weight gradient borrows it, and never overlaps this
+      // call): deep, skinny input gradients (B = 512, 1024 wide: 128 tiles x 32 dependent k-tiles) may split their reduction
+      const bool ws_free = !two;
       return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
-                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, nullptr, 0, stream);
+                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, ws_free ? d->ws_gemm : nullptr, ws_free ? d->ws_gemm_floats : 0, stream);
     };
     if (two && big_dgrad) {
       GLNN_TRY(input_gradient());

@@ -126,7 +126,7 @@ class StudentEngine:
         # latency-bound steps keep the recompute (one launch fewer per hidden layer).
         mat = os.environ.get("GLNN_STUDENT_MATERIALIZE_ACT", "auto")
         self.act = [ops.feat_empty(B, self.dims[l + 1], dev)
-                    if self.ln or mat == "1" or (mat == "auto" and self.p > 0 and self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)) else None
+                    if self.ln or mat == "1" or (mat == "auto" and self.p > 0 and self._materialize_tail(l, B)) else None
                     for l in range(self.L - 1)]
         # feats[idx] copied once per step when the batch is long enough for the first layer's weight gradient to take the
         # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches keep the gather inside the operand loads
@@ -153,6 +153,15 @@ class StudentEngine:
         self._seed_arr = (ctypes.c_uint32 * _lib.MLP_MAX_LAYERS)()
         self.exchange = None
         self.desc = self._build_desc()
+
+    def _materialize_tail(self, l, B):
+        """Store dropout(relu(norm(z_l))) once per step instead of re-evaluating it in the operand loads of its consumers?  The
+        dropout hash is the cost, and every column tile of the NEXT layer's GEMM re-evaluates it: worth a [B, h] write and
+        re-read when the next layer is >= 512 wide (4+ column tiles).  Round 2 applied it from B * h >= 2^21 (MLP3w8's first
+        hidden layer: 1.18 -> 1.00 ms); round 3 from 2^19, which adds MLP3w4 at B = 512 (0.164 -> 0.158 ms, interleaved A/B).
+        A tail that feeds only the narrow output layer (one column tile) stays recomputed: materialising it as well costs
+        MLP3w8 0.8 %."""
+        return self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 19)
 
     def enable_batch_split(self, world, rank, group=None):
         """Data-parallel over ONE batch: every rank steps on its slice of the batch rows.  BatchNorm statistics are
