@@ -86,4 +86,18 @@ struct TnProblem {
 };
 int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream);
 
+// mlp_lat.hip: the latency form of a student layer (m <= ~1k rows, k <= 256): C = A' * B + bias in 32-row tiles whose four waves split
+// K, with the reduction that used to be the next launch as epilogue.  GLNN_ERR_UNSUPPORTED = not launched, use the tiled kernels.
+struct LatStats {      // BatchNorm1d training statistics of C + finalize (arguments as bn_stats)
+  const float* gamma; const float* beta; float eps; float momentum; float* running_mean; float* running_var; int64_t* nbt;
+  float* mean_out; float* rstd_out; float* a_scale_out; float* a_shift_out; float* ws; int64_t ws_floats; int* counters;
+};
+struct LatLoss {       // log_softmax + loss + dlogits on C (n <= 64) (arguments as softmax_loss; counter and ws required)
+  int kind; const int64_t* labels; const int64_t* label_rows; const float* target_logp; int64_t ldt; const int64_t* target_rows;
+  float lamb; float* dlogits; int64_t ldg; float* loss_out; float* loss_accum; float* ws; int64_t ws_floats; int* counter; float* col_sum;
+};
+int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
+             uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
+             int64_t ldc, const LatStats* st, const LatLoss* ls, void* stream);
+
 }  // namespace glnn

@@ -1,0 +1,366 @@
+// The LATENCY form of the student's dense layers (reference MLP.forward, models.py:42-53, inside the B = 512 steps of
+// train_and_eval.py:74-85), gfx950.
+//
+// At B = 512 a layer of the arxiv student is 32 tiles of 64 x 64: the tiled kernels of gemm.hip run 8 dependent k-tiles per
+// workgroup (12 us for 0.07 GFLOP), and every reduction that follows a GEMM (BatchNorm statistics, the loss) is one more launch
+// of ~6 us whose only input is what the GEMM just wrote.  Here instead
+//   * a workgroup owns a 32 x 32 (hidden layers) or 32 x 64 (the <= 64-wide output layer) tile of C and its FOUR WAVES SPLIT K:
+//     wave q multiplies rows x columns over its quarter of the reduction straight from global memory into MFMA fragments (no LDS
+//     staging, no barrier in the loop; all of a wave's loads for up to 64 reduction terms are in flight at once), so the dependent
+//     MFMA chain is K/8 instead of K/2 long and there are 4x as many workgroups as 64 x 64 tiles;
+//   * the four partial tiles are summed in LDS in fixed order (k ascending), bias added, the tile stored, and THEN, still in the
+//     same launch, the epilogue that used to be the next kernel:
+//       STATS: per-tile (mean, M2) of the 32 rows of every column -> partials; the last workgroup of a 64-column block runs the
+//              Chan combine and the whole BatchNorm finalize (running statistics, a_scale / a_shift) -- student_dev.h;
+//       LOSS : log_softmax + NLL | KL(log-target) and d(lamb * loss)/dlogits on the complete rows of the tile, per-workgroup loss and
+//              bias-gradient partials, last workgroup folds them (same arithmetic per row as softmax_loss_kernel).
+// Results differ from the tiled kernels only by the summation order over k (four ascending quarters, then q = 0..3).
+#include <cstdlib>
+
+#include "glnn_common.h"
+#include "student_dev.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_LOSS = 2 };
+constexpr int kGroups = 8;     // k-groups (8 reduction terms: 4 per lane half) whose loads a wave keeps in flight together
+
+struct LatArgs {
+  const float* a; int64_t lda; const int64_t* a_rows; const float* a_scale; const float* a_shift;
+  uint32_t drop_thr, drop_seed; float drop_scale;
+  int64_t m; int k; const float* b; int64_t ldb; int n;
+  const float* bias; float* c; int64_t ldc; int c_vec;
+  int gpw;                                        // k-groups per wave: wave q owns groups [q * gpw, (q + 1) * gpw)
+  float* ws_mean; float* ws_m2; int* counters;    // EPI_STATS: [m tiles][n] partials, one counter per 64-column block
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 keep_first(float4 v, int left) {   // elements t < left stay, the rest read as 0
+  v.x = left > 0 ? v.x : 0.f; v.y = left > 1 ? v.y : 0.f; v.z = left > 2 ? v.z : 0.f; v.w = left > 3 ? v.w : 0.f;
+  return v;
+}
+
+// XF: 0 = A as stored; 1 = relu(a * scale[k] + shift[k]); 2 = 1 followed by the counter-hash dropout of glnn_common.h.
+// B_KN: B given as W[k, n] (the input-gradient product) instead of W[n, k].  NB: 32-column MFMA blocks per workgroup tile.
+template <int XF, bool B_KN, int NB, int EPI>
+__global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const BnFinArgs fin, const LossArgs ls) {
+  constexpr int TN = 32 * NB;
+  constexpr int LDT = TN + 4;
+  __shared__ __attribute__((aligned(16))) float red[4][32 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, li = lane & 31, kk = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * 32;
+  const int n0 = blockIdx.y * TN;
+
+  // LOSS epilogue mapping: thread = (row tid >> 3 of the tile, classes 8 (tid & 7) .. + 7).  Its targets are requested before the
+  // product so that they have arrived when the rows are complete.
+  float tv[8];
+  int64_t yv = 0;
+  if (EPI == EPI_LOSS) {
+    int64_t row = m0 + (tid >> 3);
+    if (row > g.m - 1) row = g.m - 1;
+    if (ls.kind == GLNN_LOSS_KL) {
+      const float* tr = ls.t + (ls.t_rows ? ls.t_rows[row] : row) * ls.ldt;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int cls = 8 * (tid & 7) + t;
+        tv[t] = tr[cls < ls.c ? cls : ls.c - 1];
+      }
+    } else {
+      yv = ls.labels[ls.label_rows ? ls.label_rows[row] : row];
+    }
+  }
+
+  int64_t mrow = m0 + li;
+  if (mrow > g.m - 1) mrow = g.m - 1;
+  const float* ap = g.a + (g.a_rows ? g.a_rows[mrow] : mrow) * g.lda;
+  const float* bp[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    int ng = n0 + 32 * j + li;
+    if (ng > g.n - 1) ng = g.n - 1;
+    bp[j] = B_KN ? g.b + ng : g.b + (int64_t)ng * g.ldb;
+  }
+  const int kpad = (g.k + 3) & ~3;
+  const uint32_t hrow = (uint32_t)(m0 + li);        // the dropout hash is keyed by the row of the BATCH, not of the source matrix
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int c0 = 0; c0 < g.gpw; c0 += kGroups) {
+    float4 av[kGroups], bv[NB][kGroups], sc[kGroups], sh[kGroups];
+    // every load of the chunk first (clamped, always valid addresses: groups past K re-read the last float4 and are skipped below)
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+      const int kc = (q * g.gpw + c0 + u) * 8 + kk * 4;
+      const int kcc = kc > kpad - 4 ? kpad - 4 : kc;
+      av[u] = ld4(ap + kcc);
+      if (XF) {
+        sc[u] = ld4(g.a_scale + kcc);
+        sh[u] = ld4(g.a_shift + kcc);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (B_KN) {
+          const int k0 = kc > g.k - 1 ? g.k - 1 : kc, k1 = kc + 1 > g.k - 1 ? g.k - 1 : kc + 1;
+          const int k2 = kc + 2 > g.k - 1 ? g.k - 1 : kc + 2, k3 = kc + 3 > g.k - 1 ? g.k - 1 : kc + 3;
+          bv[j][u].x = bp[j][(int64_t)k0 * g.ldb];
+          bv[j][u].y = bp[j][(int64_t)k1 * g.ldb];
+          bv[j][u].z = bp[j][(int64_t)k2 * g.ldb];
+          bv[j][u].w = bp[j][(int64_t)k3 * g.ldb];
+        } else {
+          bv[j][u] = ld4(bp[j] + kcc);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+      const int kg = q * g.gpw + c0 + u;                  // wave-uniform
+      if (c0 + u < g.gpw && kg * 8 < g.k) {
+        const int kc = kg * 8 + kk * 4;
+        const int kleft = g.k - kc;
+        float4 a4 = av[u];
+        if (XF) {
+          a4.x = fmaxf(fmaf(a4.x, sc[u].x, sh[u].x), 0.f);
+          a4.y = fmaxf(fmaf(a4.y, sc[u].y, sh[u].y), 0.f);
+          a4.z = fmaxf(fmaf(a4.z, sc[u].z, sh[u].z), 0.f);
+          a4.w = fmaxf(fmaf(a4.w, sc[u].w, sh[u].w), 0.f);
+          if (XF == 2) {
+            a4.x = glnn::drop_keep(g.drop_seed, g.drop_thr, hrow, (uint32_t)kc + 0) ? a4.x * g.drop_scale : 0.f;
+            a4.y = glnn::drop_keep(g.drop_seed, g.drop_thr, hrow, (uint32_t)kc + 1) ? a4.y * g.drop_scale : 0.f;
+            a4.z = glnn::drop_keep(g.drop_seed, g.drop_thr, hrow, (uint32_t)kc + 2) ? a4.z * g.drop_scale : 0.f;
+            a4.w = glnn::drop_keep(g.drop_seed, g.drop_thr, hrow, (uint32_t)kc + 3) ? a4.w * g.drop_scale : 0.f;
+          }
+        }
+        a4 = keep_first(a4, kleft);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const float4 b4 = keep_first(bv[j][u], kleft);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // the four waves' partial tiles -> LDS; C fragment layout: register r of lane (li, kk) is row (r & 3) + 8 (r >> 2) + 4 kk, column li
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[q][((r & 3) + 8 * (r >> 2) + 4 * kk) * LDT + 32 * j + li] = acc[j][r];
+  __syncthreads();
+  // thread -> row tid >> 3, four columns at (tid & 7) * 4 of every 32-column block; quarters summed k ascending
+  {
+    const int row = tid >> 3;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int c4 = (tid & 7) * 4 + 32 * j;
+      const float4 v0 = ld4(&red[0][row * LDT + c4]), v1 = ld4(&red[1][row * LDT + c4]);
+      const float4 v2 = ld4(&red[2][row * LDT + c4]), v3 = ld4(&red[3][row * LDT + c4]);
+      float v[4] = {((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y, ((v0.z + v1.z) + v2.z) + v3.z,
+                    ((v0.w + v1.w) + v2.w) + v3.w};
+      const int col = n0 + c4;
+      if (g.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] += g.bias[col + t < g.n ? col + t : g.n - 1];
+      }
+      if (m0 + row < g.m) {
+        float* cp = g.c + (m0 + row) * g.ldc + col;
+        if (g.c_vec && col + 3 < g.n) {
+          *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (col + t < g.n) cp[t] = v[t];
+        }
+      }
+      if (EPI != EPI_PLAIN) *reinterpret_cast<float4*>(&red[0][row * LDT + c4]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  if (EPI == EPI_PLAIN) return;
+  __syncthreads();
+
+  if (EPI == EPI_STATS) {
+    // (mean, M2) of the tile's rows per column: thread = (column c, 4-row group gq); two passes over LDS
+    __shared__ float ps[8][32];
+    const int c = tid & 31, gq = tid >> 5;
+    const int cnt = g.m - m0 < 32 ? (int)(g.m - m0) : 32;
+    float x[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[i] = red[0][(gq * 4 + i) * LDT + c];
+      s += gq * 4 + i < cnt ? x[i] : 0.f;
+    }
+    ps[gq][c] = s;
+    __syncthreads();
+    const float mean = (((ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c])) + ((ps[4][c] + ps[5][c]) + (ps[6][c] + ps[7][c]))) / (float)cnt;
+    __syncthreads();
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dlt = x[i] - mean;
+      qv = gq * 4 + i < cnt ? fmaf(dlt, dlt, qv) : qv;
+    }
+    ps[gq][c] = qv;
+    __syncthreads();
+    if (gq == 0 && n0 + c < g.n) {
+      const float m2 = ((ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c])) + ((ps[4][c] + ps[5][c]) + (ps[6][c] + ps[7][c]));
+      st_part(&g.ws_mean[(int64_t)blockIdx.x * g.n + n0 + c], mean, true);
+      st_part(&g.ws_m2[(int64_t)blockIdx.x * g.n + n0 + c], m2, true);
+    }
+    const int cb = n0 >> 6;                                         // 64-column block of the finalize; its 1 or 2 column tiles
+    const int col_tiles = g.n - 64 * cb > 32 ? 2 : 1;
+    if (last_workgroup(&g.counters[cb], (int)gridDim.x * col_tiles)) bn_finalize_columns<true>(fin, cb);
+    return;
+  }
+
+  if (EPI == EPI_LOSS) {
+    // rows of the tile are complete (n <= 64 = one tile).  All 32 rows at once: 8 threads per row, 8 classes per thread, the row
+    // reductions are 3 xor-shuffle steps inside the 8-lane group (a wave per row walked 8 rows x 4 reductions x 6 steps in sequence:
+    // 22 us for this kernel).  Same formulas as softmax_loss_kernel; the sums over classes associate differently.
+    const int r = tid >> 3, j8 = (tid & 7) * 8;
+    const int64_t row = m0 + r;
+    float z[8], gk[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      z[t] = j8 + t < ls.c ? red[0][r * LDT + j8 + t] : -INFINITY;
+      mx = fmaxf(mx, z[t]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 4));
+    float se = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) se += j8 + t < ls.c ? expf(z[t] - mx) : 0.f;
+    se += __shfl_xor(se, 1); se += __shfl_xor(se, 2); se += __shfl_xor(se, 4);
+    const float lse = mx + logf(se);
+    float row_loss = 0.f;
+    if (ls.kind == GLNN_LOSS_NLL) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float lp = z[t] - lse;
+        const bool hit = (int64_t)(j8 + t) == yv;
+        gk[t] = (expf(lp) - (hit ? 1.f : 0.f)) * ls.scale;
+        row_loss += (hit && j8 + t < ls.c) ? -lp : 0.f;
+      }
+    } else {
+      float et[8];
+      float set = 0.f;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        et[t] = j8 + t < ls.c ? expf(tv[t]) : 0.f;
+        set += et[t];
+      }
+      set += __shfl_xor(set, 1); set += __shfl_xor(set, 2); set += __shfl_xor(set, 4);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const float lp = z[t] - lse;
+        row_loss += j8 + t < ls.c ? et[t] * (tv[t] - lp) : 0.f;
+        gk[t] = (expf(lp) * set - et[t]) * ls.scale;
+      }
+    }
+    row_loss += __shfl_xor(row_loss, 1); row_loss += __shfl_xor(row_loss, 2); row_loss += __shfl_xor(row_loss, 4);
+    const bool row_ok = row < g.m;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bool ok = row_ok && j8 + t < ls.c;
+      if (ok) ls.dz[row * ls.ldg + j8 + t] = gk[t];
+      red[1][r * LDT + j8 + t] = ok ? gk[t] : 0.f;         // for the column sums (the bias gradient) below
+    }
+    __shared__ float rl[32];
+    __shared__ float sc4[4][64];
+    if ((tid & 7) == 0) rl[r] = row_ok ? row_loss : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+      float l = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) l += rl[i];
+      st_part(&ls.partial[blockIdx.x], l, true);
+    }
+    if (ls.col_sum && tid < 64) {
+      float cs = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) cs += red[1][i * LDT + tid];
+      st_part(&ls.col_partial[(int64_t)blockIdx.x * 64 + tid], cs, true);
+    }
+    if (!last_workgroup(ls.counter, (int)gridDim.x)) return;
+    loss_fold_last(ls, (int)gridDim.x, sc4);
+  }
+}
+
+template <int NB, int EPI>
+int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, bool b_kn, hipStream_t st) {
+  const dim3 grid((unsigned)((g.m + 31) / 32), (unsigned)((g.n + 32 * NB - 1) / (32 * NB)));
+  const int xf = !g.a_scale ? 0 : (g.drop_thr ? 2 : 1);
+#define GLNN_LAT_LAUNCH(XF_, KN_) hipLaunchKernelGGL((gemm_lat_kernel<XF_, KN_, NB, EPI>), grid, dim3(256), 0, st, g, fin, ls)
+  if (b_kn) {
+    if (xf == 0) GLNN_LAT_LAUNCH(0, true); else if (xf == 1) GLNN_LAT_LAUNCH(1, true); else GLNN_LAT_LAUNCH(2, true);
+  } else {
+    if (xf == 0) GLNN_LAT_LAUNCH(0, false); else if (xf == 1) GLNN_LAT_LAUNCH(1, false); else GLNN_LAT_LAUNCH(2, false);
+  }
+#undef GLNN_LAT_LAUNCH
+  return glnn::check_launch("glnn::gemm_lat");
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace
+
+// C[m,n] = A'[m,k] * B + bias with an optional fused epilogue (st: BatchNorm statistics + finalize | ls: loss + dlogits); at most one
+// of st / ls.  GLNN_ERR_UNSUPPORTED (nothing launched, no error text) when the problem is outside the latency regime or an operand
+// is not float4-addressable: the caller then issues the tiled GEMM and the separate reduction kernels.
+int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
+                   uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
+                   int64_t ldc, const LatStats* st, const LatLoss* ls, void* stream) {
+  static const int enabled = env_int("GLNN_GEMM_LAT", 1);
+  static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
+  static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
+  if (!enabled || !a || !b || !c || m < 1 || m > max_m || k < 4 || k > max_k || n < 1 || n > max_n || (st && ls)) return GLNN_ERR_UNSUPPORTED;
+  const int kpad = (k + 3) & ~3;
+  if (lda % 4 || !glnn::aligned16(a) || lda < kpad) return GLNN_ERR_UNSUPPORTED;
+  if (!b_layout && (ldb % 4 || !glnn::aligned16(b) || ldb < kpad)) return GLNN_ERR_UNSUPPORTED;
+  if (b_layout && ldb < n) return GLNN_ERR_UNSUPPORTED;
+  if ((a_scale == nullptr) != (a_shift == nullptr)) return GLNN_ERR_UNSUPPORTED;
+  if (a_scale && (k % 4 || !glnn::aligned16(a_scale) || !glnn::aligned16(a_shift))) return GLNN_ERR_UNSUPPORTED;
+  if (drop_p > 0.f && !a_scale) return GLNN_ERR_UNSUPPORTED;
+  const int64_t mt = (m + 31) / 32;
+  LatArgs g = {};
+  g.a = a; g.lda = lda; g.a_rows = a_rows; g.a_scale = a_scale; g.a_shift = a_shift;
+  g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
+  g.m = m; g.k = k; g.b = b; g.ldb = ldb; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
+  g.c_vec = (ldc % 4 == 0) && glnn::aligned16(c);
+  const int groups = (k + 7) / 8;
+  g.gpw = (groups + 3) / 4;
+  BnFinArgs fin = {};
+  LossArgs la = {};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (st) {
+    if (!st->counters || !st->ws || st->ws_floats < 2 * mt * n || !st->a_scale_out || !st->a_shift_out || (n + 63) / 64 > 512)
+      return GLNN_ERR_UNSUPPORTED;
+    g.ws_mean = st->ws; g.ws_m2 = st->ws + mt * n; g.counters = st->counters;
+    fin.ws_mean = g.ws_mean; fin.ws_m2 = g.ws_m2; fin.nparts = (int)mt; fin.pstride = n; fin.rows = m; fin.h = n; fin.chunk_rows = 32;
+    fin.gamma = st->gamma; fin.beta = st->beta; fin.eps = st->eps; fin.momentum = st->momentum; fin.running_mean = st->running_mean;
+    fin.running_var = st->running_var; fin.nbt = st->nbt; fin.mean_out = st->mean_out; fin.rstd_out = st->rstd_out;
+    fin.a_scale = st->a_scale_out; fin.a_shift = st->a_shift_out;
+    return launch_lat<1, EPI_STATS>(g, fin, la, b_layout != 0, s);
+  }
+  if (ls) {
+    if (n > 64 || !ls->counter || !ls->ws || ls->ws_floats < mt * 65 || !ls->dlogits || ls->ldg < n) return GLNN_ERR_UNSUPPORTED;
+    if (ls->kind == GLNN_LOSS_NLL ? !ls->labels : (ls->kind != GLNN_LOSS_KL || !ls->target_logp || ls->ldt < n)) return GLNN_ERR_UNSUPPORTED;
+    la.z = c; la.ldz = ldc; la.rows = m; la.c = n; la.kind = ls->kind; la.labels = ls->labels; la.label_rows = ls->label_rows;
+    la.t = ls->target_logp; la.ldt = ls->ldt; la.t_rows = ls->target_rows; la.scale = ls->lamb / (float)m;
+    la.dz = ls->dlogits; la.ldg = ls->ldg; la.partial = ls->ws; la.counter = ls->counter; la.inv_rows = 1.0f / (float)m;
+    la.loss_out = ls->loss_out; la.loss_accum = ls->loss_accum; la.col_sum = ls->col_sum; la.col_partial = ls->ws + mt;
+    return launch_lat<2, EPI_LOSS>(g, fin, la, b_layout != 0, s);
+  }
+  return launch_lat<1, EPI_PLAIN>(g, fin, la, b_layout != 0, s);
+}

@@ -49,14 +49,44 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   }
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
+  // with sync counters the loss kernel's last workgroup also finalises the loss and the last layer's bias gradient
+  const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
+  bool loss_done = false;
   for (int l = 0; l < L; ++l) {
     const bool last = (l == L - 1);
+    bool stats_done = false;
     float* out = last ? d->logits : d->z[l];
     const int64_t ldo = last ? d->ld_logits : d->ldz[l];
     const bool recompute = l > 0 && a_scale != nullptr;     // the previous layer's tail evaluated in this GEMM's operand load
-    GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, recompute ? p : 0.f, (recompute && p > 0.f) ? drop_seeds[l - 1] : 0u, m,
-                           d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
-                           d->ws_gemm, d->ws_gemm_floats, stream));
+    const float gp = recompute ? p : 0.f;
+    const uint32_t gseed = (recompute && p > 0.f) ? drop_seeds[l - 1] : 0u;
+    // small batches: the latency GEMM with the reduction behind it as epilogue (mlp_lat.hip) -- the BatchNorm statistics of a hidden
+    // layer, log_softmax + loss + dlogits (+ the bias gradient) of the last one.  UNSUPPORTED = the tiled GEMM + separate kernels below
+    int lat = GLNN_ERR_UNSUPPORTED;
+    if (cnt && !layernorm) {
+      if (last && fused_bias) {
+        const glnn::LatLoss ll = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
+                                  kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out,
+                                  d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1]};
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+                             out, ldo, nullptr, &ll, stream);
+        loss_done = lat == GLNN_OK;
+      } else if (!last && d->batchnorm == 1) {
+        const glnn::LatStats ls = {d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum, d->running_mean[l], d->running_var[l], d->nbt[l],
+                                   d->mean[l], d->rstd[l], d->a_scale[l], d->a_shift[l], d->ws_bn, d->ws_bn_floats, cnt};
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+                             out, ldo, &ls, nullptr, stream);
+        stats_done = lat == GLNN_OK;
+      } else if (!last) {
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+                             out, ldo, nullptr, nullptr, stream);
+      }
+      if (lat != GLNN_OK && lat != GLNN_ERR_UNSUPPORTED) return lat;
+    }
+    if (lat != GLNN_OK)
+      GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, gp, gseed, m,
+                             d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
+                             d->ws_gemm, d->ws_gemm_floats, stream));
     if (!last && layernorm) {
       // LayerNorm -> ReLU -> dropout in one row-wise pass; the tail is always materialised (per-row statistics cannot ride in a
       // GEMM operand transform); mean[l] / rstd[l] hold the per-ROW statistics (max_batch floats each) for the backward
@@ -68,7 +98,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       src = d->act[l];
       ld_src = d->ld_act[l];
     } else if (!last) {
-      if (d->batchnorm)
+      if (d->batchnorm && !stats_done)
         GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                    d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
                                    d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
@@ -89,8 +119,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     }
   }
   // ---- loss + dlogits ----
-  // with sync counters the loss kernel's last workgroup also finalises the loss and the last layer's bias gradient
-  const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
+  if (!loss_done)
   GLNN_TRY(glnn::softmax_loss(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
                               target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
@@ -169,6 +198,11 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       // ws_gemm is idle during the backward (two-stream form: the first layer's weight gradient borrows it, and never overlaps this
       // call): deep, skinny input gradients (B = 512, 1024 wide: 128 tiles x 32 dependent k-tiles) may split their reduction
       const bool ws_free = !two;
+      if (cnt && !two) {
+        const int rc = glnn::gemm_lat(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
+                                      nullptr, d->da, d->ld_da, nullptr, nullptr, stream);
+        if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+      }
       return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, ws_free ? d->ws_gemm : nullptr, ws_free ? d->ws_gemm_floats : 0, stream);
     };

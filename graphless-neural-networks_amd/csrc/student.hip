@@ -8,69 +8,13 @@
 #include <cstdlib>
 
 #include "glnn_common.h"
+#include "student_dev.h"
 
 namespace {
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// "Last workgroup finishes the reduction": every workgroup publishes its partials, bumps a counter, and the one that sees
-// the final count folds all partials in fixed order -- the second (finalize) launch of a two-stage reduction disappears
-// (each launch costs ~5 us of device-side latency in the small-batch student step, whatever it computes).  The counter
-// must be 0 on entry and is reset by the last workgroup; callers that cannot guarantee that (the plain C entry points,
-// whose workspaces are uninitialised) pass NULL and get the two-launch form.
-// Cross-workgroup visibility WITHOUT a device-scope fence (which writes back / invalidates the XCD's whole L2 -- measured:
-// the fenced form made the MLP3w8 step 25 % SLOWER): the partials are published with relaxed agent-scope atomic stores
-// (write-through past the per-XCD L2) and read back by the last workgroup with relaxed agent-scope atomic loads.
-// ORDER: a relaxed store followed by __syncthreads() is NOT enough -- the workgroup-scope fence of the barrier does not
-// wait for the write-through (the gfx950 ISA had `global_store_dword ... sc1; s_barrier; global_atomic_add` with no
-// s_waitcnt vmcnt(0) in between), so another XCD could see the final count before the partials.  Every storing wave
-// therefore drains its own vector-memory queue (publish_drain) before the barrier in front of the counter update;
-// tests/test_capi_symbols.py asserts the s_waitcnt vmcnt(0) on the generated ISA.
-__device__ __forceinline__ void st_part(float* p, float v, bool shared) {
-  if (shared) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-__device__ __forceinline__ float ld_part(const float* p) {
-  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// all of this wave's global stores (incl. the write-through partials) have been acknowledged by the memory system
-__device__ __forceinline__ void publish_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ bool last_workgroup(int* counter, int total) {
-  __shared__ int s_last;
-  publish_drain();                                   // this wave's partial stores have been acknowledged ...
-  __syncthreads();                                   // ... and so have every other wave's of the workgroup
-  if (threadIdx.x == 0) {
-    const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (prev == total - 1);
-    if (s_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  return s_last != 0;
-}
 
 // ------------------------------------------------------------------------------------------
 // K4: one wavefront per row (c <= 64: one class per lane; larger c loops), 4 rows per workgroup.
 // ------------------------------------------------------------------------------------------
-struct LossArgs {
-  const float* z; int64_t ldz; int64_t rows; int c; int kind;
-  const int64_t* labels; const int64_t* label_rows;
-  const float* t; int64_t ldt; const int64_t* t_rows;
-  float scale;  // lamb / rows
-  float* dz; int64_t ldg; float* logp; int64_t ldl;
-  float* partial;  // [gridDim.x] per-block loss sums, or NULL (log_softmax only)
-  // fused finalize (counter != NULL): the last workgroup writes the loss (and, with col_sum != NULL and c <= 64, the
-  // column sums of dz = the bias gradient of the layer that produced the logits; col_partial [gridDim.x][64] scratch)
-  int* counter; float inv_rows; float* loss_out; float* loss_accum; float* col_sum; float* col_partial;
-};
 
 template <bool LOSS>
 __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
@@ -132,30 +76,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
     if (!a.counter) return;
     if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]), true);
     if (!last_workgroup(a.counter, (int)gridDim.x)) return;
-    // ---- last workgroup: loss = sum of the per-workgroup partials / rows (fixed order); column sums of dz ----
-    __shared__ float red[256];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) v += ld_part(&a.partial[i]);
-    red[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      const float l = red[0] * a.inv_rows;
-      if (a.loss_out) a.loss_out[0] = l;
-      if (a.loss_accum) a.loss_accum[0] += l;
-    }
-    if (a.col_sum) {
-      float cs = 0.f;                                   // 4 partial lanes per column, folded in fixed order
-#pragma unroll 8
-      for (int k = wave; k < (int)gridDim.x; k += 4) cs += ld_part(&a.col_partial[(int64_t)k * 64 + lane]);
-      __syncthreads();
-      sc[wave][lane] = cs;
-      __syncthreads();
-      if (threadIdx.x < a.c) a.col_sum[threadIdx.x] = (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]);
-    }
+    loss_fold_last(a, (int)gridDim.x, sc);
   }
 }
 
@@ -181,99 +102,6 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 // K5: BatchNorm statistics.  Stage 1: per (row-chunk, column) mean and M2 by a two-pass over the
 // chunk (second pass hits L1/L2); stage 2: Chan's pairwise combine in double, fixed order.
 // ------------------------------------------------------------------------------------------
-constexpr int kBnRows = 128;  // rows per chunk
-
-// Column kernels below share one mapping: a workgroup owns 64 columns x one chunk of kBnRows rows; thread =
-// (column = tid & 63, row lane = tid >> 6); a row lane walks rows r0 + lane + 4*i.  Loads are issued 8 rows at a
-// time from clamped (always valid) addresses so that they pipeline instead of serialising on a loop-carried
-// dependence; rows past the chunk end are masked arithmetically.
-constexpr int kRowLanes = 4;
-constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
-constexpr int kUnroll = 8;
-constexpr int kBnGroup = 64;      // partial triples per first-level group of the two-level statistics combine
-constexpr int kManyChunks = 48;   // row chunks above which per-chunk partials are folded by a lane-split pass (> ~6k rows)
-
-struct BnFinArgs {
-  // partial k of column c:  mean = ws_mean[k*pstride + c], M2 = ws_m2[k*pstride + c], count = ws_cnt ? ws_cnt[k*pstride + c]
-  // : rows of chunk k.  (Local chunks: pstride = h, ws_cnt = NULL.  Gathered per-rank triples: pstride = 3h.)
-  const float* ws_cnt; const float* ws_mean; const float* ws_m2; int nparts; int64_t pstride; int64_t rows; int h;
-  // emit mode (emit_cnt != NULL): write the combined (count, mean, M2) and stop -- the per-rank triple that is exchanged
-  float* emit_cnt; float* emit_mean; float* emit_m2;
-  // group_len > 0 (emit mode only): workgroup (x, y) combines the partials [y*group_len, (y+1)*group_len) and emits triple y
-  // (row y of the emit arrays): the first level of a two-level combine for thousands of row chunks
-  int group_len;
-  const float* gamma; const float* beta; float eps; float momentum;
-  float* running_mean; float* running_var; int64_t* nbt;
-  float* mean_out; float* rstd_out; float* a_scale; float* a_shift; float* rows_out;
-};
-
-__device__ __forceinline__ double part_count(const BnFinArgs& a, int k, int col) {
-  if (a.ws_cnt) return (double)a.ws_cnt[(int64_t)k * a.pstride + col];
-  int64_t r0 = (int64_t)k * kBnRows, r1 = r0 + kBnRows;
-  if (r1 > a.rows) r1 = a.rows;
-  return (double)(r1 - r0);
-}
-
-// One workgroup = 64 columns x 4 partial lanes (the column kernels' mapping): lane rl combines partials rl, rl+4, ... ; the
-// four lane results are combined in fixed order through LDS.  (A single thread per column walked the nparts partials as
-// one chain of dependent L2 round trips: 13-21 us for 32 partials.)
-template <bool COH>      // COH: the partials were published by other workgroups of THIS launch -> read them past the L2
-__device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colblock) {
-  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = colblock * 64 + lc;
-  const int colc = col < a.h ? col : a.h - 1;
-  if (colblock == 0 && threadIdx.x == 0 && a.nbt && !a.emit_cnt) a.nbt[0] += 1;
-  const int p0 = a.group_len > 0 ? (int)blockIdx.y * a.group_len : 0;
-  const int p1 = a.group_len > 0 ? (p0 + a.group_len < a.nparts ? p0 + a.group_len : a.nparts) : a.nparts;
-  const int64_t eoff = a.group_len > 0 ? (int64_t)blockIdx.y * a.h : 0;
-  __shared__ double sh_n[kRowLanes][64], sh_s[kRowLanes][64];
-  // combine of the partial (count, mean, M2) triples in double, fixed order, without a loop-carried divide:
-  //   N = sum n_k ;  mean = sum n_k*mean_k / N ;  M2 = sum [ M2_k + n_k*(mean_k - mean)^2 ]
-  double n = 0.0, sum = 0.0;
-#pragma unroll 4
-  for (int k = p0 + rl; k < p1; k += kRowLanes) {
-    const double nb = part_count(a, k, colc);
-    n += nb;
-    sum += nb * (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]);
-  }
-  sh_n[rl][lc] = n;
-  sh_s[rl][lc] = sum;
-  __syncthreads();
-  n = (sh_n[0][lc] + sh_n[1][lc]) + (sh_n[2][lc] + sh_n[3][lc]);
-  const double mean = ((sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc])) / n;
-  __syncthreads();
-  double m2 = 0.0;
-#pragma unroll 4
-  for (int k = p0 + rl; k < p1; k += kRowLanes) {
-    const double nb = part_count(a, k, colc);
-    const double dm = (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]) - mean;
-    m2 += (double)(COH ? ld_part(&a.ws_m2[(int64_t)k * a.pstride + colc]) : a.ws_m2[(int64_t)k * a.pstride + colc]) + nb * dm * dm;     // nb == 0: an empty slice contributes nothing
-  }
-  sh_s[rl][lc] = m2;
-  __syncthreads();
-  if (rl != 0 || col >= a.h) return;
-  m2 = (sh_s[0][lc] + sh_s[1][lc]) + (sh_s[2][lc] + sh_s[3][lc]);
-  if (a.emit_cnt) {
-    a.emit_cnt[eoff + col] = (float)n;
-    a.emit_mean[eoff + col] = (float)mean;
-    a.emit_m2[eoff + col] = (float)m2;
-    return;
-  }
-  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
-  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
-  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
-  const float meanf = (float)mean;
-  const float rstd = 1.0f / sqrtf(var_b + a.eps);
-  if (a.mean_out) a.mean_out[col] = meanf;
-  if (a.rstd_out) a.rstd_out[col] = rstd;
-  const float g = a.gamma ? a.gamma[col] : 1.f, b = a.beta ? a.beta[col] : 0.f;
-  const float sc = g * rstd;
-  a.a_scale[col] = sc;
-  a.a_shift[col] = b - meanf * sc;
-  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
-  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
-}
-
 __global__ __launch_bounds__(256) void bn_stats_stage2(const BnFinArgs a) { bn_finalize_columns<false>(a, blockIdx.x); }
 
 // counters != NULL: the last row-chunk workgroup of a column block runs the stage-2 combine for its 64 columns itself.

@@ -1,6 +1,6 @@
 """Steady-state slice of a rocprofv3 kernel trace with the queue id: start, end, duration, queue, kernel."""
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"))[-1]
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 skip, count = int(sys.argv[2]), int(sys.argv[3])
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 ours = [r for r in rows if "anonymous namespace" in r["Kernel_Name"] or "act_fwd" in r["Kernel_Name"]]
