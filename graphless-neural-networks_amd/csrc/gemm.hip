@@ -50,6 +50,7 @@ struct GemmArgs {
   int a_vec; int b_vec;  // 1 = float4 loads are aligned and in-bounds
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;   // drop_thr == 0: no dropout
   int ksplits; int ktiles_per_split; float* ws;               // split-K (fast kernel): raw partials -> ws[z][m][n]
+  int defer_fold;     // host side only: the split-K partials are folded (sum over z + epilogue) by the CONSUMER of C, not by a launch here
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -1335,7 +1336,7 @@ int launch_gemm_kernel(K kernel, int& configured, size_t smem, const GemmArgs& g
   if (gm > 0x7fffffffLL) return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_gemm_f32: m too large");
   hipLaunchKernelGGL(kernel, dim3((unsigned)gm, (unsigned)gn, (unsigned)g.ksplits), dim3(256), smem, st, g);
   int rc = glnn::check_launch("glnn_gemm_f32");
-  if (rc == GLNN_OK && g.ksplits > 1) {
+  if (rc == GLNN_OK && g.ksplits > 1 && !g.defer_fold) {
     int64_t blocks = (g.m * g.n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g);
@@ -1393,10 +1394,10 @@ int launch_gemm_small(GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
-                             const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
-                             const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
-                             int64_t ldc, float* workspace, int64_t workspace_floats, void* stream) {
+static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
+                     const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
+                     const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
+                     int64_t ldc, float* workspace, int64_t workspace_floats, void* stream, int* defer_splits) {
   GLNN_REQUIRE(a && b && c, "glnn_gemm_f32: null pointer");
   GLNN_REQUIRE(m >= 0 && k >= 1 && n >= 1, "glnn_gemm_f32: bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
   GLNN_REQUIRE(lda >= k && ldc >= n, "glnn_gemm_f32: lda/ldc too small");
@@ -1415,7 +1416,7 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   // true for A when lda >= roundup4(k); for B only when ldb >= roundup4(extent).
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
-  g.ksplits = 1; g.ktiles_per_split = (k + BK - 1) / BK; g.ws = nullptr;
+  g.ksplits = 1; g.ktiles_per_split = (k + BK - 1) / BK; g.ws = nullptr; g.defer_fold = 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // fast path: all float4 loads legal and all-or-nothing at the k (and, for [k,n], n) boundary
   const bool fast = g.a_vec && g.b_vec && lda >= ((k + 3) & ~3) && ldb >= (((b_layout ? n : k) + 3) & ~3) &&
@@ -1438,9 +1439,15 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
           g.ws = workspace;
         }
       }
+      if (defer_splits) {                       // partials only: the caller's next kernel sums the slabs ws[z][m][n] (and adds the bias)
+        if (g.ksplits <= 1) return GLNN_ERR_UNSUPPORTED;
+        g.defer_fold = 1;
+        *defer_splits = g.ksplits;
+      }
       return b_layout ? launch_gemm_small<true>(g, st) : launch_gemm_small<false>(g, st);
     }
   }
+  if (defer_splits) return GLNN_ERR_UNSUPPORTED;
   // split-K when the output has too few tiles to fill 256 CUs twice over and K is deep enough
   if (fast && workspace) {
     const int bn = n > 64 ? 128 : 64;
@@ -1463,6 +1470,26 @@ extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows,
   }
   if (n > 64) return b_layout ? launch_gemm<128, true>(g, fast, st) : launch_gemm<128, false>(g, fast, st);
   return b_layout ? launch_gemm<64, true>(g, fast, st) : launch_gemm<64, false>(g, fast, st);
+}
+
+extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
+                             const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
+                             const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
+                             int64_t ldc, float* workspace, int64_t workspace_floats, void* stream) {
+  return gemm_impl(a, lda, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, b, ldb, b_layout, n, row_scale, ep_scale, ep_shift, relu, c, ldc,
+                   workspace, workspace_floats, stream, nullptr);
+}
+
+// The split-K product of the latency regime WITHOUT its fold launch: raw partial sums workspace[z][m][n], z < *splits; the kernel that
+// consumes C = sum_z + bias reads the slabs itself (student.hip: the loss kernel).  GLNN_ERR_UNSUPPORTED (nothing launched) when this
+// problem would not be split -- the caller then takes glnn_gemm_f32.
+int glnn::gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
+                              uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, float* workspace,
+                              int64_t workspace_floats, int* splits, void* stream) {
+  if (!a || !b || !workspace || !splits || m < 1 || k < 1 || n < 1 || lda < k || ldb < (b_layout ? n : k)) return GLNN_ERR_UNSUPPORTED;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (drop_p > 0.f && !a_scale) || drop_p < 0.f || drop_p >= 1.f) return GLNN_ERR_UNSUPPORTED;
+  return gemm_impl(a, lda, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, b, ldb, b_layout, n, nullptr, nullptr, nullptr, 0, workspace, n,
+                   workspace, workspace_floats, stream, splits);
 }
 
 // ---- several independent weight gradients in ONE gemm launch + ONE fold launch (see gemm_tn_multi_kernel) -------------------

@@ -72,7 +72,9 @@ int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamm
 int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels, const int64_t* label_rows,
                  const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
                  float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum, float* workspace, int64_t workspace_floats,
-                 void* stream, int* counter, float* col_sum);
+                 void* stream, int* counter, float* col_sum, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr);
+// slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
+// bias added and the result stored to `logits` by the loss kernel itself
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
@@ -85,6 +87,10 @@ struct TnProblem {
   const float* b_shift; float drop_p; uint32_t drop_seed; int nb; float* c; int64_t ldc;
 };
 int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream);
+// gemm.hip: split-K partials only (the consumer folds) -- see the definition
+int gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
+                        uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, float* workspace,
+                        int64_t workspace_floats, int* splits, void* stream);
 
 // mlp_lat.hip: the latency form of a student layer (m <= ~1k rows, k <= 256): C = A' * B + bias in 32-row tiles whose four waves split
 // K, with the reduction that used to be the next launch as epilogue.  GLNN_ERR_UNSUPPORTED = not launched, use the tiled kernels.
@@ -98,6 +104,7 @@ struct LatLoss {       // log_softmax + loss + dlogits on C (n <= 64) (arguments
 };
 int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
              uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
-             int64_t ldc, const LatStats* st, const LatLoss* ls, void* stream);
+             int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream);
+int bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream);
 
 }  // namespace glnn

@@ -44,11 +44,16 @@ __device__ __forceinline__ float4 keep_first(float4 v, int left) {   // elements
 
 // XF: 0 = A as stored; 1 = relu(a * scale[k] + shift[k]); 2 = 1 followed by the counter-hash dropout of glnn_common.h.
 // B_KN: B given as W[k, n] (the input-gradient product) instead of W[n, k].  NB: 32-column MFMA blocks per workgroup tile.
-template <int XF, bool B_KN, int NB, int EPI>
-__global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const BnFinArgs fin, const LossArgs ls) {
+// FIN (XF >= 1 only): a_scale / a_shift are not in memory yet -- the producing launch left per-tile (mean, M2) partials of A's
+// columns (`pend`); every workgroup combines them itself while its operand loads are in flight, and workgroup (0, 0) also stores what
+// the statistics kernel would have (mean / rstd / a_scale / a_shift for the backward, the running statistics).
+constexpr int kFinMaxK = 1024;
+template <int XF, bool B_KN, int NB, int EPI, bool FIN>
+__global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const BnFinArgs fin, const LossArgs ls, const BnFinArgs pend) {
   constexpr int TN = 32 * NB;
   constexpr int LDT = TN + 4;
   __shared__ __attribute__((aligned(16))) float red[4][32 * LDT];
+  __shared__ __attribute__((aligned(16))) float s_sc[FIN ? kFinMaxK : 4], s_sh[FIN ? kFinMaxK : 4];
   const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, li = lane & 31, kk = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * 32;
   const int n0 = blockIdx.y * TN;
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
       const int kc = (q * g.gpw + c0 + u) * 8 + kk * 4;
       const int kcc = kc > kpad - 4 ? kpad - 4 : kc;
       av[u] = ld4(ap + kcc);
-      if (XF) {
+      if (XF && !FIN) {
         sc[u] = ld4(g.a_scale + kcc);
         sh[u] = ld4(g.a_shift + kcc);
       }
@@ -115,6 +120,44 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
         } else {
           bv[j][u] = ld4(bp[j] + kcc);
         }
+      }
+    }
+    if (FIN) {
+      if (c0 == 0) {              // the chunk's operand loads are in flight: combine the pending statistics of A's columns meanwhile
+        for (int col = tid; col < g.k; col += 256) {
+          const float gam = pend.gamma ? pend.gamma[col] : 1.f, bet = pend.beta ? pend.beta[col] : 0.f;
+          double n = 0.0, sum = 0.0, qs = 0.0;
+          for (int k0 = 0; k0 < pend.nparts; k0 += 16) {        // 32 loads in flight (clamped addresses), then the arithmetic
+            float mk[16], m2k[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int kx = k0 + i < pend.nparts ? k0 + i : pend.nparts - 1;
+              mk[i] = pend.ws_mean[(int64_t)kx * pend.pstride + col];
+              m2k[i] = pend.ws_m2[(int64_t)kx * pend.pstride + col];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int64_t left = pend.rows - (int64_t)(k0 + i) * 32;       // rows of tile k0 + i (the partials are this file's 32-row tiles)
+              const double nb = k0 + i < pend.nparts ? (double)(left < 32 ? left : 32) : 0.0;
+              n += nb;
+              sum += nb * (double)mk[i];
+              qs += (k0 + i < pend.nparts ? (double)m2k[i] : 0.0) + nb * (double)mk[i] * (double)mk[i];
+            }
+          }
+          const double mean = sum / n;
+          double m2 = qs - sum * mean;
+          if (m2 < 0.0) m2 = 0.0;
+          if (col == 0 && blockIdx.x == 0 && blockIdx.y == 0 && pend.nbt) pend.nbt[0] += 1;
+          bn_emit_column(pend, col, n, mean, m2, blockIdx.x == 0 && blockIdx.y == 0, gam, bet, s_sc[col], s_sh[col]);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int u = 0; u < kGroups; ++u) {
+        const int kc = (q * g.gpw + c0 + u) * 8 + kk * 4;
+        const int kcc = kc > kpad - 4 ? kpad - 4 : kc;
+        sc[u] = ld4(&s_sc[kcc]);
+        sh[u] = ld4(&s_sh[kcc]);
       }
     }
 #pragma unroll
@@ -212,9 +255,10 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
     __syncthreads();
     if (gq == 0 && n0 + c < g.n) {
       const float m2 = ((ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c])) + ((ps[4][c] + ps[5][c]) + (ps[6][c] + ps[7][c]));
-      st_part(&g.ws_mean[(int64_t)blockIdx.x * g.n + n0 + c], mean, true);
-      st_part(&g.ws_m2[(int64_t)blockIdx.x * g.n + n0 + c], m2, true);
+      st_part(&g.ws_mean[(int64_t)blockIdx.x * g.n + n0 + c], mean, g.counters != nullptr);
+      st_part(&g.ws_m2[(int64_t)blockIdx.x * g.n + n0 + c], m2, g.counters != nullptr);
     }
+    if (!g.counters) return;                 // deferred: the next layer's launch combines the partials in its prologue (FIN)
     const int cb = n0 >> 6;                                         // 64-column block of the finalize; its 1 or 2 column tiles
     const int col_tiles = g.n - 64 * cb > 32 ? 2 : 1;
     if (last_workgroup(&g.counters[cb], (int)gridDim.x * col_tiles)) bn_finalize_columns<true>(fin, cb);
@@ -295,14 +339,19 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
 }
 
 template <int NB, int EPI>
-int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, bool b_kn, hipStream_t st) {
+int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, const BnFinArgs* pend, bool b_kn, hipStream_t st) {
   const dim3 grid((unsigned)((g.m + 31) / 32), (unsigned)((g.n + 32 * NB - 1) / (32 * NB)));
-  const int xf = !g.a_scale ? 0 : (g.drop_thr ? 2 : 1);
-#define GLNN_LAT_LAUNCH(XF_, KN_) hipLaunchKernelGGL((gemm_lat_kernel<XF_, KN_, NB, EPI>), grid, dim3(256), 0, st, g, fin, ls)
+  const int xf = (!g.a_scale && !pend) ? 0 : (g.drop_thr ? 2 : 1);
+  const BnFinArgs none = {};
+#define GLNN_LAT_LAUNCH(XF_, KN_, FIN_) \
+  hipLaunchKernelGGL((gemm_lat_kernel<XF_, KN_, NB, EPI, FIN_>), grid, dim3(256), 0, st, g, fin, ls, pend ? *pend : none)
   if (b_kn) {
-    if (xf == 0) GLNN_LAT_LAUNCH(0, true); else if (xf == 1) GLNN_LAT_LAUNCH(1, true); else GLNN_LAT_LAUNCH(2, true);
+    if (xf != 0 || EPI != EPI_PLAIN) return GLNN_ERR_UNSUPPORTED;       // the input-gradient product: plain operands, no epilogue
+    if constexpr (EPI == EPI_PLAIN) GLNN_LAT_LAUNCH(0, true, false);
+  } else if (pend) {
+    if (xf == 1) GLNN_LAT_LAUNCH(1, false, true); else GLNN_LAT_LAUNCH(2, false, true);
   } else {
-    if (xf == 0) GLNN_LAT_LAUNCH(0, false); else if (xf == 1) GLNN_LAT_LAUNCH(1, false); else GLNN_LAT_LAUNCH(2, false);
+    if (xf == 0) GLNN_LAT_LAUNCH(0, false, false); else if (xf == 1) GLNN_LAT_LAUNCH(1, false, false); else GLNN_LAT_LAUNCH(2, false, false);
   }
 #undef GLNN_LAT_LAUNCH
   return glnn::check_launch("glnn::gemm_lat");
@@ -313,14 +362,31 @@ int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+__global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const BnFinArgs a) { bn_finalize_columns<false>(a, blockIdx.x); }
+
+
+BnFinArgs fin_args(const glnn::LatStats& st, const float* ws_mean, const float* ws_m2, int64_t mt, int64_t m, int n) {
+  BnFinArgs fin = {};
+  fin.ws_mean = ws_mean; fin.ws_m2 = ws_m2; fin.nparts = (int)mt; fin.pstride = n; fin.rows = m; fin.h = n; fin.chunk_rows = 32;
+  fin.gamma = st.gamma; fin.beta = st.beta; fin.eps = st.eps; fin.momentum = st.momentum; fin.running_mean = st.running_mean;
+  fin.running_var = st.running_var; fin.nbt = st.nbt; fin.mean_out = st.mean_out; fin.rstd_out = st.rstd_out;
+  fin.a_scale = st.a_scale_out; fin.a_shift = st.a_shift_out;
+  return fin;
+}
+
 }  // namespace
 
-// C[m,n] = A'[m,k] * B + bias with an optional fused epilogue (st: BatchNorm statistics + finalize | ls: loss + dlogits); at most one
-// of st / ls.  GLNN_ERR_UNSUPPORTED (nothing launched, no error text) when the problem is outside the latency regime or an operand
-// is not float4-addressable: the caller then issues the tiled GEMM and the separate reduction kernels.
+// C[m,n] = A'[m,k] * B + bias with an optional fused epilogue (st: BatchNorm statistics | ls: loss + dlogits); at most one of st / ls.
+//   st->counters != NULL: statistics finished inside the launch (last workgroup); NULL: DEFERRED -- only the per-tile partials are
+//   written (st->ws: 2 * ceil(m/32) * n floats) and the launch that consumes C must be given the same LatStats as `pend`
+//   (or glnn::bn_finalize_tiles run on it).
+//   pend: A's columns carry deferred statistics (a_scale / a_shift arguments are ignored; pend->ws holds the partials of A = the C of
+//   the producing call with the same m).
+// GLNN_ERR_UNSUPPORTED (nothing launched, no error text) when the problem is outside the latency regime or an operand is not
+// float4-addressable: the caller then issues the tiled GEMM and the separate reduction kernels.
 int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
                    uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
-                   int64_t ldc, const LatStats* st, const LatLoss* ls, void* stream) {
+                   int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream) {
   static const int enabled = env_int("GLNN_GEMM_LAT", 1);
   static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
   static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
@@ -329,29 +395,30 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   if (lda % 4 || !glnn::aligned16(a) || lda < kpad) return GLNN_ERR_UNSUPPORTED;
   if (!b_layout && (ldb % 4 || !glnn::aligned16(b) || ldb < kpad)) return GLNN_ERR_UNSUPPORTED;
   if (b_layout && ldb < n) return GLNN_ERR_UNSUPPORTED;
-  if ((a_scale == nullptr) != (a_shift == nullptr)) return GLNN_ERR_UNSUPPORTED;
-  if (a_scale && (k % 4 || !glnn::aligned16(a_scale) || !glnn::aligned16(a_shift))) return GLNN_ERR_UNSUPPORTED;
-  if (drop_p > 0.f && !a_scale) return GLNN_ERR_UNSUPPORTED;
   const int64_t mt = (m + 31) / 32;
+  if (pend) {
+    if (b_layout || k % 4 || k > kFinMaxK || !pend->ws || pend->ws_floats < 2 * mt * k || !pend->a_scale_out || !pend->a_shift_out) return GLNN_ERR_UNSUPPORTED;
+  } else {
+    if ((a_scale == nullptr) != (a_shift == nullptr)) return GLNN_ERR_UNSUPPORTED;
+    if (a_scale && (k % 4 || !glnn::aligned16(a_scale) || !glnn::aligned16(a_shift))) return GLNN_ERR_UNSUPPORTED;
+    if (drop_p > 0.f && !a_scale) return GLNN_ERR_UNSUPPORTED;
+  }
   LatArgs g = {};
-  g.a = a; g.lda = lda; g.a_rows = a_rows; g.a_scale = a_scale; g.a_shift = a_shift;
+  g.a = a; g.lda = lda; g.a_rows = a_rows; g.a_scale = pend ? nullptr : a_scale; g.a_shift = pend ? nullptr : a_shift;
   g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
   g.m = m; g.k = k; g.b = b; g.ldb = ldb; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
   g.c_vec = (ldc % 4 == 0) && glnn::aligned16(c);
   const int groups = (k + 7) / 8;
   g.gpw = (groups + 3) / 4;
-  BnFinArgs fin = {};
+  BnFinArgs fin = {}, pfin = {};
+  if (pend) pfin = fin_args(*pend, pend->ws, pend->ws + mt * k, mt, m, k);
   LossArgs la = {};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (st) {
-    if (!st->counters || !st->ws || st->ws_floats < 2 * mt * n || !st->a_scale_out || !st->a_shift_out || (n + 63) / 64 > 512)
-      return GLNN_ERR_UNSUPPORTED;
+    if (!st->ws || st->ws_floats < 2 * mt * n || !st->a_scale_out || !st->a_shift_out || (n + 63) / 64 > 512) return GLNN_ERR_UNSUPPORTED;
     g.ws_mean = st->ws; g.ws_m2 = st->ws + mt * n; g.counters = st->counters;
-    fin.ws_mean = g.ws_mean; fin.ws_m2 = g.ws_m2; fin.nparts = (int)mt; fin.pstride = n; fin.rows = m; fin.h = n; fin.chunk_rows = 32;
-    fin.gamma = st->gamma; fin.beta = st->beta; fin.eps = st->eps; fin.momentum = st->momentum; fin.running_mean = st->running_mean;
-    fin.running_var = st->running_var; fin.nbt = st->nbt; fin.mean_out = st->mean_out; fin.rstd_out = st->rstd_out;
-    fin.a_scale = st->a_scale_out; fin.a_shift = st->a_shift_out;
-    return launch_lat<1, EPI_STATS>(g, fin, la, b_layout != 0, s);
+    fin = fin_args(*st, g.ws_mean, g.ws_m2, mt, m, n);
+    return launch_lat<1, EPI_STATS>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
   }
   if (ls) {
     if (n > 64 || !ls->counter || !ls->ws || ls->ws_floats < mt * 65 || !ls->dlogits || ls->ldg < n) return GLNN_ERR_UNSUPPORTED;
@@ -360,7 +427,16 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
     la.t = ls->target_logp; la.ldt = ls->ldt; la.t_rows = ls->target_rows; la.scale = ls->lamb / (float)m;
     la.dz = ls->dlogits; la.ldg = ls->ldg; la.partial = ls->ws; la.counter = ls->counter; la.inv_rows = 1.0f / (float)m;
     la.loss_out = ls->loss_out; la.loss_accum = ls->loss_accum; la.col_sum = ls->col_sum; la.col_partial = ls->ws + mt;
-    return launch_lat<2, EPI_LOSS>(g, fin, la, b_layout != 0, s);
+    return launch_lat<2, EPI_LOSS>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
   }
-  return launch_lat<1, EPI_PLAIN>(g, fin, la, b_layout != 0, s);
+  return launch_lat<1, EPI_PLAIN>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
+}
+
+// the deferred statistics of gemm_lat finished by a launch of their own (the consumer turned out not to be a latency GEMM)
+int glnn::bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream) {
+  const int64_t mt = (m + 31) / 32;
+  GLNN_REQUIRE(st.ws && st.ws_floats >= 2 * mt * n && st.a_scale_out && st.a_shift_out, "glnn::bn_finalize_tiles: bad arguments");
+  const BnFinArgs fin = fin_args(st, st.ws, st.ws + mt * n, mt, m, n);
+  hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((n + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fin);
+  return glnn::check_launch("glnn::bn_finalize_tiles");
 }

@@ -52,9 +52,14 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   // with sync counters the loss kernel's last workgroup also finalises the loss and the last layer's bias gradient
   const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
   bool loss_done = false;
+  int logit_slabs = 0;
+  const char* dfe = getenv("GLNN_STUDENT_DEFER_STATS");
+  const bool defer_stats = !(dfe && dfe[0] == '0');
+  glnn::LatStats pend = {}, next = {};
+  bool have_pend = false;
   for (int l = 0; l < L; ++l) {
     const bool last = (l == L - 1);
-    bool stats_done = false;
+    bool stats_done = false, have_next = false;
     float* out = last ? d->logits : d->z[l];
     const int64_t ldo = last ? d->ld_logits : d->ldz[l];
     const bool recompute = l > 0 && a_scale != nullptr;     // the previous layer's tail evaluated in this GEMM's operand load
@@ -64,24 +69,41 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     // layer, log_softmax + loss + dlogits (+ the bias gradient) of the last one.  UNSUPPORTED = the tiled GEMM + separate kernels below
     int lat = GLNN_ERR_UNSUPPORTED;
     if (cnt && !layernorm) {
+      const glnn::LatStats* pin = have_pend ? &pend : nullptr;         // the previous layer's statistics are still per-tile partials
       if (last && fused_bias) {
         const glnn::LatLoss ll = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
                                   kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out,
                                   d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1]};
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, nullptr, &ll, stream);
+                             out, ldo, pin, nullptr, &ll, stream);
         loss_done = lat == GLNN_OK;
       } else if (!last && d->batchnorm == 1) {
-        const glnn::LatStats ls = {d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum, d->running_mean[l], d->running_var[l], d->nbt[l],
-                                   d->mean[l], d->rstd[l], d->a_scale[l], d->a_shift[l], d->ws_bn, d->ws_bn_floats, cnt};
+        // statistics partials of layer l alternate between the halves of ws_bn: the consumer's workgroups read layer l-1's while
+        // others already write layer l's.  Deferred (no counters) when the tail is recomputed by the next layer's GEMM.
+        const int64_t half = d->ws_bn_floats / 2;
+        next = {d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum, d->running_mean[l], d->running_var[l], d->nbt[l],
+                d->mean[l], d->rstd[l], d->a_scale[l], d->a_shift[l], d->ws_bn + (l & 1) * half, half, (defer_stats && !d->act[l]) ? nullptr : cnt};
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, &ls, nullptr, stream);
+                             out, ldo, pin, &next, nullptr, stream);
         stats_done = lat == GLNN_OK;
+        have_next = stats_done && next.counters == nullptr;
       } else if (!last) {
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, nullptr, nullptr, stream);
+                             out, ldo, pin, nullptr, nullptr, stream);
       }
       if (lat != GLNN_OK && lat != GLNN_ERR_UNSUPPORTED) return lat;
+    }
+    if (lat != GLNN_OK && have_pend)       // the consumer is not a latency GEMM after all: finish the statistics with a launch of their own
+      GLNN_TRY(glnn::bn_finalize_tiles(pend, m, d->dims[l], stream));
+    have_pend = have_next;
+    pend = next;
+    // a deep, narrow last layer (MLP3w4: 1024 -> 40) is split over K; its partial slabs are folded by the loss kernel, not by a launch
+    if (lat != GLNN_OK && last && fused_bias && !layernorm) {
+      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0,
+                                               d->dims[l + 1], d->ws_gemm, d->ws_gemm_floats, &logit_slabs, stream);
+      if (rc == GLNN_OK) lat = GLNN_OK;
+      else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+      else logit_slabs = 0;
     }
     if (lat != GLNN_OK)
       GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, gp, gseed, m,
@@ -123,7 +145,8 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   GLNN_TRY(glnn::softmax_loss(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
                               target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
-                              cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr));
+                              cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr,
+                              logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr));
   // ---- backward ----
   // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
   // activation backward -> dz_{l-1} stays on `stream`; the weight gradients go to the aux stream.  dz_l alternates between
@@ -200,7 +223,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       const bool ws_free = !two;
       if (cnt && !two) {
         const int rc = glnn::gemm_lat(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
-                                      nullptr, d->da, d->ld_da, nullptr, nullptr, stream);
+                                      nullptr, d->da, d->ld_da, nullptr, nullptr, nullptr, stream);
         if (rc != GLNN_ERR_UNSUPPORTED) return rc;
       }
       return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],

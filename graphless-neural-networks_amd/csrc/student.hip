@@ -22,22 +22,30 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
   float wave_loss = 0.f, col_acc = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
     const float* zr = a.z + row * a.ldz;
+    float zv = 0.f;
+    if (a.nslab > 0 && lane < a.c) {         // fold the split-K partials of this row first (c <= 64: one class per lane, kept in zv)
+#pragma unroll 8
+      for (int s = 0; s < a.nslab; ++s) zv += a.slabs[(int64_t)s * a.slab_stride + row * a.c + lane];
+      zv += a.bias ? a.bias[lane] : 0.f;
+      a.z_store[row * a.ldz + lane] = zv;
+    }
+    auto Z = [&](int j) { return a.nslab > 0 ? zv : zr[j]; };
     float mx = -INFINITY;
-    for (int j = lane; j < a.c; j += 64) mx = fmaxf(mx, zr[j]);
+    for (int j = lane; j < a.c; j += 64) mx = fmaxf(mx, Z(j));
     mx = wave_max(mx);
     float se = 0.f;
-    for (int j = lane; j < a.c; j += 64) se += expf(zr[j] - mx);
+    for (int j = lane; j < a.c; j += 64) se += expf(Z(j) - mx);
     se = wave_sum(se);
     const float lse = mx + logf(se);
     if (!LOSS) {
-      for (int j = lane; j < a.c; j += 64) a.logp[row * a.ldl + j] = zr[j] - lse;
+      for (int j = lane; j < a.c; j += 64) a.logp[row * a.ldl + j] = Z(j) - lse;
       continue;
     }
     float row_loss = 0.f;
     if (a.kind == GLNN_LOSS_NLL) {
       const int64_t y = a.labels[a.label_rows ? a.label_rows[row] : row];
       for (int j = lane; j < a.c; j += 64) {
-        const float lp = zr[j] - lse;
+        const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
         const float sm = expf(lp);
         const float g = (sm - (j == y ? 1.f : 0.f)) * a.scale;
@@ -52,12 +60,12 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
       for (int j = lane; j < a.c; j += 64) {
         const float tj = tr[j], et = expf(tj);
         set += et;
-        row_loss += et * (tj - (zr[j] - lse));
+        row_loss += et * (tj - (Z(j) - lse));
       }
       set = wave_sum(set);
       row_loss = wave_sum(row_loss);
       for (int j = lane; j < a.c; j += 64) {
-        const float lp = zr[j] - lse;
+        const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
         const float g = (expf(lp) * set - expf(tr[j])) * a.scale;
         a.dz[row * a.ldg + j] = g;
@@ -494,8 +502,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
 int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels,
                        const int64_t* label_rows, const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb,
                        float* dlogits, int64_t ldg, float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
-                       float* workspace, int64_t workspace_floats, void* stream, int* counter, float* col_sum) {
+                       float* workspace, int64_t workspace_floats, void* stream, int* counter, float* col_sum, const float* slabs,
+                       int nslab, const float* bias) {
   GLNN_REQUIRE(logits && dlogits && workspace, "glnn_softmax_loss_f32: null pointer");
+  GLNN_REQUIRE(nslab == 0 || (slabs && nslab > 0 && c <= 64), "glnn_softmax_loss_f32: split-K slabs need c <= 64");
   GLNN_REQUIRE(rows >= 1 && c >= 1 && ldz >= c && ldg >= c, "glnn_softmax_loss_f32: bad sizes");
   GLNN_REQUIRE(kind == GLNN_LOSS_NLL || kind == GLNN_LOSS_KL, "glnn_softmax_loss_f32: unknown kind %d", kind);
   if (kind == GLNN_LOSS_NLL) GLNN_REQUIRE(labels, "glnn_softmax_loss_f32: NLL needs labels");
@@ -507,12 +517,13 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   if (blocks > cap) blocks = cap;
   const int64_t need = blocks * (col_sum ? 65 : 1);
   GLNN_REQUIRE(workspace_floats >= need, "glnn_softmax_loss_f32: workspace needs >= %lld floats", (long long)need);
-  LossArgs a;
+  LossArgs a = {};
   a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.kind = kind; a.labels = labels; a.label_rows = label_rows;
   a.t = target_logp; a.ldt = ldt; a.t_rows = target_rows; a.scale = lamb / (float)rows;
   a.dz = dlogits; a.ldg = ldg; a.logp = logprob_out; a.ldl = ldl; a.partial = workspace;
   a.counter = counter; a.inv_rows = 1.0f / (float)rows; a.loss_out = loss_out; a.loss_accum = loss_accum;
   a.col_sum = col_sum; a.col_partial = workspace + blocks;
+  a.slabs = slabs; a.nslab = nslab; a.slab_stride = rows * c; a.bias = bias; a.z_store = const_cast<float*>(logits);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   if (!counter)

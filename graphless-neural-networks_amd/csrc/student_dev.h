@@ -66,6 +66,9 @@ struct LossArgs {
   // fused finalize (counter != NULL): the last workgroup writes the loss (and, with col_sum != NULL and c <= 64, the
   // column sums of dz = the bias gradient of the layer that produced the logits; col_partial [gridDim.x][64] scratch)
   int* counter; float inv_rows; float* loss_out; float* loss_accum; float* col_sum; float* col_partial;
+  // nslab > 0 (c <= 64): the logits are still split-K partials -- logit(row, j) = sum_s slabs[s * slab_stride + row * c + j] + bias[j],
+  // summed here (s ascending) and stored to z (the fold launch of the producing GEMM is gone)
+  const float* slabs; int nslab; int64_t slab_stride; const float* bias; float* z_store;
 };
 
 // last workgroup of a loss launch: loss = sum of the per-workgroup partials / rows (fixed order) and, with col_sum, the column
@@ -132,6 +135,28 @@ __device__ __forceinline__ double part_count(const BnFinArgs& a, int k, int col)
   return (double)(r1 - r0);
 }
 
+// The end of the statistics of one column from its combined (N, mean, M2): normalisation constants, the fused forward transform
+// y = z * a_scale + a_shift, the running statistics (momentum, unbiased variance) -- stored only when `store`; sc / sh returned.
+// g / b: gamma[col] / beta[col] (1 / 0 without affine), loaded by the caller BEFORE it waits for the partials -- loaded here they are
+// one more dependent round trip to memory at the end of a latency chain.
+__device__ __forceinline__ void bn_emit_column(const BnFinArgs& a, int col, double n, double mean, double m2, bool store, float g, float b,
+                                               float& sc, float& sh) {
+  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
+  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
+  const float meanf = (float)mean;
+  const float rstd = 1.0f / sqrtf(var_b + a.eps);
+  sc = g * rstd;
+  sh = b - meanf * sc;
+  if (!store) return;
+  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
+  if (a.mean_out) a.mean_out[col] = meanf;
+  if (a.rstd_out) a.rstd_out[col] = rstd;
+  a.a_scale[col] = sc;
+  a.a_shift[col] = sh;
+  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
+  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
+}
+
 // One workgroup = 64 columns x 4 partial lanes (the column kernels' mapping): lane rl combines partials rl, rl+4, ... ; the
 // four lane results are combined in fixed order through LDS.  (A single thread per column walked the nparts partials as
 // one chain of dependent L2 round trips: 13-21 us for 32 partials.)
@@ -150,6 +175,7 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
   // to memory in the tail of every launch that ends with it):
   //   N = sum n_k ;  S = sum n_k*mean_k ;  Q = sum [ M2_k + n_k*mean_k^2 ] ;  mean = S / N ;  M2 = Q - S*mean
   // In double the subtraction costs ~1e-16 * N*mean^2 against M2: invisible after rounding to float unless |mean|/std > 1e6.
+  const float gam = a.gamma ? a.gamma[colc] : 1.f, bet = a.beta ? a.beta[colc] : 0.f;
   double n = 0.0, sum = 0.0, qs = 0.0;
 #pragma unroll 4
   for (int k = p0 + rl; k < p1; k += kRowLanes) {
@@ -178,19 +204,8 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
     a.emit_m2[eoff + col] = (float)m2;
     return;
   }
-  if (col == 0 && a.rows_out) a.rows_out[0] = (float)n;
-  const float var_b = (float)(m2 / n);                         // biased: used for normalisation
-  const float var_u = n > 1.0 ? (float)(m2 / (n - 1.0)) : var_b;  // unbiased: running_var
-  const float meanf = (float)mean;
-  const float rstd = 1.0f / sqrtf(var_b + a.eps);
-  if (a.mean_out) a.mean_out[col] = meanf;
-  if (a.rstd_out) a.rstd_out[col] = rstd;
-  const float g = a.gamma ? a.gamma[col] : 1.f, b = a.beta ? a.beta[col] : 0.f;
-  const float sc = g * rstd;
-  a.a_scale[col] = sc;
-  a.a_shift[col] = b - meanf * sc;
-  if (a.running_mean) a.running_mean[col] = (1.f - a.momentum) * a.running_mean[col] + a.momentum * meanf;
-  if (a.running_var) a.running_var[col] = (1.f - a.momentum) * a.running_var[col] + a.momentum * var_u;
+  float sc, sh;
+  bn_emit_column(a, col, n, mean, m2, true, gam, bet, sc, sh);
 }
 
 }  // namespace
