@@ -37,6 +37,7 @@ SIGNATURES = {
     "glnn_col_sum_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_i64, c_vp],
     "glnn_adam_step_f32": [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_vp],
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
+    "glnn_mlp_train_step_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_vp],
     "glnn_sage_fwd_bwd_f32": [c_vp, c_vp],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_norm_drop_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64, c_vp],
@@ -61,10 +62,18 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+class AdamDesc(ctypes.Structure):
+    """glnn_adam_desc of include/glnn_hip.h (field for field)."""
+    _fields_ = [("params", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("sizes", ctypes.c_void_p), ("grads_host", ctypes.c_void_p), ("num_tensors", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("max_size", c_i64), ("lr", c_f32), ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32),
+                ("reserved2", ctypes.c_int32), ("step", c_i64)]
 
 
 class MlpStepDesc(ctypes.Structure):

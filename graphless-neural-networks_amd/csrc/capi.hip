@@ -49,7 +49,7 @@ int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, 
 
 }  // namespace
 
-extern "C" int glnn_abi_version(void) { return 5; }
+extern "C" int glnn_abi_version(void) { return 6; }
 
 extern "C" const char* glnn_last_error(void) { return glnn::g_err; }
 

@@ -1492,6 +1492,17 @@ int glnn::gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows
                    workspace, workspace_floats, stream, splits);
 }
 
+// the fold launch of gemm_split_partials for a consumer that cannot read slabs: c = sum_z workspace[z][m][n] + bias
+int glnn::gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, const float* bias, float* c, int64_t ldc, void* stream) {
+  GLNN_REQUIRE(workspace && c && splits >= 1 && m >= 1 && n >= 1 && ldc >= n, "glnn::gemm_fold_partials: bad arguments");
+  GemmArgs g = {};
+  g.m = m; g.n = n; g.c = c; g.ldc = ldc; g.ksplits = splits; g.ws = const_cast<float*>(workspace); g.ep_shift = bias;
+  int64_t blocks = (m * n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g);
+  return glnn::check_launch("glnn::gemm_fold_partials");
+}
+
 // ---- several independent weight gradients in ONE gemm launch + ONE fold launch (see gemm_tn_multi_kernel) -------------------
 struct FoldMultiArgs {
   const float* ws[kTnMultiMax]; int64_t slab[kTnMultiMax]; int splits[kTnMultiMax];
@@ -1565,7 +1576,7 @@ namespace glnn {
 // launch.  Returns GLNN_ERR_UNSUPPORTED without launching anything when a problem would not take the 64 x 64 path of
 // glnn_gemm_tn_f32 or the slabs do not fit the workspace: the caller then issues the products one by one.  Results are bit-identical
 // to the one-by-one form (same tile code, same split plan computed against the same workspace size, same fold order).
-int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspace_floats, void* stream) {
+int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspace_floats, void* stream, GradFold* defer) {
   if (n < 1 || n > kTnMultiMax || !workspace) return GLNN_ERR_UNSUPPORTED;
   TnMultiArgs mm;
   FoldMultiArgs fm;
@@ -1594,8 +1605,13 @@ int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspac
       if (fb > 2048) fb = 2048;
       fm.start[f] = fblocks; fblocks += fb; fm.start[f + 1] = fblocks;
       ws_off += (int64_t)sp * slab;
+      if (defer) {
+        if (q.ldc != q.nb) return GLNN_ERR_UNSUPPORTED;            // the consumer indexes the slabs like the dense tensor
+        defer[p] = {q.c, g.c, sp, 0, slab};
+      }
     } else {
       g.c = q.c; g.ldc = q.ldc;
+      if (defer) defer[p] = {q.c, nullptr, 0, 0, 0};
     }
     mm.start[p] = blocks; mm.gi[p] = gi; mm.gj[p] = gj;
     mm.xf[p] = !q.b_scale ? 0 : (g.drop_thr ? 2 : 1);
@@ -1611,7 +1627,7 @@ int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspac
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3(blocks), dim3(256), smem_s, st, mm);
   int rc = glnn::check_launch("glnn_gemm_tn_f32(batch)");
-  if (rc != GLNN_OK || fm.n == 0) return rc;
+  if (rc != GLNN_OK || fm.n == 0 || defer) return rc;
   for (int f = fm.n; f < kTnMultiMax; ++f) fm.start[f + 1] = fblocks;
   hipLaunchKernelGGL(split_reduce_multi_kernel, dim3(fblocks), dim3(256), 0, st, fm);
   return glnn::check_launch("glnn_gemm_tn_f32(batch fold)");

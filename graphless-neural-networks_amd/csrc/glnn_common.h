@@ -68,7 +68,9 @@ struct BnGroup {
 int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps, float momentum,
              float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out, float* rstd_out,
              float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream, const BnGroup* g,
-             int* counters = nullptr);
+             int* counters = nullptr, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr);
+// slabs / nslab (<= 8) / bias: z = sum of the split-K partial slabs of gemm_split_partials + bias, folded (and stored to z) by the
+// statistics kernel itself; one-launch form only (counters, single rank) -- otherwise GLNN_ERR_UNSUPPORTED with nothing launched
 int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels, const int64_t* label_rows,
                  const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
                  float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum, float* workspace, int64_t workspace_floats,
@@ -78,7 +80,10 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
-                void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1);
+                void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0);
+// da_slabs > 1: da points at that many split-K partial slabs (da[s][rows][ldda]) which the one-launch form sums itself; any other
+// form returns GLNN_ERR_UNSUPPORTED with nothing launched (fold with gemm_fold_partials, call again)
+int gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, const float* bias, float* c, int64_t ldc, void* stream);
 
 // gemm.hip: several independent weight gradients (arguments as glnn_gemm_tn_f32, no column sums) in one gemm + one fold launch;
 // GLNN_ERR_UNSUPPORTED (nothing launched) when a problem does not qualify -- see gemm_tn_batch
@@ -86,7 +91,20 @@ struct TnProblem {
   const float* a; int64_t lda; int64_t m; int ka; const float* b; int64_t ldb; const int64_t* b_rows; const float* b_scale;
   const float* b_shift; float drop_p; uint32_t drop_seed; int nb; float* c; int64_t ldc;
 };
-int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream);
+// A gradient tensor whose final sum has been left to its consumer, the fused Adam launch (the fold launches / last-workgroup tails
+// that used to produce it are gone): grad[i] = sum over k < nslab of src[k * stride + i], k ascending (lanes4 = 0) or in four
+// interleaved lanes k = r, r + 4, ... combined as (l0 + l1) + (l2 + l3) (lanes4 = 1: the order of the column-sum folds).
+struct GradFold { const float* grad; const float* src; int nslab; int lanes4; int64_t stride; };
+struct LossFoldJob { const float* partial; int nblocks; float inv_rows; float* loss_out; float* loss_accum; };
+constexpr int kMaxGradFolds = 40;
+struct PendingFolds { int n; GradFold e[kMaxGradFolds]; int has_loss; LossFoldJob loss; };
+// defer (n entries, optional): the fold launch is skipped; defer[p] describes problem p's slabs (nslab = 0: c was written directly)
+int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream, GradFold* defer = nullptr);
+// student.hip: glnn_adam_step_f32 whose gradient reads fold the pending partial sums (and store the folded gradient); grads_host =
+// host copy of the `grads` pointer table (how a pending fold finds its tensor); pending may be NULL
+int adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,
+              int num_tensors, int64_t max_size, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+              const float* const* grads_host, const PendingFolds* pending, void* stream);
 // gemm.hip: split-K partials only (the consumer folds) -- see the definition
 int gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
                         uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, float* workspace,

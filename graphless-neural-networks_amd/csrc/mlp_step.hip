@@ -12,9 +12,12 @@
     if (rc_ != GLNN_OK) return rc_; \
   } while (0)
 
-extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* feats, int64_t ldx, const int64_t* idx,
-                                    int64_t m, int kind, const int64_t* labels, const float* target_logp, int64_t ldt,
-                                    const int64_t* target_rows, float lamb, const uint32_t* drop_seeds, void* stream) {
+// pf != NULL (glnn_mlp_train_step_f32): the fused Adam launch follows immediately and is the only consumer of the gradients, so the
+// final sums of gradient partials (split-K slabs of the weight gradients, ...) are left to it: they are registered in *pf instead of
+// being folded by launches / last-workgroup tails of their own.
+static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int64_t ldx, const int64_t* idx,
+                            int64_t m, int kind, const int64_t* labels, const float* target_logp, int64_t ldt,
+                            const int64_t* target_rows, float lamb, const uint32_t* drop_seeds, void* stream, glnn::PendingFolds* pf) {
   GLNN_REQUIRE(d && feats, "glnn_mlp_fwd_bwd_f32: null pointer");
   const int L = d->num_layers;
   GLNN_REQUIRE(L >= 1 && L <= GLNN_MLP_MAX_LAYERS, "glnn_mlp_fwd_bwd_f32: num_layers=%d outside [1,%d]", L, GLNN_MLP_MAX_LAYERS);
@@ -53,6 +56,8 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
   bool loss_done = false;
   int logit_slabs = 0;
+  const char* sce = getenv("GLNN_STUDENT_SLAB_CONSUMERS");
+  const bool slab_consumers = !(sce && sce[0] == '0');
   const char* dfe = getenv("GLNN_STUDENT_DEFER_STATS");
   const bool defer_stats = !(dfe && dfe[0] == '0');
   glnn::LatStats pend = {}, next = {};
@@ -105,6 +110,16 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
       else logit_slabs = 0;
     }
+    // a deep hidden layer (MLP3w4: 1024 -> 1024 at B = 512) likewise: the statistics kernel folds the slabs, stores z, then reduces
+    int z_slabs = 0;
+    if (lat != GLNN_OK && !last && cnt && d->batchnorm == 1 && !layernorm && slab_consumers) {
+      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0,
+                                               d->dims[l + 1], d->ws_gemm, d->ws_gemm_floats, &z_slabs, stream);
+      if (rc == GLNN_OK && z_slabs <= 8) lat = GLNN_OK;
+      else if (rc == GLNN_OK) { GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream)); lat = GLNN_OK; z_slabs = 0; }
+      else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+      else z_slabs = 0;
+    }
     if (lat != GLNN_OK)
       GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, gp, gseed, m,
                              d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
@@ -120,10 +135,19 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
       src = d->act[l];
       ld_src = d->ld_act[l];
     } else if (!last) {
-      if (d->batchnorm && !stats_done)
-        GLNN_TRY(glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
-                                   d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
-                                   d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
+      if (d->batchnorm && !stats_done) {
+        int rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
+                                d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
+                                d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, z_slabs ? d->ws_gemm : nullptr, z_slabs,
+                                z_slabs ? d->b[l] : nullptr);
+        if (rc == GLNN_ERR_UNSUPPORTED && z_slabs) {          // not the one-launch form after all: fold with a launch, then the plain call
+          GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream));
+          rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
+                              d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
+                              d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt);
+        }
+        GLNN_TRY(rc);
+      }
       rows = nullptr;
       if (d->act[l]) {       // the tail of hidden layer l materialised once: the next GEMM and the weight gradient read it plain
         GLNN_REQUIRE(d->ld_act[l] >= ((d->dims[l + 1] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_act[%d] too small", l);
@@ -217,6 +241,7 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
                               p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
                               d->ws_tn_floats, wstream);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
     };
+    int da_slabs = 0;
     auto input_gradient = [&]() -> int {
       // ws_gemm is idle during the backward (two-stream form: the first layer's weight gradient borrows it, and never overlaps this
       // call): deep, skinny input gradients (B = 512, 1024 wide: 128 tiles x 32 dependent k-tiles) may split their reduction
@@ -225,6 +250,13 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
         const int rc = glnn::gemm_lat(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                                       nullptr, d->da, d->ld_da, nullptr, nullptr, nullptr, stream);
         if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+        // deep input gradients (MLP3w4: K = 1024): split-K partials that the one-launch BatchNorm backward sums itself
+        if (d->batchnorm == 1 && !layernorm && slab_consumers) {
+          const int rs = glnn::gemm_split_partials(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1,
+                                                   d->dims[l], d->ws_gemm, d->ws_gemm_floats, &da_slabs, stream);
+          if (rs != GLNN_ERR_UNSUPPORTED) return rs;
+          da_slabs = 0;
+        }
       }
       return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                            nullptr, nullptr, nullptr, 0, d->da, d->ld_da, ws_free ? d->ws_gemm : nullptr, ws_free ? d->ws_gemm_floats : 0, stream);
@@ -249,9 +281,18 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
                                       d->mean[l - 1], d->rstd[l - 1], 1, p, seed, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1],
                                       d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream));
     } else if (d->batchnorm) {
-      GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
-                                 d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
-                                 d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt));
+      int rc = GLNN_ERR_UNSUPPORTED;
+      if (da_slabs > 0)
+        rc = glnn::bn_relu_bwd(d->ws_gemm, d->dims[l], d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
+                               d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
+                               d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, 1, da_slabs);
+      if (rc == GLNN_ERR_UNSUPPORTED) {
+        if (da_slabs > 0) GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, da_slabs, m, d->dims[l], nullptr, d->da, d->ld_da, stream));
+        rc = glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
+                               d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
+                               d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt);
+      }
+      GLNN_TRY(rc);
     } else {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
                                  nullptr, p, seed, dz_out, ld_out, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,
@@ -263,7 +304,10 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
   if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));      // join: `stream` continues behind every weight gradient
 #undef GLNN_HIP_TRY
   if (defer) {
-    const int rc = glnn::gemm_tn_batch(deferred, n_deferred, d->ws_tn, d->ws_tn_floats, stream);
+    glnn::GradFold gf[GLNN_MLP_MAX_LAYERS];
+    const int rc = glnn::gemm_tn_batch(deferred, n_deferred, d->ws_tn, d->ws_tn_floats, stream, pf ? gf : nullptr);
+    if (rc == GLNN_OK && pf)
+      for (int i = 0; i < n_deferred && pf->n < glnn::kMaxGradFolds; ++i) pf->e[pf->n++] = gf[i];
     if (rc == GLNN_ERR_UNSUPPORTED) {          // a shape outside the 64 x 64 path (or too little workspace): one by one, as before
       for (int i = 0; i < n_deferred; ++i) {
         const glnn::TnProblem& q = deferred[i];
@@ -275,4 +319,29 @@ extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* fe
     }
   }
   return GLNN_OK;
+}
+
+extern "C" int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* d, const float* feats, int64_t ldx, const int64_t* idx,
+                                    int64_t m, int kind, const int64_t* labels, const float* target_logp, int64_t ldt,
+                                    const int64_t* target_rows, float lamb, const uint32_t* drop_seeds, void* stream) {
+  return mlp_fwd_bwd_impl(d, feats, ldx, idx, m, kind, labels, target_logp, ldt, target_rows, lamb, drop_seeds, stream, nullptr);
+}
+
+// The whole optimisation step -- forward + loss + backward + Adam -- in ONE call (reference train_and_eval.py:74-85 incl.
+// optimizer.step()): glnn_mlp_fwd_bwd_f32 followed by glnn_adam_step_f32 on the same stream, for hosts that have nothing to put
+// between them (no gradient exchange).  Knowing that Adam is the next launch, the backward leaves the last sums of its gradient
+// partials to it (see mlp_fwd_bwd_impl).
+extern "C" int glnn_mlp_train_step_f32(const glnn_mlp_step_desc* d, const float* feats, int64_t ldx, const int64_t* idx,
+                                       int64_t m, int kind, const int64_t* labels, const float* target_logp, int64_t ldt,
+                                       const int64_t* target_rows, float lamb, const uint32_t* drop_seeds, const glnn_adam_desc* adam,
+                                       void* stream) {
+  GLNN_REQUIRE(adam && adam->params && adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->sizes && adam->grads_host,
+               "glnn_mlp_train_step_f32: the Adam descriptor is incomplete");
+  glnn::PendingFolds pf = {};
+  const char* e = getenv("GLNN_STUDENT_ADAM_FOLDS");
+  const bool folds = !(e && e[0] == '0') && adam->num_tensors <= 32;
+  GLNN_TRY(mlp_fwd_bwd_impl(d, feats, ldx, idx, m, kind, labels, target_logp, ldt, target_rows, lamb, drop_seeds, stream, folds ? &pf : nullptr));
+  return glnn::adam_step(adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq, adam->sizes, adam->num_tensors, adam->max_size,
+                         adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, adam->step, adam->grads_host,
+                         folds ? &pf : nullptr, stream);
 }

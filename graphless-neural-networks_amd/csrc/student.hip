@@ -113,9 +113,13 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_stats_stage2(const BnFinArgs a) { bn_finalize_columns<false>(a, blockIdx.x); }
 
 // counters != NULL: the last row-chunk workgroup of a column block runs the stage-2 combine for its 64 columns itself.
+// NS > 0: z is not in memory yet -- it is the sum of `nslab` <= NS split-K partial slabs (slabs[s][rows][h], gemm_split_partials) plus
+// the bias; this kernel folds them (s ascending), stores z and takes the statistics from the registers (the GEMM's fold launch is gone).
+struct SlabSrc { const float* slabs; int nslab; int64_t stride; const float* bias; float* z_out; };
+template <int NS>
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ z, int64_t ldz, int64_t rows, int h,
                                                         float* __restrict__ ws_mean, float* __restrict__ ws_m2, const BnFinArgs fin,
-                                                        int* counters) {
+                                                        int* counters, const SlabSrc src) {
   const int lc = threadIdx.x & 63;
   const int col = blockIdx.x * 64 + lc;
   const int colc = col < h ? col : h - 1;
@@ -129,10 +133,34 @@ __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__
   float s = 0.f;
 #pragma unroll
   for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {
+    if (NS == 0) {
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int64_t r = r0 + rl + 4 * (i0 + u);
-      v[i0 + u] = z[(r < r1 ? r : r0) * ldz + colc];
+      for (int u = 0; u < kUnroll; ++u) {
+        const int64_t r = r0 + rl + 4 * (i0 + u);
+        v[i0 + u] = z[(r < r1 ? r : r0) * ldz + colc];
+      }
+    } else {
+      float part[NS > 0 ? NS : 1][kUnroll];
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        const int64_t off = (int64_t)(t < src.nslab ? t : src.nslab - 1) * src.stride;      // slabs past nslab: re-read, weight 0
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int64_t r = r0 + rl + 4 * (i0 + u);
+          part[t][u] = src.slabs[off + (r < r1 ? r : r0) * h + colc];
+        }
+      }
+      const float bb = src.bias ? src.bias[colc] : 0.f;
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        float acc = part[0][u];
+#pragma unroll
+        for (int t = 1; t < NS; ++t) acc += t < src.nslab ? part[t][u] : 0.f;
+        acc += bb;
+        v[i0 + u] = acc;
+        const int64_t r = r0 + rl + 4 * (i0 + u);
+        if (r < r1 && col < h) src.z_out[r * ldz + col] = acc;
+      }
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) s += (r0 + rl + 4 * (i0 + u) < r1) ? v[i0 + u] : 0.f;
@@ -175,6 +203,7 @@ struct BnBwdArgs {
   const float* p1; const float* p2; int nparts; int64_t pstride; int local_part; const float* rows_total;
   int* counters; float* dz_col_sum;      // counters != NULL: the last row-chunk workgroup of a column block folds ws3 into dz_col_sum
   int relu;                              // 1: the ReLU sits behind the norm (MLP / SAGE tails); 0: no ReLU in this tail (GCN: norm -> dropout)
+  int nslab; int64_t slab_stride;        // bn_bwd_fused<NS > 0>: da = sum of nslab <= NS split-K slabs da[s * slab_stride + r * ldda + col]
 };
 
 template <bool BN>
@@ -288,6 +317,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
 // arrival counter and WAITS until all row chunks of that column block have arrived; then the same fixed-order sums and the same
 // per-element arithmetic as the two-launch form follow -- bit-identical results.  The arrival counter is counters[512 + column
 // block]; the fold counter of the bias gradient stays counters[column block]; the last workgroup through the fold resets both.
+template <int NS>
 __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
   const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lc;
@@ -307,6 +337,22 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
       const int64_t rc = r < r1 ? r : r0;
       zz[i0 + u] = a.z[rc * a.ldz + colc];
       dd[u] = a.da[rc * a.ldda + colc];
+    }
+    if (NS > 1) {                 // the other split-K slabs of the input gradient (those past nslab: re-read, weight 0)
+      float part[NS > 1 ? NS - 1 : 1][kUnroll];
+#pragma unroll
+      for (int t = 1; t < NS; ++t) {
+        const int64_t off = (int64_t)(t < a.nslab ? t : a.nslab - 1) * a.slab_stride;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          const int64_t r = r0 + rl + 4 * (i0 + u);
+          part[t - 1][u] = a.da[off + (r < r1 ? r : r0) * a.ldda + colc];
+        }
+      }
+#pragma unroll
+      for (int t = 1; t < NS; ++t)
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) dd[u] += t < a.nslab ? part[t - 1][u] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
@@ -472,20 +518,69 @@ __global__ void chunk_sum2_kernel(const float* __restrict__ ws1, const float* __
 // ------------------------------------------------------------------------------------------
 // K6: multi-tensor Adam. grid = (chunks, tensors), float4 where the tensor allows it.
 // ------------------------------------------------------------------------------------------
+constexpr int kAdamSrcMax = 32;      // tensors of one launch that may carry a fold source
+struct AdamSrc { const float* src; int nslab; int lanes4; int64_t stride; };
 struct AdamArgs {
   float* const* p; const float* const* g; float* const* m; float* const* v; const int64_t* sizes;
   float beta1, beta2, eps, wd, step_size, bc2_sqrt;
+  int nsrc;                          // tensors [0, nsrc) consult src[t]
+  AdamSrc src[kAdamSrcMax];
+  int num_tensors;                   // blockIdx.y == num_tensors: the loss-fold job (one workgroup), when lf.partial != NULL
+  glnn::LossFoldJob lf;
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   const int t = blockIdx.y;
+  if (t == a.num_tensors) {          // loss = sum of the loss kernel's per-workgroup partials / rows: loss_fold_last's sums, same order
+    if (blockIdx.x != 0 || !a.lf.partial) return;
+    __shared__ float red[256];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < a.lf.nblocks; i += 256) v += a.lf.partial[i];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const float l = red[0] * a.lf.inv_rows;
+      if (a.lf.loss_out) a.lf.loss_out[0] = l;
+      if (a.lf.loss_accum) a.lf.loss_accum[0] += l;
+    }
+    return;
+  }
   const int64_t n = a.sizes[t];
   float* __restrict__ p = a.p[t];
-  const float* __restrict__ g = a.g[t];
+  float* g = const_cast<float*>(a.g[t]);
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
+  const AdamSrc sr = t < a.nsrc ? a.src[t] : AdamSrc{nullptr, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    float gi = g[i];
+    float gi;
+    if (sr.nslab == 0) {
+      gi = g[i];
+    } else {
+      // eight partials requested together (a runtime-length loop of dependent adds waited for one load at a time: the launch took
+      // 13 us instead of 5); partials past nslab are not loaded
+      float l[4] = {0.f, 0.f, 0.f, 0.f};
+      gi = 0.f;
+      for (int k0 = 0; k0 < sr.nslab; k0 += 8) {
+        float part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] = k0 + u < sr.nslab ? sr.src[(int64_t)(k0 + u) * sr.stride + i] : 0.f;
+        if (!sr.lanes4) {            // split-K slabs of a weight gradient: k ascending (split_reduce_kernel's order)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < sr.nslab) gi = (k0 + u == 0) ? part[u] : gi + part[u];
+        } else {                     // per-chunk column sums: four interleaved lanes, (l0 + l1) + (l2 + l3) (the fold tails' order)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < sr.nslab) l[u & 3] += part[u];
+        }
+      }
+      if (sr.lanes4) gi = (l[0] + l[1]) + (l[2] + l[3]);
+      g[i] = gi;                     // the gradient itself stays observable (p.grad)
+    }
     const float pi = p[i];
     if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
     const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);          // exp_avg.lerp_(grad, 1-beta1)
@@ -562,8 +657,9 @@ static int run_exchange(const glnn::BnGroup* g, int64_t floats, void* stream, co
 int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out,
                    float* rstd_out, float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats,
-                   void* stream, const glnn::BnGroup* g, int* counters) {
+                   void* stream, const glnn::BnGroup* g, int* counters, const float* slabs, int nslab, const float* bias) {
   GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
+  if (nslab > 0 && !(slabs && nslab <= 8 && counters && !g)) return GLNN_ERR_UNSUPPORTED;       // nothing launched: fold first, call again
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
   const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
   const int64_t need_ws = 2ll * nchunks * h + (nchunks > 4 * kBnGroup ? 3ll * ((nchunks + kBnGroup - 1) / kBnGroup) * h : 0);
@@ -576,11 +672,16 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
   a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
   a.mean_out = mean_out; a.rstd_out = rstd_out; a.a_scale = a_scale_out; a.a_shift = a_shift_out;
   const dim3 fgrid((h + 63) / 64);
+  const SlabSrc src = {slabs, nslab, rows * (int64_t)h, bias, const_cast<float*>(z)};
   if (counters && !g) {     // one launch: the last row-chunk workgroup of every column block finishes the statistics
-    hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters);
+    const dim3 sgrid((h + 63) / 64, nchunks);
+    if (nslab <= 0) hipLaunchKernelGGL(bn_stats_stage1<0>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
+    else if (nslab <= 2) hipLaunchKernelGGL(bn_stats_stage1<2>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
+    else if (nslab <= 4) hipLaunchKernelGGL(bn_stats_stage1<4>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
+    else hipLaunchKernelGGL(bn_stats_stage1<8>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
     return glnn::check_launch("glnn_bn_stats_f32");
   }
-  hipLaunchKernelGGL(bn_stats_stage1, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr);
+  hipLaunchKernelGGL(bn_stats_stage1<0>, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr, src);
   if (!g && nchunks > 4 * kBnGroup) {
     // thousands of row chunks (a 500k-row activation): combine groups of kBnGroup partial triples first (Chan's combine is
     // associative), then the group triples -- a single level walked ~1000 partials per lane (0.35 ms)
@@ -612,7 +713,7 @@ extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int 
                                  int64_t* num_batches_tracked, float* mean_out, float* rstd_out, float* a_scale_out,
                                  float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream) {
   return glnn::bn_stats(z, ldz, rows, h, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out,
-                        rstd_out, a_scale_out, a_shift_out, workspace, workspace_floats, stream, nullptr);
+                        rstd_out, a_scale_out, a_shift_out, workspace, workspace_floats, stream, nullptr, nullptr, nullptr, 0, nullptr);
 }
 
 // bn_bwd_fused WAITS inside an ordinary launch: every workgroup of its grid must be resident at once or the waiting ones
@@ -628,7 +729,7 @@ static int fused_grid_limit() {
     int per_cu = 0;
     hipDeviceProp_t prop;
     int lim = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bn_bwd_fused, 256, 0) == hipSuccess &&
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bn_bwd_fused<8>, 256, 0) == hipSuccess &&
         hipGetDeviceProperties(&prop, dev) == hipSuccess)
       lim = per_cu * prop.multiProcessorCount / 2;
     limit[dev] = lim > 256 ? 256 : lim;
@@ -640,7 +741,8 @@ static int fused_grid_limit() {
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
-                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu) {
+                      float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu,
+                      int da_slabs) {
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -654,6 +756,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.dscale = 1.0f / (1.0f - drop_p); a.dz = dz; a.lddz = lddz; a.dgamma = dgamma; a.dbeta = dbeta; a.nchunks = nchunks;
   a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
   a.relu = relu ? 1 : 0;
+  a.nslab = da_slabs > 0 ? da_slabs : 1; a.slab_stride = rows * ldda;
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
   if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
@@ -666,9 +769,15 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   const bool one_launch = !(ol && ol[0] == '0');
   if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= fused_grid_limit() && grid.x <= 256) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
-    hipLaunchKernelGGL(bn_bwd_fused, grid, dim3(256), 0, st, a);     // co-resident grid: partial -> wait -> apply in one launch
+    // co-resident grid: partial -> wait -> apply in one launch
+    if (da_slabs <= 1) hipLaunchKernelGGL(bn_bwd_fused<1>, grid, dim3(256), 0, st, a);
+    else if (da_slabs <= 2) hipLaunchKernelGGL(bn_bwd_fused<2>, grid, dim3(256), 0, st, a);
+    else if (da_slabs <= 4) hipLaunchKernelGGL(bn_bwd_fused<4>, grid, dim3(256), 0, st, a);
+    else if (da_slabs <= 8) hipLaunchKernelGGL(bn_bwd_fused<8>, grid, dim3(256), 0, st, a);
+    else return GLNN_ERR_UNSUPPORTED;
     return glnn::check_launch("glnn_bn_relu_bwd_f32");
   }
+  if (da_slabs > 1) return GLNN_ERR_UNSUPPORTED;       // nothing launched: only the one-launch form folds split-K slabs
   if (gamma) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
@@ -851,22 +960,45 @@ extern "C" int glnn_dropout_mask_u8(int64_t rows, int h, float drop_p, uint32_t 
   return glnn::check_launch("glnn_dropout_mask_u8");
 }
 
-extern "C" int glnn_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,
-                                  float* const* exp_avg_sq, const int64_t* sizes, int num_tensors, int64_t max_size,
-                                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                  void* stream) {
+int glnn::adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                    const int64_t* sizes, int num_tensors, int64_t max_size, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, const float* const* grads_host, const PendingFolds* pending, void* stream) {
   GLNN_REQUIRE(params && grads && exp_avg && exp_avg_sq && sizes, "glnn_adam_step_f32: null pointer");
   GLNN_REQUIRE(num_tensors >= 1 && max_size >= 1 && step >= 1, "glnn_adam_step_f32: bad sizes/step");
-  AdamArgs a;
+  AdamArgs a = {};
   a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq; a.sizes = sizes;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
   const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
   a.step_size = (float)((double)lr / bc1);
   a.bc2_sqrt = (float)std::sqrt(bc2);
-  int64_t chunks = (max_size + 1023) / 1024;
+  a.num_tensors = num_tensors;
+  int extra = 0;
+  if (pending) {
+    GLNN_REQUIRE(grads_host && num_tensors <= kAdamSrcMax, "glnn::adam_step: pending folds need the host pointer table and <= %d tensors", kAdamSrcMax);
+    a.nsrc = num_tensors;
+    for (int i = 0; i < pending->n; ++i) {
+      const GradFold& f = pending->e[i];
+      if (f.nslab == 0) continue;
+      int t = -1;
+      for (int k = 0; k < num_tensors; ++k)
+        if (grads_host[k] == f.grad) t = k;
+      GLNN_REQUIRE(t >= 0, "glnn::adam_step: a pending gradient fold matches no tensor of the table");
+      a.src[t] = {f.src, f.nslab, f.lanes4, f.stride};
+    }
+    if (pending->has_loss) { a.lf = pending->loss; extra = 1; }
+  }
+  int64_t chunks = (max_size + (pending ? 255 : 1023)) / (pending ? 256 : 1024);       // folding: one element per thread while the grid allows
   if (chunks > 1024) chunks = 1024;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks, (unsigned)num_tensors), dim3(256), 0,
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)chunks, (unsigned)(num_tensors + extra)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   return glnn::check_launch("glnn_adam_step_f32");
+}
+
+extern "C" int glnn_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const int64_t* sizes, int num_tensors, int64_t max_size,
+                                  float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                  void* stream) {
+  return glnn::adam_step(params, grads, exp_avg, exp_avg_sq, sizes, num_tensors, max_size, lr, beta1, beta2, eps, weight_decay, step,
+                         nullptr, nullptr, stream);
 }

@@ -397,6 +397,14 @@ class TensorTable:
         self.sizes = torch.tensor([t.numel() for t in params], dtype=torch.int64, device=dev)
         self.n = len(params)
         self.max_size = max(t.numel() for t in params)
+        # glnn_adam_desc (the one-call train step): the same table + a HOST copy of the gradient pointers
+        import ctypes
+        self.g_host = (ctypes.c_void_p * self.n)(*[t.data_ptr() for t in grads])
+        self.desc = _lib.AdamDesc()
+        d = self.desc
+        d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.sizes = _p(self.p), _p(self.g), _p(self.m), _p(self.v), _p(self.sizes)
+        d.grads_host = ctypes.cast(self.g_host, ctypes.c_void_p)
+        d.num_tensors, d.max_size = self.n, self.max_size
 
 
 def adam_step(table, lr, step, weight_decay=0.0, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -107,6 +107,7 @@ class StudentEngine:
             exp_avg_sq.append(st["exp_avg_sq"])
         self.step_count = int(optimizer.state[params[0]]["step"])
         self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
+        self._one_call = os.environ.get("GLNN_STUDENT_ONE_CALL", "1") != "0"
         # workspaces
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
@@ -276,11 +277,23 @@ class StudentEngine:
         for i, sd in enumerate(seeds):
             self._seed_arr[i] = sd
         trow = idx if target_rows is None else target_rows
-        rc = _lib.lib().glnn_mlp_fwd_bwd_f32(
-            ctypes.byref(self.desc), ops._p(feats), feats.stride(0), ops._p(idx), m, kind,
-            ops._p(target) if kind == ops.LOSS_NLL else None,
-            ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
-            ops._p(trow), float(lamb), self._seed_arr, ops._stream())
+        # nothing sits between the backward and Adam (no gradient exchange): the whole step is ONE C call, and Adam folds the
+        # backward's gradient partials itself (glnn_mlp_train_step_f32)
+        one_call = self.grad_sync is None and self.exchange is None and getattr(self, "overlap", None) is None and self._one_call
+        if one_call:
+            ad = self.table.desc
+            ad.lr, ad.beta1, ad.beta2, ad.eps, ad.weight_decay, ad.step = lr, beta1, beta2, eps, wd, self.step_count
+            rc = _lib.lib().glnn_mlp_train_step_f32(
+                ctypes.byref(self.desc), ops._p(feats), feats.stride(0), ops._p(idx), m, kind,
+                ops._p(target) if kind == ops.LOSS_NLL else None,
+                ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
+                ops._p(trow), float(lamb), self._seed_arr, ctypes.byref(ad), ops._stream())
+        else:
+            rc = _lib.lib().glnn_mlp_fwd_bwd_f32(
+                ctypes.byref(self.desc), ops._p(feats), feats.stride(0), ops._p(idx), m, kind,
+                ops._p(target) if kind == ops.LOSS_NLL else None,
+                ops._p(target) if kind == ops.LOSS_KL else None, target.stride(0) if kind == ops.LOSS_KL else 0,
+                ops._p(trow), float(lamb), self._seed_arr, ops._stream())
         if rc != 0:
             # a step that aborted midway: Adam's bias correction and the dropout seeds must not advance, and the arrival / fold
             # counters of the one-launch reductions may be left non-zero (the next launch would skip its wait and read stale partials)
@@ -294,7 +307,9 @@ class StudentEngine:
         if rc != 0 and overlap is not None and overlap.error is not None:
             err, overlap.error = overlap.error, None
             raise RuntimeError("glnn_mlp_fwd_bwd_f32: a gradient all-reduce started inside the backward failed") from err
-        _lib.check(rc, "glnn_mlp_fwd_bwd_f32")
+        _lib.check(rc, "glnn_mlp_train_step_f32" if one_call else "glnn_mlp_fwd_bwd_f32")
+        if one_call:
+            return
 
         # ---- (data-parallel) gradient exchange, then Adam ---------------------------------------
         if self.grad_sync is not None:

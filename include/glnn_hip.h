@@ -353,6 +353,30 @@ GLNN_API int glnn_mlp_fwd_bwd_f32(const glnn_mlp_step_desc* desc, const float* f
                                   float lamb, const uint32_t* drop_seeds, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI 6: the WHOLE optimisation step of the student in one call -- glnn_mlp_fwd_bwd_f32 followed by glnn_adam_step_f32 on the
+ * same stream (reference train_and_eval.py:74-85: forward, loss, backward, optimizer.step()), for hosts with nothing to put
+ * between the two (no gradient exchange).  Because Adam is known to be the next launch and the only consumer of the gradients,
+ * the backward leaves the final sums of its gradient partials to it (the split-K slabs of the weight gradients, the per-chunk
+ * column sums behind the bias gradients, the per-workgroup loss partials): the fold launches and last-workgroup tails of the
+ * two-call form disappear, the sums and their order do not (same bits), and the folded gradients are still stored to `grads`.
+ * glnn_adam_desc: the arguments of glnn_adam_step_f32 plus `grads_host`, a HOST copy of the device pointer table `grads`
+ * (num_tensors entries; how a pending fold finds its tensor).  num_tensors <= 32 for the folds; more tensors take the plain form.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct glnn_adam_desc {
+  float* const* params; const float* const* grads; float* const* exp_avg; float* const* exp_avg_sq; const int64_t* sizes;
+  const float* const* grads_host;
+  int32_t num_tensors; int32_t reserved;
+  int64_t max_size;
+  float lr, beta1, beta2, eps, weight_decay; int32_t reserved2;
+  int64_t step;                       /* 1-based step count AFTER this update */
+} glnn_adam_desc;
+
+GLNN_API int glnn_mlp_train_step_f32(const glnn_mlp_step_desc* desc, const float* feats, int64_t ldx,
+                                     const int64_t* idx, int64_t m, int kind, const int64_t* labels,
+                                     const float* target_logp, int64_t ldt, const int64_t* target_rows,
+                                     float lamb, const uint32_t* drop_seeds, const glnn_adam_desc* adam, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * The whole forward + NLL + backward of ONE sampled-block GraphSAGE training step in one call (reference
  * train_and_eval.py:39-53 over SAGE.forward, models.py:101-119): per layer glnn_spmm_csr_f32 (SAGE_GCN) -> glnn_gemm_f32 ->
  * glnn_bn_stats_f32 -> glnn_act_fwd_f32; glnn_softmax_loss_f32 with labels[label_rows[i]]; backward per layer

@@ -1,0 +1,12 @@
+"""Unfiltered steady-state slice of a rocprofv3 kernel trace: every kernel, with gaps."""
+import csv, glob, sys
+f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
+skip, count = int(sys.argv[2]), int(sys.argv[3])
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+seg = rows[skip:skip + count]
+t0 = int(seg[0]["Start_Timestamp"]); prev = t0
+for r in seg:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+    print(f"{(s - t0) / 1e3:8.1f} gap {(s - prev) / 1e3:5.1f} dur {(e - s) / 1e3:6.1f}  {name}")
+    prev = e
