@@ -10,6 +10,9 @@
 
 namespace glnn {
 
+struct GradFold;
+struct PendingFolds;
+
 void set_error(const char* fmt, ...);
 
 inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -74,13 +77,17 @@ int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamm
 int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels, const int64_t* label_rows,
                  const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
                  float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum, float* workspace, int64_t workspace_floats,
-                 void* stream, int* counter, float* col_sum, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr);
+                 void* stream, int* counter, float* col_sum, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr,
+                 struct PendingFolds* pf = nullptr);
+// pf: the loss / bias-gradient partials are registered there for the fused Adam launch instead of being folded by the last workgroup
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
-                void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0);
+                void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0,
+                struct GradFold* defer_colsum = nullptr);
+// defer_colsum: (one-launch form only) dz_col_sum is NOT written; *defer_colsum describes the per-chunk partials left in `workspace`
 // da_slabs > 1: da points at that many split-K partial slabs (da[s][rows][ldda]) which the one-launch form sums itself; any other
 // form returns GLNN_ERR_UNSUPPORTED with nothing launched (fold with gemm_fold_partials, call again)
 int gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, const float* bias, float* c, int64_t ldc, void* stream);
@@ -119,6 +126,7 @@ struct LatStats {      // BatchNorm1d training statistics of C + finalize (argum
 struct LatLoss {       // log_softmax + loss + dlogits on C (n <= 64) (arguments as softmax_loss; counter and ws required)
   int kind; const int64_t* labels; const int64_t* label_rows; const float* target_logp; int64_t ldt; const int64_t* target_rows;
   float lamb; float* dlogits; int64_t ldg; float* loss_out; float* loss_accum; float* ws; int64_t ws_floats; int* counter; float* col_sum;
+  struct PendingFolds* pf;      // optional: register the partials for the fused Adam launch instead of folding them here
 };
 int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
              uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,

@@ -325,14 +325,15 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
       float l = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) l += rl[i];
-      st_part(&ls.partial[blockIdx.x], l, true);
+      st_part(&ls.partial[blockIdx.x], l, !ls.defer);
     }
     if (ls.col_sum && tid < 64) {
       float cs = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) cs += red[1][i * LDT + tid];
-      st_part(&ls.col_partial[(int64_t)blockIdx.x * 64 + tid], cs, true);
+      st_part(&ls.col_partial[(int64_t)blockIdx.x * 64 + tid], cs, !ls.defer);
     }
+    if (ls.defer) return;                   // the fused Adam launch folds the partials
     if (!last_workgroup(ls.counter, (int)gridDim.x)) return;
     loss_fold_last(ls, (int)gridDim.x, sc4);
   }
@@ -427,6 +428,12 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
     la.t = ls->target_logp; la.ldt = ls->ldt; la.t_rows = ls->target_rows; la.scale = ls->lamb / (float)m;
     la.dz = ls->dlogits; la.ldg = ls->ldg; la.partial = ls->ws; la.counter = ls->counter; la.inv_rows = 1.0f / (float)m;
     la.loss_out = ls->loss_out; la.loss_accum = ls->loss_accum; la.col_sum = ls->col_sum; la.col_partial = ls->ws + mt;
+    if (ls->pf && ls->pf->n < glnn::kMaxGradFolds) {
+      la.defer = 1;
+      ls->pf->has_loss = 1;
+      ls->pf->loss = {ls->ws, (int)mt, 1.0f / (float)m, ls->loss_out, ls->loss_accum};
+      if (ls->col_sum) ls->pf->e[ls->pf->n++] = {ls->col_sum, la.col_partial, (int)mt, 1, 64};
+    }
     return launch_lat<2, EPI_LOSS>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
   }
   return launch_lat<1, EPI_PLAIN>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);

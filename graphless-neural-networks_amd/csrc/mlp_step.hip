@@ -78,7 +78,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       if (last && fused_bias) {
         const glnn::LatLoss ll = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
                                   kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out,
-                                  d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1]};
+                                  d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1], pf};
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
                              out, ldo, pin, nullptr, &ll, stream);
         loss_done = lat == GLNN_OK;
@@ -170,7 +170,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                               target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
                               cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr,
-                              logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr));
+                              logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr, fused_bias ? pf : nullptr));
   // ---- backward ----
   // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
   // activation backward -> dz_{l-1} stays on `stream`; the weight gradients go to the aux stream.  dz_l alternates between
@@ -282,17 +282,26 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                                       d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream));
     } else if (d->batchnorm) {
       int rc = GLNN_ERR_UNSUPPORTED;
+      // deferred column sums stay in the workspace until Adam: every layer gets its own slice of ws_bn then
+      glnn::GradFold cf = {};
+      float* wsb = d->ws_bn;
+      int64_t wsb_floats = d->ws_bn_floats;
+      const int64_t need_l = 3 * ((m + 127) / 128) * d->dims[l];
+      const bool dc = pf && grp == nullptr && L >= 2 && (d->ws_bn_floats / (L - 1) / 4 * 4) >= need_l && pf->n < glnn::kMaxGradFolds;
+      if (dc) { wsb_floats = d->ws_bn_floats / (L - 1) / 4 * 4; wsb = d->ws_bn + (l - 1) * wsb_floats; }
+      glnn::GradFold* cfp = dc ? &cf : nullptr;
       if (da_slabs > 0)
         rc = glnn::bn_relu_bwd(d->ws_gemm, d->dims[l], d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
-                               d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, 1, da_slabs);
+                               d->gbeta[l - 1], d->gb[l - 1], wsb, wsb_floats, stream, grp, cnt, 1, da_slabs, cfp);
       if (rc == GLNN_ERR_UNSUPPORTED) {
         if (da_slabs > 0) GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, da_slabs, m, d->dims[l], nullptr, d->da, d->ld_da, stream));
         rc = glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
-                               d->gbeta[l - 1], d->gb[l - 1], d->ws_bn, d->ws_bn_floats, stream, grp, cnt);
+                               d->gbeta[l - 1], d->gb[l - 1], wsb, wsb_floats, stream, grp, cnt, 1, 0, cfp);
       }
       GLNN_TRY(rc);
+      if (dc && cf.nslab > 0) pf->e[pf->n++] = cf;
     } else {
       GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], nullptr, nullptr, nullptr, nullptr,
                                  nullptr, p, seed, dz_out, ld_out, nullptr, nullptr, d->gb[l - 1], d->ws_bn, d->ws_bn_floats,

@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
     sc[wave][lane] = col_acc;
     __syncthreads();
     if (threadIdx.x == 0) st_part(&a.partial[blockIdx.x], (s[0] + s[1]) + (s[2] + s[3]), a.counter != nullptr);
-    if (!a.counter) return;
-    if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]), true);
+    if (!a.counter && !a.defer) return;
+    if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]), a.counter != nullptr);
+    if (a.defer) return;
     if (!last_workgroup(a.counter, (int)gridDim.x)) return;
     loss_fold_last(a, (int)gridDim.x, sc);
   }
@@ -203,6 +204,7 @@ struct BnBwdArgs {
   const float* p1; const float* p2; int nparts; int64_t pstride; int local_part; const float* rows_total;
   int* counters; float* dz_col_sum;      // counters != NULL: the last row-chunk workgroup of a column block folds ws3 into dz_col_sum
   int relu;                              // 1: the ReLU sits behind the norm (MLP / SAGE tails); 0: no ReLU in this tail (GCN: norm -> dropout)
+  int defer_colsum;                      // bn_bwd_fused: ws3 (per-chunk column sums of dz) is left for the fused Adam launch to fold
   int nslab; int64_t slab_stride;        // bn_bwd_fused<NS > 0>: da = sum of nslab <= NS split-K slabs da[s * slab_stride + r * ldda + col]
 };
 
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
   }
   __shared__ float sh1[kRowLanes][64], sh2[kRowLanes][64];
   __shared__ int s_go;
+  int departed = -1;
   sh1[rl][lc] = s1;
   sh2[rl][lc] = s2;
   __syncthreads();
@@ -378,6 +381,9 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
     int* arrive = &a.counters[512 + blockIdx.x];
     __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.y) __builtin_amdgcn_s_sleep(1);
+    // deferred column sums: no fold tail whose last workgroup could reset the arrival counter -- count DEPARTURES from the wait
+    // instead (nothing to publish: no drain), requested here so that the round trip hides under the apply phase
+    if (a.defer_colsum) departed = __hip_atomic_fetch_add(&a.counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_go = 1;
   }
   __syncthreads();
@@ -407,7 +413,14 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
   __syncthreads();
   sh1[rl][lc] = sdz;
   __syncthreads();
-  if (rl == 0 && col < a.h) st_part(&a.ws3[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), true);
+  if (rl == 0 && col < a.h) st_part(&a.ws3[(int64_t)blockIdx.y * a.h + col], (sh1[0][lc] + sh1[1][lc]) + (sh1[2][lc] + sh1[3][lc]), !a.defer_colsum);
+  if (a.defer_colsum) {
+    if (threadIdx.x == 0 && departed == (int)gridDim.y - 1) {       // every workgroup of the column block is past the wait: reset both
+      __hip_atomic_store(&a.counters[512 + blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (last_workgroup(&a.counters[blockIdx.x], (int)gridDim.y)) {
     if (threadIdx.x == 0) __hip_atomic_store(&a.counters[512 + blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     float s = 0.f;                                      // lane-split fold of the per-chunk sums, fixed order (as bn_bwd_apply)
@@ -598,7 +611,10 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
                        const int64_t* label_rows, const float* target_logp, int64_t ldt, const int64_t* target_rows, float lamb,
                        float* dlogits, int64_t ldg, float* logprob_out, int64_t ldl, float* loss_out, float* loss_accum,
                        float* workspace, int64_t workspace_floats, void* stream, int* counter, float* col_sum, const float* slabs,
-                       int nslab, const float* bias) {
+                       int nslab, const float* bias, glnn::PendingFolds* pf) {
+  // deferral replaces the counter form only, and only for small batches: Adam's threads walk the partials of their element in sequence
+  // (B = 4096: 256 workgroup partials behind every bias-gradient element made the step 4 % SLOWER)
+  if (pf && !(counter && c <= 64 && pf->n < glnn::kMaxGradFolds && rows <= 128)) pf = nullptr;    // <= 32 workgroup partials (one row per wave)
   GLNN_REQUIRE(logits && dlogits && workspace, "glnn_softmax_loss_f32: null pointer");
   GLNN_REQUIRE(nslab == 0 || (slabs && nslab > 0 && c <= 64), "glnn_softmax_loss_f32: split-K slabs need c <= 64");
   GLNN_REQUIRE(rows >= 1 && c >= 1 && ldz >= c && ldg >= c, "glnn_softmax_loss_f32: bad sizes");
@@ -616,12 +632,18 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.kind = kind; a.labels = labels; a.label_rows = label_rows;
   a.t = target_logp; a.ldt = ldt; a.t_rows = target_rows; a.scale = lamb / (float)rows;
   a.dz = dlogits; a.ldg = ldg; a.logp = logprob_out; a.ldl = ldl; a.partial = workspace;
-  a.counter = counter; a.inv_rows = 1.0f / (float)rows; a.loss_out = loss_out; a.loss_accum = loss_accum;
+  a.counter = pf ? nullptr : counter; a.inv_rows = 1.0f / (float)rows; a.loss_out = loss_out; a.loss_accum = loss_accum;
   a.col_sum = col_sum; a.col_partial = workspace + blocks;
+  a.defer = pf ? 1 : 0;
+  if (pf) {
+    pf->has_loss = 1;
+    pf->loss = {workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum};
+    if (col_sum) pf->e[pf->n++] = {col_sum, a.col_partial, (int)blocks, 1, 64};
+  }
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = rows * c; a.bias = bias; a.z_store = const_cast<float*>(logits);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  if (!counter)
+  if (!counter && !pf)
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum);
   return glnn::check_launch("glnn_softmax_loss_f32");
 }
@@ -742,7 +764,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                       float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu,
-                      int da_slabs) {
+                      int da_slabs, glnn::GradFold* defer_colsum) {
+  if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -755,7 +778,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.a_scale = a_scale; a.a_shift = a_shift; a.dthr = glnn::drop_threshold(drop_p); a.dseed = drop_seed;
   a.dscale = 1.0f / (1.0f - drop_p); a.dz = dz; a.lddz = lddz; a.dgamma = dgamma; a.dbeta = dbeta; a.nchunks = nchunks;
   a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
-  a.relu = relu ? 1 : 0;
+  a.relu = relu ? 1 : 0; a.defer_colsum = 0;
   a.nslab = da_slabs > 0 ? da_slabs : 1; a.slab_stride = rows * ldda;
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
@@ -770,6 +793,10 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= fused_grid_limit() && grid.x <= 256) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     // co-resident grid: partial -> wait -> apply in one launch
+    if (defer_colsum && nchunks <= 8) {   // the workspace must then stay untouched until the fused Adam launch has run
+      a.defer_colsum = 1;
+      *defer_colsum = {dz_col_sum, a.ws3, nchunks, 1, (int64_t)h};
+    }
     if (da_slabs <= 1) hipLaunchKernelGGL(bn_bwd_fused<1>, grid, dim3(256), 0, st, a);
     else if (da_slabs <= 2) hipLaunchKernelGGL(bn_bwd_fused<2>, grid, dim3(256), 0, st, a);
     else if (da_slabs <= 4) hipLaunchKernelGGL(bn_bwd_fused<4>, grid, dim3(256), 0, st, a);

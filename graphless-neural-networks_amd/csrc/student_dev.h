@@ -69,6 +69,9 @@ struct LossArgs {
   // nslab > 0 (c <= 64): the logits are still split-K partials -- logit(row, j) = sum_s slabs[s * slab_stride + row * c + j] + bias[j],
   // summed here (s ascending) and stored to z (the fold launch of the producing GEMM is gone)
   const float* slabs; int nslab; int64_t slab_stride; const float* bias; float* z_store;
+  // defer != 0: the partials (loss per workgroup; with col_sum != NULL the [blocks][64] column partials) are left in memory for the
+  // fused Adam launch to fold (glnn::PendingFolds): plain stores, no counter, no last-workgroup tail
+  int defer;
 };
 
 // last workgroup of a loss launch: loss = sum of the per-workgroup partials / rows (fixed order) and, with col_sum, the column
