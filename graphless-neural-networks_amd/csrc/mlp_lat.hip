@@ -388,7 +388,7 @@ BnFinArgs fin_args(const glnn::LatStats& st, const float* ws_mean, const float* 
 int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
                    uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
                    int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream) {
-  static const int enabled = env_int("GLNN_GEMM_LAT", 1);
+  const int enabled = env_int("GLNN_GEMM_LAT", 1);            // read per call: tests and A/B runs toggle it between steps
   static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
   static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
   if (!enabled || !a || !b || !c || m < 1 || m > max_m || k < 4 || k > max_k || n < 1 || n > max_n || (st && ls)) return GLNN_ERR_UNSUPPORTED;

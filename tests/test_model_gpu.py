@@ -228,6 +228,81 @@ def test_materialised_activation_steps_equal_recomputed_ones_bit_for_bit(dims, b
         assert torch.equal(a, b)
 
 
+def _variant_run(base, dims, bsz, x, tgt, kind, steps, lr=0.01):
+    """`steps` optimiser steps of a fresh copy of `base` under the current environment -> (state, moments, grads, loss, logits)."""
+    import copy
+    from glnn_amd import ops
+    from glnn_amd.student import StudentEngine
+    model = copy.deepcopy(base)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=5e-4)
+    eng = StudentEngine(model, opt, bsz)
+    for i in range(steps):
+        eng.step(x, torch.arange(i * 7, i * 7 + bsz, device=DEV), kind, tgt, 0.7)
+    torch.cuda.synchronize()
+    if eng.sync_counters is not None:
+        assert int(eng.sync_counters.abs().sum()) == 0            # every counter protocol returned its counters to zero
+    return ([t.detach().clone() for t in model.state_dict().values()], [opt.state[q]["exp_avg"].clone() for q in model.parameters()],
+            [g.clone() for g in eng.grads], eng.loss_out.clone(), eng.logits[:bsz].clone())
+
+
+def _variant_inputs(dims, bsz, norm, p, kind, seed):
+    from glnn_amd import ops
+    from glnn_amd.models import Model
+    torch.manual_seed(seed)
+    base = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
+                      dropout_ratio=p, norm_type=norm, device=DEV))
+    x = ops.as_feat(torch.randn(2 * bsz, dims[0], device=DEV))
+    if kind == "nll":
+        return base, x, torch.randint(0, dims[-1], (2 * bsz,), device=DEV), ops.LOSS_NLL
+    return base, x, ops.as_feat(torch.log_softmax(torch.randn(2 * bsz, dims[-1], device=DEV), 1)), ops.LOSS_KL
+
+
+SMALL_STEP_CASES = [([128, 256, 256, 40], 512, "batch", 0.2, "kl"), ([100, 72, 72, 47], 300, "batch", 0.5, "nll"),
+                    ([24, 64, 64, 5], 77, "none", 0.0, "kl"), ([128, 1024, 1024, 40], 512, "batch", 0.5, "kl"),
+                    ([100, 256, 256, 47], 4096, "batch", 0.5, "kl")]
+
+
+@pytest.mark.parametrize("dims,bsz,norm,p,kind", SMALL_STEP_CASES)
+def test_one_call_train_step_equals_fwd_bwd_plus_adam_bit_for_bit(dims, bsz, norm, p, kind, monkeypatch):
+    """glnn_mlp_train_step_f32 (ABI 6) leaves the last sums of the gradient partials -- split-K slabs of the batched weight gradients,
+    per-chunk column sums of the BatchNorm backward, the loss kernel's per-workgroup loss / bias-gradient partials -- to the Adam launch.
+    Same partials, same order: three steps end in the same parameters, moments, running statistics, gradients and loss as
+    glnn_mlp_fwd_bwd_f32 + glnn_adam_step_f32, bit for bit (and with GLNN_STUDENT_ADAM_FOLDS=0, the one-call form without the folds)."""
+    base, x, tgt, k = _variant_inputs(dims, bsz, norm, p, kind, 21)
+    runs = []
+    for one_call, folds in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("GLNN_STUDENT_ONE_CALL", one_call)
+        monkeypatch.setenv("GLNN_STUDENT_ADAM_FOLDS", folds)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 3))
+    for other in runs[1:]:
+        for a, b in zip(runs[0][0] + runs[0][1] + runs[0][2] + [runs[0][3]], other[0] + other[1] + other[2] + [other[3]]):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("knob", ["GLNN_GEMM_LAT", "GLNN_STUDENT_DEFER_STATS", "GLNN_STUDENT_SLAB_CONSUMERS"])
+@pytest.mark.parametrize("dims,bsz,norm,p,kind", SMALL_STEP_CASES[:4])
+def test_small_batch_step_forms_agree(dims, bsz, norm, p, kind, knob, monkeypatch):
+    """The latency forms of the B <= 1024 step against the forms they replace, one optimiser step from the same state:
+      GLNN_GEMM_LAT=0              tiled GEMMs + separate statistics / loss launches instead of mlp_lat.hip (K split over the four waves
+                                   of a workgroup, statistics / loss as epilogue),
+      GLNN_STUDENT_DEFER_STATS=0   statistics finished by the last workgroup of the producing launch instead of in the consumer's prologue,
+      GLNN_STUDENT_SLAB_CONSUMERS=0  split-K partials folded by a launch instead of by the statistics / BatchNorm-backward kernel.
+    They differ by summation order only: logits, loss and every gradient agree to fp32 rounding (partial tiles: 300 / 77 rows, 72 and 5
+    columns, K = 100 and 24)."""
+    base, x, tgt, k = _variant_inputs(dims, bsz, norm, p, kind, 33)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv(knob, mode)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 1))
+    (_, _, g0, l0, z0), (_, _, g1, l1, z1) = runs
+    assert abs(float(l0) - float(l1)) <= 2e-6 * max(1.0, abs(float(l0)))
+    torch.testing.assert_close(z1, z0, atol=2e-5, rtol=1e-5)
+    for a, b in zip(g0, g1):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (tuple(a.shape), float((a - b).abs().max()), scale)
+
+
 @pytest.mark.parametrize("dims,bsz,p", [([128, 256, 256, 40], 512, 0.2), ([100, 256, 256, 47], 4096, 0.5), ([24, 64, 64, 5], 300, 0.0),
                                         ([128, 1024, 1024, 40], 512, 0.5)])
 def test_one_launch_batchnorm_backward_equals_the_two_launch_form_bit_for_bit(dims, bsz, p, monkeypatch):
