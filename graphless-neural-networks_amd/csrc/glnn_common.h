@@ -130,7 +130,12 @@ struct LatLoss {       // log_softmax + loss + dlogits on C (n <= 64) (arguments
 };
 int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
              uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
-             int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream);
+             int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy = nullptr,
+             int64_t ld_copy = 0);
+// a_copy (plain operands only): the rows of A (gathered through a_rows) are also stored as a dense [m, k] matrix -- the first layer's
+// batch rows, which the weight gradient reads again
+int gemm_tn_lat(const TnProblem* problems, int n, void* stream, GradFold* defer = nullptr, float* workspace = nullptr,
+                int64_t workspace_floats = 0);
 int bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream);
 
 }  // namespace glnn

@@ -32,6 +32,7 @@ struct LatArgs {
   uint32_t drop_thr, drop_seed; float drop_scale;
   int64_t m; int k; const float* b; int64_t ldb; int n;
   const float* bias; float* c; int64_t ldc; int c_vec;
+  float* a_copy; int64_t ld_copy;                 // optional: the (gathered) rows of A stored as a plain [m, k] matrix by the blockIdx.y == 0 tiles
   int gpw;                                        // k-groups per wave: wave q owns groups [q * gpw, (q + 1) * gpw)
   float* ws_mean; float* ws_m2; int* counters;    // EPI_STATS: [m tiles][n] partials, one counter per 64-column block
 };
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
       const int kc = (q * g.gpw + c0 + u) * 8 + kk * 4;
       const int kcc = kc > kpad - 4 ? kpad - 4 : kc;
       av[u] = ld4(ap + kcc);
+      if (XF == 0 && g.a_copy && blockIdx.y == 0 && c0 + u < g.gpw && kc < kpad && m0 + li < g.m)
+        *reinterpret_cast<float4*>(g.a_copy + (m0 + li) * g.ld_copy + kc) = av[u];
       if (XF && !FIN) {
         sc[u] = ld4(g.a_scale + kcc);
         sh[u] = ld4(g.a_shift + kcc);
@@ -358,6 +361,98 @@ int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, const
   return glnn::check_launch("glnn::gemm_lat");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The weight gradients of a small step in the same style: C_p[i, j] = sum_m A_p[m, i] * B'_p[m, j] for up to four problems in one
+// launch (the batched form of gemm.hip's gemm_tn_multi_kernel, which runs 64 x 64 tiles through LDS with a transposing loader and
+// splits the reduction over workgroups -- slabs + a fold).  Both operands are row-major along the NON-reduction index, which is exactly
+// what a lane of v_mfma_f32_32x32x2 wants when it loads from global memory itself: lane (li, kk) needs A[m][i0 + li] for its m's -- 32
+// lanes read 128 consecutive bytes.  So: a workgroup owns a 32 x 32 tile of one C_p, its four waves split the reduction (the batch
+// rows), each wave keeps 8 k-groups (64 dword loads) in flight, the four partial tiles are summed through LDS in fixed order and C is
+// written once: no slabs, no fold launch, no transposes.  B' = B, or dropout(relu(B * scale[j] + shift[j])) with the per-COLUMN
+// constants in two registers of the lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTnLatMax = 4;
+struct TnLatProblem {
+  const float* a; int64_t lda; const float* b; int64_t ldb; const float* b_scale; const float* b_shift;
+  uint32_t drop_thr, drop_seed; float drop_scale;
+  int m, ka, nb; float* c; int64_t ldc;
+  int gj;          // 32-column tiles per row of tiles
+  int start;       // first workgroup of this problem
+  int gpw;         // k-groups (8 batch rows) per wave
+  int splits;      // > 1: the batch rows are also split over `splits` workgroups per tile; split s writes slab c + s * slab (c = workspace)
+  int64_t slab;
+};
+struct TnLatArgs { TnLatProblem p[kTnLatMax]; int n; };
+
+__global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) {
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < kTnLatMax; ++q)
+    if (q < args.n && (int)blockIdx.x >= args.p[q].start) pi = q;
+  const TnLatProblem& g = args.p[pi];
+  constexpr int LDT = 36;
+  __shared__ __attribute__((aligned(16))) float red[4][32 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6, li = lane & 31, kk = lane >> 5;
+  const int tile = ((int)blockIdx.x - g.start) / g.splits, split = ((int)blockIdx.x - g.start) % g.splits;
+  const int i0 = (tile / g.gj) * 32, j0 = (tile % g.gj) * 32;
+  const int wq = split * 4 + q;                      // this wave's slice of the reduction
+  const int ic = i0 + li < g.ka ? i0 + li : g.ka - 1, jc = j0 + li < g.nb ? j0 + li : g.nb - 1;
+  const float* ap = g.a + ic;
+  const float* bp = g.b + jc;
+  const bool xf = g.b_scale != nullptr;
+  const float sc = xf ? g.b_scale[jc] : 1.f, sh = xf ? g.b_shift[jc] : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c0 = 0; c0 < g.gpw; c0 += kGroups) {
+    float av[kGroups][4], bv[kGroups][4];
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+      const int mb = (wq * g.gpw + c0 + u) * 8 + kk * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t mr = mb + t < g.m ? mb + t : g.m - 1;          // clamped: always a valid row, masked below
+        av[u][t] = ap[mr * g.lda];
+        bv[u][t] = bp[mr * g.ldb];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kGroups; ++u) {
+      const int kg = wq * g.gpw + c0 + u;                             // wave-uniform
+      if (c0 + u < g.gpw && kg * 8 < g.m) {
+        const int mb = kg * 8 + kk * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float bvv = bv[u][t];
+          if (xf) {
+            bvv = fmaxf(fmaf(bvv, sc, sh), 0.f);
+            if (g.drop_thr) bvv = glnn::drop_keep(g.drop_seed, g.drop_thr, (uint32_t)(mb + t), (uint32_t)jc) ? bvv * g.drop_scale : 0.f;
+          }
+          const bool in = mb + t < g.m;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? av[u][t] : 0.f, in ? bvv : 0.f, acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[q][((r & 3) + 8 * (r >> 2) + 4 * kk) * LDT + li] = acc[r];
+  __syncthreads();
+  const int row = tid >> 3, c4 = (tid & 7) * 4;
+  const float4 v0 = ld4(&red[0][row * LDT + c4]), v1 = ld4(&red[1][row * LDT + c4]);
+  const float4 v2 = ld4(&red[2][row * LDT + c4]), v3 = ld4(&red[3][row * LDT + c4]);
+  const float v[4] = {((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y, ((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w};
+  if (i0 + row < g.ka) {
+    float* cp = g.c + (int64_t)split * g.slab + (int64_t)(i0 + row) * g.ldc + j0 + c4;
+    if (j0 + c4 + 3 < g.nb && g.ldc % 4 == 0 && glnn::aligned16(g.c)) {
+      *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (j0 + c4 + t < g.nb) cp[t] = v[t];
+    }
+  }
+}
+
 int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -387,7 +482,7 @@ BnFinArgs fin_args(const glnn::LatStats& st, const float* ws_mean, const float* 
 // float4-addressable: the caller then issues the tiled GEMM and the separate reduction kernels.
 int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
                    uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
-                   int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream) {
+                   int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy, int64_t ld_copy) {
   const int enabled = env_int("GLNN_GEMM_LAT", 1);            // read per call: tests and A/B runs toggle it between steps
   static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
   static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
@@ -409,6 +504,10 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
   g.m = m; g.k = k; g.b = b; g.ldb = ldb; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
   g.c_vec = (ldc % 4 == 0) && glnn::aligned16(c);
+  if (a_copy) {
+    if (a_scale || pend || ld_copy % 4 || ld_copy < kpad || !glnn::aligned16(a_copy)) return GLNN_ERR_UNSUPPORTED;
+    g.a_copy = a_copy; g.ld_copy = ld_copy;
+  }
   const int groups = (k + 7) / 8;
   g.gpw = (groups + 3) / 4;
   BnFinArgs fin = {}, pfin = {};
@@ -446,4 +545,52 @@ int glnn::bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream) 
   const BnFinArgs fin = fin_args(st, st.ws, st.ws + mt * n, mt, m, n);
   hipLaunchKernelGGL(bn_finalize_tiles_kernel, dim3((n + 63) / 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), fin);
   return glnn::check_launch("glnn::bn_finalize_tiles");
+}
+
+// Up to four weight gradients (arguments as gemm_tn_batch) in ONE launch of the latency kernel, each written straight to its C (no
+// slabs, no fold).  GLNN_ERR_UNSUPPORTED (nothing launched) unless every problem is small (m <= 1024, ka, nb <= 256), ungathered and
+// -- with an operand transform -- has its column constants readable.
+// defer + workspace (the fused Adam launch follows): long reductions are ALSO split over workgroups so that a wave runs one 8-group
+// chunk; the slabs go to the workspace and defer[p] tells Adam how to fold them (k ascending).
+int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer, float* workspace, int64_t workspace_floats) {
+  if (!env_int("GLNN_GEMM_TN_LAT", 1) || n < 1 || n > kTnLatMax) return GLNN_ERR_UNSUPPORTED;
+  static const int max_dim = env_int("GLNN_GEMM_TN_LAT_MAX_DIM", 256);
+  TnLatArgs a = {};
+  a.n = n;
+  int blocks = 0;
+  int64_t ws_off = 0;
+  for (int p = 0; p < n; ++p) {
+    const TnProblem& q = pr[p];
+    if (!(q.a && q.b && q.c) || q.b_rows || q.m < 1 || q.m > 1024 || q.ka < 1 || q.nb < 1 || q.ka > max_dim || q.nb > max_dim) return GLNN_ERR_UNSUPPORTED;
+    if (q.lda < q.ka || q.ldb < q.nb || q.ldc < q.nb) return GLNN_ERR_UNSUPPORTED;
+    if ((q.b_scale == nullptr) != (q.b_shift == nullptr) || q.drop_p < 0.f || q.drop_p >= 1.f || (q.drop_p > 0.f && !q.b_scale)) return GLNN_ERR_UNSUPPORTED;
+    TnLatProblem& g = a.p[p];
+    g.a = q.a; g.lda = q.lda; g.b = q.b; g.ldb = q.ldb; g.b_scale = q.b_scale; g.b_shift = q.b_shift;
+    g.drop_thr = glnn::drop_threshold(q.drop_p); g.drop_seed = q.drop_seed; g.drop_scale = 1.0f / (1.0f - q.drop_p);
+    g.m = (int)q.m; g.ka = q.ka; g.nb = q.nb; g.c = q.c; g.ldc = q.ldc;
+    const int gi = (q.ka + 31) / 32;
+    g.gj = (q.nb + 31) / 32;
+    g.start = blocks;
+    const int groups = (int)((q.m + 7) / 8);
+    g.splits = 1; g.slab = 0;
+    if (defer) defer[p] = {q.c, nullptr, 0, 0, 0};
+    const int64_t slab = (int64_t)q.ka * q.nb;
+    const int gpw_target = env_int("GLNN_GEMM_TN_LAT_GPW", kGroups);
+    int sp = (groups + 4 * gpw_target - 1) / (4 * gpw_target);
+    const int max_sp = env_int("GLNN_GEMM_TN_LAT_SPLITS", 8);        // read per call: 1 = the unsplit form (bit-identical to the two-call step)
+    if (sp > max_sp) sp = max_sp;
+    if (defer && workspace && sp > 1 && q.ldc == q.nb) {
+      ws_off = (ws_off + 3) & ~(int64_t)3;
+      if (ws_off + sp * slab <= workspace_floats) {
+        g.splits = sp; g.slab = slab; g.c = workspace + ws_off; g.ldc = q.nb;
+        defer[p] = {q.c, g.c, sp, 0, slab};
+        ws_off += sp * slab;
+      }
+    }
+    g.gpw = (groups + 4 * g.splits - 1) / (4 * g.splits);
+    blocks += gi * g.gj * g.splits;
+  }
+  for (int p = n; p < kTnLatMax; ++p) a.p[p].start = blocks;
+  hipLaunchKernelGGL(gemm_tn_lat_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  return glnn::check_launch("glnn::gemm_tn_lat");
 }

@@ -42,8 +42,11 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const float* src = feats;
   int64_t ld_src = ldx;
   const int64_t* rows = idx;
-  const bool pregather = d->xb && idx;       // the batch rows copied once: layer 0's GEMMs read a plain operand
-  if (pregather) {
+  // the batch rows copied once: layer 0's GEMMs read a plain operand (float4 rows only; other inputs keep the gather in the operand loads)
+  const bool pregather = d->xb && idx && ldx % 4 == 0 && glnn::aligned16(feats) && ldx >= ((d->dims[0] + 3) & ~3);
+  // small batches: no gather launch -- the first layer's latency GEMM stores the rows it gathers (gemm_lat a_copy); decided at layer 0
+  bool lazy_copy = pregather && cnt && m <= 1024 && d->batchnorm != 2;
+  if (pregather && !lazy_copy) {
     GLNN_REQUIRE(d->ld_xb >= ((d->dims[0] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_xb too small");
     GLNN_TRY(glnn_gather_rows_f32(feats, ldx, idx, m, d->dims[0], d->xb, d->ld_xb, stream));
     src = d->xb;
@@ -75,12 +78,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     int lat = GLNN_ERR_UNSUPPORTED;
     if (cnt && !layernorm) {
       const glnn::LatStats* pin = have_pend ? &pend : nullptr;         // the previous layer's statistics are still per-tile partials
+      float* cp_dst = (l == 0 && lazy_copy) ? d->xb : nullptr;
       if (last && fused_bias) {
         const glnn::LatLoss ll = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
                                   kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out,
                                   d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1], pf};
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, pin, nullptr, &ll, stream);
+                             out, ldo, pin, nullptr, &ll, stream, cp_dst, d->ld_xb);
         loss_done = lat == GLNN_OK;
       } else if (!last && d->batchnorm == 1) {
         // statistics partials of layer l alternate between the halves of ws_bn: the consumer's workgroups read layer l-1's while
@@ -89,14 +93,20 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         next = {d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum, d->running_mean[l], d->running_var[l], d->nbt[l],
                 d->mean[l], d->rstd[l], d->a_scale[l], d->a_shift[l], d->ws_bn + (l & 1) * half, half, (defer_stats && !d->act[l]) ? nullptr : cnt};
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, pin, &next, nullptr, stream);
+                             out, ldo, pin, &next, nullptr, stream, cp_dst, d->ld_xb);
         stats_done = lat == GLNN_OK;
         have_next = stats_done && next.counters == nullptr;
       } else if (!last) {
         lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
-                             out, ldo, pin, nullptr, nullptr, stream);
+                             out, ldo, pin, nullptr, nullptr, stream, cp_dst, d->ld_xb);
       }
       if (lat != GLNN_OK && lat != GLNN_ERR_UNSUPPORTED) return lat;
+    }
+    if (l == 0 && lazy_copy && lat != GLNN_OK) {        // no latency GEMM at layer 0 after all: the gather launch, then plain operands
+      GLNN_REQUIRE(d->ld_xb >= ((d->dims[0] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_xb too small");
+      GLNN_TRY(glnn_gather_rows_f32(feats, ldx, idx, m, d->dims[0], d->xb, d->ld_xb, stream));
+      src = d->xb; ld_src = d->ld_xb; rows = nullptr;
+      lazy_copy = false;
     }
     if (lat != GLNN_OK && have_pend)       // the consumer is not a latency GEMM after all: finish the statistics with a launch of their own
       GLNN_TRY(glnn::bn_finalize_tiles(pend, m, d->dims[l], stream));
@@ -312,8 +322,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   }
   if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));      // join: `stream` continues behind every weight gradient
 #undef GLNN_HIP_TRY
-  if (defer) {
-    glnn::GradFold gf[GLNN_MLP_MAX_LAYERS];
+  glnn::GradFold gf[GLNN_MLP_MAX_LAYERS];
+  if (defer && glnn::gemm_tn_lat(deferred, n_deferred, stream, pf ? gf : nullptr, d->ws_tn, d->ws_tn_floats) == GLNN_OK) {
+    // every weight gradient of the step from one launch of the latency kernel; with Adam next, its reduction slabs are folded there
+    if (pf)
+      for (int i = 0; i < n_deferred && pf->n < glnn::kMaxGradFolds; ++i) pf->e[pf->n++] = gf[i];
+  } else if (defer) {
     const int rc = glnn::gemm_tn_batch(deferred, n_deferred, d->ws_tn, d->ws_tn_floats, stream, pf ? gf : nullptr);
     if (rc == GLNN_OK && pf)
       for (int i = 0; i < n_deferred && pf->n < glnn::kMaxGradFolds; ++i) pf->e[pf->n++] = gf[i];

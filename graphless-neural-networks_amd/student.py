@@ -132,9 +132,10 @@ class StudentEngine:
                     if self.ln or mat == "1" or (mat == "auto" and self.p > 0 and self._materialize_tail(l, B)) else None
                     for l in range(self.L - 1)]
         # feats[idx] copied once per step when the batch is long enough for the first layer's weight gradient to take the
-        # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches keep the gather inside the operand loads
+        # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches (<= 1024 rows, <= 256 features: the latency
+        # GEMM of csrc/mlp_lat.hip) get the buffer filled by the first layer's GEMM itself; the rest keep the gather in the operand loads
         pg = os.environ.get("GLNN_STUDENT_PREGATHER", "auto")
-        self.xb = ops.feat_empty(B, self.dims[0], dev) if pg == "1" or (pg == "auto" and B >= 2048 and self.dims[0] > 64) else None
+        self.xb = ops.feat_empty(B, self.dims[0], dev) if pg == "1" or (pg == "auto" and ((B >= 2048 and self.dims[0] > 64) or (B <= 1024 and self.dims[0] <= 256))) else None
         # two-stream backward (glnn_mlp_step_desc.aux_stream): the weight-gradient GEMMs on a second HIP stream, meant to run under
         # the memory-bound activation backward of the layers in front.  It does not pay on this part: the pipelined GEMM holds every
         # CU with one 4-wave workgroup that owns the whole register file, so a kernel on the other stream gets no wave slot until
