@@ -43,7 +43,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   int64_t ld_src = ldx;
   const int64_t* rows = idx;
   // the batch rows copied once: layer 0's GEMMs read a plain operand (float4 rows only; other inputs keep the gather in the operand loads)
-  const bool pregather = d->xb && idx && ldx % 4 == 0 && glnn::aligned16(feats) && ldx >= ((d->dims[0] + 3) & ~3);
+  bool pregather = d->xb && idx && ldx % 4 == 0 && glnn::aligned16(feats) && ldx >= ((d->dims[0] + 3) & ~3);
   // small batches: no gather launch -- the first layer's latency GEMM stores the rows it gathers (gemm_lat a_copy); decided at layer 0
   bool lazy_copy = pregather && cnt && m <= 1024 && d->batchnorm != 2;
   if (pregather && !lazy_copy) {
@@ -102,11 +102,9 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       }
       if (lat != GLNN_OK && lat != GLNN_ERR_UNSUPPORTED) return lat;
     }
-    if (l == 0 && lazy_copy && lat != GLNN_OK) {        // no latency GEMM at layer 0 after all: the gather launch, then plain operands
-      GLNN_REQUIRE(d->ld_xb >= ((d->dims[0] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_xb too small");
-      GLNN_TRY(glnn_gather_rows_f32(feats, ldx, idx, m, d->dims[0], d->xb, d->ld_xb, stream));
-      src = d->xb; ld_src = d->ld_xb; rows = nullptr;
-      lazy_copy = false;
+    if (l == 0 && lazy_copy && lat != GLNN_OK) {        // no latency GEMM at layer 0 after all: the gather stays in the operand loads
+      lazy_copy = false;                                 // (a small batch: a gather launch of its own costs more than it saves)
+      pregather = false;
     }
     if (lat != GLNN_OK && have_pend)       // the consumer is not a latency GEMM after all: finish the statistics with a launch of their own
       GLNN_TRY(glnn::bn_finalize_tiles(pend, m, d->dims[l], stream));

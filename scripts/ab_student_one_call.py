@@ -13,6 +13,7 @@ CONFIGS = {
     "arxiv-MLP3w4": dict(dims=[128, 1024, 1024, 40], B=512, p=0.5, n=169343, norm="batch"),
     "cora-MLP": dict(dims=[1433, 128, 7], B=140, p=0.6, n=2485, norm="none"),
     "products-MLP": dict(dims=[100, 256, 256, 47], B=4096, p=0.5, n=400000, norm="batch"),
+    "products-MLP3w8": dict(dims=[100, 2048, 2048, 47], B=4096, p=0.2, n=400000, norm="batch"),
 }
 dev = "cuda:0"
 for name, c in CONFIGS.items():
