@@ -112,6 +112,7 @@ def main():
                          "(every rank projects all rows itself; default) or its 256-wide fused output (no replicated work, 2.56x the bytes)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed output ('verified' on the JSON line)")
     ap.add_argument("--no-clustered-leg", action="store_true", help="N = 1: skip roofline_clustered (the forward on a graph with communities)")
+    ap.add_argument("--no-small-students", action="store_true", help="N = 1: skip students_small (the B = 512 arxiv students' step times)")
     ap.add_argument("--workload", default="products", choices=["products", "arxiv", "xl"],
                     help="products = the metric's config (default); xl = BASELINE.json configs[4]: 12.5M-node / 250M-edge shard per GPU "
                          "of a 100M-node / 2B-edge synthetic graph, 128-d features, SAGE layer-1 aggregation only (weak scaling)")
@@ -330,6 +331,10 @@ def main():
         if GRAPH == "ogbn-products" and not args.no_clustered_leg and args.locality == 0:
             result["roofline_clustered"] = clustered_leg(args, n, teacher, FullNeighborLoader, ops, data, dev)
 
+    # ---- the B = 512 students of BASELINE configs[2] (latency-bound: steps/s, not an MFMA fraction) -- an extra object ----
+    if world == 1 and not args.no_small_students:
+        result["students_small"] = small_student_leg(dev, Model, StudentEngine, ops)
+
     # ---- sampled-block teacher TRAINING (SURVEY 8f rows 1+2; reference train_sage, train_and_eval.py:32-56) -- an extra object ----
     if world == 1 and not args.no_train_leg:
         result["teacher_training"] = teacher_training_leg(g, feats, labels, dev, data)
@@ -518,6 +523,37 @@ def reordered_leg(args, g, feats, teacher, FullNeighborLoader, ops, data):
     obj.update({"order": "nodes renumbered by descending in-degree (stable)", "steps": args.reorder_steps,
                 "edges_per_s": 3 * g2.num_edges() * args.reorder_steps / dt, "ms_per_step": 1e3 * dt / args.reorder_steps})
     return obj
+
+
+def small_student_leg(dev, Model, StudentEngine, ops, steps=3000, warmup=100):
+    """The reference's ogbn-arxiv students (train.conf.yaml:142-154: MLP 128-256-256-40 p=0.2 and MLP3w4 128-1024-1024-40 p=0.5,
+    B = 512, BatchNorm, Adam lr 0.01) on arxiv-shaped synthetic rows: the whole KL distillation step (gather, forward, loss, backward,
+    Adam) as StudentEngine.step issues it -- ONE C call, glnn_mlp_train_step_f32.  Latency-bound: a step is 9-13 dependent launches
+    of 5-15 us (profiles/r03_student_small_timeline.txt), so the figure of merit is ms per step."""
+    out = []
+    n = 169343
+    for name, dims, p in (("MLP", [128, 256, 256, 40], 0.2), ("MLP3w4", [128, 1024, 1024, 40], 0.5)):
+        torch.manual_seed(0)
+        model = Model(dict(model_name="MLP", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type="batch", device=dev))
+        model.train()
+        eng = StudentEngine(model, torch.optim.Adam(model.parameters(), lr=0.01), 512)
+        feats = ops.as_feat(torch.randn(n, dims[0], device=dev))
+        out_t = ops.as_feat(torch.log_softmax(torch.randn(n, dims[-1], device=dev), 1))
+        nb = n // 512
+        perm = torch.randperm(n)[: nb * 512].view(nb, -1).to(dev)
+        for i in range(warmup):
+            eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out.append({"student": name, "dims": dims, "batch": 512, "dropout": p, "ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt,
+                    "steps": steps, "loss_finite": bool(torch.isfinite(eng.loss_out).all())})
+        del eng, model, feats, out_t
+    return out
 
 
 def clustered_leg(args, n, teacher, FullNeighborLoader, ops, data, dev):

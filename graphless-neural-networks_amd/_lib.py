@@ -150,7 +150,7 @@ def lib():
         h.glnn_last_error.restype = ctypes.c_char_p
         if h.glnn_abi_version() != ABI_VERSION:
             raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
-        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer)):
+        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc)):
             if h.glnn_struct_bytes(which) != ctypes.sizeof(mirror):
                 raise GlnnError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {h.glnn_struct_bytes(which)} in the library, "
                                 f"{ctypes.sizeof(mirror)} in this binding")

@@ -57,6 +57,7 @@ extern "C" int64_t glnn_struct_bytes(int which) {
   if (which == 0) return (int64_t)sizeof(glnn_mlp_step_desc);
   if (which == 1) return (int64_t)sizeof(glnn_sage_step_desc);
   if (which == 2) return (int64_t)sizeof(glnn_sage_layer);
+  if (which == 3) return (int64_t)sizeof(glnn_adam_desc);
   return -1;
 }
 

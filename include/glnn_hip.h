@@ -43,7 +43,7 @@ GLNN_API int glnn_abi_version(void);               /* bumped on any signature ch
 GLNN_API const char* glnn_last_error(void);        /* thread-local, never NULL */
 GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int arch_buf_len);
 /* sizeof of the descriptor structs below as THIS build sees them (0 = glnn_mlp_step_desc, 1 = glnn_sage_step_desc,
- * 2 = glnn_sage_layer; -1 otherwise): lets a binding in another language check its mirror of the layout at load time. */
+ * 2 = glnn_sage_layer, 3 = glnn_adam_desc; -1 otherwise): lets a binding in another language check its mirror of the layout at load time. */
 GLNN_API int64_t glnn_struct_bytes(int which);
 
 /* ------------------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ PREV=$1
 for i in 1 2; do
   for v in prev new; do
     if [ $v = prev ]; then export GLNN_LIB_PATH=$PREV; else unset GLNN_LIB_PATH; fi
-    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify 2>/dev/null | python -c "
+    python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify --no-small-students 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print('$v', round(d['ms_per_step'],2), [(x['d'], round(x['avg_ms'],3)) for x in d['roofline']['all_aggregation_launches']])"
   done
