@@ -1637,6 +1637,21 @@ int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspac
 extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                                 const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                                 uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
+  return glnn::gemm_tn(a, lda, m, ka, b, ldb, b_rows, b_scale, b_shift, drop_p, drop_seed, nb, c, ldc, col_sum_a, workspace, workspace_floats,
+                       stream, nullptr, nullptr, nullptr);
+}
+
+// glnn_gemm_tn_f32 whose final sums may be left to the fused Adam launch (glnn::PendingFolds): with `defer` the fold launch of a
+// split reduction is skipped and *defer describes the slabs (same order as the fold kernel that would have run: four interleaved
+// lanes from 16 splits on, k ascending below); with `defer_colsum` the second stage of col_sum_a likewise.  *used_floats = the
+// workspace prefix that then has to stay untouched until Adam has run.
+int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
+                  const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
+                  uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream,
+                  GradFold* defer, GradFold* defer_colsum, int64_t* used_floats) {
+  if (defer) *defer = {c, nullptr, 0, 0, 0};
+  if (defer_colsum) *defer_colsum = {col_sum_a, nullptr, 0, 0, 0};
+  if (used_floats) *used_floats = 0;
   GLNN_REQUIRE(a && b && c, "glnn_gemm_tn_f32: null pointer");
   GLNN_REQUIRE(m >= 1 && ka >= 1 && nb >= 1, "glnn_gemm_tn_f32: bad sizes");
   GLNN_REQUIRE(lda >= ka && ldb >= nb && ldc >= nb, "glnn_gemm_tn_f32: leading dimension too small");
@@ -1736,7 +1751,11 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
   }
   int rc = glnn::check_launch("glnn_gemm_tn_f32");
   if (rc != GLNN_OK) return rc;
-  if (splits > 1) {
+  if (used_floats) *used_floats = (splits > 1 ? (int64_t)splits * slab : 0) + colsum_need;
+  if (splits > 1 && defer && ldc == nb) {
+    const bool lanes = splits >= 16 && ((nb | ldc | slab) & 3) == 0 && glnn::aligned16(ws_partial) && glnn::aligned16(c);
+    *defer = {c, ws_partial, splits, lanes ? 1 : 0, slab};
+  } else if (splits > 1) {
     if (splits >= 16 && ((nb | ldc | slab) & 3) == 0 && glnn::aligned16(ws_partial) && glnn::aligned16(c)) {
       int64_t blocks = ((slab >> 2) + 63) / 64;
       if (blocks > 4096) blocks = 4096;
@@ -1755,7 +1774,9 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
     if (nblk > 64) nblk = 64;
     const int64_t rpb = (m + nblk - 1) / nblk;
     hipLaunchKernelGGL(colsum_stage1, dim3((ka + 63) / 64, nblk), dim3(256), 0, st, a, lda, m, ka, rpb, workspace);
-    hipLaunchKernelGGL(colsum_stage2, dim3((ka + 255) / 256), dim3(256), 0, st, workspace, nblk, ka, col_sum_a);
+    const int nblk_used = (int)((m + rpb - 1) / rpb);           // stage 1 writes only the blocks that own rows
+    if (defer_colsum && nblk_used == nblk) *defer_colsum = {col_sum_a, workspace, nblk, 0, (int64_t)ka};
+    else hipLaunchKernelGGL(colsum_stage2, dim3((ka + 255) / 256), dim3(256), 0, st, workspace, nblk, ka, col_sum_a);
     rc = glnn::check_launch("glnn_gemm_tn_f32(colsum)");
   }
   return rc;

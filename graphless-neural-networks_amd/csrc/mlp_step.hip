@@ -111,7 +111,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     have_pend = have_next;
     pend = next;
     // a deep, narrow last layer (MLP3w4: 1024 -> 40) is split over K; its partial slabs are folded by the loss kernel, not by a launch
-    if (lat != GLNN_OK && last && fused_bias && !layernorm) {
+    if (lat != GLNN_OK && last && d->dims[L] <= 64 && slab_consumers) {
       const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0,
                                                d->dims[l + 1], d->ws_gemm, d->ws_gemm_floats, &logit_slabs, stream);
       if (rc == GLNN_OK) lat = GLNN_OK;
@@ -178,7 +178,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                               target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
                               cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr,
-                              logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr, fused_bias ? pf : nullptr));
+                              logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr, pf));
   // ---- backward ----
   // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
   // activation backward -> dz_{l-1} stays on `stream`; the weight gradients go to the aux stream.  dz_l alternates between
@@ -204,6 +204,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                      (L == 1 || fused_bias) && !layernorm;
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
+  int64_t tn_off = 0;
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -224,11 +225,20 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       if (defer) break;
       // the first layer's weight gradient ends the critical path: it stays on `stream` (the aux stream is busy with the wide
       // layers' gradients) with its own workspace -- ws_gemm is idle during the backward
-      float* ws0 = two ? d->ws_gemm : d->ws_tn;
-      const int64_t ws0_floats = two ? d->ws_gemm_floats : d->ws_tn_floats;
-      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
-                                nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
-                                d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream));
+      const bool fold_later = pf && !two && tn_off < d->ws_tn_floats;
+      float* ws0 = two ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
+      const int64_t ws0_floats = two ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
+      glnn::GradFold fw = {}, fc = {};
+      int64_t used = 0;
+      GLNN_TRY(glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
+                             nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
+                             d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
+                             fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used));
+      if (fold_later) {
+        if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
+        if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
+        if (fw.nslab > 0 || fc.nslab > 0) tn_off += (used + 3) & ~(int64_t)3;
+      }
       if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, 0, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer 0)");
       break;
     }
@@ -240,14 +250,29 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       GLNN_HIP_TRY(hipEventRecord(ev_main, s_main));             // dz_l is complete
       GLNN_HIP_TRY(hipStreamWaitEvent(s_aux, ev_main, 0));
     }
+    // before the fused Adam launch (pf) a split reduction keeps its slabs -- and the column sums behind the last layer's bias gradient
+    // their first-stage partials -- for Adam to fold: every layer then gets its own part of ws_tn (tn_off)
     auto weight_gradient = [&]() -> int {
+      const bool fold_later = pf && !two && tn_off < d->ws_tn_floats;
+      glnn::GradFold fw = {}, fc = {};
+      int64_t used = 0;
+      float* wsp = d->ws_tn + (fold_later ? tn_off : 0);
+      const int64_t wsf = d->ws_tn_floats - (fold_later ? tn_off : 0);
+      float* colsum = (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr;
+      int rc;
       if (d->act[l - 1])
-        return glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
-                                d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
-                                d->ws_tn_floats, wstream);
-      return glnn_gemm_tn_f32(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                              p, seed, d->dims[l], d->gw[l], d->dims[l], (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr, d->ws_tn,
-                              d->ws_tn_floats, wstream);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+        rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
+                           d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used);
+      else
+        rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
+                           p, seed, d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr,
+                           fold_later ? &fc : nullptr, &used);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+      if (rc == GLNN_OK && fold_later) {
+        if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
+        if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
+        if (fw.nslab > 0 || fc.nslab > 0) tn_off += (used + 3) & ~(int64_t)3;
+      }
+      return rc;
     };
     int da_slabs = 0;
     auto input_gradient = [&]() -> int {

@@ -614,7 +614,11 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
                        int nslab, const float* bias, glnn::PendingFolds* pf) {
   // deferral replaces the counter form only, and only for small batches: Adam's threads walk the partials of their element in sequence
   // (B = 4096: 256 workgroup partials behind every bias-gradient element made the step 4 % SLOWER)
-  if (pf && !(counter && c <= 64 && pf->n < glnn::kMaxGradFolds && rows <= 128)) pf = nullptr;    // <= 32 workgroup partials (one row per wave)
+  // pf: the loss scalar is always left to the Adam launch; the bias-gradient column partials only when there are <= 32 of them (one row
+  // per wave, rows <= 128) -- larger batches keep the last-workgroup fold for them (counter form) or get col_sum elsewhere
+  const bool pf_cols = pf && counter && c <= 64 && pf->n < glnn::kMaxGradFolds && rows <= 128;
+  const bool pf_loss = pf && !pf->has_loss && (pf_cols || !counter);
+  if (!pf_cols && !pf_loss) pf = nullptr;
   GLNN_REQUIRE(logits && dlogits && workspace, "glnn_softmax_loss_f32: null pointer");
   GLNN_REQUIRE(nslab == 0 || (slabs && nslab > 0 && c <= 64), "glnn_softmax_loss_f32: split-K slabs need c <= 64");
   GLNN_REQUIRE(rows >= 1 && c >= 1 && ldz >= c && ldg >= c, "glnn_softmax_loss_f32: bad sizes");
@@ -638,7 +642,7 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   if (pf) {
     pf->has_loss = 1;
     pf->loss = {workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum};
-    if (col_sum) pf->e[pf->n++] = {col_sum, a.col_partial, (int)blocks, 1, 64};
+    if (col_sum && pf_cols) pf->e[pf->n++] = {col_sum, a.col_partial, (int)blocks, 1, 64};
   }
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = rows * c; a.bias = bias; a.z_store = const_cast<float*>(logits);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -824,7 +828,10 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   } else {
     hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
   }
-  if (dz_col_sum && !a.counters) {
+  if (dz_col_sum && !a.counters && defer_colsum && nchunks <= 32) {
+    // two-launch form before the fused Adam launch: the per-chunk column sums are folded there (chunk_sum_kernel's order: k ascending)
+    *defer_colsum = {dz_col_sum, a.ws3, nchunks, 0, (int64_t)h};
+  } else if (dz_col_sum && !a.counters) {
     if (nchunks > kManyChunks)
       fold_chunks(a.ws3, nullptr, nchunks, h, dz_col_sum, st);
     else
