@@ -140,6 +140,10 @@ int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_
 // batch rows, which the weight gradient reads again
 int gemm_tn_lat(const TnProblem* problems, int n, void* stream, GradFold* defer = nullptr, float* workspace = nullptr,
                 int64_t workspace_floats = 0);
+int lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, const float* w, int64_t ldw, int n, const float* z, int64_t ldz,
+                     const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
+                     uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
+                     float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum);
 int bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream);
 
 }  // namespace glnn

@@ -24,7 +24,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_LOSS = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_LOSS = 2, EPI_BNBWD = 3 };
 constexpr int kGroups = 8;     // k-groups (8 reduction terms: 4 per lane half) whose loads a wave keeps in flight together
 
 struct LatArgs {
@@ -35,6 +35,10 @@ struct LatArgs {
   float* a_copy; int64_t ld_copy;                 // optional: the (gathered) rows of A stored as a plain [m, k] matrix by the blockIdx.y == 0 tiles
   int gpw;                                        // k-groups per wave: wave q owns groups [q * gpw, (q + 1) * gpw)
   float* ws_mean; float* ws_m2; int* counters;    // EPI_STATS: [m tiles][n] partials, one counter per 64-column block
+  // EPI_BNBWD (the input-gradient product C = dz_{l+1} W_{l+1} of a hidden layer with BatchNorm): C is turned into
+  // dy = relu'(bn(z)) * dropout'(C) before it is stored, and the tile's column sums of dy and dy * xhat go to e_ws1 / e_ws2 [m tiles][n]
+  const float* e_z; int64_t e_ldz; const float* e_mean; const float* e_rstd; const float* e_sc; const float* e_sh;
+  uint32_t e_thr, e_seed; float e_dscale; int e_relu; float* e_ws1; float* e_ws2;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -76,6 +80,18 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
     } else {
       yv = ls.labels[ls.label_rows ? ls.label_rows[row] : row];
     }
+  }
+
+  // BNBWD epilogue mapping = the output mapping below (row tid >> 3, columns (tid & 7) * 4 ..): its z values and column constants are
+  // requested before the product
+  float4 ez = make_float4(0.f, 0.f, 0.f, 0.f), emu = ez, ers = ez, esc = ez, esh = ez;
+  if (EPI == EPI_BNBWD) {
+    int64_t er = m0 + (tid >> 3);
+    if (er > g.m - 1) er = g.m - 1;
+    int ec = n0 + (tid & 7) * 4;
+    if (ec > g.n - 4) ec = g.n - 4;                    // n % 4 == 0 (host): a clamped float4 stays inside the row
+    ez = ld4(g.e_z + er * g.e_ldz + ec);
+    emu = ld4(g.e_mean + ec); ers = ld4(g.e_rstd + ec); esc = ld4(g.e_sc + ec); esh = ld4(g.e_sh + ec);
   }
 
   int64_t mrow = m0 + li;
@@ -216,6 +232,20 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] += g.bias[col + t < g.n ? col + t : g.n - 1];
       }
+      float qv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BNBWD) {                           // C -> dy (bn_dy of student.hip); qv = dy * xhat
+        const float zz[4] = {ez.x, ez.y, ez.z, ez.w}, mu[4] = {emu.x, emu.y, emu.z, emu.w}, rs[4] = {ers.x, ers.y, ers.z, ers.w};
+        const float sc4[4] = {esc.x, esc.y, esc.z, esc.w}, sh4[4] = {esh.x, esh.y, esh.z, esh.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float dav = v[t];
+          if (g.e_thr) dav = glnn::drop_keep(g.e_seed, g.e_thr, (uint32_t)(m0 + row), (uint32_t)(col + t)) ? dav * g.e_dscale : 0.f;
+          float dyv = (!g.e_relu || fmaf(zz[t], sc4[t], sh4[t]) > 0.f) ? dav : 0.f;
+          if (m0 + row >= g.m || col + t >= g.n) dyv = 0.f;
+          v[t] = dyv;
+          qv[t] = dyv * ((zz[t] - mu[t]) * rs[t]);
+        }
+      }
       if (m0 + row < g.m) {
         float* cp = g.c + (m0 + row) * g.ldc + col;
         if (g.c_vec && col + 3 < g.n) {
@@ -227,10 +257,31 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
         }
       }
       if (EPI != EPI_PLAIN) *reinterpret_cast<float4*>(&red[0][row * LDT + c4]) = make_float4(v[0], v[1], v[2], v[3]);
+      if (EPI == EPI_BNBWD) *reinterpret_cast<float4*>(&red[1][row * LDT + c4]) = make_float4(qv[0], qv[1], qv[2], qv[3]);
     }
   }
   if (EPI == EPI_PLAIN) return;
   __syncthreads();
+
+  if (EPI == EPI_BNBWD) {
+    // column sums of the tile's dy and dy * xhat (rows past m were zeroed): thread = (column c, 4-row group gq), fixed order
+    __shared__ float p1[8][32], p2[8][32];
+    const int c = tid & 31, gq = tid >> 5;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s1 += red[0][(gq * 4 + i) * LDT + c];
+      s2 += red[1][(gq * 4 + i) * LDT + c];
+    }
+    p1[gq][c] = s1;
+    p2[gq][c] = s2;
+    __syncthreads();
+    if (gq == 0 && n0 + c < g.n) {
+      g.e_ws1[(int64_t)blockIdx.x * g.n + n0 + c] = ((p1[0][c] + p1[1][c]) + (p1[2][c] + p1[3][c])) + ((p1[4][c] + p1[5][c]) + (p1[6][c] + p1[7][c]));
+      g.e_ws2[(int64_t)blockIdx.x * g.n + n0 + c] = ((p2[0][c] + p2[1][c]) + (p2[2][c] + p2[3][c])) + ((p2[4][c] + p2[5][c]) + (p2[6][c] + p2[7][c]));
+    }
+    return;
+  }
 
   if (EPI == EPI_STATS) {
     // (mean, M2) of the tile's rows per column: thread = (column c, 4-row group gq); two passes over LDS
@@ -350,8 +401,10 @@ int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, const
 #define GLNN_LAT_LAUNCH(XF_, KN_, FIN_) \
   hipLaunchKernelGGL((gemm_lat_kernel<XF_, KN_, NB, EPI, FIN_>), grid, dim3(256), 0, st, g, fin, ls, pend ? *pend : none)
   if (b_kn) {
-    if (xf != 0 || EPI != EPI_PLAIN) return GLNN_ERR_UNSUPPORTED;       // the input-gradient product: plain operands, no epilogue
-    if constexpr (EPI == EPI_PLAIN) GLNN_LAT_LAUNCH(0, true, false);
+    if (xf != 0 || (EPI != EPI_PLAIN && EPI != EPI_BNBWD)) return GLNN_ERR_UNSUPPORTED;       // the input-gradient product: plain operands
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_BNBWD) GLNN_LAT_LAUNCH(0, true, false);
+  } else if (EPI == EPI_BNBWD) {
+    return GLNN_ERR_UNSUPPORTED;
   } else if (pend) {
     if (xf == 1) GLNN_LAT_LAUNCH(1, false, true); else GLNN_LAT_LAUNCH(2, false, true);
   } else {
@@ -451,6 +504,75 @@ __global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) 
         if (j0 + c4 + t < g.nb) cp[t] = v[t];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The BatchNorm / ReLU / dropout backward of a small step without a wait inside a launch: the column sums S1 = sum dy, S2 = sum dy * xhat
+// come as per-tile partials from the epilogue of the input-gradient GEMM above (EPI_BNBWD, which also stored dy); this kernel folds the
+// partials of its 64 columns while its dy / z loads are in flight (k ascending: every workgroup the same bits), applies
+//   dz = gamma * rstd * (dy - S1/B - xhat * S2/B)
+// and leaves the per-chunk column sums of dz (the bias gradient of the Linear in front) as partials for the Adam launch or a fold
+// launch; chunk 0 stores dgamma = S2, dbeta = S1.  Grid (64-column blocks, 32-row chunks); thread = (column, row lane of 8 rows).
+// ---------------------------------------------------------------------------------------------
+struct BnApplyArgs {
+  const float* dy; int64_t lddy; const float* z; int64_t ldz; int64_t rows; int h;
+  const float* gamma; const float* mean; const float* rstd; const float* p1; const float* p2; int nparts;
+  float* dz; int64_t lddz; float* dgamma; float* dbeta; float* ws3;
+};
+__global__ __launch_bounds__(256) void bn_apply_tiles_kernel(const BnApplyArgs a) {
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lc;
+  const int colc = col < a.h ? col : a.h - 1;
+  const int64_t r0 = (int64_t)blockIdx.y * 32;
+  float dyv[8], zv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t r = r0 + rl + 4 * i;
+    const int64_t rc = r < a.rows ? r : a.rows - 1;
+    dyv[i] = a.dy[rc * a.lddy + colc];
+    zv[i] = a.z[rc * a.ldz + colc];
+  }
+  const float mu = a.mean[colc], rs = a.rstd[colc], g = a.gamma[colc];
+  float S1 = 0.f, S2 = 0.f;
+  for (int k0 = 0; k0 < a.nparts; k0 += 16) {
+    float q1[16], q2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + u < a.nparts ? k0 + u : a.nparts - 1;
+      q1[u] = a.p1[(int64_t)k * a.h + colc];
+      q2[u] = a.p2[(int64_t)k * a.h + colc];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < a.nparts) { S1 += q1[u]; S2 += q2[u]; }
+  }
+  if (blockIdx.y == 0 && rl == 0 && col < a.h) {
+    a.dbeta[col] = S1;
+    a.dgamma[col] = S2;
+  }
+  const float inv_b = 1.0f / (float)a.rows;
+  const float c1 = S1 * inv_b, c2 = S2 * inv_b, grs = g * rs;
+  float sdz = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t r = r0 + rl + 4 * i;
+    if (r < a.rows) {
+      const float out = grs * (dyv[i] - c1 - (zv[i] - mu) * rs * c2);
+      if (col < a.h) a.dz[r * a.lddz + col] = out;
+      sdz += out;
+    }
+  }
+  __shared__ float sh[4][64];
+  sh[rl][lc] = sdz;
+  __syncthreads();
+  if (rl == 0 && col < a.h && a.ws3) a.ws3[(int64_t)blockIdx.y * a.h + col] = (sh[0][lc] + sh[1][lc]) + (sh[2][lc] + sh[3][lc]);
+}
+__global__ void tile_chunk_sum_kernel(const float* __restrict__ ws, int nchunks, int h, float* __restrict__ out) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= h) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += ws[(int64_t)k * h + col];
+  out[col] = s;
 }
 
 int env_int(const char* name, int dflt) {
@@ -593,4 +715,50 @@ int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer,
   for (int p = n; p < kTnLatMax; ++p) a.p[p].start = blocks;
   hipLaunchKernelGGL(gemm_tn_lat_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   return glnn::check_launch("glnn::gemm_tn_lat");
+}
+
+// The input gradient of a hidden layer followed by its BatchNorm / ReLU / dropout backward as TWO launches without a wait between
+// workgroups: da = dz_up[m, k] * W[k, n] on the latency kernel whose epilogue turns it into dy (stored to `da`) and leaves the tile
+// partials of sum dy / sum dy * xhat in `workspace` (3 * ceil(m/32) * n floats: S1, S2, then the chunk sums of dz), then
+// bn_apply_tiles_kernel.  The bias-gradient column sums are folded by a launch here, or -- defer_colsum -- left for the fused Adam
+// launch (k ascending).  GLNN_ERR_UNSUPPORTED (nothing launched) outside the latency regime.
+int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, const float* w, int64_t ldw, int n, const float* z, int64_t ldz,
+                           const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
+                           uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
+                           float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum) {
+  static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024);
+  const int max_n = env_int("GLNN_LAT_BN_BWD_MAX_N", 1024), max_k = env_int("GLNN_LAT_BN_BWD_MAX_K", 1024);
+  if (!env_int("GLNN_GEMM_LAT", 1) || !env_int("GLNN_STUDENT_LAT_BN_BWD", 1)) return GLNN_ERR_UNSUPPORTED;
+  if (!(dz_up && w && z && gamma && mean && rstd && a_scale && a_shift && da && dz && dgamma && dbeta && workspace)) return GLNN_ERR_UNSUPPORTED;
+  if (m < 1 || m > max_m || k < 4 || k > max_k || n < 4 || n > max_n || n % 4) return GLNN_ERR_UNSUPPORTED;
+  const int kpad = (k + 3) & ~3;
+  if (ld_up % 4 || !glnn::aligned16(dz_up) || ld_up < kpad || ldw < n || ldz % 4 || !glnn::aligned16(z) || ldz < n) return GLNN_ERR_UNSUPPORTED;
+  if (!glnn::aligned16(mean) || !glnn::aligned16(rstd) || !glnn::aligned16(a_scale) || !glnn::aligned16(a_shift)) return GLNN_ERR_UNSUPPORTED;
+  if (ldda < n || lddz < n || drop_p < 0.f || drop_p >= 1.f) return GLNN_ERR_UNSUPPORTED;
+  const int64_t mt = (m + 31) / 32;
+  if (workspace_floats < 3 * mt * n) return GLNN_ERR_UNSUPPORTED;
+  LatArgs g = {};
+  g.a = dz_up; g.lda = ld_up; g.m = m; g.k = k; g.b = w; g.ldb = ldw; g.n = n; g.c = da; g.ldc = ldda;
+  g.c_vec = (ldda % 4 == 0) && glnn::aligned16(da);
+  g.drop_scale = 1.f;
+  g.gpw = ((k + 7) / 8 + 3) / 4;
+  g.e_z = z; g.e_ldz = ldz; g.e_mean = mean; g.e_rstd = rstd; g.e_sc = a_scale; g.e_sh = a_shift;
+  g.e_thr = glnn::drop_threshold(drop_p); g.e_seed = drop_seed; g.e_dscale = 1.0f / (1.0f - drop_p); g.e_relu = 1;
+  g.e_ws1 = workspace; g.e_ws2 = workspace + mt * n;
+  const BnFinArgs none = {};
+  const LossArgs nol = {};
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc = launch_lat<1, EPI_BNBWD>(g, none, nol, nullptr, true, st);
+  if (rc != GLNN_OK) return rc;
+  BnApplyArgs a = {da, ldda, z, ldz, m, n, gamma, mean, rstd, g.e_ws1, g.e_ws2, (int)mt, dz, lddz, dgamma, dbeta,
+                   dz_col_sum ? workspace + 2 * mt * n : nullptr};
+  hipLaunchKernelGGL(bn_apply_tiles_kernel, dim3((n + 63) / 64, (unsigned)mt), dim3(256), 0, st, a);
+  if (dz_col_sum) {
+    if (defer_colsum && mt <= 32) *defer_colsum = {dz_col_sum, a.ws3, (int)mt, 0, (int64_t)n};
+    else {
+      if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
+      hipLaunchKernelGGL(tile_chunk_sum_kernel, dim3((n + 127) / 128), dim3(128), 0, st, a.ws3, (int)mt, n, dz_col_sum);
+    }
+  }
+  return glnn::check_launch("glnn::lat_dgrad_bn_bwd");
 }

@@ -305,10 +305,32 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     if (!defer) GLNN_TRY(weight_gradient());
     if (two) { GLNN_HIP_TRY(hipEventRecord(ev_aux, s_aux)); aux_used = true; }
     if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, wstream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
-    if (!(two && big_dgrad)) GLNN_TRY(input_gradient());
     const bool alt = (two || defer) && ((L - 1 - l) & 1);            // alternate: dz of the layer above is still needed (aux stream / deferred dW)
     float* dz_out = alt ? d->dz2 : d->dz;
     const int64_t ld_out = alt ? d->ld_dz2 : d->ld_dz;
+    // small batches: input gradient + BatchNorm backward as two launches with no wait between workgroups (mlp_lat.hip: the column
+    // partial sums come out of the GEMM's epilogue, an apply kernel folds them in its prologue); each layer has its own slice of ws_bn
+    bool lat_bn = false;
+    if (cnt && !two && d->batchnorm == 1 && grp == nullptr && L >= 2) {
+      const int64_t per = d->ws_bn_floats / (L - 1) / 4 * 4;
+      glnn::GradFold cf = {};
+      const int rc = glnn::lat_dgrad_bn_bwd(dz, ld_dz, m, d->dims[l + 1], d->w[l], d->dims[l], d->dims[l], d->z[l - 1], d->ldz[l - 1],
+                                            d->gamma[l - 1], d->mean[l - 1], d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed,
+                                            d->da, d->ld_da, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1], d->gb[l - 1],
+                                            d->ws_bn + (l - 1) * per, per, stream, (pf && pf->n < glnn::kMaxGradFolds) ? &cf : nullptr);
+      if (rc == GLNN_OK) {
+        lat_bn = true;
+        if (cf.nslab > 0) pf->e[pf->n++] = cf;
+      } else if (rc != GLNN_ERR_UNSUPPORTED) {
+        return rc;
+      }
+    }
+    if (lat_bn) {
+      dz = dz_out;
+      ld_dz = ld_out;
+      continue;
+    }
+    if (!(two && big_dgrad)) GLNN_TRY(input_gradient());
     if (layernorm) {
       GLNN_TRY(glnn_layernorm_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->beta[l - 1],
                                       d->mean[l - 1], d->rstd[l - 1], 1, p, seed, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1],

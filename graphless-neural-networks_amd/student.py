@@ -112,7 +112,7 @@ class StudentEngine:
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
         self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax * max(self.L - 1, 1), 1024,   # x (L-1): per-layer slices when Adam folds the column sums
-                                      4 * ((B + 31) // 32) * hmax if B <= 1024 else 0,   # mlp_lat.hip: 32-row statistics partials, two layers in flight
+                                      max(4, 3 * (self.L - 1)) * ((B + 31) // 32) * hmax if B <= 1024 else 0,   # mlp_lat.hip: 32-row tile partials (statistics: two layers in flight; backward: 3 per layer)
                                       _lib.lib().glnn_layernorm_bwd_workspace_floats(B, hmax) if self.ln else 0), **f32)
         self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
