@@ -1508,6 +1508,7 @@ struct FoldMultiArgs {
   const float* ws[kTnMultiMax]; int64_t slab[kTnMultiMax]; int splits[kTnMultiMax];
   float* c[kTnMultiMax]; int64_t ldc[kTnMultiMax]; int ka[kTnMultiMax], nb[kTnMultiMax];
   int start[kTnMultiMax + 1]; int n;
+  int lanes[kTnMultiMax];     // 1: the order of split_reduce_lanes_kernel (what glnn_gemm_tn_f32 uses from 16 splits on), else k ascending
 };
 // split_reduce_kernel for every problem with more than one split: the same sums in the same order (k = 0, 1, 2, ...)
 __global__ void split_reduce_multi_kernel(const FoldMultiArgs fm) {
@@ -1525,10 +1526,28 @@ __global__ void split_reduce_multi_kernel(const FoldMultiArgs fm) {
     const int64_t total4 = total >> 2;
     const int nb4 = nb >> 2;
     for (int64_t i = b0 * blockDim.x + threadIdx.x; i < total4; i += nblk * blockDim.x) {
-      float4 s = *reinterpret_cast<const float4*>(ws + 4 * i);
-      for (int k = 1; k < splits; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      float4 s;
+      if (fm.lanes[p]) {        // four interleaved lanes k = j, j + 4, ... (each from 0, k ascending), combined (l0 + l1) + (l2 + l3)
+        float4 l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < splits; k0 += 4) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (k0 + j < splits) {
+              const float4 v = *reinterpret_cast<const float4*>(ws + (k0 + j) * slab + 4 * i);
+              l[j].x += v.x; l[j].y += v.y; l[j].z += v.z; l[j].w += v.w;
+            }
+          }
+        }
+        s = make_float4((l[0].x + l[1].x) + (l[2].x + l[3].x), (l[0].y + l[1].y) + (l[2].y + l[3].y), (l[0].z + l[1].z) + (l[2].z + l[3].z),
+                        (l[0].w + l[1].w) + (l[2].w + l[3].w));
+      } else {
+        s = *reinterpret_cast<const float4*>(ws + 4 * i);
+        for (int k = 1; k < splits; ++k) {
+          const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
       }
       const int64_t r = i / nb4, cc = (i - r * nb4) * 4;
       *reinterpret_cast<float4*>(c + r * ldc + cc) = s;
@@ -1601,13 +1620,16 @@ int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspac
       g.c = workspace + ws_off; g.ldc = q.nb;
       const int f = fm.n++;
       fm.ws[f] = g.c; fm.slab[f] = slab; fm.splits[f] = sp; fm.c[f] = q.c; fm.ldc[f] = q.ldc; fm.ka[f] = q.ka; fm.nb[f] = q.nb;
+      // the fold order glnn_gemm_tn_f32 would use for this problem (its float4 conditions; the slab base is 16-byte aligned by ws_off)
+      const bool lanes = sp >= 16 && ((q.nb | q.ldc | slab) & 3) == 0 && glnn::aligned16(g.c) && glnn::aligned16(q.c);
+      fm.lanes[f] = lanes ? 1 : 0;
       int fb = (int)((slab + 255) / 256);
       if (fb > 2048) fb = 2048;
       fm.start[f] = fblocks; fblocks += fb; fm.start[f + 1] = fblocks;
       ws_off += (int64_t)sp * slab;
       if (defer) {
         if (q.ldc != q.nb) return GLNN_ERR_UNSUPPORTED;            // the consumer indexes the slabs like the dense tensor
-        defer[p] = {q.c, g.c, sp, 0, slab};
+        defer[p] = {q.c, g.c, sp, lanes ? 1 : 0, slab};
       }
     } else {
       g.c = q.c; g.ldc = q.ldc;
@@ -1638,7 +1660,7 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
                                 const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                                 uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
   return glnn::gemm_tn(a, lda, m, ka, b, ldb, b_rows, b_scale, b_shift, drop_p, drop_seed, nb, c, ldc, col_sum_a, workspace, workspace_floats,
-                       stream, nullptr, nullptr, nullptr);
+                       stream, nullptr, nullptr, nullptr, 0);
 }
 
 // glnn_gemm_tn_f32 whose final sums may be left to the fused Adam launch (glnn::PendingFolds): with `defer` the fold launch of a
@@ -1648,7 +1670,7 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
 int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                   const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                   uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream,
-                  GradFold* defer, GradFold* defer_colsum, int64_t* used_floats) {
+                  GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats) {
   if (defer) *defer = {c, nullptr, 0, 0, 0};
   if (defer_colsum) *defer_colsum = {col_sum_a, nullptr, 0, 0, 0};
   if (used_floats) *used_floats = 0;
@@ -1687,7 +1709,10 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
     splits = (wg_target + gi * gj - 1) / (gi * gj);
     const int64_t max_by_rows = (m + min_ktiles * BK - 1) / (min_ktiles * BK);      // at least min_ktiles k-tiles per split
     if (splits > max_by_rows) splits = (int)max_by_rows;
-    const int64_t avail = workspace_floats - colsum_need;
+    // plan_floats: plan as if the workspace had that size (a caller that hands every problem of a step its own PART of one workspace
+    // wants the split plan -- hence the bits -- of the call that gets all of it); what does not fit the real size is cut down
+    const int64_t avail_plan = (plan_floats > 0 ? plan_floats : workspace_floats) - colsum_need, avail = workspace_floats - colsum_need;
+    if ((int64_t)splits * slab > avail_plan) splits = (int)(avail_plan / slab);
     if ((int64_t)splits * slab > avail) splits = (int)(avail / slab);
     if (splits < 1) splits = 1;
   }

@@ -110,7 +110,7 @@ int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t wo
 // gemm.hip: glnn_gemm_tn_f32 with its folds optionally left to the fused Adam launch -- see the definition
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,
             const float* b_shift, float drop_p, uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace,
-            int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats);
+            int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0);
 // student.hip: glnn_adam_step_f32 whose gradient reads fold the pending partial sums (and store the folded gradient); grads_host =
 // host copy of the `grads` pointer table (how a pending fold finds its tensor); pending may be NULL
 int adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,

@@ -726,7 +726,7 @@ int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, 
                            const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                            uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                            float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum) {
-  static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024);
+  const int max_m = env_int("GLNN_LAT_BN_BWD_MAX_M", 1024);
   const int max_n = env_int("GLNN_LAT_BN_BWD_MAX_N", 1024), max_k = env_int("GLNN_LAT_BN_BWD_MAX_K", 1024);
   if (!env_int("GLNN_GEMM_LAT", 1) || !env_int("GLNN_STUDENT_LAT_BN_BWD", 1)) return GLNN_ERR_UNSUPPORTED;
   if (!(dz_up && w && z && gamma && mean && rstd && a_scale && a_shift && da && dz && dgamma && dbeta && workspace)) return GLNN_ERR_UNSUPPORTED;

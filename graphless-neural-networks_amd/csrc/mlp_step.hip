@@ -233,7 +233,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       GLNN_TRY(glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
                              nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
                              d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
-                             fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used));
+                             fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats));
       if (fold_later) {
         if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
         if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
@@ -262,11 +262,11 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       int rc;
       if (d->act[l - 1])
         rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
-                           d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used);
+                           d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
       else
         rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
                            p, seed, d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr,
-                           fold_later ? &fc : nullptr, &used);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
+                           fold_later ? &fc : nullptr, &used, d->ws_tn_floats);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
       if (rc == GLNN_OK && fold_later) {
         if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
         if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
@@ -380,7 +380,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       for (int i = 0; i < n_deferred; ++i) {
         const glnn::TnProblem& q = deferred[i];
         GLNN_TRY(glnn_gemm_tn_f32(q.a, q.lda, q.m, q.ka, q.b, q.ldb, q.b_rows, q.b_scale, q.b_shift, q.drop_p, q.drop_seed, q.nb, q.c, q.ldc,
-                                  nullptr, d->ws_tn, d->ws_tn_floats, stream));
+                                  nullptr, d->ws_tn, d->ws_tn_floats, stream));    // each with the whole workspace: the plan of the two-call form
       }
     } else if (rc != GLNN_OK) {
       return rc;

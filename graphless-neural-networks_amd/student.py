@@ -112,9 +112,12 @@ class StudentEngine:
         hk = max(self.dims)
         n_chunks = (B + 127) // 128
         self.ws_bn = torch.empty(max((3 * n_chunks + 2) * hmax * max(self.L - 1, 1), 1024,   # x (L-1): per-layer slices when Adam folds the column sums
-                                      max(4, 3 * (self.L - 1)) * ((B + 31) // 32) * hmax if B <= 1024 else 0,   # mlp_lat.hip: 32-row tile partials (statistics: two layers in flight; backward: 3 per layer)
+                                      max(4, 3 * (self.L - 1)) * ((B + 31) // 32) * hmax if B * hmax <= (1 << 20) else 0,   # mlp_lat.hip: 32-row tile partials (statistics: two layers in flight; backward: 3 per layer)
                                       _lib.lib().glnn_layernorm_bwd_workspace_floats(B, hmax) if self.ln else 0), **f32)
-        self.ws_tn = torch.empty(64 * hk + 256 * 128 * 128 + 2 * hk * hk, **f32)
+        # weight-gradient workspace: split-reduction slabs.  When affordable (<= 16 M floats) it holds the slabs of EVERY layer at once
+        # (<= ceil(B/64) splits each): the batched weight-gradient launch needs that, and so does leaving the folds to Adam
+        all_slabs = 64 * hk + ((B + 63) // 64) * sum(self.dims[l] * self.dims[l + 1] for l in range(self.L))
+        self.ws_tn = torch.empty(max(64 * hk + 256 * 128 * 128 + 2 * hk * hk, all_slabs if all_slabs <= (1 << 24) else 0), **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
         self.ws_loss = torch.empty(256 * 65 + 1024, **f32)
         # fused finalizes (last workgroup folds the partials: 7 launches fewer per step): arxiv MLP 0.143 -> 0.136 ms, MLP3w4 0.193 ->
