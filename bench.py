@@ -528,8 +528,8 @@ def reordered_leg(args, g, feats, teacher, FullNeighborLoader, ops, data):
 def small_student_leg(dev, Model, StudentEngine, ops, steps=3000, warmup=100):
     """The reference's ogbn-arxiv students (train.conf.yaml:142-154: MLP 128-256-256-40 p=0.2 and MLP3w4 128-1024-1024-40 p=0.5,
     B = 512, BatchNorm, Adam lr 0.01) on arxiv-shaped synthetic rows: the whole KL distillation step (gather, forward, loss, backward,
-    Adam) as StudentEngine.step issues it -- ONE C call, glnn_mlp_train_step_f32.  Latency-bound: a step is 9-13 dependent launches
-    of 5-15 us (profiles/r03_student_small_timeline.txt), so the figure of merit is ms per step."""
+    Adam) as StudentEngine.step issues it -- ONE C call, glnn_mlp_train_step_f32.  Latency-bound: a step is 11-13 dependent launches
+    of 5-28 us (profiles/r03_student_arxiv_mlp_timeline.txt, ..._mlp3w4_timeline.txt), so the figure of merit is ms per step."""
     out = []
     n = 169343
     for name, dims, p in (("MLP", [128, 256, 256, 40], 0.2), ("MLP3w4", [128, 1024, 1024, 40], 0.5)):
