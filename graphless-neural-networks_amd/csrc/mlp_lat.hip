@@ -14,7 +14,10 @@
 //              Chan combine and the whole BatchNorm finalize (running statistics, a_scale / a_shift) -- student_dev.h;
 //       LOSS : log_softmax + NLL | KL(log-target) and d(lamb * loss)/dlogits on the complete rows of the tile, per-workgroup loss and
 //              bias-gradient partials, last workgroup folds them (same arithmetic per row as softmax_loss_kernel).
+//       BNBWD: (input-gradient product of a hidden layer) C -> dy = relu'(bn(z)) * dropout'(C) before the store + the tile's column sums of
+//              dy and dy * xhat; bn_apply_tiles_kernel behind it is the BatchNorm backward without any wait between workgroups.
 // Results differ from the tiled kernels only by the summation order over k (four ascending quarters, then q = 0..3).
+// Also here: gemm_tn_lat_kernel (all weight gradients of a small step from one launch, same loading style).
 #include <cstdlib>
 
 #include "glnn_common.h"
