@@ -1,7 +1,10 @@
 // One C call = forward + loss + backward of the MLP student step (reference train_and_eval.py:74-84): the
 // same kernel sequence glnn_amd/student.py documents, issued from C++ so that small configurations are not
-// bound by ~30 Python->ctypes round trips per step.  The gradient exchange (data parallel) and the fused Adam
-// (glnn_adam_step_f32) stay separate calls so that an all-reduce can sit between them.
+// bound by ~30 Python->ctypes round trips per step.  glnn_mlp_fwd_bwd_f32 leaves the gradient exchange (data parallel) and the
+// fused Adam (glnn_adam_step_f32) to separate calls so that an all-reduce can sit between them; glnn_mlp_train_step_f32 (ABI 6)
+// includes Adam and lets it fold whatever the backward left in partial form.  Batches of <= 1024 rows take the latency kernels
+// of mlp_lat.hip wherever a layer qualifies (every such call returns GLNN_ERR_UNSUPPORTED without launching when it does not, and
+// the tiled GEMM + separate reduction kernels follow).
 #include <cstdlib>
 
 #include "glnn_common.h"
@@ -46,6 +49,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   bool pregather = d->xb && idx && ldx % 4 == 0 && glnn::aligned16(feats) && ldx >= ((d->dims[0] + 3) & ~3);
   // small batches: no gather launch -- the first layer's latency GEMM stores the rows it gathers (gemm_lat a_copy); decided at layer 0
   bool lazy_copy = pregather && cnt && m <= 1024 && d->batchnorm != 2;
+  if (pregather && !lazy_copy && m <= 1024) pregather = false;      // a small batch without that kernel: a gather launch costs more than it saves
   if (pregather && !lazy_copy) {
     GLNN_REQUIRE(d->ld_xb >= ((d->dims[0] + 3) & ~3), "glnn_mlp_fwd_bwd_f32: ld_xb too small");
     GLNN_TRY(glnn_gather_rows_f32(feats, ldx, idx, m, d->dims[0], d->xb, d->ld_xb, stream));
