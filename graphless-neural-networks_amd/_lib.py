@@ -115,7 +115,8 @@ class SageStepDesc(ctypes.Structure):
                 ("x", c_vp), ("ldx", c_i64), ("x_rows", c_i64), ("labels", c_vp), ("label_rows", c_vp),
                 ("dlogits", c_vp), ("ld_dlogits", c_i64), ("dagg", c_vp), ("ld_dagg", c_i64), ("dh", c_vp), ("ld_dh", c_i64),
                 ("ws_bn", c_vp), ("ws_bn_floats", c_i64), ("ws_tn", c_vp), ("ws_tn_floats", c_i64), ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64),
-                ("ws_loss", c_vp), ("ws_loss_floats", c_i64), ("loss_out", c_vp), ("loss_accum", c_vp)]
+                ("ws_loss", c_vp), ("ws_loss_floats", c_i64), ("loss_out", c_vp), ("loss_accum", c_vp),
+                ("aux_stream", c_vp), ("ev_fork", c_vp), ("ev_join", c_vp)]
 
 
 _lib = None

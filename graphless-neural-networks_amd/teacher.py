@@ -28,6 +28,7 @@ synchronisation:
 The engine works IN PLACE on the Model's parameters / BatchNorm buffers and on the torch optimizer's state tensors, exactly
 like glnn_amd.student.StudentEngine, so state_dict(), early-stopping snapshots and optimizer.state_dict() keep working."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -120,6 +121,13 @@ class TeacherEngine:
         self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
+        # step_sage: the transposed blocks of the backward are built on a second HIP stream under the forward (glnn_sage_step_desc.aux_stream)
+        self.aux_stream = self.ev_fork = self.ev_join = None
+        if os.environ.get("GLNN_TEACHER_AUX_STREAM", "1") != "0" and torch.device(self.dev).type == "cuda":
+            self.aux_stream = torch.cuda.Stream(device=self.dev)
+            self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
+            for ev in (self.ev_fork, self.ev_join):
+                ev.record()                                   # (torch creates the hipEvent_t lazily at the first record)
         self.ws_loss = torch.empty(1024, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.grad_sync = None
@@ -257,6 +265,9 @@ class TeacherEngine:
         d.labels, d.label_rows = ptr(labels), ptr(output_nodes)
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+        if self.aux_stream is not None:
+            d.aux_stream, d.ev_fork, d.ev_join = self.aux_stream.cuda_stream, self.ev_fork.cuda_event, self.ev_join.cuda_event
+            arena.record_stream(self.aux_stream)                # the transposes write into it on the aux stream
         keep = [arena, x]                                       # alive until the call below is queued (same-stream reuse is ordered)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         if rc != 0:

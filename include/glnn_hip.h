@@ -417,6 +417,11 @@ typedef struct glnn_sage_step_desc {
   float* ws_bn; int64_t ws_bn_floats; float* ws_tn; int64_t ws_tn_floats; float* ws_gemm; int64_t ws_gemm_floats;
   float* ws_loss; int64_t ws_loss_floats;
   float* loss_out; float* loss_accum;
+  /* optional (ABI 6; all NULL = everything on `stream`): the transposed blocks + 1/(deg+1) vectors the BACKWARD needs depend only on
+   * the blocks, so they are built on aux_stream (hipStream_t) while the forward runs on `stream`: ev_fork is recorded on `stream` at
+   * entry, ev_join on aux_stream behind the last transpose; `stream` waits for ev_join before the first transposed aggregation
+   * (hipEvent_t, both created by the caller).  ~12 launches of ~5 us leave the step's critical path. */
+  void* aux_stream; void* ev_fork; void* ev_join;
 } glnn_sage_step_desc;
 
 GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream);

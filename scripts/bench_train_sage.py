@@ -44,6 +44,7 @@ for _ in range(3):
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(50):
     eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
+t_issue = (time.perf_counter() - t0) / 50            # host time to ISSUE a step (the queue is far from full after 50 steps)
 torch.cuda.synchronize(); t_c = (time.perf_counter() - t0) / 50
 print(f"per step: sampling + blocks {1e3 * t_s:.2f} ms (side stream, overlapped in the epochs above), fwd + loss + bwd + Adam "
-      f"(TeacherEngine, transposed blocks cached) {1e3 * t_c:.2f} ms; sources of that batch {input_nodes.numel()}", flush=True)
+      f"(TeacherEngine) {1e3 * t_c:.2f} ms of which host issue {1e3 * t_issue:.2f} ms; sources of that batch {input_nodes.numel()}", flush=True)
