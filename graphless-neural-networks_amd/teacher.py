@@ -121,9 +121,11 @@ class TeacherEngine:
         self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
-        # step_sage: the transposed blocks of the backward are built on a second HIP stream under the forward (glnn_sage_step_desc.aux_stream)
+        # step_sage can build the transposed blocks of the backward on a second HIP stream under the forward (glnn_sage_step_desc.aux_stream).
+        # OPT-IN: measured without effect (engine-only step 0.46 vs 0.47 ms; 12-epoch runs land in the same 1450 / 1550 / 1690 steps/s
+        # modes with and without it -- DESIGN.md section 3, TeacherEngine)
         self.aux_stream = self.ev_fork = self.ev_join = None
-        if os.environ.get("GLNN_TEACHER_AUX_STREAM", "1") != "0" and torch.device(self.dev).type == "cuda":
+        if os.environ.get("GLNN_TEACHER_AUX_STREAM", "0") == "1" and torch.device(self.dev).type == "cuda":
             self.aux_stream = torch.cuda.Stream(device=self.dev)
             self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
             for ev in (self.ev_fork, self.ev_join):

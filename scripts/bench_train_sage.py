@@ -20,7 +20,7 @@ opt = torch.optim.Adam(model.parameters(), lr=c["lr"])
 idx_train = torch.randperm(n)[:c["n_train"]].to(dev)
 loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=c["B"], shuffle=True, drop_last=False)
 crit = torch.nn.NLLLoss()
-for ep in range(3):
+for ep in range(int(os.environ.get("GLNN_BENCH_EPOCHS", "3"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loss = te.train_sage(model, loader, feats, labels, crit, opt)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
