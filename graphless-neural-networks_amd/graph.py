@@ -251,7 +251,8 @@ class NodeDataLoader:
         for the reference, here as stream-level concurrency on the GPU)."""
         self._epoch += 1
         n = self.nids.numel()
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        from . import ops
+        order = ops.randperm_cpu(n) if self.shuffle else torch.arange(n)
         fanouts = self.sampler.fanouts if isinstance(self.sampler, MultiLayerNeighborSampler) else [None] * self.sampler.n_layers
         chunks = [order[s:s + self.batch_size] for s in range(0, n, self.batch_size)]
         if self.drop_last and chunks and chunks[-1].numel() < self.batch_size:

@@ -92,6 +92,21 @@ def feat_empty(n, d, device, zero=False):
     return buf[:, :d]
 
 
+def randperm_cpu(n):
+    """torch.randperm(n) from the global CPU generator (what the reference draws its mini-batches with, train_and_eval.py:66), issued
+    with ONE intra-op thread: the CPU kernel is a serial shuffle, so the permutation is the same for any thread count
+    (scripts/probe_randperm.py), but with the 128-thread pool of a GPU host awake the 0.3 ms job took 7-17 ms -- as long as the 177
+    optimiser steps of an ogbn-arxiv pass."""
+    k = torch.get_num_threads()
+    if k <= 1:
+        return torch.randperm(n)
+    torch.set_num_threads(1)
+    try:
+        return torch.randperm(n)
+    finally:
+        torch.set_num_threads(k)
+
+
 def as_feat(t):
     """Return t itself if its layout suits the float4 kernels, else a padded copy."""
     _mat(t, "as_feat")

@@ -62,7 +62,7 @@ def train_sage(model, dataloader, feats, labels, criterion, optimizer, lamb=1):
 def _batch_indices(n, batch_size):
     """reference train_and_eval.py:65-71: CPU randperm, remainder dropped, [nb, B] view."""
     num_batches = max(1, n // batch_size)
-    idx_batch = torch.randperm(n)[: num_batches * batch_size]
+    idx_batch = ops.randperm_cpu(n)[: num_batches * batch_size]
     idx_batch = idx_batch.view(1, -1) if num_batches == 1 else idx_batch.view(num_batches, batch_size)
     return num_batches, idx_batch
 

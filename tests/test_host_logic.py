@@ -212,3 +212,18 @@ def test_ogb_loader_arxiv_symmetrise_and_self_loops(monkeypatch):
     monkeypatch.setitem(sys.modules, "ogb.nodeproppred", None)
     with pytest.raises(ImportError):
         load_data("ogbn-arxiv", "./data")
+
+
+def test_randperm_cpu_is_torch_randperm_on_one_thread():
+    """ops.randperm_cpu: the reference's mini-batch permutation (train_and_eval.py:66) drawn with one intra-op thread -- the same
+    numbers from the same global generator state, and the thread count is put back."""
+    import torch
+    from glnn_amd import ops
+    k = torch.get_num_threads()
+    torch.manual_seed(123)
+    want = [torch.randperm(n) for n in (1, 7, 90941)]
+    torch.manual_seed(123)
+    got = [ops.randperm_cpu(n) for n in (1, 7, 90941)]
+    assert torch.get_num_threads() == k
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
