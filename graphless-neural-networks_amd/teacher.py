@@ -121,6 +121,7 @@ class TeacherEngine:
         self.table = ops.TensorTable(params, self.grads, exp_avg, exp_avg_sq)
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
+        self._sage_desc = self._arena = self._arena_stream = None      # step_sage: persistent descriptor and scratch arena
         # step_sage can build the transposed blocks of the backward on a second HIP stream under the forward (glnn_sage_step_desc.aux_stream).
         # OPT-IN: measured without effect (engine-only step 0.46 vs 0.47 ms; 12-epoch runs land in the same 1450 / 1550 / 1690 steps/s
         # modes with and without it -- DESIGN.md section 3, TeacherEngine)
@@ -202,20 +203,42 @@ class TeacherEngine:
         if x.shape[0] < (blocks[0].num_src_nodes() if blocks[0].gindices is None else 1):
             raise ValueError("TeacherEngine.step_sage: the layer-0 source matrix is smaller than the outermost block")
         self.step_count += 1
-        d = _lib.SageStepDesc()
-        dims = [enc.layers[0].fc_neigh.weight.shape[1]] + [lay.fc_neigh.weight.shape[0] for lay in enc.layers]
-        d.num_layers, d.batchnorm, d.dropout_p, d.lamb = L, 1 if self.bn else 0, self.p, float(lamb)
-        for i, v in enumerate(dims):
-            d.dims[i] = v
-        # Every buffer of the step is scratch that only the C call touches, so they are carved as raw pointers out of ONE arena
-        # (52 torch.empty calls per step cost ~80 us of host time -- the sampled-block loop is bound by the host, not the GPU).
-        # Two passes over the same layout code: the first sizes the arena, the second hands out the pointers.
+        # The descriptor lives across steps: everything that does not depend on the batch (parameter / gradient / BatchNorm pointers, sizes,
+        # loss buffers) is written once; a step only fills in the blocks, the dropout seeds and the scratch pointers.  (Building the
+        # ~150 ctypes fields from nothing was 0.1 ms of the 0.25 ms of host time per step of a loop that is host-bound.)
         r4 = lambda c: (c + 3) // 4 * 4
         ptr = lambda t: None if t is None else t.data_ptr()
+        d = self._sage_desc
+        if d is None:
+            d = self._sage_desc = _lib.SageStepDesc()
+            self._sage_dims = [enc.layers[0].fc_neigh.weight.shape[1]] + [lay.fc_neigh.weight.shape[0] for lay in enc.layers]
+            d.num_layers, d.batchnorm, d.dropout_p = L, 1 if self.bn else 0, self.p
+            for i, v in enumerate(self._sage_dims):
+                d.dims[i] = v
+            for l, layer in enumerate(enc.layers):
+                y = d.layer[l]
+                w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+                y.w, y.b, y.gw, y.gb = ptr(w), ptr(b), ptr(self.grad(w)), ptr(self.grad(b))
+                if l != L - 1 and self.bn:
+                    bn = enc.norms[l]
+                    d.bn_eps, d.bn_momentum = bn.eps, bn.momentum
+                    y.gamma, y.beta, y.ggamma, y.gbeta = ptr(bn.weight), ptr(bn.bias), ptr(self.grad(bn.weight)), ptr(self.grad(bn.bias))
+                    y.running_mean, y.running_var, y.nbt = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
+            d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
+            d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
+            self._sage_static = [(ptr(layer.fc_neigh.weight), ptr(layer.fc_neigh.bias)) for layer in enc.layers]
+        elif any(st != (ptr(layer.fc_neigh.weight), ptr(layer.fc_neigh.bias)) for st, layer in zip(self._sage_static, enc.layers)):
+            self._sage_desc = None                          # the parameters were re-allocated (load_state_dict keeps them; .to() does not)
+            self.step_count -= 1
+            return self.step_sage(blocks, feats, labels, output_nodes, lamb, input_nodes)
+        dims = self._sage_dims
+        d.lamb = float(lamb)
+        # Every buffer of the step is scratch that only the C call touches, so they are carved as raw pointers out of ONE arena that
+        # persists across steps (same-stream reuse is ordered; it grows when a batch needs more).  ONE pass hands out the pointers.
 
         def layout(A):
             max_rows, max_hidden = 1, 4
-            for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):
+            for l, blk in enumerate(blocks):
                 y = d.layer[l]
                 n_dst, n_src, nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
                 y.agg, y.ld_agg = A.take(4 * n_dst * r4(dims[l])), r4(dims[l])
@@ -244,33 +267,31 @@ class TeacherEngine:
             d.ws_bn, d.ws_tn, d.ws_gemm = A.take(4 * d.ws_bn_floats), A.take(4 * d.ws_tn_floats), A.take(4 * d.ws_gemm_floats)
             return A.off
 
-        for l, (layer, blk) in enumerate(zip(enc.layers, blocks)):       # everything that is not scratch
+        for l, blk in enumerate(blocks):       # the batch: blocks and dropout seeds
             y = d.layer[l]
-            n_dst, n_src, nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
             glob = l == 0 and blk.gindices is not None
             y.indptr, y.indices = ptr(blk.indptr), ptr(blk.gindices if glob else blk.indices)
-            y.n_dst, y.n_src, y.nnz = n_dst, n_src, nnz
+            y.n_dst, y.n_src, y.nnz = blk.num_dst_nodes(), blk.num_src_nodes(), blk.num_edges()
             y.self_rows = ptr(blk.dst_nodes) if glob else None
-            w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
-            y.w, y.b, y.gw, y.gb = ptr(w), ptr(b), ptr(self.grad(w)), ptr(self.grad(b))
             if l != L - 1:
                 y.drop_seed = self._seed(l)
-                if self.bn:
-                    bn = enc.norms[l]
-                    d.bn_eps, d.bn_momentum = bn.eps, bn.momentum
-                    y.gamma, y.beta, y.ggamma, y.gbeta = ptr(bn.weight), ptr(bn.bias), ptr(self.grad(bn.weight)), ptr(self.grad(bn.bias))
-                    y.running_mean, y.running_var, y.nbt = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
-        total = layout(_Arena(None))
-        arena = torch.empty(total + 256, dtype=torch.uint8, device=dev)
-        layout(_Arena((arena.data_ptr() + 255) // 256 * 256))
+        cur = torch.cuda.current_stream(dev)
+        if self._arena_stream is not None and self._arena_stream != cur:
+            cur.wait_stream(self._arena_stream)            # the previous step used the arena on another stream
+        self._arena_stream = cur
+        arena = self._arena
+        base = 0 if arena is None else (arena.data_ptr() + 255) // 256 * 256
+        total = layout(_Arena(base))
+        if arena is None or total + 256 > arena.numel():    # first step / a bigger batch: (re)allocate with headroom, lay out again
+            arena = self._arena = torch.empty(int(total * 1.25) + 256, dtype=torch.uint8, device=dev)
+            layout(_Arena((arena.data_ptr() + 255) // 256 * 256))
         d.x, d.ldx, d.x_rows = ptr(x), x.stride(0), x.shape[0]
         d.labels, d.label_rows = ptr(labels), ptr(output_nodes)
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
         if self.aux_stream is not None:
             d.aux_stream, d.ev_fork, d.ev_join = self.aux_stream.cuda_stream, self.ev_fork.cuda_event, self.ev_join.cuda_event
-            arena.record_stream(self.aux_stream)                # the transposes write into it on the aux stream
-        keep = [arena, x]                                       # alive until the call below is queued (same-stream reuse is ordered)
+        keep = [x]                                              # alive until the call below is queued (same-stream reuse is ordered)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         if rc != 0:
             self.step_count -= 1          # the step never happened: Adam's bias correction and the dropout seeds stay where they were
