@@ -97,6 +97,10 @@ int gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, con
 struct TnProblem {
   const float* a; int64_t lda; int64_t m; int ka; const float* b; int64_t ldb; const int64_t* b_rows; const float* b_scale;
   const float* b_shift; float drop_p; uint32_t drop_seed; int nb; float* c; int64_t ldc;
+  // optional, gemm_tn_lat only (zero otherwise): `a` is dy and A = the BatchNorm backward's apply of (dy, bn_z) with the S1 / S2 tile partials
+  // bn_p1 / bn_p2 [bn_nparts][ka] -- see TnLatProblem; bn_colsum = the bias-gradient tensor whose column sums are left to Adam
+  const float* bn_z; int64_t bn_ldz; const float* bn_gamma; const float* bn_mean; const float* bn_rstd; const float* bn_p1; const float* bn_p2;
+  int bn_nparts; float* bn_dgamma; float* bn_dbeta; float* bn_colsum;
 };
 // A gradient tensor whose final sum has been left to its consumer, the fused Adam launch (the fold launches / last-workgroup tails
 // that used to produce it are gone): grad[i] = sum over k < nslab of src[k * stride + i], k ascending (lanes4 = 0) or in four
@@ -138,12 +142,16 @@ int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_
              int64_t ld_copy = 0);
 // a_copy (plain operands only): the rows of A (gathered through a_rows) are also stored as a dense [m, k] matrix -- the first layer's
 // batch rows, which the weight gradient reads again
+// defer holds n + 2 entries: [n], [n + 1] = the column-sum folds of problems that carry a BatchNorm apply (nslab 0 = none)
 int gemm_tn_lat(const TnProblem* problems, int n, void* stream, GradFold* defer = nullptr, float* workspace = nullptr,
                 int64_t workspace_floats = 0);
 int lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, const float* w, int64_t ldw, int n, const float* z, int64_t ldz,
                      const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                      uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
-                     float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum);
+                     float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum, int skip_apply = 0);
+int bn_apply_tiles(const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t m, int n, const float* gamma, const float* mean,
+                   const float* rstd, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                   int64_t workspace_floats, void* stream, GradFold* defer_colsum);
 int bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream);
 
 }  // namespace glnn

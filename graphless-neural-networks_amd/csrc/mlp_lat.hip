@@ -437,6 +437,12 @@ struct TnLatProblem {
   int gpw;         // k-groups (8 batch rows) per wave
   int splits;      // > 1: the batch rows are also split over `splits` workgroups per tile; split s writes slab c + s * slab (c = workspace)
   int64_t slab;
+  // bn_z != NULL: `a` is dy and the operand is the BatchNorm backward's apply, dz = gamma * rstd * (dy - S1/B - xhat * S2/B), evaluated in
+  // the loads (bn_apply_tiles_kernel's expression and partial order: dz is never stored).  Column i of A is ONE lane's, so its constants
+  // and the fold of the S1 / S2 tile partials are per-lane scalars.  The j0 == 0 tiles also leave the column sums of dz per (split, wave)
+  // in bn_ws3 [4 * splits][ka] (the bias gradient in front of the BatchNorm; Adam folds them); split 0 / wave 0 stores dgamma, dbeta.
+  const float* bn_z; int64_t bn_ldz; const float* bn_gamma; const float* bn_mean; const float* bn_rstd; const float* bn_p1; const float* bn_p2;
+  int bn_nparts; float* bn_dgamma; float* bn_dbeta; float* bn_ws3;
 };
 struct TnLatArgs { TnLatProblem p[kTnLatMax]; int n; };
 
@@ -457,11 +463,37 @@ __global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) 
   const float* bp = g.b + jc;
   const bool xf = g.b_scale != nullptr;
   const float sc = xf ? g.b_scale[jc] : 1.f, sh = xf ? g.b_shift[jc] : 0.f;
+  const bool bn = g.bn_z != nullptr;
+  float mu = 0.f, rs = 1.f, grs = 1.f, c1 = 0.f, c2 = 0.f, cs = 0.f;
+  const float* zp = bn ? g.bn_z + ic : nullptr;
+  if (bn) {
+    float S1 = 0.f, S2 = 0.f;
+    for (int k0 = 0; k0 < g.bn_nparts; k0 += 16) {          // bn_apply_tiles_kernel's fold: k ascending, 16 partials of each in flight
+      float q1[16], q2[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + u < g.bn_nparts ? k0 + u : g.bn_nparts - 1;
+        q1[u] = g.bn_p1[(int64_t)k * g.ka + ic];
+        q2[u] = g.bn_p2[(int64_t)k * g.ka + ic];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u < g.bn_nparts) { S1 += q1[u]; S2 += q2[u]; }
+    }
+    mu = g.bn_mean[ic]; rs = g.bn_rstd[ic];
+    grs = g.bn_gamma[ic] * rs;
+    const float inv_b = 1.0f / (float)g.m;
+    c1 = S1 * inv_b; c2 = S2 * inv_b;
+    if (j0 == 0 && split == 0 && q == 0 && kk == 0 && i0 + li < g.ka) {
+      g.bn_dbeta[ic] = S1;
+      g.bn_dgamma[ic] = S2;
+    }
+  }
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (int c0 = 0; c0 < g.gpw; c0 += kGroups) {
-    float av[kGroups][4], bv[kGroups][4];
+    float av[kGroups][4], bv[kGroups][4], zv[kGroups][4];
 #pragma unroll
     for (int u = 0; u < kGroups; ++u) {
       const int mb = (wq * g.gpw + c0 + u) * 8 + kk * 4;
@@ -470,6 +502,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) 
         const int64_t mr = mb + t < g.m ? mb + t : g.m - 1;          // clamped: always a valid row, masked below
         av[u][t] = ap[mr * g.lda];
         bv[u][t] = bp[mr * g.ldb];
+        zv[u][t] = bn ? zp[mr * g.bn_ldz] : 0.f;
       }
     }
 #pragma unroll
@@ -485,10 +518,19 @@ __global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) 
             if (g.drop_thr) bvv = glnn::drop_keep(g.drop_seed, g.drop_thr, (uint32_t)(mb + t), (uint32_t)jc) ? bvv * g.drop_scale : 0.f;
           }
           const bool in = mb + t < g.m;
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? av[u][t] : 0.f, in ? bvv : 0.f, acc, 0, 0, 0);
+          float avv = av[u][t];
+          if (bn) {
+            avv = in ? grs * (avv - c1 - (zv[u][t] - mu) * rs * c2) : 0.f;
+            cs += avv;
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? avv : 0.f, in ? bvv : 0.f, acc, 0, 0, 0);
         }
       }
     }
+  }
+  if (bn) {                       // this wave's column sums of dz: the two lane halves hold different batch rows of the same column
+    cs += __shfl_xor(cs, 32);
+    if (j0 == 0 && kk == 0 && i0 + li < g.ka) g.bn_ws3[(int64_t)(split * 4 + q) * g.ka + ic] = cs;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[q][((r & 3) + 8 * (r >> 2) + 4 * kk) * LDT + li] = acc[r];
@@ -684,6 +726,8 @@ int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer,
   a.n = n;
   int blocks = 0;
   int64_t ws_off = 0;
+  GradFold extra[2];            // column-sum folds of problems with a BatchNorm apply in their operand: reported behind defer[n - 1]
+  int n_extra = 0;
   for (int p = 0; p < n; ++p) {
     const TnProblem& q = pr[p];
     if (!(q.a && q.b && q.c) || q.b_rows || q.m < 1 || q.m > 1024 || q.ka < 1 || q.nb < 1 || q.ka > max_dim || q.nb > max_dim) return GLNN_ERR_UNSUPPORTED;
@@ -714,7 +758,19 @@ int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer,
     }
     g.gpw = (groups + 4 * g.splits - 1) / (4 * g.splits);
     blocks += gi * g.gj * g.splits;
+    if (q.bn_z) {            // the operand is an un-applied BatchNorm backward: only with Adam next (its column sums are folded there)
+      if (!defer || !workspace || !q.bn_gamma || !q.bn_mean || !q.bn_rstd || !q.bn_p1 || !q.bn_p2 || q.bn_nparts < 1 || !q.bn_dgamma || !q.bn_dbeta ||
+          !q.bn_colsum || q.bn_ldz < q.ka || n_extra >= 2)
+        return GLNN_ERR_UNSUPPORTED;
+      ws_off = (ws_off + 3) & ~(int64_t)3;
+      if (ws_off + 4 * (int64_t)g.splits * q.ka > workspace_floats) return GLNN_ERR_UNSUPPORTED;
+      g.bn_z = q.bn_z; g.bn_ldz = q.bn_ldz; g.bn_gamma = q.bn_gamma; g.bn_mean = q.bn_mean; g.bn_rstd = q.bn_rstd; g.bn_p1 = q.bn_p1; g.bn_p2 = q.bn_p2;
+      g.bn_nparts = q.bn_nparts; g.bn_dgamma = q.bn_dgamma; g.bn_dbeta = q.bn_dbeta; g.bn_ws3 = workspace + ws_off;
+      extra[n_extra++] = {q.bn_colsum, g.bn_ws3, 4 * g.splits, 0, (int64_t)q.ka};
+      ws_off += 4 * (int64_t)g.splits * q.ka;
+    }
   }
+  if (defer) for (int e = 0; e < 2; ++e) defer[n + e] = e < n_extra ? extra[e] : GradFold{nullptr, nullptr, 0, 0, 0};
   for (int p = n; p < kTnLatMax; ++p) a.p[p].start = blocks;
   hipLaunchKernelGGL(gemm_tn_lat_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   return glnn::check_launch("glnn::gemm_tn_lat");
@@ -728,7 +784,7 @@ int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer,
 int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, const float* w, int64_t ldw, int n, const float* z, int64_t ldz,
                            const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                            uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
-                           float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum) {
+                           float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum, int skip_apply) {
   const int max_m = env_int("GLNN_LAT_BN_BWD_MAX_M", 1024);
   const int max_n = env_int("GLNN_LAT_BN_BWD_MAX_N", 1024), max_k = env_int("GLNN_LAT_BN_BWD_MAX_K", 1024);
   if (!env_int("GLNN_GEMM_LAT", 1) || !env_int("GLNN_STUDENT_LAT_BN_BWD", 1)) return GLNN_ERR_UNSUPPORTED;
@@ -752,8 +808,19 @@ int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, 
   const LossArgs nol = {};
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc = launch_lat<1, EPI_BNBWD>(g, none, nol, nullptr, true, st);
-  if (rc != GLNN_OK) return rc;
-  BnApplyArgs a = {da, ldda, z, ldz, m, n, gamma, mean, rstd, g.e_ws1, g.e_ws2, (int)mt, dz, lddz, dgamma, dbeta,
+  if (rc != GLNN_OK || skip_apply) return rc;          // skip_apply: the caller's weight-gradient launch applies (TnProblem::bn_z) or calls bn_apply_tiles
+  return glnn::bn_apply_tiles(da, ldda, z, ldz, m, n, gamma, mean, rstd, dz, lddz, dgamma, dbeta, dz_col_sum, workspace, workspace_floats, stream,
+                              defer_colsum);
+}
+
+// the apply half of lat_dgrad_bn_bwd on its own (workspace = the one the GEMM's epilogue filled: S1 partials, S2 partials, room for ws3)
+int glnn::bn_apply_tiles(const float* dy, int64_t lddy, const float* z, int64_t ldz, int64_t m, int n, const float* gamma, const float* mean,
+                         const float* rstd, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace,
+                         int64_t workspace_floats, void* stream, GradFold* defer_colsum) {
+  const int64_t mt = (m + 31) / 32;
+  GLNN_REQUIRE(dy && z && gamma && mean && rstd && dz && dgamma && dbeta && workspace && workspace_floats >= 3 * mt * n, "glnn::bn_apply_tiles: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  BnApplyArgs a = {dy, lddy, z, ldz, m, n, gamma, mean, rstd, workspace, workspace + mt * n, (int)mt, dz, lddz, dgamma, dbeta,
                    dz_col_sum ? workspace + 2 * mt * n : nullptr};
   hipLaunchKernelGGL(bn_apply_tiles_kernel, dim3((n + 63) / 64, (unsigned)mt), dim3(256), 0, st, a);
   if (dz_col_sum) {
@@ -763,5 +830,5 @@ int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, 
       hipLaunchKernelGGL(tile_chunk_sum_kernel, dim3((n + 127) / 128), dim3(128), 0, st, a.ws3, (int)mt, n, dz_col_sum);
     }
   }
-  return glnn::check_launch("glnn::lat_dgrad_bn_bwd");
+  return glnn::check_launch("glnn::bn_apply_tiles");
 }

@@ -209,11 +209,18 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
   int64_t tn_off = 0;
+  // the FIRST hidden layer's dz has one consumer besides the bias / BatchNorm gradients: the first layer's weight gradient.  In the
+  // one-call form with the latency kernels its apply pass rides in that product's operand loads (TnProblem::bn_z) -- one launch less
+  struct { const float* z; int64_t ldz; const float* gamma; const float* mean; const float* rstd; float* ws; int64_t ws_floats; int64_t mt;
+           float* dgamma; float* dbeta; float* colsum; float* dz_out; int64_t ld_out; } unapplied = {};
+  const char* fae = getenv("GLNN_STUDENT_FUSE_APPLY");
+  const bool fuse_apply = !(fae && fae[0] == '0') && pf && defer;
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
     if (defer) {
       glnn::TnProblem& q = deferred[n_deferred++];
+      q = {};
       q.a = dz; q.lda = ld_dz; q.m = m; q.ka = d->dims[l + 1]; q.nb = d->dims[l]; q.c = d->gw[l]; q.ldc = d->dims[l];
       q.b_rows = nullptr; q.b_scale = q.b_shift = nullptr; q.drop_p = 0.f; q.drop_seed = 0u;
       if (l == 0) {
@@ -224,6 +231,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         q.b = d->z[l - 1]; q.ldb = d->ldz[l - 1]; q.b_scale = d->a_scale[l - 1]; q.b_shift = d->a_shift[l - 1];
         q.drop_p = p; q.drop_seed = p > 0.f ? drop_seeds[l - 1] : 0u;
       }
+    }
+    if (defer && unapplied.z) {            // this layer's dz exists only as (dy, tile partials): its weight gradient applies it in the loads
+      glnn::TnProblem& q = deferred[n_deferred - 1];
+      q.a = d->da; q.lda = d->ld_da;
+      q.bn_z = unapplied.z; q.bn_ldz = unapplied.ldz; q.bn_gamma = unapplied.gamma; q.bn_mean = unapplied.mean; q.bn_rstd = unapplied.rstd;
+      q.bn_p1 = unapplied.ws; q.bn_p2 = unapplied.ws + unapplied.mt * q.ka; q.bn_nparts = (int)unapplied.mt;
+      q.bn_dgamma = unapplied.dgamma; q.bn_dbeta = unapplied.dbeta; q.bn_colsum = unapplied.colsum;
     }
     if (l == 0) {
       if (defer) break;
@@ -318,12 +332,17 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     if (cnt && !two && d->batchnorm == 1 && grp == nullptr && L >= 2) {
       const int64_t per = d->ws_bn_floats / (L - 1) / 4 * 4;
       glnn::GradFold cf = {};
+      bool skip = fuse_apply && l == 1 && (pregather || !idx);              // gemm_tn_lat's conditions: plain B operands, every dim <= 256
+      for (int i = 0; i <= L; ++i) skip = skip && d->dims[i] <= 256;
       const int rc = glnn::lat_dgrad_bn_bwd(dz, ld_dz, m, d->dims[l + 1], d->w[l], d->dims[l], d->dims[l], d->z[l - 1], d->ldz[l - 1],
                                             d->gamma[l - 1], d->mean[l - 1], d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed,
                                             d->da, d->ld_da, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1], d->gb[l - 1],
-                                            d->ws_bn + (l - 1) * per, per, stream, (pf && pf->n < glnn::kMaxGradFolds) ? &cf : nullptr);
+                                            d->ws_bn + (l - 1) * per, per, stream, (pf && pf->n < glnn::kMaxGradFolds) ? &cf : nullptr, skip ? 1 : 0);
       if (rc == GLNN_OK) {
         lat_bn = true;
+        if (skip)
+          unapplied = {d->z[l - 1], d->ldz[l - 1], d->gamma[l - 1], d->mean[l - 1], d->rstd[l - 1], d->ws_bn + (l - 1) * per, per, (m + 31) / 32,
+                       d->ggamma[l - 1], d->gbeta[l - 1], d->gb[l - 1], dz_out, ld_out};
         if (cf.nslab > 0) pf->e[pf->n++] = cf;
       } else if (rc != GLNN_ERR_UNSUPPORTED) {
         return rc;
@@ -371,11 +390,26 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   }
   if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));      // join: `stream` continues behind every weight gradient
 #undef GLNN_HIP_TRY
-  glnn::GradFold gf[GLNN_MLP_MAX_LAYERS];
+  glnn::GradFold gf[GLNN_MLP_MAX_LAYERS + 2];
+  bool tn_done = false;
   if (defer && glnn::gemm_tn_lat(deferred, n_deferred, stream, pf ? gf : nullptr, d->ws_tn, d->ws_tn_floats) == GLNN_OK) {
     // every weight gradient of the step from one launch of the latency kernel; with Adam next, its reduction slabs are folded there
+    tn_done = true;
     if (pf)
-      for (int i = 0; i < n_deferred && pf->n < glnn::kMaxGradFolds; ++i) pf->e[pf->n++] = gf[i];
+      for (int i = 0; i < n_deferred + 2 && pf->n < glnn::kMaxGradFolds; ++i)
+        if (i < n_deferred || gf[i].nslab > 0) pf->e[pf->n++] = gf[i];
+  }
+  if (defer && !tn_done && unapplied.z) {      // the latency kernel did not take the batch after all: apply with a launch, plain operand
+    glnn::GradFold cf = {};
+    GLNN_TRY(glnn::bn_apply_tiles(d->da, d->ld_da, unapplied.z, unapplied.ldz, m, d->dims[1], unapplied.gamma, unapplied.mean, unapplied.rstd,
+                                  unapplied.dz_out, unapplied.ld_out, unapplied.dgamma, unapplied.dbeta, unapplied.colsum, unapplied.ws,
+                                  unapplied.ws_floats, stream, (pf && pf->n < glnn::kMaxGradFolds) ? &cf : nullptr));
+    if (cf.nslab > 0) pf->e[pf->n++] = cf;
+    glnn::TnProblem& q = deferred[n_deferred - 1];
+    q.a = unapplied.dz_out; q.lda = unapplied.ld_out;
+    q.bn_z = nullptr;
+  }
+  if (tn_done) {
   } else if (defer) {
     const int rc = glnn::gemm_tn_batch(deferred, n_deferred, d->ws_tn, d->ws_tn_floats, stream, pf ? gf : nullptr);
     if (rc == GLNN_OK && pf)

@@ -274,6 +274,7 @@ def test_one_call_train_step_equals_fwd_bwd_plus_adam_bit_for_bit(dims, bsz, nor
     # the one-call form also splits the latency weight-gradient kernel's reduction over workgroups (Adam folds the slabs): another
     # summation order, compared to fp32 rounding in test_small_batch_step_forms_agree; switched off here
     monkeypatch.setenv("GLNN_GEMM_TN_LAT_SPLITS", "1")
+    monkeypatch.setenv("GLNN_STUDENT_FUSE_APPLY", "0")        # (the first hidden layer's apply pass inside the weight-gradient launch: one-call form only)
     for one_call, folds in (("0", "1"), ("1", "1"), ("1", "0")):
         monkeypatch.setenv("GLNN_STUDENT_ONE_CALL", one_call)
         monkeypatch.setenv("GLNN_STUDENT_ADAM_FOLDS", folds)
@@ -285,7 +286,7 @@ def test_one_call_train_step_equals_fwd_bwd_plus_adam_bit_for_bit(dims, bsz, nor
 
 @pytest.mark.parametrize("knob,modes", [("GLNN_GEMM_LAT", "01"), ("GLNN_STUDENT_DEFER_STATS", "01"), ("GLNN_STUDENT_SLAB_CONSUMERS", "01"),
                                         ("GLNN_GEMM_TN_LAT", "01"), ("GLNN_GEMM_TN_LAT_SPLITS", "18"), ("GLNN_STUDENT_ONE_CALL", "01"),
-                                        ("GLNN_STUDENT_LAT_BN_BWD", "01")])
+                                        ("GLNN_STUDENT_LAT_BN_BWD", "01"), ("GLNN_STUDENT_FUSE_APPLY", "01")])
 @pytest.mark.parametrize("dims,bsz,norm,p,kind", SMALL_STEP_CASES[:4])
 def test_small_batch_step_forms_agree(dims, bsz, norm, p, kind, knob, modes, monkeypatch):
     """The latency forms of the B <= 1024 step against the forms they replace, one optimiser step from the same state:
@@ -296,6 +297,8 @@ def test_small_batch_step_forms_agree(dims, bsz, norm, p, kind, knob, modes, mon
       GLNN_GEMM_TN_LAT=0           the batched 64 x 64 weight-gradient kernel + fold instead of gemm_tn_lat_kernel,
       GLNN_GEMM_TN_LAT_SPLITS=1|8  its reduction kept inside one workgroup or split over up to 8 (the one-call form, Adam folds),
       GLNN_STUDENT_ONE_CALL=0      glnn_mlp_fwd_bwd_f32 + glnn_adam_step_f32 instead of glnn_mlp_train_step_f32,
+      GLNN_STUDENT_FUSE_APPLY=0    the first hidden layer's BatchNorm apply as a launch of its own instead of in the operand loads of the
+                                   weight-gradient launch (TnProblem::bn_z),
       GLNN_STUDENT_LAT_BN_BWD=0    input-gradient GEMM + one-launch BatchNorm backward (workgroups wait for each other) instead of the
                                    GEMM whose epilogue leaves the column partial sums + bn_apply_tiles_kernel (glnn::lat_dgrad_bn_bwd).
     They differ by summation order only: logits, loss and every gradient agree to fp32 rounding (partial tiles: 300 / 77 rows, 72 and 5
