@@ -35,6 +35,7 @@ struct LatArgs {
   uint32_t drop_thr, drop_seed; float drop_scale;
   int64_t m; int k; const float* b; int64_t ldb; int n;
   const float* bias; float* c; int64_t ldc; int c_vec;
+  int b_vec;                                      // W[n, k] rows float4-addressable (ldb % 4 == 0, 16-byte base); else four dword loads per fragment
   float* a_copy; int64_t ld_copy;                 // optional: the (gathered) rows of A stored as a plain [m, k] matrix by the blockIdx.y == 0 tiles
   int gpw;                                        // k-groups per wave: wave q owns groups [q * gpw, (q + 1) * gpw)
   float* ws_mean; float* ws_m2; int* counters;    // EPI_STATS: [m tiles][n] partials, one counter per 64-column block
@@ -56,7 +57,8 @@ __device__ __forceinline__ float4 keep_first(float4 v, int left) {   // elements
 // columns (`pend`); every workgroup combines them itself while its operand loads are in flight, and workgroup (0, 0) also stores what
 // the statistics kernel would have (mean / rstd / a_scale / a_shift for the backward, the running statistics).
 constexpr int kFinMaxK = 1024;
-template <int XF, bool B_KN, int NB, int EPI, bool FIN>
+// BU (first layers only: XF = 0, W as [n, k]): W's rows are not float4-addressable -- four dword loads per fragment.
+template <int XF, bool B_KN, int NB, int EPI, bool FIN, bool BU = false>
 __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const BnFinArgs fin, const LossArgs ls, const BnFinArgs pend) {
   constexpr int TN = 32 * NB;
   constexpr int LDT = TN + 4;
@@ -139,8 +141,15 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
           bv[j][u].y = bp[j][(int64_t)k1 * g.ldb];
           bv[j][u].z = bp[j][(int64_t)k2 * g.ldb];
           bv[j][u].w = bp[j][(int64_t)k3 * g.ldb];
-        } else {
+        } else if (!BU) {
           bv[j][u] = ld4(bp[j] + kcc);
+        } else {                 // rows of W that start off a 16-byte boundary (cora: 1433 features): the lane's four k's one by one
+          const int k0 = kc > g.k - 1 ? g.k - 1 : kc, k1 = kc + 1 > g.k - 1 ? g.k - 1 : kc + 1;
+          const int k2 = kc + 2 > g.k - 1 ? g.k - 1 : kc + 2, k3 = kc + 3 > g.k - 1 ? g.k - 1 : kc + 3;
+          bv[j][u].x = bp[j][k0];
+          bv[j][u].y = bp[j][k1];
+          bv[j][u].z = bp[j][k2];
+          bv[j][u].w = bp[j][k3];
         }
       }
     }
@@ -408,6 +417,10 @@ int launch_lat(const LatArgs& g, const BnFinArgs& fin, const LossArgs& ls, const
     if constexpr (EPI == EPI_PLAIN || EPI == EPI_BNBWD) GLNN_LAT_LAUNCH(0, true, false);
   } else if (EPI == EPI_BNBWD) {
     return GLNN_ERR_UNSUPPORTED;
+  } else if (!g.b_vec) {
+    if (pend || xf != 0 || NB != 1 || EPI == EPI_LOSS) return GLNN_ERR_UNSUPPORTED;   // unaligned W: first layers (plain A, hidden output) only
+    if constexpr (NB == 1 && EPI != EPI_LOSS)
+      hipLaunchKernelGGL((gemm_lat_kernel<0, false, NB, EPI, false, true>), grid, dim3(256), 0, st, g, fin, ls, none);
   } else if (pend) {
     if (xf == 1) GLNN_LAT_LAUNCH(1, false, true); else GLNN_LAT_LAUNCH(2, false, true);
   } else {
@@ -653,10 +666,14 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   const int enabled = env_int("GLNN_GEMM_LAT", 1);            // read per call: tests and A/B runs toggle it between steps
   static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
   static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
-  if (!enabled || !a || !b || !c || m < 1 || m > max_m || k < 4 || k > max_k || n < 1 || n > max_n || (st && ls)) return GLNN_ERR_UNSUPPORTED;
+  // W[n, k] whose rows are not float4-addressable (a feature width that is not a multiple of 4: cora's 1433) would take the guarded
+  // generic GEMM (206 us for 140 x 128 x 1433): here it is loaded dword by dword, and K may be as deep as it comes
+  const bool b_vec = b_layout || (ldb % 4 == 0 && glnn::aligned16(b));
+  const int k_lim = b_vec ? max_k : (max_k > 4096 ? max_k : 4096);
+  if (!enabled || !a || !b || !c || m < 1 || m > max_m || k < 4 || k > k_lim || n < 1 || n > max_n || (st && ls)) return GLNN_ERR_UNSUPPORTED;
   const int kpad = (k + 3) & ~3;
   if (lda % 4 || !glnn::aligned16(a) || lda < kpad) return GLNN_ERR_UNSUPPORTED;
-  if (!b_layout && (ldb % 4 || !glnn::aligned16(b) || ldb < kpad)) return GLNN_ERR_UNSUPPORTED;
+  if (!b_layout && ldb < (b_vec ? kpad : k)) return GLNN_ERR_UNSUPPORTED;
   if (b_layout && ldb < n) return GLNN_ERR_UNSUPPORTED;
   const int64_t mt = (m + 31) / 32;
   if (pend) {
@@ -671,6 +688,7 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   g.drop_thr = glnn::drop_threshold(drop_p); g.drop_seed = drop_seed; g.drop_scale = 1.0f / (1.0f - drop_p);
   g.m = m; g.k = k; g.b = b; g.ldb = ldb; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
   g.c_vec = (ldc % 4 == 0) && glnn::aligned16(c);
+  g.b_vec = b_vec ? 1 : 0;
   if (a_copy) {
     if (a_scale || pend || ld_copy % 4 || ld_copy < kpad || !glnn::aligned16(a_copy)) return GLNN_ERR_UNSUPPORTED;
     g.a_copy = a_copy; g.ld_copy = ld_copy;
