@@ -1423,8 +1423,9 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
                     (!a_scale || (k % 4 == 0 && glnn::aligned16(a_scale) && glnn::aligned16(a_shift)));
   // W[n, k] with rows off the 16-byte grid (a feature width that is not a multiple of 4: cora's 1433-wide first layers) and a plain
   // epilogue: the dword-loading latency kernel of mlp_lat.hip instead of the guarded generic one (2485 x 64 x 1433: 240 us)
-  if (!fast && !defer_splits && !b_layout && g.a_vec && lda >= ((k + 3) & ~3) && !g.b_vec && !a_scale && !row_scale && !ep_scale && !relu) {
-    const int rc = glnn::gemm_lat(a, lda, a_rows, nullptr, nullptr, 0.f, 0u, m, k, b, ldb, 0, n, ep_shift, c, ldc, nullptr, nullptr, nullptr, stream);
+  if (!fast && !defer_splits && !b_layout && g.a_vec && lda >= ((k + 3) & ~3) && !g.b_vec && !a_scale && !row_scale) {
+    const int rc = glnn::gemm_lat(a, lda, a_rows, nullptr, nullptr, 0.f, 0u, m, k, b, ldb, 0, n, ep_shift, c, ldc, nullptr, nullptr, nullptr, stream,
+                                  nullptr, 0, ep_scale, relu);
     if (rc != GLNN_ERR_UNSUPPORTED) return rc;
   }
   // latency regime: fewer than 64 tiles of 128 x (128|64) -> 64 x 64 tiles, four times the workgroups, a quarter of the

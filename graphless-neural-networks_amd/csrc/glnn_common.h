@@ -139,7 +139,7 @@ struct LatLoss {       // log_softmax + loss + dlogits on C (n <= 64) (arguments
 int gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
              uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
              int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy = nullptr,
-             int64_t ld_copy = 0);
+             int64_t ld_copy = 0, const float* ep_scale = nullptr, int relu = 0);
 // a_copy (plain operands only): the rows of A (gathered through a_rows) are also stored as a dense [m, k] matrix -- the first layer's
 // batch rows, which the weight gradient reads again
 // defer holds n + 2 entries: [n], [n + 1] = the column-sum folds of problems that carry a BatchNorm apply (nslab 0 = none)

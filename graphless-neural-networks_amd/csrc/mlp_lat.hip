@@ -35,6 +35,7 @@ struct LatArgs {
   uint32_t drop_thr, drop_seed; float drop_scale;
   int64_t m; int k; const float* b; int64_t ldb; int n;
   const float* bias; float* c; int64_t ldc; int c_vec;
+  const float* ep_scale; int relu;                // plain epilogue only: C = relu?(acc * ep_scale[col] + bias[col]) (eval-mode BatchNorm folded into the layer)
   int b_vec;                                      // W[n, k] rows float4-addressable (ldb % 4 == 0, 16-byte base); else four dword loads per fragment
   float* a_copy; int64_t ld_copy;                 // optional: the (gathered) rows of A stored as a plain [m, k] matrix by the blockIdx.y == 0 tiles
   int gpw;                                        // k-groups per wave: wave q owns groups [q * gpw, (q + 1) * gpw)
@@ -240,9 +241,19 @@ __global__ __launch_bounds__(256) void gemm_lat_kernel(const LatArgs g, const Bn
       float v[4] = {((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y, ((v0.z + v1.z) + v2.z) + v3.z,
                     ((v0.w + v1.w) + v2.w) + v3.w};
       const int col = n0 + c4;
-      if (g.bias) {
+      if (g.ep_scale) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int cc = col + t < g.n ? col + t : g.n - 1;
+          v[t] = fmaf(v[t], g.ep_scale[cc], g.bias ? g.bias[cc] : 0.f);
+        }
+      } else if (g.bias) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] += g.bias[col + t < g.n ? col + t : g.n - 1];
+      }
+      if (g.relu) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.f);
       }
       float qv[4] = {0.f, 0.f, 0.f, 0.f};
       if (EPI == EPI_BNBWD) {                           // C -> dy (bn_dy of student.hip); qv = dy * xhat
@@ -662,7 +673,8 @@ BnFinArgs fin_args(const glnn::LatStats& st, const float* ws_mean, const float* 
 // float4-addressable: the caller then issues the tiled GEMM and the separate reduction kernels.
 int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale, const float* a_shift, float drop_p,
                    uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
-                   int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy, int64_t ld_copy) {
+                   int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy, int64_t ld_copy,
+                   const float* ep_scale, int relu) {
   const int enabled = env_int("GLNN_GEMM_LAT", 1);            // read per call: tests and A/B runs toggle it between steps
   static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
   static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
@@ -690,6 +702,8 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   g.m = m; g.k = k; g.b = b; g.ldb = ldb; g.n = n; g.bias = bias; g.c = c; g.ldc = ldc;
   g.c_vec = (ldc % 4 == 0) && glnn::aligned16(c);
   g.b_vec = b_vec ? 1 : 0;
+  if ((ep_scale || relu) && (st || ls)) return GLNN_ERR_UNSUPPORTED;
+  g.ep_scale = ep_scale; g.relu = relu ? 1 : 0;
   if (a_copy) {
     if (a_scale || pend || ld_copy % 4 || ld_copy < kpad || !glnn::aligned16(a_copy)) return GLNN_ERR_UNSUPPORTED;
     g.a_copy = a_copy; g.ld_copy = ld_copy;
