@@ -688,6 +688,7 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   if (lda % 4 || !glnn::aligned16(a) || lda < kpad) return GLNN_ERR_UNSUPPORTED;
   if (!b_layout && ldb < (b_vec ? kpad : k)) return GLNN_ERR_UNSUPPORTED;
   if (b_layout && ldb < n) return GLNN_ERR_UNSUPPORTED;
+  if (!b_vec && (pend || a_scale || ls)) return GLNN_ERR_UNSUPPORTED;          // the dword-loading variant exists for plain first layers only
   const int64_t mt = (m + 31) / 32;
   if (pend) {
     if (b_layout || k % 4 || k > kFinMaxK || !pend->ws || pend->ws_floats < 2 * mt * k || !pend->a_scale_out || !pend->a_shift_out) return GLNN_ERR_UNSUPPORTED;
@@ -727,13 +728,15 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
     la.t = ls->target_logp; la.ldt = ls->ldt; la.t_rows = ls->target_rows; la.scale = ls->lamb / (float)m;
     la.dz = ls->dlogits; la.ldg = ls->ldg; la.partial = ls->ws; la.counter = ls->counter; la.inv_rows = 1.0f / (float)m;
     la.loss_out = ls->loss_out; la.loss_accum = ls->loss_accum; la.col_sum = ls->col_sum; la.col_partial = ls->ws + mt;
-    if (ls->pf && ls->pf->n < glnn::kMaxGradFolds) {
-      la.defer = 1;
+    const bool defer = ls->pf && ls->pf->n < glnn::kMaxGradFolds;
+    la.defer = defer ? 1 : 0;
+    const int rc = launch_lat<2, EPI_LOSS>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
+    if (rc == GLNN_OK && defer) {          // registered only once the launch is in the queue: an UNSUPPORTED variant must leave *pf alone
       ls->pf->has_loss = 1;
       ls->pf->loss = {ls->ws, (int)mt, 1.0f / (float)m, ls->loss_out, ls->loss_accum};
       if (ls->col_sum) ls->pf->e[ls->pf->n++] = {ls->col_sum, la.col_partial, (int)mt, 1, 64};
     }
-    return launch_lat<2, EPI_LOSS>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
+    return rc;
   }
   return launch_lat<1, EPI_PLAIN>(g, fin, la, pend ? &pfin : nullptr, b_layout != 0, s);
 }

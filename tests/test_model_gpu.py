@@ -285,6 +285,19 @@ def test_one_call_train_step_equals_fwd_bwd_plus_adam_bit_for_bit(dims, bsz, nor
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_small_step_forms_agree_on_random_shapes(seed):
+    """scripts/fuzz_small_step.py: 40 random (layers, widths, batch, norm, dropout, loss, weight decay) per seed -- odd widths (7, 50, 130,
+    257, 1433: rows that are not float4-addressable), partial tiles (1 ... 1100 rows), 1-3 layers -- default forms (latency kernels, one-call
+    step, Adam folds) against the tiled two-call forms: logits, loss, every gradient.  (It found the one-layer student with an unaligned
+    weight registering Adam folds for a launch that then did not happen.)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_small_step
+    bad = [(d, e) for d, e, ok in fuzz_small_step.run(seed, 40, verbose=False) if not ok or e >= 2e-3]
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("knob,modes", [("GLNN_GEMM_LAT", "01"), ("GLNN_STUDENT_DEFER_STATS", "01"), ("GLNN_STUDENT_SLAB_CONSUMERS", "01"),
                                         ("GLNN_GEMM_TN_LAT", "01"), ("GLNN_GEMM_TN_LAT_SPLITS", "18"), ("GLNN_STUDENT_ONE_CALL", "01"),
                                         ("GLNN_STUDENT_LAT_BN_BWD", "01"), ("GLNN_STUDENT_FUSE_APPLY", "01")])
