@@ -704,3 +704,15 @@ def test_randomized_gemm_sweep_all_variants():
         got = ops.gemm_tn(ops.as_feat(dev(dz)), ad, b_rows=dev(rows) if gather else None, m=m, col_sum_a=colsum, **kt)
         np.testing.assert_allclose(got.cpu().numpy(), dz.astype(np.float64).T @ a_eff, atol=3e-4, rtol=1e-5, err_msg="TN " + tag)
         np.testing.assert_allclose(colsum.cpu().numpy(), dz.astype(np.float64).sum(0), atol=2e-4, rtol=1e-5, err_msg="colsum " + tag)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_gemm_dispatch_on_random_shapes(seed):
+    """scripts/fuzz_gemm.py: 60 random glnn_gemm_f32 problems per seed against float64 torch -- widths that are not multiples of 4 (the
+    dword-loading latency kernel, the generic kernel), row gathers, operand transform + counter-hash dropout, epilogue scale / shift /
+    ReLU, both weight layouts, 1 ... 4096 rows: every kernel the dispatcher can pick."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_gemm
+    bad = [(d, e) for d, e, ok in fuzz_gemm.run(seed, 60, verbose=False) if not ok or e >= 2e-5]
+    assert not bad, bad
