@@ -205,7 +205,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   // (arxiv MLP 0.127 -> 0.10x ms).  dz_l then has to outlive the loop: it alternates between d->dz and d->dz2 as in the two-stream form.
   const char* dwe = getenv("GLNN_STUDENT_BATCHED_WGRAD");
   const bool defer = !(dwe && dwe[0] == '0') && cnt && !two && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
-                     (L == 1 || fused_bias) && !layernorm;
+                     fused_bias && !layernorm;      // (the last layer's bias gradient must come from the loss kernel: the batched launch has no column sums)
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
   int64_t tn_off = 0;
