@@ -2,6 +2,8 @@
 (integer work: bit-exact against numpy restatements), the neighbour sampler's statistics, and TeacherEngine's
 forward + loss + backward + Adam against the golden vectors the reference's own train_sage / train produced
 (tests/golden/teacher_training.npz) and against the numpy oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -570,3 +572,100 @@ def test_block_builder_and_loader_edge_cases():
     # transposing an empty block
     t = _graph(np.zeros(4, np.int64), np.zeros(0, np.int32), 9).transposed(add_self=True)
     assert t.indptr.tolist() == [0, 1, 2, 3, 3, 3, 3, 3, 3, 3] and t.indices.tolist() == [0, 1, 2]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GLNN_FUZZ_CASES", "12"))))
+def test_sage_and_gcn_teachers_on_random_shapes_vs_oracle(seed):
+    """Randomised shapes (feature / hidden / class widths that are not multiples of 4, 1-3 layers, short last batches, hubs and
+    isolated rows): SAGE inference through both sweeps, one sampled-block training step, and one full-graph GCN step, each
+    against the numpy oracle.  The fixed cases above pin the reference's configurations; this one walks the dispatch
+    (unaligned operands -> latency GEMM, narrow tails, one-layer models) that no configuration names."""
+    from glnn_amd import ops
+    from glnn_amd.graph import FullNeighborLoader, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    from oracle import student_oracle as so
+    from oracle import teacher_oracle as to
+    rs = np.random.RandomState(1000 + seed)
+    pick = lambda xs: xs[rs.randint(len(xs))]
+    L = pick([1, 2, 2, 3])
+    f, h, c = pick([5, 7, 33, 50, 100, 130, 257]), pick([8, 17, 33, 64, 100, 256]), pick([2, 3, 7, 40, 47, 70])
+    norm = pick(["batch", "none"])
+    n = int(pick([300, 1111, 4000, 9000]))
+    dims = [f] + [h] * (L - 1) + [c]
+    indptr, indices = random_graph(n, pick([2, 6, 14]), seed=seed, power=pick([0.0, 0.6]), isolated=pick([0, 7]), hub=pick([0, n // 3]))
+    feats = rs.standard_normal((n, f)).astype(np.float32)
+    labels = rs.randint(0, c, n).astype(np.int64)
+    g = _graph(indptr, indices)
+    fd, ld = ops.as_feat(torch.from_numpy(feats).to(DEV)), torch.from_numpy(labels).to(DEV)
+    tag = f"seed={seed} dims={dims} norm={norm} n={n}"
+
+    # ---- SAGE: inference (eval) through the whole-graph path and the chunked sweep
+    torch.manual_seed(seed)
+    model = Model(dict(model_name="SAGE", num_layers=L, feat_dim=f, hidden_dim=h, label_dim=c, dropout_ratio=0.0, norm_type=norm, device=DEV))
+    with torch.no_grad():
+        for bn in model.encoder.norms:
+            bn.weight.copy_(torch.from_numpy(rs.uniform(.5, 1.5, bn.weight.shape[0]).astype(np.float32)))
+            bn.bias.copy_(torch.from_numpy(rs.uniform(-.2, .2, bn.weight.shape[0]).astype(np.float32)))
+            bn.running_mean.copy_(torch.from_numpy(rs.uniform(-.3, .3, bn.weight.shape[0]).astype(np.float32)))
+            bn.running_var.copy_(torch.from_numpy(rs.uniform(.5, 1.5, bn.weight.shape[0]).astype(np.float32)))
+    sd0 = {k: v.cpu().numpy().copy() for k, v in model.state_dict().items()}
+    layers = [dict(weight=sd0[f"encoder.layers.{i}.fc_neigh.weight"], bias=sd0[f"encoder.layers.{i}.fc_neigh.bias"]) for i in range(L)]
+    norms = [dict(weight=sd0[f"encoder.norms.{i}.weight"], bias=sd0[f"encoder.norms.{i}.bias"], running_mean=sd0[f"encoder.norms.{i}.running_mean"],
+                  running_var=sd0[f"encoder.norms.{i}.running_var"]) for i in range(L - 1)] if norm == "batch" else None
+    want = to.sage_inference(indptr, indices, feats, layers, norms)
+    model.eval()
+    loader = FullNeighborLoader(g, int(pick([100, 512, 3000])))
+    with torch.no_grad():
+        got = model.inference(loader, fd)
+        got_chunked = model.encoder.inference(loader, fd, whole_graph=False)
+    scale = max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL * scale, rtol=0, err_msg=tag)
+    np.testing.assert_allclose(got_chunked.cpu().numpy(), want, atol=TOL * scale, rtol=0, err_msg=tag)
+
+    # ---- SAGE: one sampled-block training step on the short last batch
+    bs = int(pick([64, 200, 512]))
+    n_seed = min(n, bs + int(pick([1, 37, bs - 1])))
+    nl = NodeDataLoader(g, torch.arange(n_seed), MultiLayerNeighborSampler([int(pick([3, 5, 10]))] * L), batch_size=bs, shuffle=False, seed=seed)
+    input_nodes, output_nodes, blocks = list(nl)[-1]
+    opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
+    model.train()
+    eng = TeacherEngine(model, opt)
+    eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+    st = tt.TeacherState(sd0, "sage", L, norm)
+    nb = [(b.indptr.cpu().numpy(), b.indices.cpu().numpy(), b.num_src_nodes()) for b in blocks]
+    logits, cache = tt.sage_forward(st, nb, feats[input_nodes.cpu().numpy()])
+    loss, dl = so.loss_and_dlogits(logits, labels[output_nodes.cpu().numpy()], "nll", 1.0)
+    assert abs(eng.loss_out.item() - float(loss)) < TOL * max(1.0, abs(float(loss))), tag
+    grads = tt.sage_backward(st, cache, dl)
+    gmax = max(float(np.abs(gr).max()) for gr in grads)
+    edge = min([float(np.abs(t["y"]).min() / np.abs(t["y"]).max()) for t in cache["tails"]] + [1.0])
+    for (pname, prm), gr in zip(model.named_parameters(), grads):
+        if edge < 3e-7:
+            break          # a pre-activation within two fp32 ulps of 0: which side of the ReLU it falls on is rounding, not arithmetic
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=2e-5 * max(1.0, gmax), rtol=1e-4, err_msg=f"{tag} {pname} edge={edge:.2e}")
+
+    # ---- GCN: one full-graph step (symmetric graph with self loops, both weight orders decided by the widths)
+    ip2, ix2 = random_graph(n, 4, seed=seed + 50, symmetric=True, self_loops=True, isolated=0)
+    g2 = _graph(ip2, ix2)
+    torch.manual_seed(seed)
+    gcn = Model(dict(model_name="GCN", num_layers=max(L, 2), feat_dim=f, hidden_dim=h, label_dim=c, dropout_ratio=0.0, norm_type="none", device=DEV))
+    sd1 = {k: v.cpu().numpy().copy() for k, v in gcn.state_dict().items()}
+    opt2 = torch.optim.Adam(gcn.parameters(), lr=0.01, weight_decay=0.0)
+    gcn.train()
+    eng2 = TeacherEngine(gcn, opt2)
+    idx = np.sort(rs.choice(n, size=max(1, n // 3), replace=False))
+    eng2.step_gcn(g2, fd, ld, torch.from_numpy(idx).to(DEV), 1.0)
+    st2 = tt.TeacherState(sd1, "gcn", max(L, 2), "none")
+    logits2, cache2 = tt.gcn_forward(st2, ip2, ix2, feats)
+    loss2, dl2 = so.loss_and_dlogits(logits2[idx], labels[idx], "nll", 1.0)
+    dfull = np.zeros_like(logits2)
+    dfull[idx] = dl2
+    assert abs(eng2.loss_out.item() - float(loss2)) < TOL * max(1.0, abs(float(loss2))), tag
+    grads2 = tt.gcn_backward(st2, cache2, dfull)
+    gmax2 = max(float(np.abs(gr).max()) for gr in grads2)
+    edge2 = min(float(np.abs(t["pre"]).min() / np.abs(t["pre"]).max()) for t in cache2["tails"])
+    for (pname, prm), gr in zip(gcn.named_parameters(), grads2):
+        if edge2 < 3e-7:
+            break
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=2e-5 * max(1.0, gmax2), rtol=1e-4, err_msg=f"{tag} gcn {pname} edge={edge2:.2e}")
