@@ -50,11 +50,11 @@ def run(seed=0, n_cases=40, verbose=True):
             # gradient (pure rounding noise, ~1e-9), which no two summation orders reproduce
             gscale = max(float(a.abs().max()) for a in g0) + 1e-12
             names = [nm for nm, _ in base.named_parameters()]
-            bad_t = ""
+            bad_t, bad_d = "", None
             for nm, a, b in zip(names, g0, g1):
                 e = float((a - b).abs().max()) / gscale
                 if e > err:
-                    err, bad_t = e, nm
+                    err, bad_t, bad_d = e, nm, (a - b)
             err = max(err, abs(float(l0) - float(l1)) / max(1.0, abs(float(l0))))
             desc = f"case {case:3d}: L={L} dims {feat}-{hid}-{c} B={B} norm={norm} p={p} {kind} wd={wd}"
             out.append((desc, err, ok))
@@ -62,6 +62,11 @@ def run(seed=0, n_cases=40, verbose=True):
                 # a pre-activation within rounding of 0 may open its ReLU gate in one form and not in the other: one term of a weight
                 # gradient appears / disappears (seen: 6.6e-4 of the largest gradient) -- 2e-3, three orders above rounding noise
                 print(f"{'ok ' if ok and err < 2e-3 else 'BAD'} {desc}: max rel diff {err:.2e} {bad_t}", flush=True)
+                if err >= 1e-4 and bad_d is not None and bad_d.dim() == 2:
+                    # a ReLU gate that opens in one form only changes ONE sample's contribution: the difference of a weight gradient is (nearly) rank 1
+                    sv = torch.linalg.svdvals(bad_d.double())
+                    rows = int((bad_d.abs().amax(1) > 0.05 * bad_d.abs().max()).sum())
+                    print(f"      difference of {bad_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{" -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""}; rows above 5 % of its max: {rows} / {bad_d.shape[0]}", flush=True)
     finally:
         for kn, v in saved.items():
             if v is None:

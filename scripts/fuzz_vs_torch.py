@@ -57,11 +57,11 @@ def run(seed=0, n_cases=40, verbose=True):
         err = abs(float(eng.loss_out) - float(loss.detach())) / max(1.0, abs(float(loss.detach())))
         err = max(err, float((eng.logits[:B, :c].double() - h.detach()).abs().max()) / (float(h.detach().abs().max()) + 1e-12))
         gscale = max(float(q.grad.abs().max()) for q in ref.parameters()) + 1e-12
-        worst_t = ""
+        worst_t, worst_d = "", None
         for (nm, q), g in zip(ref.named_parameters(), eng.grads):
             e = float((g.double() - q.grad).abs().max()) / gscale
             if e > err:
-                err, worst_t = e, nm
+                err, worst_t, worst_d = e, nm, g.double() - q.grad
         desc = f"case {case:3d}: L={L} dims {feat}-{hid}-{c} B={B} norm={norm} p={p} {kind} lamb={lamb}"
         # BatchNorm over a handful of rows is ill-conditioned in fp32 (two nearly equal samples: rstd ~ 1e3 and dz = dy - mean - xhat * ... cancels):
         # seen 3.3e-4 at B = 2; those cases are held to 2e-3
@@ -69,6 +69,10 @@ def run(seed=0, n_cases=40, verbose=True):
         out.append((desc, err / tol * 1e-4))                     # normalised so that callers compare with 1e-4
         if verbose:
             print(f"{'ok ' if err < tol else 'BAD'} {desc}: max rel err vs float64 torch {err:.2e} {worst_t}", flush=True)
+            if err >= tol and worst_d is not None and worst_d.dim() == 2:
+                sv = torch.linalg.svdvals(worst_d)
+                rows = int((worst_d.abs().amax(1) > 0.05 * worst_d.abs().max()).sum())
+                print(f"      difference of {worst_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{" -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""}; rows above 5 % of its max: {rows} / {worst_d.shape[0]}", flush=True)
     return out
 
 
