@@ -82,11 +82,15 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 // pf: the loss / bias-gradient partials are registered there for the fused Adam launch instead of being folded by the last workgroup
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
+// da = dl[rows, k] . w[k, h] (w rows ldw apart: a Linear's [out = k, in = h] weight), k <= 64: see bn_bwd_*_sk in student.hip
+struct NarrowProduct { const float* dl; int64_t lddl; int k; const float* w; int64_t ldw; };
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
                 void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0,
-                struct GradFold* defer_colsum = nullptr);
+                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr);
+// prod: the input gradient da is NOT in memory (da / ldda ignored): both passes recompute da = dl . w on the matrix cores; BatchNorm
+// two-launch form only (GLNN_ERR_UNSUPPORTED with nothing launched otherwise)
 // defer_colsum: (one-launch form only) dz_col_sum is NOT written; *defer_colsum describes the per-chunk partials left in `workspace`
 // da_slabs > 1: da points at that many split-K partial slabs (da[s][rows][ldda]) which the one-launch form sums itself; any other
 // form returns GLNN_ERR_UNSUPPORTED with nothing launched (fold with gemm_fold_partials, call again)

@@ -215,6 +215,10 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
            float* dgamma; float* dbeta; float* colsum; float* dz_out; int64_t ld_out; } unapplied = {};
   const char* fae = getenv("GLNN_STUDENT_FUSE_APPLY");
   const bool fuse_apply = !(fae && fae[0] == '0') && pf && defer;
+  const char* nbe = getenv("GLNN_STUDENT_NARROW_BWD");              // "0": always write the classifier's input gradient (A/B runs, tests)
+  const bool narrow_bwd = !(nbe && nbe[0] == '0');
+  const char* nme = getenv("GLNN_STUDENT_NARROW_BWD_MIN");
+  const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -353,7 +357,14 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       ld_dz = ld_out;
       continue;
     }
-    if (!(two && big_dgrad)) GLNN_TRY(input_gradient());
+    // a NARROW layer behind (the classifier) and a large batch: its input gradient is never written -- both BatchNorm backward passes
+    // recompute da = dz . W on the matrix cores (student.hip, bn_bwd_*_sk)
+    const bool narrow = narrow_bwd && !two && grp == nullptr && d->batchnorm == 1 && !layernorm && d->dims[l + 1] <= 64 &&
+                        (int64_t)m * d->dims[l] >= narrow_min;
+    const glnn::NarrowProduct np = {dz, ld_dz, d->dims[l + 1], d->w[l], d->dims[l]};
+    bool need_da = !(two && big_dgrad);
+    if (narrow) need_da = false;
+    if (need_da) GLNN_TRY(input_gradient());
     if (layernorm) {
       GLNN_TRY(glnn_layernorm_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->beta[l - 1],
                                       d->mean[l - 1], d->rstd[l - 1], 1, p, seed, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1],
@@ -368,6 +379,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       const bool dc = pf && grp == nullptr && L >= 2 && (d->ws_bn_floats / (L - 1) / 4 * 4) >= need_l && pf->n < glnn::kMaxGradFolds;
       if (dc) { wsb_floats = d->ws_bn_floats / (L - 1) / 4 * 4; wsb = d->ws_bn + (l - 1) * wsb_floats; }
       glnn::GradFold* cfp = dc ? &cf : nullptr;
+      if (narrow) {
+        rc = glnn::bn_relu_bwd(nullptr, 0, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
+                               d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
+                               d->gbeta[l - 1], d->gb[l - 1], wsb, wsb_floats, stream, nullptr, nullptr, 1, 0, cfp, &np);
+        if (rc == GLNN_ERR_UNSUPPORTED) GLNN_TRY(input_gradient());
+      }
       if (da_slabs > 0)
         rc = glnn::bn_relu_bwd(d->ws_gemm, d->dims[l], d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],

@@ -206,6 +206,9 @@ struct BnBwdArgs {
   int relu;                              // 1: the ReLU sits behind the norm (MLP / SAGE tails); 0: no ReLU in this tail (GCN: norm -> dropout)
   int defer_colsum;                      // bn_bwd_fused: ws3 (per-chunk column sums of dz) is left for the fused Adam launch to fold
   int nslab; int64_t slab_stride;        // bn_bwd_fused<NS > 0>: da = sum of nslab <= NS split-K slabs da[s * slab_stride + r * ldda + col]
+  // bn_bwd_*_sk: da is never materialised -- da = dl[rows, kk] . w[kk, h] (the input gradient of a NARROW layer, kk <= 64 classes),
+  // recomputed on the matrix cores by both passes
+  const float* dl; int64_t lddl; const float* w; int64_t ldw; int kk;
 };
 
 template <bool BN>
@@ -311,6 +314,264 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
     }
   }
   (void)sh2;
+}
+
+// ---- the same two passes when the layer behind is NARROW (the classifier: 47 / 40 / 7 outputs) and the batch is large -------------
+// da = dl . w has a reduction of <= 64: 0.8 GFLOP for MLP3w8's [4096, 2048] -- 5 us of MFMA time -- against 34 MB written by an input
+// gradient GEMM and read back twice.  Both passes therefore RECOMPUTE their 128 x 64 tile of da on the matrix cores and da never exists
+// in memory.  A workgroup stages its dl rows [128][2 KH] and its w panel [2 KH][64] in LDS once (coalesced float4 loads, zero behind
+// kk; dl is 0.8 MB, w 0.4 MB: L2 hits), requests its z values, and each wave multiplies 32 rows x two 32-column blocks with operands
+// read from LDS just in time (the register file holds the accumulators and z, not the operands: 4 waves per SIMD, the whole grid of
+// MLP3w8 resident at once).  The reduction index is split between the two lane halves of v_mfma_f32_32x32x2_f32 as [0, KH) / [KH, 2 KH)
+// (any pairing of k is a valid order), so a lane's A operands are KH consecutive floats of one row: ds_read_b128.
+typedef float sk_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int KH>
+struct SkLds {
+  static constexpr int LDA = 2 * KH + 4;     // (2 KH + 4) * row mod 32 banks: the eight rows of one ds_read_b128 pass never collide
+  float a[kBnRows][LDA];
+  float b[2 * KH][64];
+};
+
+// stage operands (all 256 threads): every global load is issued before the first LDS store; the caller syncs before sk_mma
+template <int KH>
+__device__ __forceinline__ void sk_stage(const BnBwdArgs& g, SkLds<KH>& L, int64_t r0, int c0) {
+  constexpr int K2 = 2 * KH, A4 = kBnRows * (K2 / 4), B4 = K2 * 16;
+  constexpr int NA = (A4 + 255) / 256, NB = (B4 + 255) / 256;
+  const int tid = threadIdx.x;
+  float4 va[NA], vb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = tid + 256 * i < A4 ? tid + 256 * i : A4 - 1;
+    const int row = e / (K2 / 4), k4 = (e % (K2 / 4)) * 4;
+    const int64_t r = r0 + row < g.rows ? r0 + row : g.rows - 1;
+    const int64_t kc = k4 + 4 <= g.lddl ? k4 : g.lddl - 4;       // stay inside the row's pitch; everything at k >= kk is zeroed below
+    va[i] = *reinterpret_cast<const float4*>(g.dl + r * g.lddl + kc);
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int e = tid + 256 * i < B4 ? tid + 256 * i : B4 - 1;
+    const int k = e / 16, c4 = (e % 16) * 4;
+    const float* p = g.w + (int64_t)(k < g.kk ? k : g.kk - 1) * g.ldw;
+    vb[i] = *reinterpret_cast<const float4*>(p + (c0 + c4 + 4 <= g.h ? c0 + c4 : g.h - 4));      // h % 4 == 0; columns >= h are never used
+  }
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int e = tid + 256 * i;
+    const int row = e / (K2 / 4), k4 = (e % (K2 / 4)) * 4;
+    float4 v = va[i];
+    if (k4 + 4 > g.lddl) v = make_float4(0.f, 0.f, 0.f, 0.f);   // k4 >= lddl - 3 >= kk - 3 and k4 % 4 == 0 == lddl % 4  =>  k4 >= lddl >= kk
+    v.x = k4 < g.kk ? v.x : 0.f; v.y = k4 + 1 < g.kk ? v.y : 0.f; v.z = k4 + 2 < g.kk ? v.z : 0.f; v.w = k4 + 3 < g.kk ? v.w : 0.f;
+    if (e < A4) *reinterpret_cast<float4*>(&L.a[row][k4]) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int e = tid + 256 * i;
+    const int k = e / 16, c4 = (e % 16) * 4;
+    if (e < B4) *reinterpret_cast<float4*>(&L.b[k][c4]) = k < g.kk ? vb[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// C fragment: register i of lane (li, kk) is row (i & 3) + 8 (i >> 2) + 4 kk of the wave's 32, column li of the block
+__device__ __forceinline__ void sk_load_z(const BnBwdArgs& g, int64_t wr0, int c0, int li, int kk, float (&zz)[2][16]) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int colc = c0 + 32 * b + li < g.h ? c0 + 32 * b + li : g.h - 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t r = wr0 + (i & 3) + 8 * (i >> 2) + 4 * kk;
+      zz[b][i] = g.z[(r < g.rows ? r : g.rows - 1) * g.ldz + colc];
+    }
+  }
+}
+
+template <int KH>
+__device__ __forceinline__ void sk_mma(const SkLds<KH>& L, int wave, int li, int kk, sk_f32x16 (&acc)[2]) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KH; s += 4) {
+    const float4 a4 = *reinterpret_cast<const float4*>(&L.a[32 * wave + li][kk * KH + s]);
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], L.b[kk * KH + s + t][32 * b + li], acc[b], 0, 0, 0);
+    }
+  }
+}
+
+// dy of one element, branch-free (bn_dy's arithmetic: the same hash, the same comparisons).  hcol = seed ^ ((col >> 1) * 0x85EBCA77 +
+// 0x632BE5AB) is hoisted per column, `row` is the global row of the element.
+template <bool DROP>
+__device__ __forceinline__ float sk_dy(const BnBwdArgs& a, float dav, float zz, uint32_t hcol, bool hi, uint32_t row, float sc, float sf, bool valid) {
+  if (DROP) {
+    uint32_t h = hcol ^ (row * 0x9E3779B1u);
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    dav = (hi ? (h >> 16) : (h & 0xFFFFu)) >= a.dthr ? dav * a.dscale : 0.f;
+  }
+  const bool on = !a.relu || fmaf(zz, sc, sf) > 0.f;
+  return (on && valid) ? dav : 0.f;
+}
+
+template <bool DROP, bool FULL>
+__device__ __forceinline__ void sk_partial_tail(const BnBwdArgs& a, const sk_f32x16 (&acc)[2], const float (&zz)[2][16], int64_t wr0, int c0, int li,
+                                                int kk, int wave, float (&sh1)[8][64], float (&sh2)[8][64]) {
+  const uint32_t rbase = (uint32_t)wr0 + 4u * kk;
+  const int left = (int)((a.rows - wr0 < 32 ? a.rows - wr0 : 32)) - 4 * kk;     // local row (i & 3) + 8 (i >> 2) is valid iff < left
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = c0 + 32 * b + li;
+    const int colc = FULL || col < a.h ? col : a.h - 1;
+    const float mu = a.mean[colc], rs = a.rstd[colc], sc = a.a_scale[colc], sf = a.a_shift[colc];
+    const uint32_t hcol = a.dseed ^ (((uint32_t)colc >> 1) * 0x85EBCA77u + 0x632BE5ABu);
+    const bool hi = colc & 1;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lr = (i & 3) + 8 * (i >> 2);
+      const float dy = sk_dy<DROP>(a, acc[b][i], zz[b][i], hcol, hi, rbase + lr, sc, sf, FULL || lr < left);
+      s1 += dy;
+      s2 = fmaf(dy, (zz[b][i] - mu) * rs, s2);
+    }
+    sh1[wave * 2 + kk][32 * b + li] = s1;
+    sh2[wave * 2 + kk][32 * b + li] = s2;
+  }
+}
+
+template <bool DROP, bool FULL>
+__device__ __forceinline__ void sk_apply_tail(const BnBwdArgs& a, const sk_f32x16 (&acc)[2], const float (&zz)[2][16], const float (&S1v)[2],
+                                              const float (&S2v)[2], int64_t wr0, int c0, int li, int kk, int wave, float (&sh1)[8][64]) {
+  const float inv_b = 1.0f / (a.rows_total ? a.rows_total[0] : (float)a.rows);
+  const uint32_t rbase = (uint32_t)wr0 + 4u * kk;
+  const int left = (int)((a.rows - wr0 < 32 ? a.rows - wr0 : 32)) - 4 * kk;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = c0 + 32 * b + li;
+    const int colc = FULL || col < a.h ? col : a.h - 1;
+    const float S1 = S1v[b], S2 = S2v[b];
+    const float mu = a.mean[colc], rs = a.rstd[colc], sc = a.a_scale[colc], sf = a.a_shift[colc], grs = a.gamma[colc] * rs;
+    if (blockIdx.y == 0 && wave == 0 && kk == 0 && col < a.h) {
+      a.dbeta[col] = a.local_part < 0 ? S1 : a.p1[(int64_t)a.local_part * a.pstride + col];
+      a.dgamma[col] = a.local_part < 0 ? S2 : a.p2[(int64_t)a.local_part * a.pstride + col];
+    }
+    const float c1 = S1 * inv_b, c2 = S2 * inv_b;
+    const uint32_t hcol = a.dseed ^ (((uint32_t)colc >> 1) * 0x85EBCA77u + 0x632BE5ABu);
+    const bool hi = colc & 1;
+    float* outp = a.dz + (wr0 + 4 * kk) * a.lddz + colc;
+    float sdz = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lr = (i & 3) + 8 * (i >> 2);
+      const bool valid = FULL || lr < left;
+      const float dy = sk_dy<DROP>(a, acc[b][i], zz[b][i], hcol, hi, rbase + lr, sc, sf, valid);
+      const float out = grs * (dy - c1 - (zz[b][i] - mu) * rs * c2);
+      if (FULL || (valid && col < a.h)) outp[(int64_t)lr * a.lddz] = out;
+      sdz += valid ? out : 0.f;
+    }
+    sh1[wave * 2 + kk][32 * b + li] = sdz;
+  }
+}
+
+template <int KH, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bn_bwd_partial_sk(const BnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
+  const int c0 = blockIdx.x * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
+  __shared__ __attribute__((aligned(16))) SkLds<KH> L;
+  float (&sh1)[8][64] = *reinterpret_cast<float (*)[8][64]>(&L.a[0][0]);        // the operand tiles are dead behind the MFMAs:
+  float (&sh2)[8][64] = *reinterpret_cast<float (*)[8][64]>(&L.a[0][0] + 512);   // 4 KB of them carry the wave sums (4 workgroups per CU)
+  static_assert(sizeof(L.a) >= 2 * 8 * 64 * sizeof(float), "SkLds::a too small for the wave sums");
+  float zz[2][16];
+  sk_load_z(a, wr0, c0, li, kk, zz);
+  sk_stage<KH>(a, L, r0, c0);
+  __syncthreads();
+  sk_f32x16 acc[2];
+  sk_mma<KH>(L, wave, li, kk, acc);
+  __syncthreads();
+  const bool full = r0 + kBnRows <= a.rows && c0 + 64 <= a.h;          // uniform: no per-element row / column checks
+  if (full) sk_partial_tail<DROP, true>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2);
+  else sk_partial_tail<DROP, false>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2);
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.h) {
+    const int c = threadIdx.x;
+    a.ws1[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh1[0][c] + sh1[1][c]) + (sh1[2][c] + sh1[3][c])) + ((sh1[4][c] + sh1[5][c]) + (sh1[6][c] + sh1[7][c]));
+    a.ws2[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh2[0][c] + sh2[1][c]) + (sh2[2][c] + sh2[3][c])) + ((sh2[4][c] + sh2[5][c]) + (sh2[6][c] + sh2[7][c]));
+  }
+}
+
+template <int KH, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bn_bwd_apply_sk(const BnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
+  const int c0 = blockIdx.x * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
+  __shared__ __attribute__((aligned(16))) SkLds<KH> L;
+  __shared__ float sh1[8][64];
+  float zz[2][16];
+  sk_load_z(a, wr0, c0, li, kk, zz);
+  sk_stage<KH>(a, L, r0, c0);
+  // S1 / S2 of the 64 columns, once per workgroup: wave j sums partials j*8 .. j*8+7 (+32, ...) of column c0 + lane in ascending order
+  // (16 loads in flight, under the staging loads), the four wave sums are added pairwise behind the barrier -- the same order in every
+  // workgroup, so all of them hold identical S1 / S2
+  {
+    const int colc = c0 + lane < a.h ? c0 + lane : a.h - 1;
+    float q1 = 0.f, q2 = 0.f;
+    for (int k0 = wave * 8; k0 < a.nparts; k0 += 32) {
+      float t1[8], t2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u < a.nparts ? k0 + u : a.nparts - 1;
+        t1[u] = a.p1[(int64_t)k * a.pstride + colc];
+        t2[u] = a.p2[(int64_t)k * a.pstride + colc];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < a.nparts) { q1 += t1[u]; q2 += t2[u]; }
+    }
+    sh1[wave][lane] = q1;
+    sh1[4 + wave][lane] = q2;
+  }
+  __syncthreads();
+  float S1v[2], S2v[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    S1v[b] = (sh1[0][32 * b + li] + sh1[1][32 * b + li]) + (sh1[2][32 * b + li] + sh1[3][32 * b + li]);
+    S2v[b] = (sh1[4][32 * b + li] + sh1[5][32 * b + li]) + (sh1[6][32 * b + li] + sh1[7][32 * b + li]);
+  }
+  sk_f32x16 acc[2];
+  sk_mma<KH>(L, wave, li, kk, acc);
+  __syncthreads();                                   // sh1 is reused for the column sums of dz
+  const bool full = r0 + kBnRows <= a.rows && c0 + 64 <= a.h;
+  if (full) sk_apply_tail<DROP, true>(a, acc, zz, S1v, S2v, wr0, c0, li, kk, wave, sh1);
+  else sk_apply_tail<DROP, false>(a, acc, zz, S1v, S2v, wr0, c0, li, kk, wave, sh1);
+  if (a.ws3) {
+    __syncthreads();
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.h) {
+      const int c = threadIdx.x;
+      a.ws3[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh1[0][c] + sh1[1][c]) + (sh1[2][c] + sh1[3][c])) + ((sh1[4][c] + sh1[5][c]) + (sh1[6][c] + sh1[7][c]));
+    }
+  }
+}
+
+template <int KH>
+static void launch_bn_bwd_sk(bool apply, dim3 grid, hipStream_t st, const BnBwdArgs& a) {
+  if (apply) {
+    if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply_sk<KH, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_bwd_apply_sk<KH, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (a.dthr) hipLaunchKernelGGL((bn_bwd_partial_sk<KH, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_bwd_partial_sk<KH, false>), grid, dim3(256), 0, st, a);
+  }
+}
+static void launch_bn_bwd_sk(bool apply, dim3 grid, hipStream_t st, const BnBwdArgs& a) {
+  const int kh = (a.kk + 1) / 2;
+  if (kh <= 4) launch_bn_bwd_sk<4>(apply, grid, st, a);
+  else if (kh <= 8) launch_bn_bwd_sk<8>(apply, grid, st, a);
+  else if (kh <= 16) launch_bn_bwd_sk<16>(apply, grid, st, a);
+  else if (kh <= 24) launch_bn_bwd_sk<24>(apply, grid, st, a);
+  else launch_bn_bwd_sk<32>(apply, grid, st, a);
 }
 
 // BN / ReLU / dropout backward in ONE launch, for grids small enough to be co-resident (<= 256 workgroups: the latency-bound
@@ -768,8 +1029,15 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                       float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu,
-                      int da_slabs, glnn::GradFold* defer_colsum) {
+                      int da_slabs, glnn::GradFold* defer_colsum, const glnn::NarrowProduct* prod) {
   if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
+  if (prod) {                                            // da = dl . w, recomputed by both passes (bn_bwd_*_sk): two-launch BatchNorm form only
+    if (!gamma || g || da_slabs > 1 || prod->k < 1 || prod->k > 64 || !prod->dl || !prod->w || prod->lddl < prod->k || prod->ldw < h ||
+        (prod->lddl | prod->ldw | h) % 4 != 0 || !glnn::aligned16(prod->dl) || !glnn::aligned16(prod->w))     // float4 staging loads
+      return GLNN_ERR_UNSUPPORTED;
+    counters = nullptr;
+    da = prod->dl; ldda = h;                             // placeholders for the checks below; the kernels never read a.da
+  }
   GLNN_REQUIRE(da && z && dz, "glnn_bn_relu_bwd_f32: null pointer");
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldda >= h && ldz >= h && lddz >= h, "glnn_bn_relu_bwd_f32: bad sizes");
   GLNN_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "glnn_bn_relu_bwd_f32: drop_p must be in [0,1)");
@@ -784,6 +1052,10 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
   a.relu = relu ? 1 : 0; a.defer_colsum = 0;
   a.nslab = da_slabs > 0 ? da_slabs : 1; a.slab_stride = rows * ldda;
+  a.dl = nullptr; a.lddl = 0; a.w = nullptr; a.ldw = 0; a.kk = 0;
+  if (prod) {
+    a.dl = prod->dl; a.lddl = prod->lddl; a.w = prod->w; a.ldw = prod->ldw; a.kk = prod->k;
+  }
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;
   if (gamma) { a.ws1 = w; a.ws2 = w + (int64_t)nchunks * h; w += 2ll * nchunks * h; }
@@ -811,7 +1083,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   if (da_slabs > 1) return GLNN_ERR_UNSUPPORTED;       // nothing launched: only the one-launch form folds split-K slabs
   if (gamma) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
-    hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
+    if (prod) launch_bn_bwd_sk(false, grid, st, a);
+    else hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
     if (g) {
       hipLaunchKernelGGL(chunk_sum2_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws1, a.ws2, nchunks, h, g->send);
       const int rc = glnn::check_launch("glnn_bn_relu_bwd_f32");
@@ -824,7 +1097,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
       fold_chunks(a.ws1, a.ws2, nchunks, h, totals, st);
       a.p1 = totals; a.p2 = totals + h; a.nparts = 1; a.pstride = 0;
     }
-    hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
+    if (prod) launch_bn_bwd_sk(true, grid, st, a);
+    else hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
   }

@@ -66,7 +66,8 @@ def run(seed=0, n_cases=40, verbose=True):
                     # a ReLU gate that opens in one form only changes ONE sample's contribution: the difference of a weight gradient is (nearly) rank 1
                     sv = torch.linalg.svdvals(bad_d.double())
                     rows = int((bad_d.abs().amax(1) > 0.05 * bad_d.abs().max()).sum())
-                    print(f"      difference of {bad_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{" -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""}; rows above 5 % of its max: {rows} / {bad_d.shape[0]}", flush=True)
+                    note = " -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""
+                    print(f"      difference of {bad_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{note}; rows above 5 % of its max: {rows} / {bad_d.shape[0]}", flush=True)
     finally:
         for kn, v in saved.items():
             if v is None:

@@ -72,7 +72,8 @@ def run(seed=0, n_cases=40, verbose=True):
             if err >= tol and worst_d is not None and worst_d.dim() == 2:
                 sv = torch.linalg.svdvals(worst_d)
                 rows = int((worst_d.abs().amax(1) > 0.05 * worst_d.abs().max()).sum())
-                print(f"      difference of {worst_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{" -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""}; rows above 5 % of its max: {rows} / {worst_d.shape[0]}", flush=True)
+                note = " -- rank 1 in one row: ONE ReLU gate within rounding of 0, not an arithmetic difference" if rows == 1 and sv[1] < 1e-3 * sv[0] else ""
+                print(f"      difference of {worst_t}: singular values {sv[0]:.2e} {sv[1]:.2e} {sv[2] if len(sv) > 2 else 0:.2e}{note}; rows above 5 % of its max: {rows} / {worst_d.shape[0]}", flush=True)
     return out
 
 

@@ -343,6 +343,28 @@ def test_small_batch_step_forms_agree(dims, bsz, norm, p, kind, knob, modes, mon
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, (tuple(a.shape), float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("dims,bsz,p,kind", [([100, 256, 256, 47], 4096, 0.5, "kl"), ([100, 2048, 2048, 47], 4096, 0.2, "kl"),
+                                             ([50, 72, 7], 1100, 0.0, "nll"), ([24, 260, 260, 64], 1500, 0.3, "kl"),
+                                             ([130, 128, 2], 2049, 0.5, "nll"), ([64, 512, 40], 1301, 0.2, "kl")])
+def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bsz, p, kind, monkeypatch):
+    """Large batches in front of a NARROW last layer: the input gradient da = dlogits . W is never written -- both passes of the BatchNorm
+    backward recompute their tile of it on the matrix cores (student.hip bn_bwd_partial_sk / bn_bwd_apply_sk) -- against the form that
+    writes it with a GEMM (GLNN_STUDENT_NARROW_BWD=0).  Different summation orders only: loss identical (the forward is untouched),
+    every gradient to fp32 rounding; ragged shapes (rows % 128, hidden % 64, 2 ... 64 classes), with and without dropout."""
+    monkeypatch.setenv("GLNN_STUDENT_NARROW_BWD_MIN", "1")
+    base, x, tgt, k = _variant_inputs(dims, bsz, "batch", p, kind, 35)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_STUDENT_NARROW_BWD", mode)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 1))
+    (_, _, g0, l0, z0), (_, _, g1, l1, z1) = runs
+    assert float(l0) == float(l1) and torch.equal(z0, z1)
+    gs = max(float(a.abs().max()) for a in g0)
+    assert any(not torch.equal(a, b) for a, b in zip(g0, g1)), "both runs took the same path"
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
+
+
 @pytest.mark.parametrize("dims,bsz,p", [([128, 256, 256, 40], 512, 0.2), ([100, 256, 256, 47], 4096, 0.5), ([24, 64, 64, 5], 300, 0.0),
                                         ([128, 1024, 1024, 40], 512, 0.5)])
 def test_one_launch_batchnorm_backward_equals_the_two_launch_form_bit_for_bit(dims, bsz, p, monkeypatch):
