@@ -83,7 +83,12 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
 // da = dl[rows, k] . w[k, h] (w rows ldw apart: a Linear's [out = k, in = h] weight), k <= 64: see bn_bwd_*_sk in student.hip
-struct NarrowProduct { const float* dl; int64_t lddl; int k; const float* w; int64_t ldw; };
+struct NarrowProduct {
+  const float* dl; int64_t lddl; int k; const float* w; int64_t ldw;
+  // optional (both or dw_ws alone): the first pass also leaves the narrow layer's OWN gradients as row-chunk partials -- dw_ws[chunk][k][h]
+  // (dW = dl^T . act(z), 16-byte aligned) and db_ws[chunk][k] (column sums of dl), chunk < ceil(rows / 128): fold k ascending
+  float* dw_ws; float* db_ws;
+};
 int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
@@ -95,6 +100,8 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
 // da_slabs > 1: da points at that many split-K partial slabs (da[s][rows][ldda]) which the one-launch form sums itself; any other
 // form returns GLNN_ERR_UNSUPPORTED with nothing launched (fold with gemm_fold_partials, call again)
 int gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, const float* bias, float* c, int64_t ldc, void* stream);
+// student.hip: out[0:h] = sum over k < nchunks of ws[k][0:h], k ascending (the order in which the fused Adam launch folds a GradFold with lanes4 = 0)
+int chunk_sum(const float* ws, int nchunks, int h, float* out, void* stream);
 
 // gemm.hip: several independent weight gradients (arguments as glnn_gemm_tn_f32, no column sums) in one gemm + one fold launch;
 // GLNN_ERR_UNSUPPORTED (nothing launched) when a problem does not qualify -- see gemm_tn_batch

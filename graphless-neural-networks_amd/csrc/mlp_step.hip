@@ -219,6 +219,8 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const bool narrow_bwd = !(nbe && nbe[0] == '0');
   const char* nme = getenv("GLNN_STUDENT_NARROW_BWD_MIN");
   const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
+  const char* nwe = getenv("GLNN_STUDENT_NARROW_WGRAD");            // "0": the classifier's weight gradient stays a gemm_tn launch
+  const bool narrow_wgrad = !(nwe && nwe[0] == '0');
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -324,12 +326,22 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     // before the activation backward below overwrites the buffer dz_{l+1} lived in, the weight gradient that reads it (issued
     // on the aux stream one layer ago) must be done; the wait is enqueued BEFORE this layer's weight gradient re-records ev_aux
     if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));
-    if (!defer) GLNN_TRY(weight_gradient());
-    if (two) { GLNN_HIP_TRY(hipEventRecord(ev_aux, s_aux)); aux_used = true; }
-    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, wstream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
     const bool alt = (two || defer) && ((L - 1 - l) & 1);            // alternate: dz of the layer above is still needed (aux stream / deferred dW)
     float* dz_out = alt ? d->dz2 : d->dz;
     const int64_t ld_out = alt ? d->ld_dz2 : d->ld_dz;
+    // a NARROW layer behind (the classifier) and a large batch: its input gradient is never written -- both BatchNorm backward passes
+    // recompute da = dz . W on the matrix cores (student.hip, bn_bwd_*_sk; they read dz while dz_out is written: distinct buffers only)
+    const bool narrow = narrow_bwd && !two && grp == nullptr && d->batchnorm == 1 && !layernorm && d->dims[l + 1] <= 64 &&
+                        (int64_t)m * d->dims[l] >= narrow_min && dz != dz_out;
+    // ... and its first pass, holding dz and act(z) on chip, also leaves the narrow layer's own weight / bias gradient as row-chunk
+    // partials in ws_tn (bn_bwd_partial_wg_sk) instead of a gemm_tn launch that re-reads z: folded by Adam, or by chunk_sum launches
+    const int64_t wg_chunks = (m + 127) / 128;
+    const int64_t wg_need = ((wg_chunks * d->dims[l + 1] * d->dims[l] + 3) & ~(int64_t)3) + ((wg_chunks * d->dims[l + 1] + 3) & ~(int64_t)3);
+    const bool wg_colsum = l == L - 1 && !fused_bias;
+    bool narrow_wg = narrow && narrow_wgrad && !defer && !d->act[l - 1] && !d->grad_ready && wg_chunks <= 64 && tn_off + wg_need <= d->ws_tn_floats;
+    if (!defer && !narrow_wg) GLNN_TRY(weight_gradient());
+    if (two) { GLNN_HIP_TRY(hipEventRecord(ev_aux, s_aux)); aux_used = true; }
+    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, wstream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
     // small batches: input gradient + BatchNorm backward as two launches with no wait between workgroups (mlp_lat.hip: the column
     // partial sums come out of the GEMM's epilogue, an apply kernel folds them in its prologue); each layer has its own slice of ws_bn
     bool lat_bn = false;
@@ -344,6 +356,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                                             d->ws_bn + (l - 1) * per, per, stream, (pf && pf->n < glnn::kMaxGradFolds) ? &cf : nullptr, skip ? 1 : 0);
       if (rc == GLNN_OK) {
         lat_bn = true;
+        if (narrow_wg) { GLNN_TRY(weight_gradient()); narrow_wg = false; }     // (dz is still intact: lat_dgrad_bn_bwd wrote dz_out != dz)
         if (skip)
           unapplied = {d->z[l - 1], d->ldz[l - 1], d->gamma[l - 1], d->mean[l - 1], d->rstd[l - 1], d->ws_bn + (l - 1) * per, per, (m + 31) / 32,
                        d->ggamma[l - 1], d->gbeta[l - 1], d->gb[l - 1], dz_out, ld_out};
@@ -357,11 +370,9 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       ld_dz = ld_out;
       continue;
     }
-    // a NARROW layer behind (the classifier) and a large batch: its input gradient is never written -- both BatchNorm backward passes
-    // recompute da = dz . W on the matrix cores (student.hip, bn_bwd_*_sk)
-    const bool narrow = narrow_bwd && !two && grp == nullptr && d->batchnorm == 1 && !layernorm && d->dims[l + 1] <= 64 &&
-                        (int64_t)m * d->dims[l] >= narrow_min;
-    const glnn::NarrowProduct np = {dz, ld_dz, d->dims[l + 1], d->w[l], d->dims[l]};
+    float* wg_dw = narrow_wg ? d->ws_tn + tn_off : nullptr;
+    float* wg_db = (narrow_wg && wg_colsum) ? wg_dw + ((wg_chunks * d->dims[l + 1] * d->dims[l] + 3) & ~(int64_t)3) : nullptr;
+    const glnn::NarrowProduct np = {dz, ld_dz, d->dims[l + 1], d->w[l], d->dims[l], wg_dw, wg_db};
     bool need_da = !(two && big_dgrad);
     if (narrow) need_da = false;
     if (need_da) GLNN_TRY(input_gradient());
@@ -383,7 +394,21 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         rc = glnn::bn_relu_bwd(nullptr, 0, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
                                d->gbeta[l - 1], d->gb[l - 1], wsb, wsb_floats, stream, nullptr, nullptr, 1, 0, cfp, &np);
-        if (rc == GLNN_ERR_UNSUPPORTED) GLNN_TRY(input_gradient());
+        if (rc == GLNN_ERR_UNSUPPORTED) {
+          if (narrow_wg) { GLNN_TRY(weight_gradient()); narrow_wg = false; }
+          GLNN_TRY(input_gradient());
+        } else if (rc == GLNN_OK && narrow_wg) {
+          // dW_l / db_l: wg_chunks partials each, k ascending -- by the fused Adam launch (pf) or here
+          const int kcls = d->dims[l + 1];
+          if (pf && pf->n + 2 <= glnn::kMaxGradFolds) {
+            pf->e[pf->n++] = {d->gw[l], wg_dw, (int)wg_chunks, 0, (int64_t)kcls * d->dims[l]};
+            if (wg_db) pf->e[pf->n++] = {d->gb[l], wg_db, (int)wg_chunks, 0, (int64_t)kcls};
+            tn_off += wg_need;
+          } else {
+            GLNN_TRY(glnn::chunk_sum(wg_dw, (int)wg_chunks, kcls * d->dims[l], d->gw[l], stream));
+            if (wg_db) GLNN_TRY(glnn::chunk_sum(wg_db, (int)wg_chunks, kcls, d->gb[l], stream));
+          }
+        }
       }
       if (da_slabs > 0)
         rc = glnn::bn_relu_bwd(d->ws_gemm, d->dims[l], d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],

@@ -208,7 +208,7 @@ struct BnBwdArgs {
   int nslab; int64_t slab_stride;        // bn_bwd_fused<NS > 0>: da = sum of nslab <= NS split-K slabs da[s * slab_stride + r * ldda + col]
   // bn_bwd_*_sk: da is never materialised -- da = dl[rows, kk] . w[kk, h] (the input gradient of a NARROW layer, kk <= 64 classes),
   // recomputed on the matrix cores by both passes
-  const float* dl; int64_t lddl; const float* w; int64_t ldw; int kk;
+  const float* dl; int64_t lddl; const float* w; int64_t ldw; int kk; float* dw_ws; float* db_ws;
 };
 
 template <bool BN>
@@ -416,9 +416,11 @@ __device__ __forceinline__ float sk_dy(const BnBwdArgs& a, float dav, float zz, 
   return (on && valid) ? dav : 0.f;
 }
 
-template <bool DROP, bool FULL>
+// WG: also leave a1 = dropout(relu(z * a_scale + a_shift)) of every element -- the operand of the classifier's weight gradient, in the
+// arithmetic of the forward operand transform (gemm.hip XF == 2) -- zero outside the tile's valid rows / columns
+template <bool DROP, bool FULL, bool WG>
 __device__ __forceinline__ void sk_partial_tail(const BnBwdArgs& a, const sk_f32x16 (&acc)[2], const float (&zz)[2][16], int64_t wr0, int c0, int li,
-                                                int kk, int wave, float (&sh1)[8][64], float (&sh2)[8][64]) {
+                                                int kk, int wave, float* sh1, float* sh2, float (&a1)[2][16]) {
   const uint32_t rbase = (uint32_t)wr0 + 4u * kk;
   const int left = (int)((a.rows - wr0 < 32 ? a.rows - wr0 : 32)) - 4 * kk;     // local row (i & 3) + 8 (i >> 2) is valid iff < left
 #pragma unroll
@@ -432,12 +434,28 @@ __device__ __forceinline__ void sk_partial_tail(const BnBwdArgs& a, const sk_f32
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int lr = (i & 3) + 8 * (i >> 2);
-      const float dy = sk_dy<DROP>(a, acc[b][i], zz[b][i], hcol, hi, rbase + lr, sc, sf, FULL || lr < left);
-      s1 += dy;
-      s2 = fmaf(dy, (zz[b][i] - mu) * rs, s2);
+      const bool valid = FULL || lr < left;
+      if (WG) {
+        bool keep = true;
+        if (DROP) {
+          uint32_t h = hcol ^ ((rbase + lr) * 0x9E3779B1u);
+          h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+          keep = (hi ? (h >> 16) : (h & 0xFFFFu)) >= a.dthr;
+        }
+        const float y = fmaf(zz[b][i], sc, sf);
+        const bool on = y > 0.f;                                       // WG requires a.relu
+        const float dy = (keep && on && valid) ? (DROP ? acc[b][i] * a.dscale : acc[b][i]) : 0.f;
+        a1[b][i] = (keep && on && valid && (FULL || col < a.h)) ? (DROP ? y * a.dscale : y) : 0.f;
+        s1 += dy;
+        s2 = fmaf(dy, (zz[b][i] - mu) * rs, s2);
+      } else {
+        const float dy = sk_dy<DROP>(a, acc[b][i], zz[b][i], hcol, hi, rbase + lr, sc, sf, valid);
+        s1 += dy;
+        s2 = fmaf(dy, (zz[b][i] - mu) * rs, s2);
+      }
     }
-    sh1[wave * 2 + kk][32 * b + li] = s1;
-    sh2[wave * 2 + kk][32 * b + li] = s2;
+    sh1[(wave * 2 + kk) * 64 + 32 * b + li] = s1;
+    sh2[(wave * 2 + kk) * 64 + 32 * b + li] = s2;
   }
 }
 
@@ -492,13 +510,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
   sk_mma<KH>(L, wave, li, kk, acc);
   __syncthreads();
   const bool full = r0 + kBnRows <= a.rows && c0 + 64 <= a.h;          // uniform: no per-element row / column checks
-  if (full) sk_partial_tail<DROP, true>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2);
-  else sk_partial_tail<DROP, false>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2);
+  float unused[2][16];
+  if (full) sk_partial_tail<DROP, true, false>(a, acc, zz, wr0, c0, li, kk, wave, &sh1[0][0], &sh2[0][0], unused);
+  else sk_partial_tail<DROP, false, false>(a, acc, zz, wr0, c0, li, kk, wave, &sh1[0][0], &sh2[0][0], unused);
   __syncthreads();
   if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.h) {
     const int c = threadIdx.x;
     a.ws1[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh1[0][c] + sh1[1][c]) + (sh1[2][c] + sh1[3][c])) + ((sh1[4][c] + sh1[5][c]) + (sh1[6][c] + sh1[7][c]));
     a.ws2[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh2[0][c] + sh2[1][c]) + (sh2[2][c] + sh2[3][c])) + ((sh2[4][c] + sh2[5][c]) + (sh2[6][c] + sh2[7][c]));
+  }
+}
+
+// The first pass PLUS the classifier's own gradients: with dl and a1 = act(z) both on chip, dW[k, c] = sum_r dl[r, k] a1[r, c] of the
+// tile is 64 more MFMAs per wave -- B operands are the a1 registers themselves (C-fragment row order = the reduction order: any pairing
+// of rows is valid), A operands dl[row][class] come from the LDS tile.  The four waves' 32-row partials are summed through LDS (fixed
+// order) and stored as row-chunk slab dw_ws[chunk][k][h] (folded by Adam or chunk_sum_kernel: k ascending); workgroups of the first
+// column block also store the chunk's column sums of dl (the bias gradient) to db_ws[chunk][k].  Replaces a gemm_tn launch that re-read z.
+template <int KH, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bn_bwd_partial_wg_sk(const BnBwdArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
+  const int c0 = blockIdx.x * 64;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
+  constexpr int LF = sizeof(SkLds<KH>) / 4, N = LF > 9216 ? LF : 9216;      // floats: the operand tiles, later red[4][32][64] + the wave sums
+  constexpr int LDA = SkLds<KH>::LDA;
+  __shared__ __attribute__((aligned(16))) float raw[N];
+  SkLds<KH>& L = *reinterpret_cast<SkLds<KH>*>(raw);
+  float* sh1 = raw + N - 1024;                                               // behind L.a (needed until the A operands are read) and red
+  float* sh2 = raw + N - 512;
+  static_assert(N - 1024 >= 8192 && N - 1024 >= (int)(sizeof(L.a) / 4), "wave sums overlap red / the dl tile");
+  float zz[2][16];
+  sk_load_z(a, wr0, c0, li, kk, zz);
+  sk_stage<KH>(a, L, r0, c0);
+  __syncthreads();
+  sk_f32x16 acc[2];
+  sk_mma<KH>(L, wave, li, kk, acc);
+  __syncthreads();                                                           // L.b is dead: the wave sums may land in it
+  const bool full = r0 + kBnRows <= a.rows && c0 + 64 <= a.h;
+  float a1[2][16];
+  if (full) sk_partial_tail<DROP, true, true>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2, a1);
+  else sk_partial_tail<DROP, false, true>(a, acc, zz, wr0, c0, li, kk, wave, sh1, sh2, a1);
+  if (blockIdx.x == 0 && a.db_ws && threadIdx.x < a.kk) {                   // bias gradient partial: column sums of the chunk's dl rows
+    const int nv = (int)(a.rows - r0 < kBnRows ? a.rows - r0 : kBnRows);
+    float s = 0.f;
+    for (int r = 0; r < nv; ++r) s += L.a[r][threadIdx.x];
+    a.db_ws[(int64_t)blockIdx.y * a.kk + threadIdx.x] = s;
+  }
+  const int nmb = a.kk > 32 ? 2 : 1;
+  float aop[2][16];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int cidx = 32 * mb + li < LDA ? 32 * mb + li : LDA - 1;           // classes >= kk: finite garbage into rows of D that are never stored
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aop[mb][i] = (mb < nmb) ? L.a[32 * wave + (i & 3) + 8 * (i >> 2) + 4 * kk][cidx] : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.h) {
+    const int c = threadIdx.x;
+    a.ws1[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh1[c] + sh1[64 + c]) + (sh1[128 + c] + sh1[192 + c])) + ((sh1[256 + c] + sh1[320 + c]) + (sh1[384 + c] + sh1[448 + c]));
+    a.ws2[(int64_t)blockIdx.y * a.h + c0 + c] = ((sh2[c] + sh2[64 + c]) + (sh2[128 + c] + sh2[192 + c])) + ((sh2[256 + c] + sh2[320 + c]) + (sh2[384 + c] + sh2[448 + c]));
+  }
+  float* red = raw;                                                          // [4 waves][32 classes][64 columns]
+  for (int mb = 0; mb < nmb; ++mb) {
+    sk_f32x16 dw[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dw[nb][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float av = mb == 0 ? aop[0][i] : aop[1][i];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) dw[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, a1[nb][i], dw[nb], 0, 0, 0);
+    }
+    if (mb) __syncthreads();                                                 // the previous block's sums have been read
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) red[wave * 2048 + ((j & 3) + 8 * (j >> 2) + 4 * kk) * 64 + 32 * nb + li] = dw[nb][j];
+    __syncthreads();
+    {
+      const int m = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8, cls = 32 * mb + m;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float* rp = red + m * 64 + c8 + 4 * q;
+        const float4 v0 = *reinterpret_cast<const float4*>(rp), v1 = *reinterpret_cast<const float4*>(rp + 2048);
+        const float4 v2 = *reinterpret_cast<const float4*>(rp + 4096), v3 = *reinterpret_cast<const float4*>(rp + 6144);
+        const float4 o = make_float4((v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z),
+                                     (v0.w + v1.w) + (v2.w + v3.w));
+        const int col = c0 + c8 + 4 * q;
+        if (cls < a.kk && col + 4 <= a.h)                                    // h % 4 == 0
+          *reinterpret_cast<float4*>(a.dw_ws + ((int64_t)blockIdx.y * a.kk + cls) * a.h + col) = o;
+      }
+    }
   }
 }
 
@@ -560,6 +663,9 @@ static void launch_bn_bwd_sk(bool apply, dim3 grid, hipStream_t st, const BnBwdA
   if (apply) {
     if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply_sk<KH, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((bn_bwd_apply_sk<KH, false>), grid, dim3(256), 0, st, a);
+  } else if (a.dw_ws) {
+    if (a.dthr) hipLaunchKernelGGL((bn_bwd_partial_wg_sk<KH, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_bwd_partial_wg_sk<KH, false>), grid, dim3(256), 0, st, a);
   } else {
     if (a.dthr) hipLaunchKernelGGL((bn_bwd_partial_sk<KH, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((bn_bwd_partial_sk<KH, false>), grid, dim3(256), 0, st, a);
@@ -1025,6 +1131,12 @@ static int fused_grid_limit() {
   return limit[dev];
 }
 
+int glnn::chunk_sum(const float* ws, int nchunks, int h, float* out, void* stream) {
+  GLNN_REQUIRE(ws && out && nchunks >= 1 && h >= 1, "glnn::chunk_sum: bad arguments");
+  hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ws, nchunks, h, out);
+  return glnn::check_launch("glnn::chunk_sum");
+}
+
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
@@ -1033,7 +1145,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
   if (prod) {                                            // da = dl . w, recomputed by both passes (bn_bwd_*_sk): two-launch BatchNorm form only
     if (!gamma || g || da_slabs > 1 || prod->k < 1 || prod->k > 64 || !prod->dl || !prod->w || prod->lddl < prod->k || prod->ldw < h ||
-        (prod->lddl | prod->ldw | h) % 4 != 0 || !glnn::aligned16(prod->dl) || !glnn::aligned16(prod->w))     // float4 staging loads
+        (prod->lddl | prod->ldw | h) % 4 != 0 || !glnn::aligned16(prod->dl) || !glnn::aligned16(prod->w) ||    // float4 staging loads
+        (prod->dw_ws && (!relu || !glnn::aligned16(prod->dw_ws))))
       return GLNN_ERR_UNSUPPORTED;
     counters = nullptr;
     da = prod->dl; ldda = h;                             // placeholders for the checks below; the kernels never read a.da
@@ -1052,9 +1165,9 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   a.counters = (dz_col_sum && counters) ? counters : nullptr; a.dz_col_sum = dz_col_sum;
   a.relu = relu ? 1 : 0; a.defer_colsum = 0;
   a.nslab = da_slabs > 0 ? da_slabs : 1; a.slab_stride = rows * ldda;
-  a.dl = nullptr; a.lddl = 0; a.w = nullptr; a.ldw = 0; a.kk = 0;
+  a.dl = nullptr; a.lddl = 0; a.w = nullptr; a.ldw = 0; a.kk = 0; a.dw_ws = nullptr; a.db_ws = nullptr;
   if (prod) {
-    a.dl = prod->dl; a.lddl = prod->lddl; a.w = prod->w; a.ldw = prod->ldw; a.kk = prod->k;
+    a.dl = prod->dl; a.lddl = prod->lddl; a.w = prod->w; a.ldw = prod->ldw; a.kk = prod->k; a.dw_ws = prod->dw_ws; a.db_ws = prod->db_ws;
   }
   float* w = workspace;
   a.ws1 = a.ws2 = a.ws3 = nullptr;

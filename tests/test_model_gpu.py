@@ -200,8 +200,11 @@ def test_materialised_activation_steps_equal_recomputed_ones_bit_for_bit(dims, b
     """glnn_mlp_step_desc.act: the stored tail and the one re-evaluated in the GEMM operand loads are the same fp32 expression
     on the same counter-based mask, so three optimiser steps end in identical parameters, moments and running statistics --
     as long as both run the same GEMM kernels: the pipelined kernels (plain operands only) are switched off here, because the
-    weight-gradient launcher gives them other reduction splits than the operand-transform kernels get (another summation order)."""
+    weight-gradient launcher gives them other reduction splits than the operand-transform kernels get (another summation order);
+    likewise the classifier's weight gradient out of the BatchNorm backward's first pass (bn_bwd_partial_wg_sk), which only the
+    re-evaluating form takes (it has act(z) on chip; a stored tail goes through gemm_tn)."""
     monkeypatch.setenv("GLNN_GEMM_PIPE", "0")
+    monkeypatch.setenv("GLNN_STUDENT_NARROW_WGRAD", "0")
     import copy
     from glnn_amd import ops
     from glnn_amd.models import Model
@@ -345,13 +348,19 @@ def test_small_batch_step_forms_agree(dims, bsz, norm, p, kind, knob, modes, mon
 
 @pytest.mark.parametrize("dims,bsz,p,kind", [([100, 256, 256, 47], 4096, 0.5, "kl"), ([100, 2048, 2048, 47], 4096, 0.2, "kl"),
                                              ([50, 72, 7], 1100, 0.0, "nll"), ([24, 260, 260, 64], 1500, 0.3, "kl"),
-                                             ([130, 128, 2], 2049, 0.5, "nll"), ([64, 512, 40], 1301, 0.2, "kl")])
-def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bsz, p, kind, monkeypatch):
+                                             ([130, 128, 2], 2049, 0.5, "nll"), ([64, 512, 40], 1301, 0.2, "kl"),
+                                             ([100, 256, 64, 47], 2048, 0.2, "kl")])
+@pytest.mark.parametrize("wgrad", ["1", "0"])
+def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bsz, p, kind, wgrad, monkeypatch):
     """Large batches in front of a NARROW last layer: the input gradient da = dlogits . W is never written -- both passes of the BatchNorm
     backward recompute their tile of it on the matrix cores (student.hip bn_bwd_partial_sk / bn_bwd_apply_sk) -- against the form that
     writes it with a GEMM (GLNN_STUDENT_NARROW_BWD=0).  Different summation orders only: loss identical (the forward is untouched),
-    every gradient to fp32 rounding; ragged shapes (rows % 128, hidden % 64, 2 ... 64 classes), with and without dropout."""
+    every gradient to fp32 rounding; ragged shapes (rows % 128, hidden % 64, 2 ... 64 classes), with and without dropout.
+    wgrad = 1: the first pass also leaves the classifier's own weight / bias gradient as row-chunk partials (bn_bwd_partial_wg_sk)
+    instead of a gemm_tn launch.  [100, 256, 64, 47]: a narrow HIDDEN layer as well -- its dz lives in the buffer the pass writes, so
+    only the last layer may take the recomputing form."""
     monkeypatch.setenv("GLNN_STUDENT_NARROW_BWD_MIN", "1")
+    monkeypatch.setenv("GLNN_STUDENT_NARROW_WGRAD", wgrad)
     base, x, tgt, k = _variant_inputs(dims, bsz, "batch", p, kind, 35)
     runs = []
     for mode in ("0", "1"):
