@@ -494,7 +494,7 @@ __device__ __forceinline__ void sk_apply_tail(const BnBwdArgs& a, const sk_f32x1
 }
 
 template <int KH, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bn_bwd_partial_sk(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? 4 : 3))) void bn_bwd_partial_sk(const BnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
   const int c0 = blockIdx.x * 64;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void b
 // order) and stored as row-chunk slab dw_ws[chunk][k][h] (folded by Adam or chunk_sum_kernel: k ascending); workgroups of the first
 // column block also store the chunk's column sums of dl (the bias gradient) to db_ws[chunk][k].  Replaces a gemm_tn launch that re-read z.
 template <int KH, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void bn_bwd_partial_wg_sk(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? 3 : 2))) void bn_bwd_partial_wg_sk(const BnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
   const int c0 = blockIdx.x * 64;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
