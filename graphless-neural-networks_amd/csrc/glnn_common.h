@@ -49,6 +49,14 @@ __host__ __device__ inline uint32_t drop_hash(uint32_t seed, uint32_t row, uint3
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
+// dz of one element of a BatchNorm backward:  gamma*rstd * (dy - S1/B - xhat * S2/B),  xhat = (z - mean) * rstd.  ONE definition with the
+// contraction pinned (one fma, chosen here), because five kernels evaluate it and several pairs of them are held to identical bits.
+__device__ __forceinline__ float bn_dz(float grs, float dy, float c1, float z, float mu, float rs, float c2) {
+#pragma clang fp contract(off)
+  const float xh = (z - mu) * rs;
+  const float t = dy - c1;
+  return grs * fmaf(-xh, c2, t);
+}
 __host__ __device__ inline uint32_t drop_threshold(float p) {   // keep iff the element's 16 bits >= threshold
   return (uint32_t)(p * 65536.0f);
 }

@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void gemm_tn_lat_kernel(const TnLatArgs args) 
           const bool in = mb + t < g.m;
           float avv = av[u][t];
           if (bn) {
-            avv = in ? grs * (avv - c1 - (zv[u][t] - mu) * rs * c2) : 0.f;
+            avv = in ? glnn::bn_dz(grs, avv, c1, zv[u][t], mu, rs, c2) : 0.f;
             cs += avv;
           }
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(in ? avv : 0.f, in ? bvv : 0.f, acc, 0, 0, 0);
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void bn_apply_tiles_kernel(const BnApplyArgs a
   for (int i = 0; i < 8; ++i) {
     const int64_t r = r0 + rl + 4 * i;
     if (r < a.rows) {
-      const float out = grs * (dyv[i] - c1 - (zv[i] - mu) * rs * c2);
+      const float out = glnn::bn_dz(grs, dyv[i], c1, zv[i], mu, rs, c2);
       if (col < a.h) a.dz[r * a.lddz + col] = out;
       sdz += out;
     }

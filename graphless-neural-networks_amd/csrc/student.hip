@@ -216,7 +216,14 @@ __device__ __forceinline__ float bn_dy(const BnBwdArgs& a, float zz, float dav, 
   if (a.dthr) dav = glnn::drop_keep(a.dseed, a.dthr, (uint32_t)r, (uint32_t)col) ? dav * a.dscale : 0.f;
   return (!a.relu || (BN ? fmaf(zz, sc, sf) : zz) > 0.f) ? dav : 0.f;
 }
+// the same with the dropout decision made at launch (two instantiations): no branch per element in the streaming kernels
+template <bool BN, bool DROP>
+__device__ __forceinline__ float bn_dy_s(const BnBwdArgs& a, float zz, float dav, int64_t r, int col, float sc, float sf) {
+  if (DROP) dav = glnn::drop_keep(a.dseed, a.dthr, (uint32_t)r, (uint32_t)col) ? dav * a.dscale : 0.f;
+  return (!a.relu || (BN ? fmaf(zz, sc, sf) : zz) > 0.f) ? dav : 0.f;
+}
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const BnBwdArgs a) {
   const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lc;
@@ -239,7 +246,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const BnBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t r = r0 + rl + 4 * (i0 + u);
-      const float dy = r < r1 ? bn_dy<true>(a, zz[u], dd[u], r, colc, sc, sf) : 0.f;
+      const float dyv = bn_dy_s<true, DROP>(a, zz[u], dd[u], r, colc, sc, sf);
+      const float dy = r < r1 ? dyv : 0.f;
       s1 += dy;
       s2 = fmaf(dy, (zz[u] - mu) * rs, s2);
     }
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const BnBwdArgs a) {
   }
 }
 
-template <bool BN>
+template <bool BN, bool DROP>
 __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
   const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lc;
@@ -266,9 +274,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
   float S1 = 0.f, S2 = 0.f, mu = 0.f, rs = 1.f, sc = 1.f, sf = 0.f, g = 1.f;
   if (BN) {
     // every row lane sums the same partials in the same order -> identical S1/S2 in all four lanes, no LDS hop
-    for (int k = 0; k < a.nparts; ++k) {
-      S1 += a.p1[(int64_t)k * a.pstride + colc];
-      S2 += a.p2[(int64_t)k * a.pstride + colc];
+    // (the loads of 16 partials are issued together -- one memory round trip per batch, not per partial: the plain loop compiled to
+    //  load, wait, add, branch, 32 dependent round trips at the head of every workgroup -- and added in the same ascending order)
+    for (int k0 = 0; k0 < a.nparts; k0 += 16) {
+      float t1[16], t2[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k = k0 + u < a.nparts ? k0 + u : a.nparts - 1;
+        t1[u] = a.p1[(int64_t)k * a.pstride + colc];
+        t2[u] = a.p2[(int64_t)k * a.pstride + colc];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (k0 + u < a.nparts) { S1 += t1[u]; S2 += t2[u]; }
     }
     mu = a.mean[colc]; rs = a.rstd[colc]; sc = a.a_scale[colc]; sf = a.a_shift[colc]; g = a.gamma[colc];
     if (blockIdx.y == 0 && rl == 0 && col < a.h) {
@@ -292,12 +310,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int64_t r = r0 + rl + 4 * (i0 + u);
-      if (r < r1) {
-        const float dy = bn_dy<BN>(a, zz[u], dd[u], r, colc, sc, sf);
-        const float out = BN ? grs * (dy - c1 - (zz[u] - mu) * rs * c2) : dy;
-        if (col < a.h) a.dz[r * a.lddz + col] = out;
-        sdz += out;
-      }
+      const float dy = bn_dy_s<BN, DROP>(a, zz[u], dd[u], r, colc, sc, sf);       // (rows past r1: the clamped row's values, discarded)
+      const float out = BN ? glnn::bn_dz(grs, dy, c1, zz[u], mu, rs, c2) : dy;
+      if (r < r1 && col < a.h) a.dz[r * a.lddz + col] = out;
+      sdz += r < r1 ? out : 0.f;
     }
   }
   if (a.ws3) {
@@ -485,7 +501,7 @@ __device__ __forceinline__ void sk_apply_tail(const BnBwdArgs& a, const sk_f32x1
       const int lr = (i & 3) + 8 * (i >> 2);
       const bool valid = FULL || lr < left;
       const float dy = sk_dy<DROP>(a, acc[b][i], zz[b][i], hcol, hi, rbase + lr, sc, sf, valid);
-      const float out = grs * (dy - c1 - (zz[b][i] - mu) * rs * c2);
+      const float out = glnn::bn_dz(grs, dy, c1, zz[b][i], mu, rs, c2);
       if (FULL || (valid && col < a.h)) outp[(int64_t)lr * a.lddz] = out;
       sdz += valid ? out : 0.f;
     }
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
   for (int i = 0; i < kRowsPerLane; ++i) {
     const int64_t r = r0 + rl + 4 * i;
     if (r < r1) {
-      const float out = grs * (dy[i] - c1 - (zz[i] - mu) * rs * c2);
+      const float out = glnn::bn_dz(grs, dy[i], c1, zz[i], mu, rs, c2);
       if (col < a.h) a.dz[r * a.lddz + col] = out;
       sdz += out;
     }
@@ -1197,7 +1213,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   if (gamma) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     if (prod) launch_bn_bwd_sk(false, grid, st, a);
-    else hipLaunchKernelGGL(bn_bwd_partial, grid, dim3(256), 0, st, a);
+    else if (a.dthr) hipLaunchKernelGGL(bn_bwd_partial<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_partial<false>, grid, dim3(256), 0, st, a);
     if (g) {
       hipLaunchKernelGGL(chunk_sum2_kernel, dim3((h + 127) / 128), dim3(128), 0, st, a.ws1, a.ws2, nchunks, h, g->send);
       const int rc = glnn::check_launch("glnn_bn_relu_bwd_f32");
@@ -1211,9 +1228,11 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
       a.p1 = totals; a.p2 = totals + h; a.nparts = 1; a.pstride = 0;
     }
     if (prod) launch_bn_bwd_sk(true, grid, st, a);
-    else hipLaunchKernelGGL((bn_bwd_apply<true>), grid, dim3(256), 0, st, a);
+    else if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply<true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_bwd_apply<true, false>), grid, dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL((bn_bwd_apply<false>), grid, dim3(256), 0, st, a);
+    if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((bn_bwd_apply<false, false>), grid, dim3(256), 0, st, a);
   }
   if (dz_col_sum && !a.counters && defer_colsum && nchunks <= 32) {
     // two-launch form before the fused Adam launch: the per-chunk column sums are folded there (chunk_sum_kernel's order: k ascending)
