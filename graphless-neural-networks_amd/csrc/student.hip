@@ -22,6 +22,19 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
   float wave_loss = 0.f, col_acc = 0.f;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
     const float* zr = a.z + row * a.ldz;
+    // the row's target / label is requested FIRST: behind the z_store below the compiler may not move these loads up (possible alias),
+    // and index -> row -> value would be two more dependent round trips at the end of the row's chain
+    const float* tr = nullptr;
+    float tj0 = 0.f;
+    int64_t yrow = 0;
+    if (LOSS) {
+      if (a.kind == GLNN_LOSS_NLL) {
+        yrow = a.labels[a.label_rows ? a.label_rows[row] : row];
+      } else {
+        tr = a.t + (a.t_rows ? a.t_rows[row] : row) * a.ldt;
+        tj0 = lane < a.c ? tr[lane] : 0.f;
+      }
+    }
     float zv = 0.f;
     if (a.nslab > 0 && lane < a.c) {         // fold the split-K partials of this row first (c <= 64: one class per lane, kept in zv)
 #pragma unroll 8
@@ -43,7 +56,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
     }
     float row_loss = 0.f;
     if (a.kind == GLNN_LOSS_NLL) {
-      const int64_t y = a.labels[a.label_rows ? a.label_rows[row] : row];
+      const int64_t y = yrow;
       for (int j = lane; j < a.c; j += 64) {
         const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
@@ -55,10 +68,9 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
       }
       row_loss = wave_sum(row_loss);
     } else {
-      const float* tr = a.t + (a.t_rows ? a.t_rows[row] : row) * a.ldt;
       float set = 0.f;
       for (int j = lane; j < a.c; j += 64) {
-        const float tj = tr[j], et = expf(tj);
+        const float tj = j == lane ? tj0 : tr[j], et = expf(tj);
         set += et;
         row_loss += et * (tj - (Z(j) - lse));
       }
@@ -67,7 +79,7 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
       for (int j = lane; j < a.c; j += 64) {
         const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
-        const float g = (expf(lp) * set - expf(tr[j])) * a.scale;
+        const float g = (expf(lp) * set - expf(j == lane ? tj0 : tr[j])) * a.scale;
         a.dz[row * a.ldg + j] = g;
         col_acc += g;
       }

@@ -180,14 +180,27 @@ __device__ __forceinline__ void bn_finalize_columns(const BnFinArgs& a, int colb
   // In double the subtraction costs ~1e-16 * N*mean^2 against M2: invisible after rounding to float unless |mean|/std > 1e6.
   const float gam = a.gamma ? a.gamma[colc] : 1.f, bet = a.beta ? a.beta[colc] : 0.f;
   double n = 0.0, sum = 0.0, qs = 0.0;
-#pragma unroll 4
-  for (int k = p0 + rl; k < p1; k += kRowLanes) {
-    const double nb = part_count(a, k, colc);
-    const double mk = (double)(COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc]);
-    const double m2k = (double)(COH ? ld_part(&a.ws_m2[(int64_t)k * a.pstride + colc]) : a.ws_m2[(int64_t)k * a.pstride + colc]);
-    n += nb;
-    sum += nb * mk;
-    qs += m2k + nb * mk * mk;                              // nb == 0: an empty slice contributes nothing
+  // eight partials of this row lane per batch: all their loads are issued before the first is used (the plain loop compiled to
+  // load, wait, accumulate, branch -- one memory round trip per partial at the end of a latency chain); same order of accumulation
+  for (int k0 = p0 + rl; k0 < p1; k0 += 8 * kRowLanes) {
+    float mk[8], m2k[8], ck[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * kRowLanes < p1 ? k0 + u * kRowLanes : p1 - 1;
+      mk[u] = COH ? ld_part(&a.ws_mean[(int64_t)k * a.pstride + colc]) : a.ws_mean[(int64_t)k * a.pstride + colc];
+      m2k[u] = COH ? ld_part(&a.ws_m2[(int64_t)k * a.pstride + colc]) : a.ws_m2[(int64_t)k * a.pstride + colc];
+      ck[u] = a.ws_cnt ? a.ws_cnt[(int64_t)k * a.pstride + colc] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * kRowLanes;
+      if (k < p1) {
+        const double nb = a.ws_cnt ? (double)ck[u] : part_count(a, k, colc);
+        n += nb;
+        sum += nb * (double)mk[u];
+        qs += (double)m2k[u] + nb * (double)mk[u] * (double)mk[u];       // nb == 0: an empty slice contributes nothing
+      }
+    }
   }
   __shared__ double sh_q[kRowLanes][64];
   sh_n[rl][lc] = n;
