@@ -950,7 +950,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
     const int64_t row = i / g.n;
     const int col = (int)(i - row * g.n);
     float v = 0.f;
-    for (int z = 0; z < g.ksplits; ++z) v += g.ws[(int64_t)z * total + i];
+    const float* __restrict__ wsz = g.ws;
+#pragma unroll 8
+    for (int z = 0; z < g.ksplits; ++z) v += wsz[(int64_t)z * total + i];
     if (g.row_scale) v *= g.row_scale[row];
     v = fmaf(v, g.ep_scale ? g.ep_scale[col] : 1.f, g.ep_shift ? g.ep_shift[col] : 0.f);
     if (g.relu) v = fmaxf(v, 0.f);
@@ -1266,6 +1268,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
     const int nb4 = nb >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
       float4 s = *reinterpret_cast<const float4*>(ws + 4 * i);
+#pragma unroll 8
       for (int k = 1; k < splits; ++k) {
         const float4 v = *reinterpret_cast<const float4*>(ws + k * slab + 4 * i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -1277,6 +1280,7 @@ __global__ void split_reduce_kernel(const float* __restrict__ ws, int64_t slab, 
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < splits; ++k) s += ws[k * slab + i];
     const int64_t r = i / nb, cc = i - r * nb;
     c[r * ldc + cc] = s;
@@ -1314,6 +1318,7 @@ __global__ void colsum_stage2(const float* __restrict__ partial, int nblk, int n
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= nb) return;
   float s = 0.f;
+#pragma unroll 8
   for (int k = 0; k < nblk; ++k) s += partial[(int64_t)k * nb + col];
   out[col] = s;
 }

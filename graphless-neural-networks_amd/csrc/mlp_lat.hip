@@ -640,6 +640,7 @@ __global__ void tile_chunk_sum_kernel(const float* __restrict__ ws, int nchunks,
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= h) return;
   float s = 0.f;
+#pragma unroll 8
   for (int k = 0; k < nchunks; ++k) s += ws[(int64_t)k * h + col];
   out[col] = s;
 }

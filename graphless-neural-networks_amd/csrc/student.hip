@@ -1381,7 +1381,15 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __res
   int64_t r1 = r0 + kBnRows;
   if (r1 > rows) r1 = rows;
   float s = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += 4) s += x[r * ldx + colc];
+  {                                  // the lane's 32 rows in four batches of eight loads (same order of addition; the plain loop was one
+    float t[8];                      // memory round trip per row)
+    for (int64_t rb = r0 + rl; rb < r1; rb += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = x[(rb + 4 * u < r1 ? rb + 4 * u : r0) * ldx + colc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += rb + 4 * u < r1 ? t[u] : 0.f;
+    }
+  }
   __shared__ float sh[4][64];
   sh[rl][lc] = s;
   __syncthreads();
