@@ -91,6 +91,7 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
 // da = dl[rows, k] . w[k, h] (w rows ldw apart: a Linear's [out = k, in = h] weight), k <= 64: see bn_bwd_*_sk in student.hip
+struct BnPartials { const float* p1; const float* p2; int nparts; int64_t pstride; };
 struct NarrowProduct {
   const float* dl; int64_t lddl; int k; const float* w; int64_t ldw;
   // optional (both or dw_ws alone): the first pass also leaves the narrow layer's OWN gradients as row-chunk partials -- dw_ws[chunk][k][h]
@@ -101,7 +102,9 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
                 void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0,
-                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr);
+                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr, struct BnPartials* partial_only = nullptr);
+// partial_only: launch the FIRST pass only and describe its S1 / S2 partials (in `workspace`: keep it until they are consumed); dz, dgamma,
+// dbeta, dz_col_sum are NOT written (glnn::gemm_tn_bn finishes the job inside a weight-gradient GEMM)
 // prod: the input gradient da is NOT in memory (da / ldda ignored): both passes recompute da = dl . w on the matrix cores; BatchNorm
 // two-launch form only (GLNN_ERR_UNSUPPORTED with nothing launched otherwise)
 // defer_colsum: (one-launch form only) dz_col_sum is NOT written; *defer_colsum describes the per-chunk partials left in `workspace`
@@ -134,6 +137,16 @@ int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t wo
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,
             const float* b_shift, float drop_p, uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace,
             int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0);
+// gemm.hip: c[ka, nb] = dz^T . b with dz = the BatchNorm / ReLU / dropout backward of (da, z) evaluated in the operand loads (never written);
+// p1 / p2 = the per-row-chunk sums of dy and dy * xhat (bn_bwd_partial: glnn::bn_relu_bwd with `partial_only`).  Also emits dgamma, dbeta
+// and, with col_sum, the column sums of dz (the bias gradient in front of the norm).  GLNN_ERR_UNSUPPORTED = nothing launched.
+struct TnBnA {
+  const float* z; int64_t ldz; const float* gamma; const float* mean; const float* rstd; const float* a_scale; const float* a_shift;
+  const float* p1; const float* p2; int nparts; int64_t pstride; float drop_p; uint32_t drop_seed; float* dgamma; float* dbeta;
+};
+int gemm_tn_bn(const float* da, int64_t ldda, int64_t m, int ka, const TnBnA& bn, const float* b, int64_t ldb, int nb, float* c, int64_t ldc,
+               float* col_sum, float* workspace, int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum,
+               int64_t* used_floats);
 // student.hip: glnn_adam_step_f32 whose gradient reads fold the pending partial sums (and store the folded gradient); grads_host =
 // host copy of the `grads` pointer table (how a pending fold finds its tensor); pending may be NULL
 int adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,

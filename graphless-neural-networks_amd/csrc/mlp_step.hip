@@ -221,6 +221,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
   const char* nwe = getenv("GLNN_STUDENT_NARROW_WGRAD");            // "0": the classifier's weight gradient stays a gemm_tn launch
   const bool narrow_wgrad = !(nwe && nwe[0] == '0');
+  // large batches: the FIRST hidden layer's dz has one consumer, the first layer's weight gradient -- only the first pass of its
+  // BatchNorm backward is launched (S1 / S2 partials), the rest is applied in that GEMM's operand loads (glnn::gemm_tn_bn)
+  // -- OPT-IN (GLNN_STUDENT_FUSE_APPLY_BIG=1): measured break-even on MLP3w8 (41 us against 20 + 22 us for the apply pass + the pipelined
+  // product: the transform keeps the 64 x 128-tile kernel off the hand-scheduled main loop) and slower on 512-wide students
+  const char* fbe = getenv("GLNN_STUDENT_FUSE_APPLY_BIG");
+  const bool fuse_big = fbe && fbe[0] == '1';
+  struct { bool on; glnn::BnPartials bp; uint32_t seed; float* dz_out; int64_t ld_out; float* wsb; int64_t wsb_floats; } big0 = {};
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -254,10 +261,25 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       const int64_t ws0_floats = two ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
       glnn::GradFold fw = {}, fc = {};
       int64_t used = 0;
-      GLNN_TRY(glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
-                             nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
-                             d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
-                             fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats));
+      int rc0 = GLNN_ERR_UNSUPPORTED;
+      if (big0.on) {
+        const glnn::TnBnA bn = {d->z[0], d->ldz[0], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0], d->a_shift[0], big0.bp.p1, big0.bp.p2,
+                                big0.bp.nparts, big0.bp.pstride, p, big0.seed, d->ggamma[0], d->gbeta[0]};
+        rc0 = glnn::gemm_tn_bn(d->da, d->ld_da, m, d->dims[1], bn, pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, d->dims[0], d->gw[0],
+                               d->dims[0], d->gb[0], ws0, ws0_floats, stream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used);
+        if (rc0 == GLNN_ERR_UNSUPPORTED) {               // (alignment): finish the BatchNorm backward the plain way, then the plain product
+          GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[0], d->ldz[0], m, d->dims[1], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0],
+                                     d->a_shift[0], p, big0.seed, big0.dz_out, big0.ld_out, d->ggamma[0], d->gbeta[0], d->gb[0], big0.wsb,
+                                     big0.wsb_floats, stream, nullptr, nullptr));
+          dz = big0.dz_out; ld_dz = big0.ld_out;
+        }
+      }
+      if (rc0 == GLNN_ERR_UNSUPPORTED)
+        rc0 = glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
+                            nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
+                            d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
+                            fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
+      GLNN_TRY(rc0);
       if (fold_later) {
         if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
         if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
@@ -390,6 +412,18 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       const bool dc = pf && grp == nullptr && L >= 2 && (d->ws_bn_floats / (L - 1) / 4 * 4) >= need_l && pf->n < glnn::kMaxGradFolds;
       if (dc) { wsb_floats = d->ws_bn_floats / (L - 1) / 4 * 4; wsb = d->ws_bn + (l - 1) * wsb_floats; }
       glnn::GradFold* cfp = dc ? &cf : nullptr;
+      if (fuse_big && l == 1 && !narrow && !two && grp == nullptr && !defer && !d->grad_ready && da_slabs == 0 && (pregather || !idx) &&
+          (int64_t)m * d->dims[1] >= (1ll << 20)) {
+        rc = glnn::bn_relu_bwd(d->da, d->ld_da, d->z[0], d->ldz[0], m, d->dims[1], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0],
+                               d->a_shift[0], p, seed, dz_out, ld_out, d->ggamma[0], d->gbeta[0], nullptr, wsb, wsb_floats, stream, nullptr,
+                               nullptr, 1, 0, nullptr, nullptr, &big0.bp);
+        if (rc == GLNN_OK) {
+          big0.on = true; big0.seed = seed; big0.dz_out = dz_out; big0.ld_out = ld_out; big0.wsb = wsb; big0.wsb_floats = wsb_floats;
+          dz = dz_out; ld_dz = ld_out;                    // (not written: the l == 0 product reads da / z instead)
+          continue;
+        }
+        if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+      }
       if (narrow) {
         rc = glnn::bn_relu_bwd(nullptr, 0, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
