@@ -59,8 +59,28 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   }
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
+  const char* nbe = getenv("GLNN_STUDENT_NARROW_BWD");              // "0": always write the classifier's input gradient (A/B runs, tests)
+  const bool narrow_bwd = !(nbe && nbe[0] == '0');
+  const char* nme = getenv("GLNN_STUDENT_NARROW_BWD_MIN");
+  const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
+  const char* nwe = getenv("GLNN_STUDENT_NARROW_WGRAD");            // "0": the classifier's weight gradient stays a gemm_tn launch
+  const bool narrow_wgrad = !(nwe && nwe[0] == '0');
+  // Will the backward take the classifier's weight AND bias gradient out of the BatchNorm backward's first pass (bn_bwd_partial_wg_sk, see
+  // the loop below)?  Then the loss kernel need not sum the bias gradient: it runs its 1024-workgroup form without the last-workgroup fold
+  // (products MLP, B = 4096: 17 -> 7 us) and leaves the loss scalar to Adam.  The conditions mirror the backward's; should it fall back
+  // after all, gemm_tn computes the column sums (fused_bias = false asks it to).
+  bool expect_wg = false;
+  if (L >= 2 && narrow_bwd && narrow_wgrad && grp == nullptr && d->batchnorm == 1 && d->dims[L] <= 64 && m > 1024 &&
+      (int64_t)m * d->dims[L - 1] >= narrow_min && !d->act[L - 2] && !d->grad_ready && (m + 127) / 128 <= 64 &&
+      !(d->aux_stream && d->ev_main && d->ev_aux && d->dz2)) {
+    const int64_t chunks = (m + 127) / 128;
+    const int64_t need = ((chunks * d->dims[L] * d->dims[L - 1] + 3) & ~(int64_t)3) + ((chunks * d->dims[L] + 3) & ~(int64_t)3);
+    expect_wg = need <= d->ws_tn_floats && d->dims[L - 1] % 4 == 0 && d->ld_dlogits % 4 == 0 && d->ld_dlogits >= d->dims[L] &&
+                glnn::aligned16(d->dlogits) && glnn::aligned16(d->w[L - 1]) && glnn::aligned16(d->ws_tn);
+  }
   // with sync counters the loss kernel's last workgroup also finalises the loss and the last layer's bias gradient
-  const bool fused_bias = cnt && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
+  int* loss_cnt = (cnt && !expect_wg) ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr;
+  const bool fused_bias = cnt && !expect_wg && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
   bool loss_done = false;
   int logit_slabs = 0;
   const char* sce = getenv("GLNN_STUDENT_SLAB_CONSUMERS");
@@ -181,7 +201,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   GLNN_TRY(glnn::softmax_loss(d->logits, d->ld_logits, m, d->dims[L], kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr,
                               target_logp, ldt, kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits,
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
-                              cnt ? cnt + GLNN_MLP_COUNTERS - 1 : nullptr, fused_bias ? d->gb[L - 1] : nullptr,
+                              loss_cnt, fused_bias ? d->gb[L - 1] : nullptr,
                               logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr, pf));
   // ---- backward ----
   // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
@@ -205,7 +225,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   // (arxiv MLP 0.127 -> 0.10x ms).  dz_l then has to outlive the loop: it alternates between d->dz and d->dz2 as in the two-stream form.
   const char* dwe = getenv("GLNN_STUDENT_BATCHED_WGRAD");
   const bool defer = !(dwe && dwe[0] == '0') && cnt && !two && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
-                     fused_bias && !layernorm;      // (the last layer's bias gradient must come from the loss kernel: the batched launch has no column sums)
+                     m <= 1024 && fused_bias && !layernorm;      // (larger batches: neither batched kernel takes them -- per layer, folds left to Adam)      // (the last layer's bias gradient must come from the loss kernel: the batched launch has no column sums)
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
   int64_t tn_off = 0;
@@ -215,12 +235,6 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
            float* dgamma; float* dbeta; float* colsum; float* dz_out; int64_t ld_out; } unapplied = {};
   const char* fae = getenv("GLNN_STUDENT_FUSE_APPLY");
   const bool fuse_apply = !(fae && fae[0] == '0') && pf && defer;
-  const char* nbe = getenv("GLNN_STUDENT_NARROW_BWD");              // "0": always write the classifier's input gradient (A/B runs, tests)
-  const bool narrow_bwd = !(nbe && nbe[0] == '0');
-  const char* nme = getenv("GLNN_STUDENT_NARROW_BWD_MIN");
-  const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
-  const char* nwe = getenv("GLNN_STUDENT_NARROW_WGRAD");            // "0": the classifier's weight gradient stays a gemm_tn launch
-  const bool narrow_wgrad = !(nwe && nwe[0] == '0');
   // large batches: the FIRST hidden layer's dz has one consumer, the first layer's weight gradient -- only the first pass of its
   // BatchNorm backward is launched (S1 / S2 partials), the rest is applied in that GEMM's operand loads (glnn::gemm_tn_bn)
   // -- OPT-IN (GLNN_STUDENT_FUSE_APPLY_BIG=1): measured break-even on MLP3w8 (41 us against 20 + 22 us for the apply pass + the pipelined

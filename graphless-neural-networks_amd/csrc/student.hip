@@ -785,9 +785,17 @@ __global__ __launch_bounds__(256) void bn_bwd_fused(const BnBwdArgs a) {
   (void)s_go;
   // every row lane sums the same partials in the same order -> identical S1/S2 everywhere (as bn_bwd_apply)
   float S1 = 0.f, S2 = 0.f;
-  for (int k = 0; k < a.nchunks; ++k) {
-    S1 += ld_part(&a.ws1[(int64_t)k * a.h + colc]);
-    S2 += ld_part(&a.ws2[(int64_t)k * a.h + colc]);
+  for (int k0 = 0; k0 < a.nchunks; k0 += 16) {          // 32 loads in flight per batch (the plain loop: one round trip per partial), same order
+    float t1[16], t2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + u < a.nchunks ? k0 + u : a.nchunks - 1;
+      t1[u] = ld_part(&a.ws1[(int64_t)k * a.h + colc]);
+      t2[u] = ld_part(&a.ws2[(int64_t)k * a.h + colc]);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < a.nchunks) { S1 += t1[u]; S2 += t2[u]; }
   }
   if (blockIdx.y == 0 && rl == 0 && col < a.h) {
     a.dbeta[col] = S1;
