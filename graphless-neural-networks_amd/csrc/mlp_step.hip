@@ -224,7 +224,14 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   // split plan, same fold order -> the same bits) instead of one gemm + one fold per layer: 4 launches fewer per 3-layer step
   // (arxiv MLP 0.127 -> 0.10x ms).  dz_l then has to outlive the loop: it alternates between d->dz and d->dz2 as in the two-stream form.
   const char* dwe = getenv("GLNN_STUDENT_BATCHED_WGRAD");
-  const bool defer = !(dwe && dwe[0] == '0') && cnt && !two && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
+  // (both batched kernels want every product inside glnn_gemm_tn_f32's 64 x 64 regime -- <= 64 tiles of 128 x 128|64 -- or they fall back
+  //  to one gemm + one fold launch per layer: penn94's 4814 x 256 first layer.  Decide that here and keep the folds for Adam instead.)
+  bool batch_shapes = true;
+  for (int l = 0; l < L; ++l) {
+    const int ti = (d->dims[l + 1] + 127) / 128, tj = d->dims[l] > 64 ? (d->dims[l] + 127) / 128 : 1;
+    batch_shapes = batch_shapes && ti * tj <= 64;
+  }
+  const bool defer = batch_shapes && !(dwe && dwe[0] == '0') && cnt && !two && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
                      m <= 1024 && fused_bias && !layernorm;      // (larger batches: neither batched kernel takes them -- per layer, folds left to Adam)      // (the last layer's bias gradient must come from the loss kernel: the batched launch has no column sums)
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
@@ -270,9 +277,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       if (defer) break;
       // the first layer's weight gradient ends the critical path: it stays on `stream` (the aux stream is busy with the wide
       // layers' gradients) with its own workspace -- ws_gemm is idle during the backward
-      const bool fold_later = pf && !two && tn_off < d->ws_tn_floats;
-      float* ws0 = two ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
-      const int64_t ws0_floats = two ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
+      // (earlier layers' slabs wait in ws_tn for Adam; if what is left cannot hold a few slabs of this product it would run unsplit --
+      //  4 workgroups for vk_class' 512 x 100 over 6754 rows -- so it takes the idle ws_gemm and folds at once instead)
+      const bool cramped = pf && !two && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[1] * d->dims[0] &&
+                           d->ws_gemm_floats > d->ws_tn_floats - tn_off;
+      const bool fold_later = pf && !two && !cramped && tn_off < d->ws_tn_floats;
+      float* ws0 = (two || cramped) ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
+      const int64_t ws0_floats = (two || cramped) ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
       glnn::GradFold fw = {}, fc = {};
       int64_t used = 0;
       int rc0 = GLNN_ERR_UNSUPPORTED;
@@ -313,11 +324,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     // before the fused Adam launch (pf) a split reduction keeps its slabs -- and the column sums behind the last layer's bias gradient
     // their first-stage partials -- for Adam to fold: every layer then gets its own part of ws_tn (tn_off)
     auto weight_gradient = [&]() -> int {
-      const bool fold_later = pf && !two && tn_off < d->ws_tn_floats;
+      const bool cramped = pf && !two && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[l + 1] * d->dims[l] &&
+                           d->ws_gemm_floats > d->ws_tn_floats - tn_off;      // see the first layer's product above
+      const bool fold_later = pf && !two && !cramped && tn_off < d->ws_tn_floats;
       glnn::GradFold fw = {}, fc = {};
       int64_t used = 0;
-      float* wsp = d->ws_tn + (fold_later ? tn_off : 0);
-      const int64_t wsf = d->ws_tn_floats - (fold_later ? tn_off : 0);
+      float* wsp = cramped ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
+      const int64_t wsf = cramped ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
       float* colsum = (l == L - 1 && !fused_bias) ? d->gb[l] : nullptr;
       int rc;
       if (d->act[l - 1])

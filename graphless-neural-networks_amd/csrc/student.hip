@@ -1262,7 +1262,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
     if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply<false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((bn_bwd_apply<false, false>), grid, dim3(256), 0, st, a);
   }
-  if (dz_col_sum && !a.counters && defer_colsum && nchunks <= 32) {
+  if (dz_col_sum && !a.counters && defer_colsum && nchunks <= 64) {
     // two-launch form before the fused Adam launch: the per-chunk column sums are folded there (chunk_sum_kernel's order: k ascending)
     *defer_colsum = {dz_col_sum, a.ws3, nchunks, 0, (int64_t)h};
   } else if (dz_col_sum && !a.counters) {

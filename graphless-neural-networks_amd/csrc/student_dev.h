@@ -113,7 +113,7 @@ constexpr int kRowLanes = 4;
 constexpr int kRowsPerLane = kBnRows / kRowLanes;   // 32
 constexpr int kUnroll = 8;
 constexpr int kBnGroup = 64;      // partial triples per first-level group of the two-level statistics combine
-constexpr int kManyChunks = 48;   // row chunks above which per-chunk partials are folded by a lane-split pass (> ~6k rows)
+constexpr int kManyChunks = 64;   // row chunks above which per-chunk partials are folded by a lane-split pass (> 8192 rows)
 
 struct BnFinArgs {
   // partial k of column c:  mean = ws_mean[k*pstride + c], M2 = ws_m2[k*pstride + c], count = ws_cnt ? ws_cnt[k*pstride + c]

@@ -117,7 +117,19 @@ class StudentEngine:
         # weight-gradient workspace: split-reduction slabs.  When affordable (<= 16 M floats) it holds the slabs of EVERY layer at once
         # (<= ceil(B/64) splits each): the batched weight-gradient launch needs that, and so does leaving the folds to Adam
         all_slabs = 64 * hk + ((B + 63) // 64) * sum(self.dims[l] * self.dims[l + 1] for l in range(self.L))
-        self.ws_tn = torch.empty(max(64 * hk + 256 * 128 * 128 + 2 * hk * hk, all_slabs if all_slabs <= (1 << 24) else 0), **f32)
+        if all_slabs > (1 << 24):
+            # large steps: what glnn_gemm_tn_f32 really plans -- the reduction is split until ~1024 workgroups exist (64 x 64 tiles), never
+            # below two 32-row k-tiles per split -- plus the classifier's row-chunk partials out of the BatchNorm backward (<= 64 classes).
+            # Without room for ALL layers' slabs a later layer's product loses its split (vk_class MLP, 512 x 100 over 6754 rows: one
+            # workgroup column of 211 k-tiles, 60 us instead of 10) because the earlier layers' slabs wait in ws_tn for Adam to fold them.
+            def planned(l):
+                t64 = -(-self.dims[l + 1] // 64) * -(-self.dims[l] // 64)
+                return min(-(-1024 // t64) if t64 < 1024 else 1, (B + 63) // 64) * self.dims[l] * self.dims[l + 1]
+            tight = 64 * hk + sum(planned(l) + 4 for l in range(self.L))
+            if self.dims[-1] <= 64:
+                tight += n_chunks * (self.dims[-1] * self.dims[-2] + self.dims[-1]) + 8
+            all_slabs = tight if tight <= (1 << 26) else 0
+        self.ws_tn = torch.empty(max(64 * hk + 256 * 128 * 128 + 2 * hk * hk, all_slabs), **f32)
         self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
         self.ws_loss = torch.empty(256 * 65 + 1024, **f32)
         # fused finalizes (last workgroup folds the partials: 7 launches fewer per step): arxiv MLP 0.143 -> 0.136 ms, MLP3w4 0.193 ->
