@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int kLnRows = 32;          // rows per backward workgroup
+constexpr int kLnRows = 16;          // rows per backward workgroup (32: 81 workgroups for house_class' 2580 rows)
 constexpr int kMaxQuads = 8;         // float4 per lane held in registers by the forward (64 lanes x 8 x 4 = 2048 columns)
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -141,18 +141,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     }
   const float inv_h = 1.0f / (float)a.h;
   int buf = 0;
+  // the NEXT row's operands are requested before this row's reduction and barrier (a row was: load, wait, reduce, barrier, store --
+  // one memory round trip per row, 32 in a chain per workgroup); the last iteration re-requests its own row (in bounds, unused)
+  float4 zn[kQ], dn[kQ];
+  float mun = a.mean[r0], rsn = a.rstd[r0];
+#pragma unroll
+  for (int j = 0; j < kQ; ++j) {
+    const int c = (j * 256 + tid) * 4;
+    zn[j] = dn[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < a.h) {
+      zn[j] = *reinterpret_cast<const float4*>(a.z + r0 * a.ldz + c);
+      dn[j] = *reinterpret_cast<const float4*>(a.da + r0 * a.ldda + c);
+    }
+  }
   for (int64_t r = r0; r < r1; ++r, buf ^= 1) {
-    const float mu = a.mean[r], rs = a.rstd[r];
+    const float mu = mun, rs = rsn;
+    float4 zc[kQ], dc[kQ];
+#pragma unroll
+    for (int j = 0; j < kQ; ++j) { zc[j] = zn[j]; dc[j] = dn[j]; }
+    {
+      const int64_t rn = r + 1 < r1 ? r + 1 : r;
+      mun = a.mean[rn]; rsn = a.rstd[rn];
+#pragma unroll
+      for (int j = 0; j < kQ; ++j) {
+        const int c = (j * 256 + tid) * 4;
+        if (c < a.h) {
+          zn[j] = *reinterpret_cast<const float4*>(a.z + rn * a.ldz + c);
+          dn[j] = *reinterpret_cast<const float4*>(a.da + rn * a.ldda + c);
+        }
+      }
+    }
     float xh[kQ][4], dxh[kQ][4], dy[kQ][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < kQ; ++j) {
       const int c = (j * 256 + tid) * 4;
-      float4 zz = make_float4(0.f, 0.f, 0.f, 0.f), dd = zz;
-      if (c < a.h) {
-        zz = *reinterpret_cast<const float4*>(a.z + r * a.ldz + c);
-        dd = *reinterpret_cast<const float4*>(a.da + r * a.ldda + c);
-      }
+      const float4 zz = zc[j], dd = dc[j];
       const float zv[4] = {zz.x, zz.y, zz.z, zz.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -206,25 +230,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   }
 }
 
-// out_k[c] = sum over chunks of ws[chunk][k][c], fixed order, k = 0..2 (NULL outputs skipped)
-__global__ void ln_fold_kernel(const float* __restrict__ ws, int nchunks, int h, float* dgamma, float* dbeta, float* dzsum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= h) return;
+// out_k[c] = sum over chunks of ws[chunk][k][c], k = 0..2 (NULL outputs skipped): four interleaved chains per column -- chunk lane j sums
+// chunks j, j + 4, ... (< 4 floor(n / 4)), lane 0 then the up to three left over -- folded (s0 + s1) + (s2 + s3).  One thread per
+// (column, lane), the three outputs together, eight chunks' loads in flight (a thread per column walking one output after the other
+// was 3 x n / 4 dependent round trips: 21 us for 81 chunks).
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ ws, int nchunks, int h, float* dgamma, float* dbeta, float* dzsum) {
+  const int lc = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  const int cc = c < h ? c : h - 1;
+  const int n4 = nchunks & ~3;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int i0 = j; i0 < n4; i0 += 32) {
+    float t[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 4 * u < n4 ? i0 + 4 * u : j;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[u][k] = ws[((int64_t)i * 3 + k) * h + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 4 * u < n4) { s[0] += t[u][0]; s[1] += t[u][1]; s[2] += t[u][2]; }
+  }
+  if (j == 0)
+    for (int i = n4; i < nchunks; ++i) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s[k] += ws[((int64_t)i * 3 + k) * h + cc];
+    }
+  __shared__ float sh[3][4][64];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) sh[k][j][lc] = s[k];
+  __syncthreads();
+  if (j != 0 || c >= h) return;
   float* outs[3] = {dgamma, dbeta, dzsum};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (!outs[k]) continue;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four interleaved chains (chunk counts reach thousands), folded in fixed order
-    int i = 0;
-    for (; i + 3 < nchunks; i += 4) {
-      s0 += ws[((int64_t)i * 3 + k) * h + c];
-      s1 += ws[((int64_t)(i + 1) * 3 + k) * h + c];
-      s2 += ws[((int64_t)(i + 2) * 3 + k) * h + c];
-      s3 += ws[((int64_t)(i + 3) * 3 + k) * h + c];
-    }
-    for (; i < nchunks; ++i) s0 += ws[((int64_t)i * 3 + k) * h + c];
-    outs[k][c] = (s0 + s1) + (s2 + s3);
-  }
+  for (int k = 0; k < 3; ++k)
+    if (outs[k]) outs[k][c] = (sh[k][0][lc] + sh[k][1][lc]) + (sh[k][2][lc] + sh[k][3][lc]);
 }
 
 }  // namespace
@@ -282,6 +323,6 @@ extern "C" int glnn_layernorm_bwd_f32(const float* da, int64_t ldda, const float
   else hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nchunks), dim3(256), 0, st, a);
   int rc = glnn::check_launch("glnn_layernorm_bwd_f32");
   if (rc != GLNN_OK || !want_cols) return rc;
-  hipLaunchKernelGGL(ln_fold_kernel, dim3((h + 127) / 128), dim3(128), 0, st, workspace, nchunks, h, dgamma, dbeta, dz_col_sum);
+  hipLaunchKernelGGL(ln_fold_kernel, dim3((h + 63) / 64), dim3(256), 0, st, workspace, nchunks, h, dgamma, dbeta, dz_col_sum);
   return glnn::check_launch("glnn_layernorm_bwd_f32(fold)");
 }
