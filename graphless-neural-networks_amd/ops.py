@@ -107,13 +107,30 @@ def randperm_cpu(n):
         torch.set_num_threads(k)
 
 
+_PADDED = []            # [(weakref to the source tensor, its _version, padded copy)], most recent first, <= 2 entries
+
+
 def as_feat(t):
-    """Return t itself if its layout suits the float4 kernels, else a padded copy."""
+    """Return t itself if its layout suits the float4 kernels, else a padded copy.
+    The copy of a LARGE matrix is remembered while the very same tensor object is passed again unmodified (identity + torch's in-place
+    version counter): the reference hands the same `feats` to every epoch's train / evaluate call, and re-padding penn94's 41554 x 4814
+    features (0.8 GB: a zero fill and a copy) cost 0.4 ms of every 1.8 ms GCN epoch."""
     _mat(t, "as_feat")
     if t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
         return t
+    big = t.numel() >= (1 << 20) and not t.requires_grad
+    if big:
+        for i, (ref, ver, pad) in enumerate(_PADDED):
+            if ref() is t and ver == t._version and pad.shape == t.shape and pad.device == t.device:
+                if i:
+                    _PADDED.insert(0, _PADDED.pop(i))
+                return pad
     out = feat_empty(t.shape[0], t.shape[1], t.device, zero=True)
     out.copy_(t)
+    if big:
+        import weakref
+        _PADDED[:] = [e for e in _PADDED if e[0]() is not None and e[0]() is not t][:1]
+        _PADDED.insert(0, (weakref.ref(t), t._version, out))
     return out
 
 

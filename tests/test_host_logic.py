@@ -227,3 +227,25 @@ def test_randperm_cpu_is_torch_randperm_on_one_thread():
     assert torch.get_num_threads() == k
     for a, b in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_as_feat_remembers_the_padded_copy_of_an_unchanged_tensor():
+    """ops.as_feat pads rows that are not float4-addressable (cora's 1433 features, penn94's 4814).  The copy of a large matrix is reused
+    while the SAME tensor object comes back unmodified (identity + in-place version counter), so the reference's per-epoch train / evaluate
+    calls do not re-pad the feature matrix; any in-place change, or another tensor at the same address, gets a fresh copy."""
+    import torch
+    from glnn_amd import ops
+    t = torch.randn(1500, 1433)
+    a = ops.as_feat(t)
+    assert a.stride(0) % 4 == 0 and torch.equal(a[:, :1433], t) and ops.as_feat(t) is a
+    t.mul_(2.0)
+    b = ops.as_feat(t)
+    assert b is not a and torch.equal(b[:, :1433], t)
+    u = torch.randn(1500, 1433)
+    c = ops.as_feat(u)
+    assert ops.as_feat(t) is b and ops.as_feat(u) is c                    # two entries
+    assert ops.as_feat(t.detach()) is not b                               # another tensor object: never trusted
+    small = torch.randn(10, 7)
+    assert ops.as_feat(small) is not ops.as_feat(small)                   # small matrices are not kept
+    al = torch.randn(64, 128)
+    assert ops.as_feat(al) is al
