@@ -1534,7 +1534,18 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
     const int bn = n > 64 ? 128 : 64;
     const int64_t tiles = ((m + BM - 1) / BM) * ((n + bn - 1) / bn);
     const int nk = (k + BK - 1) / BK;
-    if (tiles < 256 && nk >= 4) {
+    // a narrow output over a deep reduction and many rows is a STREAM of A (penn94's GCN: 41554 x 4814 -> 64, 0.8 GB): a few hundred
+    // workgroups with one k-tile in flight each leave it at 2.3 TB/s; split until ~2048 exist (347 -> 285 us)
+    if (n <= 64 && nk >= 64 && tiles >= 256 && tiles < 2048) {
+      int64_t sp = (2048 + tiles - 1) / tiles;
+      if (sp > nk / 8) sp = nk / 8;
+      if (sp * m * n > workspace_floats) sp = workspace_floats / (m * n);
+      if (sp > 1) {
+        g.ktiles_per_split = (nk + (int)sp - 1) / (int)sp;
+        g.ksplits = (nk + g.ktiles_per_split - 1) / g.ktiles_per_split;
+        g.ws = workspace;
+      }
+    } else if (tiles < 256 && nk >= 4) {
       int64_t sp = (512 + tiles - 1) / tiles;
       // big problems keep >= 4 k-tiles per split (the slab round trip must stay small next to the MFMA work); tiny
       // ones (a handful of tiles, e.g. the B=512 student) are pure latency chains of dependent k-tiles: cut them to
@@ -1849,7 +1860,9 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   const bool pipe_shape = fast && bnt == 128 && !b_scale && !b_rows && pipe_enabled() && (lda > ldb ? lda : ldb) < (1 << 20);
   // latency regime (see gemm_kernel_fast): a few dozen output tiles -> 64 x 64 tiles, a quarter of the per-wave MFMA chain --
   // unless the reduction is long enough for the pipelined kernel's deeper k-loop to pay (>= 2048 rows)
-  const bool small = fast && gi * gj <= 64 && !(pipe_shape && m >= 2048);
+  // -- nor when a WIDE a is streamed over many rows (penn94's GCN: 4814 x 64 over 41554 rows, 0.8 GB): 64-column tiles read 256-byte
+  // pieces of 19 KB rows (1.45 TB/s), 128-column tiles 2.2 TB/s (552 -> 369 us)
+  const bool small = fast && gi * gj <= 64 && !(pipe_shape && m >= 2048) && !(m >= 8192 && ka >= 1024);
   if (small) { bnt = 64; gi = (ka + 63) / 64; gj = (nb + 63) / 64; }
   // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
   int splits = 1;

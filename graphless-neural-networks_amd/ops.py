@@ -227,6 +227,17 @@ def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True, transform=DEG_RAW
     return in_deg, out_deg
 
 
+_DEFAULT_WS = {}
+
+
+def _default_ws(device):
+    """One lazily allocated 64 MB split-K workspace per device for callers that pass none (stream-ordered reuse: one stream per device)."""
+    key = str(device)
+    if key not in _DEFAULT_WS:
+        _DEFAULT_WS[key] = torch.empty(1 << 24, dtype=torch.float32, device=device)
+    return _DEFAULT_WS[key]
+
+
 def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale=None, ep_scale=None,
          ep_shift=None, relu=False, out=None, m=None, drop_p=0.0, drop_seed=0, workspace=None):
     """K3 glnn_gemm_f32: out = epi(A' @ W^T) (w [n,k], torch Linear layout) or epi(A' @ W) (w [k,n])."""
@@ -244,6 +255,8 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     if out is None:
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
+    if workspace is None and m * n <= (1 << 22) and k >= 2048:
+        workspace = _default_ws(a.device)          # lets a deep, narrow product split its reduction (see gemm.hip)
     with _Timed("gemm", m=m, k=k, n=n):
         rc = _gemm_call(a, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, w, w_is_kn, n, row_scale, ep_scale, ep_shift, relu, out,
                         workspace)
