@@ -16,11 +16,27 @@ namespace {
 // K4: one wavefront per row (c <= 64: one class per lane; larger c loops), 4 rows per workgroup.
 // ------------------------------------------------------------------------------------------
 
-template <bool LOSS>
+// LPR = 8: c <= 8 (the two-class sets pokec / penn94: 1.6 M rows) -- eight rows per wavefront, eight lanes per row, the same arithmetic per
+// row; a wave per row left 62 lanes idle and took 424 us for pokec's full-graph loss.
+template <int LPR>
+__device__ __forceinline__ float grp_max(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <bool LOSS, int LPR = 64>
 __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPW = 64 / LPR;                       // rows per wavefront
+  const int lane = threadIdx.x & (LPR - 1), wave = (threadIdx.x >> 6) * RPW + ((threadIdx.x & 63) / LPR);     // "wave" = row slot of the workgroup
   float wave_loss = 0.f, col_acc = 0.f;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < a.rows; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * 4 * RPW + wave; row < a.rows; row += (int64_t)gridDim.x * 4 * RPW) {
     const float* zr = a.z + row * a.ldz;
     // the row's target / label is requested FIRST: behind the z_store below the compiler may not move these loads up (possible alias),
     // and index -> row -> value would be two more dependent round trips at the end of the row's chain
@@ -44,20 +60,20 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
     }
     auto Z = [&](int j) { return a.nslab > 0 ? zv : zr[j]; };
     float mx = -INFINITY;
-    for (int j = lane; j < a.c; j += 64) mx = fmaxf(mx, Z(j));
-    mx = wave_max(mx);
+    for (int j = lane; j < a.c; j += LPR) mx = fmaxf(mx, Z(j));
+    mx = grp_max<LPR>(mx);
     float se = 0.f;
-    for (int j = lane; j < a.c; j += 64) se += expf(Z(j) - mx);
-    se = wave_sum(se);
+    for (int j = lane; j < a.c; j += LPR) se += expf(Z(j) - mx);
+    se = grp_sum<LPR>(se);
     const float lse = mx + logf(se);
     if (!LOSS) {
-      for (int j = lane; j < a.c; j += 64) a.logp[row * a.ldl + j] = Z(j) - lse;
+      for (int j = lane; j < a.c; j += LPR) a.logp[row * a.ldl + j] = Z(j) - lse;
       continue;
     }
     float row_loss = 0.f;
     if (a.kind == GLNN_LOSS_NLL) {
       const int64_t y = yrow;
-      for (int j = lane; j < a.c; j += 64) {
+      for (int j = lane; j < a.c; j += LPR) {
         const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
         const float sm = expf(lp);
@@ -66,17 +82,17 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
         col_acc += g;
         if (j == y) row_loss = -lp;
       }
-      row_loss = wave_sum(row_loss);
+      row_loss = grp_sum<LPR>(row_loss);
     } else {
       float set = 0.f;
-      for (int j = lane; j < a.c; j += 64) {
+      for (int j = lane; j < a.c; j += LPR) {
         const float tj = j == lane ? tj0 : tr[j], et = expf(tj);
         set += et;
         row_loss += et * (tj - (Z(j) - lse));
       }
-      set = wave_sum(set);
-      row_loss = wave_sum(row_loss);
-      for (int j = lane; j < a.c; j += 64) {
+      set = grp_sum<LPR>(set);
+      row_loss = grp_sum<LPR>(row_loss);
+      for (int j = lane; j < a.c; j += LPR) {
         const float lp = Z(j) - lse;
         if (a.logp) a.logp[row * a.ldl + j] = lp;
         const float g = (expf(lp) * set - expf(j == lane ? tj0 : tr[j])) * a.scale;
@@ -89,12 +105,17 @@ __global__ __launch_bounds__(256) void softmax_loss_kernel(const LossArgs a) {
   if (LOSS) {
     __shared__ float s[4];
     __shared__ float sc[4][64];
-    if (lane == 0) s[wave] = wave_loss;
-    sc[wave][lane] = col_acc;
+    if (LPR < 64) {                                   // fold the wave's row slots first: losses of the RPW rows, column sums per class
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { wave_loss += __shfl_xor(wave_loss, o); col_acc += __shfl_xor(col_acc, o); }
+    }
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    if (ln == 0) s[wv] = wave_loss;
+    sc[wv][ln] = ln < LPR ? col_acc : 0.f;
     __syncthreads();
     if (threadIdx.x == 0) st_part(&a.partial[blockIdx.x], (s[0] + s[1]) + (s[2] + s[3]), a.counter != nullptr);
     if (!a.counter && !a.defer) return;
-    if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][lane] + sc[1][lane]) + (sc[2][lane] + sc[3][lane]), a.counter != nullptr);
+    if (a.col_sum && threadIdx.x < 64) st_part(&a.col_partial[(int64_t)blockIdx.x * 64 + threadIdx.x], (sc[0][threadIdx.x] + sc[1][threadIdx.x]) + (sc[2][threadIdx.x] + sc[3][threadIdx.x]), a.counter != nullptr);
     if (a.defer) return;
     if (!last_workgroup(a.counter, (int)gridDim.x)) return;
     loss_fold_last(a, (int)gridDim.x, sc);
@@ -1030,7 +1051,9 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   if (kind == GLNN_LOSS_KL) GLNN_REQUIRE(target_logp && ldt >= c, "glnn_softmax_loss_f32: KL needs target_logp");
   GLNN_REQUIRE(!logprob_out || ldl >= c, "glnn_softmax_loss_f32: ldl too small");
   GLNN_REQUIRE(!col_sum || (counter && c <= 64), "glnn_softmax_loss_f32: fused column sums need the counter and c <= 64");
-  int64_t blocks = (rows + 3) / 4;
+  const bool narrow8 = c <= 8 && rows >= 4096;         // eight rows per wavefront (softmax_loss_kernel<.., 8>)
+  const int rpb = narrow8 ? 32 : 4;
+  int64_t blocks = (rows + rpb - 1) / rpb;
   const int64_t cap = counter ? 256 : 1024;            // fused finalize: fewer, longer workgroups keep the last one's fold short
   if (blocks > cap) blocks = cap;
   const int64_t need = blocks * (col_sum ? 65 : 1);
@@ -1049,7 +1072,8 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   }
   a.slabs = slabs; a.nslab = nslab; a.slab_stride = rows * c; a.bias = bias; a.z_store = const_cast<float*>(logits);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (narrow8) hipLaunchKernelGGL((softmax_loss_kernel<true, 8>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((softmax_loss_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   if (!counter && !pf)
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, 1.0f / (float)rows, loss_out, loss_accum);
   return glnn::check_launch("glnn_softmax_loss_f32");
