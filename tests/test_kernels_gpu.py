@@ -353,7 +353,8 @@ def test_act_fwd_and_its_backward_pair(rows, h, bn, p):
 
 
 # ------------------------------------------------------------------------------------------- K4
-@pytest.mark.parametrize("rows,c", [(512, 40), (4096, 47), (140, 7), (37, 100)])
+@pytest.mark.parametrize("rows,c", [(512, 40), (4096, 47), (140, 7), (37, 100),
+                                    (5003, 2), (70001, 7), (4096, 8), (33333, 1)])      # >= 4096 rows of <= 8 classes: eight rows per wavefront
 @pytest.mark.parametrize("kind", ["nll", "kl"])
 def test_softmax_loss_vs_oracle(rows, c, kind):
     from glnn_amd import ops
@@ -372,10 +373,10 @@ def test_softmax_loss_vs_oracle(rows, c, kind):
     np.testing.assert_allclose(dz.cpu().numpy(), dz_w, atol=1e-6, rtol=1e-4)
 
 
-def test_softmax_loss_indexed_targets_and_accum():
+@pytest.mark.parametrize("n,rows,c", [(900, 256, 40), (9000, 4500, 2)])
+def test_softmax_loss_indexed_targets_and_accum(n, rows, c):
     from glnn_amd import ops
     r = np.random.RandomState(0)
-    n, rows, c = 900, 256, 40
     z = r.standard_normal((rows, c)).astype(np.float32)
     labels_all = r.randint(0, c, n).astype(np.int64)
     t_all = so.log_softmax(r.standard_normal((n, c)).astype(np.float32))
