@@ -683,7 +683,7 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
   // generic GEMM (206 us for 140 x 128 x 1433): here it is loaded dword by dword, and K may be as deep as it comes
   const bool b_vec = b_layout || (ldb % 4 == 0 && glnn::aligned16(b));
   const int k_lim = b_vec ? max_k : (max_k > (1 << 16) ? max_k : (1 << 16));   // (penn94: 4814 features; the alternative runs at 1.6 TF)
-  const int64_t m_lim = b_vec ? max_m : (1 << 20);          // (the alternative for unaligned W is a kernel of 2 workgroups per 128 x 128 tile)
+  const int64_t m_lim = b_vec ? max_m : ((int64_t)1 << 28);          // (the alternative for unaligned W is a kernel of 2 workgroups per 128 x 128 tile)
   if (!enabled || !a || !b || !c || m < 1 || m > m_lim || k < 4 || k > k_lim || n < 1 || n > max_n || (st && ls)) return GLNN_ERR_UNSUPPORTED;
   const int kpad = (k + 3) & ~3;
   if (lda % 4 || !glnn::aligned16(a) || lda < kpad) return GLNN_ERR_UNSUPPORTED;

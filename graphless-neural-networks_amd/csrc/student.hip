@@ -1093,11 +1093,14 @@ extern "C" int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t ro
   GLNN_REQUIRE(logits && out, "glnn_log_softmax_f32: null pointer");
   GLNN_REQUIRE(rows >= 0 && c >= 1 && ldz >= c && ldo >= c, "glnn_log_softmax_f32: bad sizes");
   if (rows == 0) return GLNN_OK;
-  int64_t blocks = (rows + 3) / 4;
+  const bool narrow8 = c <= 8 && rows >= 4096;         // eight rows per wavefront
+  const int rpb = narrow8 ? 32 : 4;
+  int64_t blocks = (rows + rpb - 1) / rpb;
   if (blocks > 8192) blocks = 8192;
   LossArgs a = {};
   a.z = logits; a.ldz = ldz; a.rows = rows; a.c = c; a.logp = out; a.ldl = ldo;
-  hipLaunchKernelGGL((softmax_loss_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  if (narrow8) hipLaunchKernelGGL((softmax_loss_kernel<false, 8>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  else hipLaunchKernelGGL((softmax_loss_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   return glnn::check_launch("glnn_log_softmax_f32");
 }
 

@@ -255,10 +255,12 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     if out is None:
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
-    if w.stride(0) % 4 and w.numel() <= (1 << 20) and (w_is_kn or k < 4 or n > 512):
-        w = as_feat(w)                              # small weights whose rows are not float4-addressable and that the unaligned-W latency kernel does
-                                                    # not take ([k, n] with n % 4 != 0: the 2 classes of pokec / penn94; [n, k] with k < 4: their
-                                                    # input gradient): padded rows, else the generic kernel (1.6 M x 32 x 2: 317 us instead of 180)
+    if w.stride(0) % 4 and w.numel() <= (1 << 22) and (w_is_kn or k < 4 or n > 512 or m >= 4096):
+        w = as_feat(w)                              # weights whose rows are not float4-addressable and that the unaligned-W latency kernel does not
+                                                    # take, or takes badly: [k, n] with n % 4 != 0 (the 2 classes of pokec / penn94), [n, k] with k < 4
+                                                    # (their input gradient), or thousands of rows of A (penn94's 4814-feature first layer over all
+                                                    # 41,554 nodes in evaluate: 3.65 ms at 28 TF on 32-row tiles) -- padded rows (remembered by
+                                                    # as_feat while the weight is unchanged), then the tiled kernels
     if workspace is None and m * n <= (1 << 22) and k >= 2048:
         workspace = _default_ws(a.device)          # lets a deep, narrow product split its reduction (see gemm.hip)
     with _Timed("gemm", m=m, k=k, n=n):

@@ -93,12 +93,24 @@ def evaluate(model, data, feats, labels, criterion, evaluator, idx_eval=None):
         logits = model.inference(data, feats)
         out = ops.log_softmax(logits)
         if idx_eval is None:
-            loss = criterion(out, labels)
+            loss = _apply_criterion(criterion, out, labels)
             score = evaluator(out, labels)
         else:
-            loss = criterion(out[idx_eval], labels[idx_eval])
+            loss = _apply_criterion(criterion, out[idx_eval], labels[idx_eval])
             score = evaluator(out[idx_eval], labels[idx_eval])
     return out, loss.item(), score
+
+
+def _apply_criterion(criterion, out, labels):
+    """criterion(out, labels) -- the reference passes torch.nn.NLLLoss() (train_teacher.py / train_student.py).  torch's CUDA kernel for it
+    reduces a [N, C] matrix in ONE workgroup: 1.46 ms for pokec's 1.6 M rows, a third of an evaluate call.  A plain default NLLLoss is
+    therefore evaluated as -mean(out[i, labels[i]]) with a gather and a grid-wide mean (same value to fp32 summation order); anything else
+    (weights, ignore_index hits, another reduction, another callable) goes to the callable itself."""
+    if (type(criterion) is torch.nn.NLLLoss and criterion.reduction == "mean" and criterion.weight is None and out.dim() == 2 and
+            labels.dim() == 1 and labels.dtype == torch.int64 and out.shape[0] >= 65536):
+        if not bool((labels == criterion.ignore_index).any()):
+            return -out.gather(1, labels.view(-1, 1)).mean()
+    return criterion(out, labels)
 
 
 def evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, idx_eval=None):
@@ -110,13 +122,14 @@ def evaluate_mini_batch(model, feats, labels, criterion, batch_size, evaluator, 
         # row blocks bounded so that a wide student over millions of rows does not materialise tens of GB of activations
         blk = max(int(batch_size), EVAL_BLOCK_ROWS)
         out_all = torch.empty((feats.shape[0], model.encoder.layers[-1].out_features), dtype=torch.float32, device=feats.device)
+        x = ops.as_feat(feats)                     # padded ONCE (and remembered across calls), not per row block: the slices of x are float4 rows
         for s0 in range(0, feats.shape[0], blk):
-            ops.log_softmax(model.inference(None, feats[s0:s0 + blk]), out=out_all[s0:s0 + blk])
+            ops.log_softmax(model.inference(None, x[s0:s0 + blk]), out=out_all[s0:s0 + blk])
         if idx_eval is None:
-            loss = criterion(out_all, labels)
+            loss = _apply_criterion(criterion, out_all, labels)
             score = evaluator(out_all, labels)
         else:
-            loss = criterion(out_all[idx_eval], labels[idx_eval])
+            loss = _apply_criterion(criterion, out_all[idx_eval], labels[idx_eval])
             score = evaluator(out_all[idx_eval], labels[idx_eval])
     return out_all, loss.item(), score
 

@@ -249,3 +249,19 @@ def test_as_feat_remembers_the_padded_copy_of_an_unchanged_tensor():
     assert ops.as_feat(small) is not ops.as_feat(small)                   # small matrices are not kept
     al = torch.randn(64, 128)
     assert ops.as_feat(al) is al
+
+
+def test_default_nllloss_is_evaluated_by_gather_and_mean_and_everything_else_by_the_callable():
+    """evaluate / evaluate_mini_batch keep the reference's signature (the criterion is the caller's callable, train_and_eval.py:89-136); a
+    plain default torch.nn.NLLLoss over >= 65536 rows is computed as -mean(out[i, y_i]) (torch's CUDA kernel reduces in one workgroup),
+    anything else -- weights, another reduction, ignore_index hits, few rows, other callables -- is passed through untouched."""
+    import torch
+    from glnn_amd import train_and_eval as te
+    out = torch.log_softmax(torch.randn(70000, 5), 1)
+    y = torch.randint(0, 5, (70000,))
+    assert abs(float(te._apply_criterion(torch.nn.NLLLoss(), out, y)) - float(torch.nn.NLLLoss()(out, y))) < 1e-5
+    y2 = y.clone(); y2[3] = -100
+    assert float(te._apply_criterion(torch.nn.NLLLoss(), out, y2)) == float(torch.nn.NLLLoss()(out, y2))
+    for crit in (torch.nn.NLLLoss(reduction="sum"), torch.nn.NLLLoss(weight=torch.rand(5)), lambda o, l: o.sum() * 0 + 7.0):
+        assert float(te._apply_criterion(crit, out, y)) == float(crit(out, y))
+    assert float(te._apply_criterion(torch.nn.NLLLoss(), out[:100], y[:100])) == float(torch.nn.NLLLoss()(out[:100], y[:100]))

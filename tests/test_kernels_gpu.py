@@ -391,9 +391,10 @@ def test_softmax_loss_indexed_targets_and_accum(n, rows, c):
     np.testing.assert_allclose(d2.cpu().numpy(), g2, atol=1e-6, rtol=1e-4)
 
 
-def test_log_softmax():
+@pytest.mark.parametrize("rows,c", [(1000, 47), (50001, 2), (4096, 7)])          # the last two: eight rows per wavefront
+def test_log_softmax(rows, c):
     from glnn_amd import ops
-    z = (np.random.RandomState(1).standard_normal((1000, 47)) * 3).astype(np.float32)
+    z = (np.random.RandomState(1).standard_normal((rows, c)) * 3).astype(np.float32)
     np.testing.assert_allclose(ops.log_softmax(dev(z)).cpu().numpy(), so.log_softmax(z), atol=1e-5, rtol=0)
 
 
