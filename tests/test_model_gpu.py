@@ -374,6 +374,34 @@ def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bs
         assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
 
 
+@pytest.mark.parametrize("dims,bsz,norm", [([100, 512, 512, 7], 6754, "batch"), ([100, 512, 512, 70], 2580, "none"), ([4814, 256, 256, 2], 512, "none")])
+def test_large_step_with_a_cramped_weight_gradient_workspace(dims, bsz, norm):
+    """In the one-call step every layer's split-reduction slabs wait in ws_tn for the Adam launch to fold them.  The Python mirror sizes
+    ws_tn for all of them; a host that gives less must not end with a later layer running UNSPLIT (vk_class: four workgroups for 60 us):
+    a product that finds ws_tn cramped takes the idle ws_gemm and folds at once.  Same arithmetic, other split plans: gradients to fp32
+    rounding of the largest one.  (The shapes are the reference's vk_class / house_class-sized / penn94 students.)"""
+    import copy
+    from glnn_amd import ops
+    from glnn_amd.student import StudentEngine
+    base, x, tgt, k = _variant_inputs(dims, bsz, norm, 0.0, "kl", 41)
+    grads = []
+    for shrink in (False, True):
+        model = copy.deepcopy(base)
+        model.train()
+        eng = StudentEngine(model, torch.optim.Adam(model.parameters(), lr=0.01), bsz)
+        if shrink:
+            full = int(eng.desc.ws_tn_floats)
+            eng.desc.ws_tn_floats = min(full, 64 * max(dims) + 5 * dims[1] * dims[2] // 4 + dims[1] * dims[0] // 2)   # room for ~1 slab of the middle layer
+            assert int(eng.desc.ws_tn_floats) < full
+        eng.step(x, torch.arange(bsz, device=DEV), k, tgt, 1.0)
+        torch.cuda.synchronize()
+        grads.append([g.clone() for g in eng.grads] + [eng.loss_out.clone()])
+    gs = max(float(a.abs().max()) for a in grads[0][:-1])
+    assert float(grads[0][-1]) == float(grads[1][-1])
+    for a, b in zip(grads[0][:-1], grads[1][:-1]):
+        assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
+
+
 @pytest.mark.parametrize("dims,bsz,p,kind", [([100, 2048, 2048, 47], 4096, 0.2, "kl"), ([100, 512, 512, 70], 4096, 0.3, "kl"),
                                              ([100, 520, 520, 33], 4100, 0.0, "nll"), ([72, 600, 300, 33], 3500, 0.5, "kl")])
 def test_first_layer_batchnorm_backward_applied_in_the_weight_gradient_loads(dims, bsz, p, kind, monkeypatch):
