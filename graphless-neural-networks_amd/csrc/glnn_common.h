@@ -111,6 +111,8 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
 // da_slabs > 1: da points at that many split-K partial slabs (da[s][rows][ldda]) which the one-launch form sums itself; any other
 // form returns GLNN_ERR_UNSUPPORTED with nothing launched (fold with gemm_fold_partials, call again)
 int gemm_fold_partials(const float* workspace, int splits, int64_t m, int n, const float* bias, float* c, int64_t ldc, void* stream);
+// student.hip: dst[r][0:ldd] = src[r][0:cols] followed by zeros (ldd % 4 == 0, dst 16-byte aligned): a float4-addressable copy of a matrix
+int pad_rows(const float* src, int64_t lds, int64_t rows, int cols, float* dst, int64_t ldd, void* stream);
 // student.hip: out[0:h] = sum over k < nchunks of ws[k][0:h], k ascending (the order in which the fused Adam launch folds a GradFold with lanes4 = 0)
 int chunk_sum(const float* ws, int nchunks, int h, float* out, void* stream);
 

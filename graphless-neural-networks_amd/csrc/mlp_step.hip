@@ -83,6 +83,8 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const bool fused_bias = cnt && !expect_wg && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
   bool loss_done = false;
   int logit_slabs = 0;
+  const char* pwe = getenv("GLNN_STUDENT_PAD_W0");                  // "0": wide unaligned first layers stay on the unaligned-W latency kernel
+  const bool pad_w0 = !(pwe && pwe[0] == '0');
   const char* sce = getenv("GLNN_STUDENT_SLAB_CONSUMERS");
   const bool slab_consumers = !(sce && sce[0] == '0');
   const char* dfe = getenv("GLNN_STUDENT_DEFER_STATS");
@@ -97,6 +99,21 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     const bool recompute = l > 0 && a_scale != nullptr;     // the previous layer's tail evaluated in this GEMM's operand load
     const float gp = recompute ? p : 0.f;
     const uint32_t gseed = (recompute && p > 0.f) ? drop_seeds[l - 1] : 0u;
+    // W_0 over WIDE feature rows that are not float4-addressable (citeseer 3703, penn94 4814, cora 1433 features): a padded shadow in the
+    // tail of ws_gemm, refreshed by one small launch, puts the product on the tiled split-K kernels -- the unaligned-W latency kernel
+    // walks all of K in 64 workgroups (55 of the 114 us of a citeseer-shaped step)
+    const float* w_l = d->w[l];
+    int64_t ldw_l = d->dims[l];
+    float* wsg = d->ws_gemm;
+    int64_t wsg_floats = d->ws_gemm_floats;
+    if (l == 0 && pad_w0 && d->dims[0] >= 512 && (d->dims[0] % 4 != 0 || !glnn::aligned16(d->w[0])) && d->ws_gemm) {
+      const int64_t kp = (d->dims[0] + 3) & ~(int64_t)3, need = ((int64_t)d->dims[1] * kp + 3) & ~(int64_t)3;
+      if (d->ws_gemm_floats >= need + 4ll * m * d->dims[1] && glnn::aligned16(d->ws_gemm)) {
+        float* shadow = d->ws_gemm + ((d->ws_gemm_floats - need) & ~(int64_t)3);
+        GLNN_TRY(glnn::pad_rows(d->w[0], d->dims[0], d->dims[1], d->dims[0], shadow, kp, stream));
+        w_l = shadow; ldw_l = kp; wsg_floats = (d->ws_gemm_floats - need) & ~(int64_t)3;
+      }
+    }
     // small batches: the latency GEMM with the reduction behind it as epilogue (mlp_lat.hip) -- the BatchNorm statistics of a hidden
     // layer, log_softmax + loss + dlogits (+ the bias gradient) of the last one.  UNSUPPORTED = the tiled GEMM + separate kernels below
     int lat = GLNN_ERR_UNSUPPORTED;
@@ -107,7 +124,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         const glnn::LatLoss ll = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
                                   kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out,
                                   d->loss_accum, d->ws_loss, d->ws_loss_floats, cnt + GLNN_MLP_COUNTERS - 1, d->gb[L - 1], pf};
-        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0, d->dims[l + 1], d->b[l],
                              out, ldo, pin, nullptr, &ll, stream, cp_dst, d->ld_xb);
         loss_done = lat == GLNN_OK;
       } else if (!last && d->batchnorm == 1) {
@@ -116,12 +133,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         const int64_t half = d->ws_bn_floats / 2;
         next = {d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum, d->running_mean[l], d->running_var[l], d->nbt[l],
                 d->mean[l], d->rstd[l], d->a_scale[l], d->a_shift[l], d->ws_bn + (l & 1) * half, half, (defer_stats && !d->act[l]) ? nullptr : cnt};
-        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0, d->dims[l + 1], d->b[l],
                              out, ldo, pin, &next, nullptr, stream, cp_dst, d->ld_xb);
         stats_done = lat == GLNN_OK;
         have_next = stats_done && next.counters == nullptr;
       } else if (!last) {
-        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], d->b[l],
+        lat = glnn::gemm_lat(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0, d->dims[l + 1], d->b[l],
                              out, ldo, pin, nullptr, nullptr, stream, cp_dst, d->ld_xb);
       }
       if (lat != GLNN_OK && lat != GLNN_ERR_UNSUPPORTED) return lat;
@@ -136,8 +153,8 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     pend = next;
     // a deep, narrow last layer (MLP3w4: 1024 -> 40) is split over K; its partial slabs are folded by the loss kernel, not by a launch
     if (lat != GLNN_OK && last && d->dims[L] <= 64 && slab_consumers) {
-      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0,
-                                               d->dims[l + 1], d->ws_gemm, d->ws_gemm_floats, &logit_slabs, stream);
+      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0,
+                                               d->dims[l + 1], wsg, wsg_floats, &logit_slabs, stream);
       if (rc == GLNN_OK) lat = GLNN_OK;
       else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
       else logit_slabs = 0;
@@ -145,17 +162,17 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     // a deep hidden layer (MLP3w4: 1024 -> 1024 at B = 512) likewise: the statistics kernel folds the slabs, stores z, then reduces
     int z_slabs = 0;
     if (lat != GLNN_OK && !last && cnt && d->batchnorm == 1 && !layernorm && slab_consumers) {
-      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], d->w[l], d->dims[l], 0,
-                                               d->dims[l + 1], d->ws_gemm, d->ws_gemm_floats, &z_slabs, stream);
+      const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0,
+                                               d->dims[l + 1], wsg, wsg_floats, &z_slabs, stream);
       if (rc == GLNN_OK && z_slabs <= 8) lat = GLNN_OK;
-      else if (rc == GLNN_OK) { GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream)); lat = GLNN_OK; z_slabs = 0; }
+      else if (rc == GLNN_OK) { GLNN_TRY(glnn::gemm_fold_partials(wsg, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream)); lat = GLNN_OK; z_slabs = 0; }
       else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
       else z_slabs = 0;
     }
     if (lat != GLNN_OK)
       GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, gp, gseed, m,
-                             d->dims[l], d->w[l], d->dims[l], 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
-                             d->ws_gemm, d->ws_gemm_floats, stream));
+                             d->dims[l], w_l, ldw_l, 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
+                             wsg, wsg_floats, stream));
     if (!last && layernorm) {
       // LayerNorm -> ReLU -> dropout in one row-wise pass; the tail is always materialised (per-row statistics cannot ride in a
       // GEMM operand transform); mean[l] / rstd[l] hold the per-ROW statistics (max_batch floats each) for the backward
@@ -170,10 +187,10 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       if (d->batchnorm && !stats_done) {
         int rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                 d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
-                                d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, z_slabs ? d->ws_gemm : nullptr, z_slabs,
+                                d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, z_slabs ? wsg : nullptr, z_slabs,
                                 z_slabs ? d->b[l] : nullptr);
         if (rc == GLNN_ERR_UNSUPPORTED && z_slabs) {          // not the one-launch form after all: fold with a launch, then the plain call
-          GLNN_TRY(glnn::gemm_fold_partials(d->ws_gemm, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream));
+          GLNN_TRY(glnn::gemm_fold_partials(wsg, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream));
           rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                               d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
                               d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt);

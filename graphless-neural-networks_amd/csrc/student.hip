@@ -1194,6 +1194,30 @@ static int fused_grid_limit() {
   return limit[dev];
 }
 
+namespace {
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int64_t lds, int64_t rows, int cols, float* __restrict__ dst,
+                                                       int64_t ldd) {
+  const int q4 = (int)(ldd >> 2);
+  const int64_t total = rows * q4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q4;
+    const int c = (int)(i - r * q4) * 4;
+    const float* p = src + r * lds + c;
+    float4 v;
+    v.x = c < cols ? p[0] : 0.f; v.y = c + 1 < cols ? p[1] : 0.f; v.z = c + 2 < cols ? p[2] : 0.f; v.w = c + 3 < cols ? p[3] : 0.f;
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+}  // namespace
+
+int glnn::pad_rows(const float* src, int64_t lds, int64_t rows, int cols, float* dst, int64_t ldd, void* stream) {
+  GLNN_REQUIRE(src && dst && rows >= 1 && cols >= 1 && lds >= cols && ldd >= cols && ldd % 4 == 0 && glnn::aligned16(dst), "glnn::pad_rows: bad arguments");
+  int64_t blocks = (rows * (ldd >> 2) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, lds, rows, cols, dst, ldd);
+  return glnn::check_launch("glnn::pad_rows");
+}
+
 int glnn::chunk_sum(const float* ws, int nchunks, int h, float* out, void* stream) {
   GLNN_REQUIRE(ws && out && nchunks >= 1 && h >= 1, "glnn::chunk_sum: bad arguments");
   hipLaunchKernelGGL(chunk_sum_kernel, dim3((h + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ws, nchunks, h, out);

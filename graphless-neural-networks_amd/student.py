@@ -130,7 +130,9 @@ class StudentEngine:
                 tight += n_chunks * (self.dims[-1] * self.dims[-2] + self.dims[-1]) + 8
             all_slabs = tight if tight <= (1 << 26) else 0
         self.ws_tn = torch.empty(max(64 * hk + 256 * 128 * 128 + 2 * hk * hk, all_slabs), **f32)
-        self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20), **f32)
+        # (+ a float4-addressable shadow of W_0 when the feature rows are wide and unaligned: csrc/mlp_step.hip, GLNN_STUDENT_PAD_W0)
+        shadow = self.dims[1] * ((self.dims[0] + 3) // 4 * 4) + 4 * B * self.dims[1] if self.dims[0] >= 512 and self.dims[0] % 4 else 0
+        self.ws_gemm = torch.empty(max(16 * B * min(self.dims[1:]), 1 << 20) + shadow, **f32)
         self.ws_loss = torch.empty(256 * 65 + 1024, **f32)
         # fused finalizes (last workgroup folds the partials: 7 launches fewer per step): arxiv MLP 0.143 -> 0.136 ms, MLP3w4 0.193 ->
         # 0.185, products MLP 0.229 -> 0.226, MLP3w8 1.196 -> 1.203 (interleaved A/B) -> only for the small, latency-bound steps

@@ -374,6 +374,26 @@ def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bs
         assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
 
 
+@pytest.mark.parametrize("dims,bsz,norm,p", [([1433, 128, 7], 140, "none", 0.6), ([3703, 128, 6], 512, "none", 0.6), ([4814, 64, 64, 2], 300, "batch", 0.2),
+                                             ([1433, 256, 256, 40], 4096, "batch", 0.5)])
+def test_wide_unaligned_first_layer_through_a_padded_shadow_of_its_weight(dims, bsz, norm, p, monkeypatch):
+    """Feature rows that are not float4-addressable and >= 1024 wide (cora 1433, citeseer 3703, penn94 4814): the step copies W_0 into a
+    padded shadow (tail of ws_gemm, one small launch) so that the first layer's product runs on the tiled split-K kernels instead of the
+    unaligned-W latency kernel (GLNN_STUDENT_PAD_W0=0).  Other summation order: logits, loss and gradients to fp32 rounding."""
+    base, x, tgt, k = _variant_inputs(dims, bsz, norm, p, "kl", 43)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_STUDENT_PAD_W0", mode)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 1))
+    (_, _, g0, l0, z0), (_, _, g1, l1, z1) = runs
+    assert not torch.equal(z0, z1), "both runs took the same path"
+    assert abs(float(l0) - float(l1)) <= 2e-6 * max(1.0, abs(float(l0)))
+    torch.testing.assert_close(z1, z0, atol=3e-5, rtol=1e-5)
+    gs = max(float(a.abs().max()) for a in g0)
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 2e-5 * gs + 1e-7, (tuple(a.shape), float((a - b).abs().max()), gs)
+
+
 @pytest.mark.parametrize("dims,bsz,norm", [([100, 512, 512, 7], 6754, "batch"), ([100, 512, 512, 70], 2580, "none"), ([4814, 256, 256, 2], 512, "none")])
 def test_large_step_with_a_cramped_weight_gradient_workspace(dims, bsz, norm):
     """In the one-call step every layer's split-reduction slabs wait in ws_tn for the Adam launch to fold them.  The Python mirror sizes
