@@ -531,17 +531,19 @@ def small_student_leg(dev, Model, StudentEngine, ops, steps=3000, warmup=100):
     Adam) as StudentEngine.step issues it -- ONE C call, glnn_mlp_train_step_f32.  Latency-bound: a step is 11-13 dependent launches
     of 5-28 us (profiles/r03_student_arxiv_mlp_timeline.txt, ..._mlp3w4_timeline.txt), so the figure of merit is ms per step."""
     out = []
-    n = 169343
-    for name, dims, p in (("MLP", [128, 256, 256, 40], 0.2), ("MLP3w4", [128, 1024, 1024, 40], 0.5)):
+    # + two more sections of the reference's train.conf.yaml, one per other regime of the step: the products MLP (B = 4096 between the
+    # latency and the streaming kernels, :179-185) and the cora MLP (BASELINE configs[0]: 1433 unaligned features, no norm, :17-21)
+    for name, dims, p, B, norm, n in (("MLP", [128, 256, 256, 40], 0.2, 512, "batch", 169343), ("MLP3w4", [128, 1024, 1024, 40], 0.5, 512, "batch", 169343),
+                                      ("products-MLP", [100, 256, 256, 47], 0.5, 4096, "batch", 400000), ("cora-MLP", [1433, 128, 7], 0.6, 140, "none", 2485)):
         torch.manual_seed(0)
-        model = Model(dict(model_name="MLP", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
-                           norm_type="batch", device=dev))
+        model = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type=norm, device=dev))
         model.train()
-        eng = StudentEngine(model, torch.optim.Adam(model.parameters(), lr=0.01), 512)
+        eng = StudentEngine(model, torch.optim.Adam(model.parameters(), lr=0.01), B)
         feats = ops.as_feat(torch.randn(n, dims[0], device=dev))
         out_t = ops.as_feat(torch.log_softmax(torch.randn(n, dims[-1], device=dev), 1))
-        nb = n // 512
-        perm = torch.randperm(n)[: nb * 512].view(nb, -1).to(dev)
+        nb = n // B
+        perm = torch.randperm(n)[: nb * B].view(nb, -1).to(dev)
         for i in range(warmup):
             eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
         torch.cuda.synchronize()
@@ -550,7 +552,7 @@ def small_student_leg(dev, Model, StudentEngine, ops, steps=3000, warmup=100):
             eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        out.append({"student": name, "dims": dims, "batch": 512, "dropout": p, "ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt,
+        out.append({"student": name, "dims": dims, "batch": B, "norm": norm, "dropout": p, "ms_per_step": 1e3 * dt, "steps_per_s": 1.0 / dt,
                     "steps": steps, "loss_finite": bool(torch.isfinite(eng.loss_out).all())})
         del eng, model, feats, out_t
     return out
