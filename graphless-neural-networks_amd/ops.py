@@ -114,7 +114,8 @@ def as_feat(t):
     """Return t itself if its layout suits the float4 kernels, else a padded copy.
     The copy of a LARGE matrix is remembered while the very same tensor object is passed again unmodified (identity + torch's in-place
     version counter): the reference hands the same `feats` to every epoch's train / evaluate call, and re-padding penn94's 41554 x 4814
-    features (0.8 GB: a zero fill and a copy) cost 0.4 ms of every 1.8 ms GCN epoch."""
+    features (0.8 GB: a zero fill and a copy) cost 0.4 ms of every 1.8 ms GCN epoch.  The result of a padding call is READ-ONLY for the
+    caller (it may be handed out again); every call site in this package only reads it."""
     _mat(t, "as_feat")
     if t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
         return t
