@@ -1497,6 +1497,21 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
                     (!a_scale || (k % 4 == 0 && glnn::aligned16(a_scale) && glnn::aligned16(a_shift)));
   // W[n, k] with rows off the 16-byte grid (a feature width that is not a multiple of 4: cora's 1433-wide first layers) and a plain
   // epilogue: the dword-loading latency kernel of mlp_lat.hip instead of the guarded generic one (2485 x 64 x 1433: 240 us)
+  // W[n, k] whose rows are not float4-addressable over a deep reduction (cora 1433, citeseer 3703, penn94 4814 features), a caller with
+  // workspace to spare: a padded shadow in the workspace's tail (one small launch) and the tiled kernels, split-K included -- the
+  // unaligned-W latency kernel below walks all of K in (m / 32) x (n / 32) workgroups (citeseer's SAGE projection: 107 us)
+  if (!fast && !defer_splits && !b_layout && g.a_vec && lda >= ((k + 3) & ~3) && !g.b_vec && k >= 512 && m >= 256 && workspace &&
+      glnn::aligned16(workspace)) {
+    const int64_t kp = (k + 3) & ~(int64_t)3, need = ((int64_t)n * kp + 3) & ~(int64_t)3;
+    const int64_t left = (workspace_floats - need) & ~(int64_t)3;
+    if (left >= 2 * m * n) {
+      float* shadow = workspace + left;
+      const int rc = glnn::pad_rows(b, ldb, n, k, shadow, kp, stream);
+      if (rc != GLNN_OK) return rc;
+      return gemm_impl(a, lda, a_rows, a_scale, a_shift, drop_p, drop_seed, m, k, shadow, kp, 0, n, row_scale, ep_scale, ep_shift, relu, c, ldc,
+                       workspace, left, stream, defer_splits);
+    }
+  }
   if (!fast && !defer_splits && !b_layout && g.a_vec && lda >= ((k + 3) & ~3) && !g.b_vec && !a_scale && !row_scale) {
     const int rc = glnn::gemm_lat(a, lda, a_rows, nullptr, nullptr, 0.f, 0u, m, k, b, ldb, 0, n, ep_shift, c, ldc, nullptr, nullptr, nullptr, stream,
                                   nullptr, 0, ep_scale, relu);

@@ -243,7 +243,17 @@ __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int 
 }
 
 template <int LPR, int U, int MODE, bool CS>
-__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a) {
+__global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
+  // rows wider than 256 floats (raw cora / citeseer features): blockIdx.y = the 256-column tile of this workgroup -- one launch instead
+  // of one per tile (14 for citeseer's 3703 features)
+  SpmmArgs a = a0;
+  if (gridDim.y > 1) {
+    const int off = 256 * (int)blockIdx.y;
+    a.x += off; a.out += off; a.d = a0.d - off < 256 ? a0.d - off : 256;
+    if (a.x_self) a.x_self += off;
+    if (a.ep_scale) a.ep_scale += off;
+    if (a.ep_shift) a.ep_shift += off;
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane % LPR;
@@ -672,14 +682,15 @@ int launch_gpr(const SpmmArgs& a, int mode, hipStream_t st, int grid) {
 }
 
 template <int LPR, int U>
-int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid) {
+int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1) {
   const bool cs = a.col_scale != nullptr;
+  const dim3 g(grid, col_tiles);
   if (mode == GLNN_AGG_SAGE_GCN) {
-    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), g, dim3(kBlock), 0, st, a);
   } else if (cs) {
-    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, true>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, true>), g, dim3(kBlock), 0, st, a);
   } else {
-    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, false>), g, dim3(kBlock), 0, st, a);
   }
   return glnn::check_launch("glnn_spmm_csr_f32");
 }
@@ -733,12 +744,14 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
   if (n_dst == 0) return GLNN_OK;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
-  // column tiles of <= 256 floats (64 lanes x float4); wider rows (raw cora features in feature_prop) loop.
-  for (int c0 = 0; c0 < d; c0 += 256) {
-    const int dt = (d - c0) < 256 ? (d - c0) : 256;
+  // column tiles of <= 256 floats (64 lanes x float4); wider rows (raw cora / citeseer features) take ONE launch whose blockIdx.y is the
+  // tile (the kernel shifts its pointers): `wide` runs this loop body once with the whole width
+  const bool wide = d > 256 && (d + 255) / 256 <= 65535;
+  for (int c0 = 0; c0 < d; c0 += (wide ? d : 256)) {
+    const int dt = wide ? 256 : ((d - c0) < 256 ? (d - c0) : 256);
     SpmmArgs a;
     a.indptr = indptr; a.indices = indices; a.n_dst = n_dst;
-    a.x = x + c0; a.ldx = ldx; a.d = dt;
+    a.x = x + c0; a.ldx = ldx; a.d = wide ? d : dt;
     a.row_scale = row_scale; a.col_scale = col_scale;
     a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self; a.self_rows = self_rows;
     a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
@@ -767,7 +780,7 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     const int gpr_env = ge ? atoi(ge) : 0;
     const char* gm = getenv("GLNN_SPMM_GPR_MIN_ROWS");
     const int64_t gpr_min_rows = gm ? atoll(gm) : 131072;
-    if (gpr_env && !col_scale && dv > 8 && n_dst >= gpr_min_rows) {
+    if (gpr_env && !wide && !col_scale && dv > 8 && n_dst >= gpr_min_rows) {
       int64_t nb = n_dst / (2048 * kBatchRows);            // batches per workgroup: two per wave on whole graphs
       if (nb < 1) nb = 1;
       if (nb > 2 * kWavesPerBlock) nb = 2 * kWavesPerBlock;
@@ -785,7 +798,7 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     else if (dv <= 8) rc = launch_lpr<8, GLNN_SPMM_U>(a, mode, st, grid);
     else if (dv <= 16) rc = launch_lpr<16, GLNN_SPMM_U>(a, mode, st, grid);
     else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid);
-    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid);
+    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid, wide ? (d + 255) / 256 : 1);
     if (rc != GLNN_OK) return rc;
   }
   return GLNN_OK;
