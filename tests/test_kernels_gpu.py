@@ -95,7 +95,8 @@ def test_spmm_block_ndst_lt_nsrc():
     np.testing.assert_array_equal(got, np.array([[15 / 4], [5.0]], np.float32))
 
 
-@pytest.mark.parametrize("d,use_rs,use_cs", [(64, True, True), (7, True, False), (128, False, True), (33, False, False)])
+@pytest.mark.parametrize("d,use_rs,use_cs", [(64, True, True), (7, True, False), (128, False, True), (33, False, False),
+                                              (700, True, True), (3703, False, False)])      # > 256 columns: one launch, blockIdx.y = column tile
 def test_spmm_sum_scaled_vs_oracle(d, use_rs, use_cs):
     from glnn_amd import ops
     n = 2500
@@ -110,10 +111,11 @@ def test_spmm_sum_scaled_vs_oracle(d, use_rs, use_cs):
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=1e-5)
 
 
-def test_spmm_epilogue_scale_shift_relu():
+@pytest.mark.parametrize("d", [47, 601])
+def test_spmm_epilogue_scale_shift_relu(d):
     from glnn_amd import ops
-    n, d = 1200, 47
-    indptr, indices = random_graph(n, 20, seed=3, power=0.5)
+    n = 1200
+    indptr, indices = random_graph(n, 20, seed=3, power=0.5, hub=700)
     r = np.random.RandomState(1)
     x = r.standard_normal((n, d)).astype(np.float32)
     sc, sh = r.uniform(0.5, 1.5, d).astype(np.float32), r.standard_normal(d).astype(np.float32)
