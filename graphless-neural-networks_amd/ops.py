@@ -256,7 +256,7 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     if out is None:
         out = feat_empty(m, n, a.device)
     _mat(out, "gemm out")
-    if w.stride(0) % 4 and w.numel() <= (1 << 22) and (w_is_kn or k < 4 or n > 512 or m >= 4096):
+    if w.stride(0) % 4 and w.numel() <= (1 << 22) and (w_is_kn or k < 4 or n > 512 or m >= 1024):
         w = as_feat(w)                              # weights whose rows are not float4-addressable and that the unaligned-W latency kernel does not
                                                     # take, or takes badly: [k, n] with n % 4 != 0 (the 2 classes of pokec / penn94), [n, k] with k < 4
                                                     # (their input gradient), or thousands of rows of A (penn94's 4814-feature first layer over all
