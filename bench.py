@@ -115,7 +115,16 @@ def main():
     ap.add_argument("--no-small-students", action="store_true", help="N = 1: skip students_small (the B = 512 arxiv students' step times)")
     ap.add_argument("--workload", default="products", choices=["products", "arxiv", "xl"],
                     help="products = the metric's config (default); xl = BASELINE.json configs[4]: 12.5M-node / 250M-edge shard per GPU "
-                         "of a 100M-node / 2B-edge synthetic graph, 128-d features, SAGE layer-1 aggregation only (weak scaling)")
+                         "of a 100M-node / 2B-edge synthetic graph, 128-d features, the 3-layer SAGE teacher forward 128-256-256-47 through "
+                         "glnn_amd.dist.ShardedTeacher (weak scaling); N = 1 times ONE rank's shard of the 8-rank run with the peers emulated")
+    ap.add_argument("--xl-chunks", type=int, default=4, help="--workload xl: chunks of the overlapped exchange (RowShards.chunks)")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="--workload xl at N = 1: which rank of the --xl-shards-way run to play (default: the middle one)")
+    ap.add_argument("--emulate", type=str, default=None,
+                    help="N = 1, products: comma-separated world sizes (e.g. 2,4,8).  Times EVERY rank's shard of the N-rank sharded forward on this "
+                         "one GPU (glnn_amd.dist.EmulatedPeers: each collective replaced by a local fill of the same bytes with the rows an unsharded "
+                         "forward produced), for the all-gather exchange (narrow and wide layer 1) and the halo exchange on a clustered graph with "
+                         "shuffled ids re-partitioned by label propagation: the compute half of DESIGN.md section 6's scaling model, measured")
+    ap.add_argument("--detail-file", default=None, help="also write the long detail object to this file (default: gpurun_out/bench_detail.json when that directory exists)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -153,6 +162,10 @@ def main():
 
     if args.workload == "xl":
         return run_xl(args, rank, world, dev, barrier)
+    if args.emulate:
+        if world != 1:
+            raise SystemExit("--emulate runs on ONE GPU (it plays the ranks of an N-rank job one after the other)")
+        return run_emulated(args, dev)
     global SAGE_DIMS, STUDENT, GRAPH, CPU_SAMPLE_SCALE
     if args.workload == "arxiv":
         SAGE_DIMS, STUDENT, GRAPH, CPU_SAMPLE_SCALE = ARXIV["sage_dims"], ARXIV["student"], ARXIV["graph"], ARXIV["cpu_sample_scale"]
@@ -343,7 +356,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, dev, min(CPU_SAMPLE_SCALE, args.scale), 1.0 if args.scale >= 1.0 else 0.1)
 
-    print(json.dumps(result), flush=True)
+    emit(result, args)
     if world > 1:
         dist.destroy_process_group()
 
@@ -586,66 +599,468 @@ def clustered_leg(args, n, teacher, FullNeighborLoader, ops, data, dev):
     return obj
 
 
+class CheckedBackend:
+    """A proxy of glnn_amd.ops for ONE verification forward of a sharded teacher (never inside a timed region): every aggregation /
+    fused / GEMM launch runs as usual, then `sample` of its rows are (a) recomputed independently with torch index arithmetic in
+    fp64 from the launch's own inputs -- mean = (sum_{e in row} x[src_e] + x_self) / (deg + 1), projections as fp64 matmuls, the
+    epilogue per column -- and compared within `tol`, and (b) for stand-alone aggregations re-launched as a row range of their own,
+    which must reproduce the rows bit for bit.  Works whatever filled the input buffers (real collectives, truth fills, synthetic
+    fills): each launch is checked against ITS inputs."""
+
+    def __init__(self, be, sample=4096, tol=1e-4, conservation=False):
+        """conservation: stand-alone SAGE aggregations (no ReLU) are also held to the identity over ALL their rows, in fp64:
+        sum_v (deg_v + 1) * mean_v == sum_u (edges of the launch out of u) * x_u + sum_v x_self_v  (a full pass over x per launch)."""
+        self.be, self.sample, self.tol, self.report, self.ok, self.conservation = be, int(sample), tol, [], True, conservation
+
+    def _conservation(self, indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift):
+        d, dev = x.shape[1], x.device
+        e0, e1 = int(indptr[0]), int(indptr[n_dst])
+        cnt = torch.bincount(indices[e0:e1].long(), minlength=x.shape[0]).double()
+        deg1 = (indptr[1:n_dst + 1] - indptr[:n_dst]).double() + 1
+        lhs = torch.zeros(d, dtype=torch.float64, device=dev)
+        rhs = torch.zeros(d, dtype=torch.float64, device=dev)
+        step = 1 << 20                                         # fp64 reductions in slabs (bounded temporaries)
+        for s0 in range(0, n_dst, step):
+            sl = slice(s0, min(n_dst, s0 + step))
+            y = out[sl, :d].double()
+            if ep_shift is not None:
+                y = y - ep_shift.double()
+            if ep_scale is not None:
+                y = y / ep_scale.double()
+            lhs += (deg1[sl].unsqueeze(1) * y).sum(0)
+            rhs += xs[sl, :d].double().sum(0)
+        for s0 in range(0, x.shape[0], step):
+            sl = slice(s0, min(x.shape[0], s0 + step))
+            rhs += (cnt[sl].unsqueeze(1) * x[sl, :d].double()).sum(0)
+        return float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1))
+
+    def __getattr__(self, name):
+        return getattr(self.be, name)
+
+    def _range(self, n):
+        k = min(self.sample, n)
+        r0 = (n - k) // 2
+        return r0, k
+
+    def _agg_ref(self, indptr, indices, x, r0, k, mode, x_self, row_scale=None, col_scale=None):
+        d = x.shape[1]
+        e0, e1 = int(indptr[r0]), int(indptr[r0 + k])
+        idx = indices[e0:e1].long()
+        deg = indptr[r0 + 1:r0 + k + 1] - indptr[r0:r0 + k]
+        dst = torch.repeat_interleave(torch.arange(k, device=x.device), deg)
+        rows = x[idx][:, :d].double()
+        if col_scale is not None:
+            rows = rows * col_scale[idx].double().unsqueeze(1)
+        acc = torch.zeros(k, d, dtype=torch.float64, device=x.device).index_add_(0, dst, rows)
+        if mode == self.be.AGG_SAGE_GCN:
+            return (acc + x_self[r0:r0 + k, :d].double()) / (deg.double() + 1).unsqueeze(1)
+        return acc * row_scale[r0:r0 + k].double().unsqueeze(1) if row_scale is not None else acc
+
+    @staticmethod
+    def _epi(y, ep_scale, ep_shift, relu):
+        if ep_scale is not None:
+            y = y * ep_scale.double()
+        if ep_shift is not None:
+            y = y + ep_shift.double()
+        return y.clamp(min=0) if relu else y
+
+    def _note(self, what, diff, exact=None):
+        good = bool(diff <= self.tol) and (exact is None or exact)
+        self.ok = self.ok and good
+        self.report.append({"launch": what, "max_abs_diff_vs_fp64": diff, **({} if exact is None else {"row_range_relaunch_bit_equal": exact})})
+
+    def spmm(self, indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None, relu=False, out=None,
+             x_self=None, self_rows=None):
+        out = self.be.spmm(indptr, indices, x, n_dst, mode, row_scale=row_scale, col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift,
+                           relu=relu, out=out, x_self=x_self, self_rows=self_rows)
+        if n_dst and self_rows is None:
+            xs = x if x_self is None else x_self
+            r0, k = self._range(n_dst)
+            ref = self._epi(self._agg_ref(indptr, indices, x, r0, k, mode, xs, row_scale, col_scale), ep_scale, ep_shift, relu)
+            diff = float((out[r0:r0 + k].double() - ref).abs().max())
+            again = self.be.spmm(indptr[r0:r0 + k + 1], indices, x, k, mode, row_scale=None if row_scale is None else row_scale[r0:r0 + k],
+                                 col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, x_self=xs[r0:r0 + k])
+            self._note(f"spmm d={x.shape[1]} rows={n_dst}", diff, bool(torch.equal(again, out[r0:r0 + k])))
+            if self.conservation and mode == self.be.AGG_SAGE_GCN and not relu:
+                err = self._conservation(indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift)
+                self.report[-1]["conservation_rel_err_fp64_all_rows"] = err
+                self.ok = self.ok and err < 1e-5
+        return out
+
+    def gemm(self, a, w, ep_scale=None, ep_shift=None, relu=False, out=None, **kw):
+        out = self.be.gemm(a, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out, **kw)
+        if not kw and a.shape[0]:
+            r0, k = self._range(a.shape[0])
+            ref = self._epi(a[r0:r0 + k].double() @ w.detach().double().t(), ep_scale, ep_shift, relu)
+            self._note(f"gemm m={a.shape[0]} k={a.shape[1]} n={w.shape[0]}", float((out[r0:r0 + k].double() - ref).abs().max()))
+        return out
+
+    def sage_fused(self, indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
+                   w_next=None, out_next=None, want_out=True):
+        res = self.be.sage_fused(indptr, indices, x, n_dst, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out, x_self=x_self,
+                                 w_packed=w_packed, w_next=w_next, out_next=out_next, want_out=want_out)
+        if n_dst:
+            xs = x if x_self is None else x_self
+            r0, k = self._range(n_dst)
+            h = self._epi(self._agg_ref(indptr, indices, x, r0, k, self.be.AGG_SAGE_GCN, xs) @ w.detach().double().t(), ep_scale, ep_shift, relu)
+            o, o2 = (res, None) if w_next is None else res
+            diff = 0.0
+            if o is not None:
+                diff = float((o[r0:r0 + k].double() - h).abs().max())
+            if w_next is not None:
+                diff = max(diff, float((o2[r0:r0 + k].double() - h @ w_next.detach().double().t()).abs().max()))
+            self._note(f"sage_fused d={x.shape[1]}->{w.shape[0]}" + (f"->{w_next.shape[0]}" if w_next is not None else "") + f" rows={n_dst}", diff)
+        return res
+
+
+XL_DIMS = [128, 256, 256, 47]      # 128-d features (BASELINE configs[4]); hidden 256 / 47 classes / BatchNorm as the products teacher (train.conf.yaml:196-204)
+XGMI_LINK_GBS = (64.0, 77.0)       # effective one-direction rate of ONE xGMI link (DESIGN.md section 6); 7 links per GPU, one per peer
+
+
+def kernel_breakdown(timing, steps):
+    """{launch family: ms per forward} from ops' (name, info, start, end) records (call after a synchronize)."""
+    per = {}
+    for name, info, s, e in timing:
+        if name == "gemm":
+            key = f"gemm k={info['k']} n={info['n']}"
+        elif name == "sage_fused":
+            key = f"sage_fused d={info['d']}->{info['d_out']}" + (f"->{info['d_chain']}" if info.get("d_chain") else "")
+        else:
+            key = f"spmm d={info['d']}"
+        per[key] = per.get(key, 0.0) + s.elapsed_time(e)
+    return {k: v / steps for k, v in per.items()}
+
+
 def run_xl(args, rank, world, dev, barrier):
-    """BASELINE.json configs[4]: synthetic 100M-node / 2B-edge graph over 8 GPUs = 12.5M destination rows and 250M
-    in-edges per GPU (generated on the device, never crossing PCIe), 128-d fp32 features replicated (static layer-1
-    input), SAGE-gcn layer-1 aggregation.  Weak scaling: per-GPU work is fixed, value = total edges/s."""
+    """BASELINE.json configs[4] as a TEACHER FORWARD (reference models.py:121-148: L layers of aggregate -> project -> BatchNorm(eval)
+    -> ReLU): synthetic 100M-node / 2B-edge graph over 8 GPUs = 12.5M destination rows and 250M in-edges per GPU (generated on the
+    device, never crossing PCIe), 128-d fp32 features replicated (static layer-1 input), 3-layer SAGE 128-256-256-47 through
+    glnn_amd.dist.ShardedTeacher: layer 1 aggregates at D=128 and exchanges the narrow aggregate (every rank projects all rows
+    itself) or its 256-wide output (--layer1-exchange wide); layer 2 is the fused aggregate + project kernel at D=256 chained
+    into layer 3's 256->47 projection; layer 3 exchanges the 47-wide rows and aggregates them.  Weak scaling: per-GPU work is
+    fixed, value = total edges/s.  N = 1 plays ONE rank of the --xl-shards-way run (dist.EmulatedPeers): every collective is a
+    local fill of the same bytes into the same slots -- the peers' rows are copies of this rank's own slab (the unsharded forward
+    needs 8 GPUs), so every kernel gathers over the full 100M-row buffers with the real run's (absent) locality; the fills stand
+    where the xGMI transfers would and are reported separately."""
     import torch.distributed as dist
-    from glnn_amd import ops
-    from glnn_amd.graph import CSRGraph
-    rows, deg, d = int(12_500_000 * args.scale), 20, 128
-    shards = world if world > 1 else max(1, args.xl_shards)      # N = 1: ONE rank's shard of the xl_shards-way run
-    n_total = rows * shards
+    from glnn_amd import data, ops
+    from glnn_amd import dist as gdist
+    from glnn_amd.models import Model
+    rows, deg, dims = int(12_500_000 * args.scale), 20, XL_DIMS
+    shards_n = world if world > 1 else max(1, args.xl_shards)      # N = 1: ONE rank's shard of the xl_shards-way run
+    me = rank if world > 1 else (args.emulate_rank if args.emulate_rank is not None else shards_n // 2)
+    n_total = rows * shards_n
+    g = data.make_xl_shard(rows, deg, n_total, seed=1000 + me, device=dev)
+    nnz = g.num_edges()
     gen = torch.Generator(device=dev)
-    gen.manual_seed(1000 + rank)
-    nnz = rows * deg
-    dst = torch.randint(0, rows, (nnz,), generator=gen, device=dev)
-    src = torch.randint(0, n_total, (nnz,), generator=gen, device=dev)
-    order = torch.argsort(dst)
-    indices = src[order].to(torch.int32)
-    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(torch.bincount(dst, minlength=rows), 0, out=indptr[1:])
-    del dst, src, order
-    g = CSRGraph(indptr, indices, rows, n_total)
-    x = torch.empty(n_total, d, device=dev)          # replicated static input (51.2 GB at 8 x 12.5M rows), filled in slabs
+    gen.manual_seed(4242)                                          # the replicated input: identical on every rank
+    x = torch.empty(n_total, dims[0], device=dev)                  # 51.2 GB at 8 x 12.5M rows, filled in slabs
     for s0 in range(0, n_total, 1 << 23):
         x[s0:s0 + (1 << 23)].normal_(generator=gen)
-    out = ops.feat_empty(rows, d, dev)
-    lo = (rank if world > 1 else shards // 2) * rows
+    torch.manual_seed(0)
+    teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.5,
+                         norm_type="batch", device=dev))
+    teacher.eval()
+    sh = gdist.RowShards(n_total, shards_n, me, chunks=args.xl_chunks)
+    peers = gdist.EmulatedPeers(shards_n, me) if world == 1 and shards_n > 1 else None
+    sharded = gdist.ShardedTeacher(teacher.encoder, g, sh, ops, group=peers, widening_exchange=args.layer1_exchange)
 
     def step():
-        ops.spmm(g.indptr, g.indices, x, rows, ops.AGG_SAGE_GCN, out=out, x_self=x[lo:lo + rows])
+        with torch.no_grad():
+            return sharded.forward(x)
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
+    timing = []
     barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if rank == 0:
+        ops.set_timing(timing)
+        if peers is not None:
+            peers.events = []
+    gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
     t0 = time.perf_counter()
-    for s_, e_ in evs:
-        s_.record(); step(); e_.record()
+    for _ in range(args.steps):
+        out = step()
     barrier()
     dt = time.perf_counter() - t0
+    ops.set_timing(None)
+    exch_gb = 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / args.steps
+    n_coll = gdist.EXCHANGE_STATS["collectives"] / args.steps
+    fills = peers.events if peers is not None else []
+    if peers is not None:
+        peers.events = None
+    verify = None
+    if not args.no_verify:                   # one more forward through the checking proxy (outside the timed region)
+        chk = CheckedBackend(ops, conservation=True)
+        sharded.be = chk
+        out_c = step()
+        sharded.be = ops
+        same = bool(torch.equal(out_c, out))
+        finite = bool(torch.isfinite(out).all())
+        t = torch.tensor([0.0 if (chk.ok and same and finite) else 1.0], device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        verify = {"ok": float(t.item()) == 0.0, "tolerance": chk.tol, "rows_sampled_per_launch": chk.sample, "launches": chk.report,
+                  "repeat_forward_bit_equal": same, "finite": finite,
+                  "what": "every launch of one extra forward: a sample of its rows recomputed in torch fp64 from the launch's own inputs, stand-alone "
+                          "aggregations also re-launched as a row range (bit-equal); max over ranks"}
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    if rank == 0:
-        kms = float(np.mean([s_.elapsed_time(e_) for s_, e_ in evs]))
-        b = alg_bytes(nnz, rows, d)
-        print(json.dumps({
-            "metric": "aggregated edges/sec, SAGE layer-1 aggregation, synthetic 100M-node / 2B-edge graph (BASELINE configs[4])",
-            "value": world * nnz * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": "synthetic-XL shard: uniform random multigraph, sources drawn over ALL nodes_total rows of the replicated "
-                                                        "feature matrix", "rows_per_gpu": rows,
-                                            "nnz_per_gpu": nnz, "nodes_total": n_total, "source_matrix_GB": 4e-9 * n_total * d, "d": d,
-                                            "parallelism": f"row shards x{shards}" + (f" ({world} of them timed)" if world != shards else "")
-                                                           + ", no collective (static input replicated)"},
-            "roofline": {"bound": "hbm", "kernel": f"spmm_csr_kernel<LPR={lanes_per_row(d)},U={SPMM_U},SAGE_GCN> (D={d})", "achieved": b / kms / 1e6,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / kms / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": b, "avg_launch_ms": kms}}), flush=True)
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    torch.cuda.synchronize()
+    ms = kernel_breakdown(timing, args.steps)
+    fill_ms = {}
+    for tag, nbytes, s_, e_ in fills:
+        k = f"{tag[0]}{tag[1]}"
+        fill_ms[k] = fill_ms.get(k, 0.0) + s_.elapsed_time(e_) / args.steps
+    d0, d1, d2, c = dims
+    wide = args.layer1_exchange == "wide"
+    layers = []
+
+    def agg_layer(name, key, d, d_written, what):
+        t = ms.get(key)
+        if t is None:
+            return
+        b = alg_bytes(nnz, rows, d, d_written)
+        layers.append({"layer": name, "kernel": what, "bound": "hbm", "ms": t, "alg_GB": b / 1e9, "achieved": b / t / 1e6, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": b / t / 1e6 / HBM_PEAK_GBS, "Gedges_per_s": nnz / t / 1e6})
+
+    def gemm_layer(name, key, m, k, n):
+        t = ms.get(key)
+        if t is None:
+            return
+        fl = 2.0 * m * k * n
+        layers.append({"layer": name, "kernel": key, "bound": "mfma", "ms": t, "GFLOP": fl / 1e9, "achieved": fl / t / 1e9, "peak": 157.3,
+                       "unit": "TFLOP/s", "frac": fl / t / 1e9 / 157.3})
+
+    def exchange_layer(name, key, width):
+        gb = 4e-9 * sh.n_pad * ((width + 3) // 4 * 4) * (shards_n - 1) / shards_n
+        link = [1e3 * gb / (shards_n - 1) / r for r in XGMI_LINK_GBS] if shards_n > 1 else [0.0, 0.0]
+        layers.append({"layer": name, "kernel": "all-gather over xGMI" + (" (EMULATED: local fill of the same bytes)" if peers is not None else ""),
+                       "GB_received_per_rank": gb, "emulated_fill_ms": fill_ms.get(key), "modelled_link_ms": link,
+                       "model": f"{shards_n - 1} peers on {shards_n - 1} links in parallel at {XGMI_LINK_GBS[0]:.0f}-{XGMI_LINK_GBS[1]:.0f} GB/s each; chunked x{sh.chunks}: "
+                                "all but the first chunk can hide under the producing kernel"})
+
+    if wide:
+        agg_layer("1 aggregate+project (own rows)", f"sage_fused d={d0}->{d1}", d0, d1, f"sage_fused_kernel<LPR={lanes_per_row(d0)}>")
+        exchange_layer("1 exchange (256-wide output)", "y0", d1)
+    else:
+        agg_layer("1 aggregate (own rows)", f"spmm d={d0}", d0, None, f"spmm_csr_kernel<LPR={lanes_per_row(d0)},U={SPMM_U},SAGE_GCN>")
+        exchange_layer("1 exchange (128-wide aggregate)", "agg0", d0)
+        gemm_layer("1 projection (replicated: ALL rows on every rank)", f"gemm k={d0} n={d1}", sh.n_pad, d0, d1)
+    agg_layer("2 aggregate+project+chained 256->47 (own rows)", f"sage_fused d={d1}->{d2}->{c}", d1, c,
+              f"sage_fused_kernel<LPR=64> (only the 47 chained floats per row are written)")
+    exchange_layer("3 exchange (47-wide projected rows)", "hw2", c)
+    agg_layer("3 aggregate (own rows)", f"spmm d={c}", c, None, f"spmm_csr_kernel<LPR={lanes_per_row(c)},U={SPMM_U},SAGE_GCN>")
+    kernel_ms = sum(ms.values())
+    fill_total = sum(fill_ms.values())
+    dom = max((l for l in layers if l.get("bound") == "hbm"), key=lambda l: l["ms"])
+    result = {
+        "metric": "aggregated edges/sec, 3-layer SAGE teacher forward, synthetic 100M-node / 2B-edge graph (BASELINE configs[4])",
+        "value": world * 3 * nnz * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "verified": None if verify is None else verify["ok"],
+        "config": {"workload": f"synthetic-XL teacher forward: SAGE {'-'.join(map(str, dims))} (BN eval), one rank's shard of a uniform random multigraph "
+                               "whose sources are drawn over ALL nodes_total rows", "rows_per_gpu": rows, "nnz_per_gpu": nnz, "nodes_total": n_total,
+                   "shards": shards_n, "rank_timed": me, "chunks": sh.chunks, "layer1_exchange": args.layer1_exchange,
+                   "input_GB": 4e-9 * n_total * d0, "hidden_GB": 4e-9 * sh.n_pad * d1,
+                   "parallelism": f"row shards x{shards_n}, ShardedTeacher" + (f"; N = 1: rank {me} with EMULATED peers (collectives = local fills, peers' rows = "
+                                                                              "copies of the own slab)" if peers is not None else ", RCCL all-gathers")},
+        "per_forward": {"wall_ms": 1e3 * dt / args.steps, "kernel_ms": kernel_ms, "emulated_fill_ms": fill_total if peers is not None else None,
+                        "GB_received_per_rank": exch_gb, "collectives": n_coll, "kernels": ms},
+        "layers": layers,
+        "roofline": {"bound": "hbm", "kernel": f"{dom['kernel']} (layer {dom['layer']})", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac"], "traffic": None, "algorithmic_bytes_per_launch_sum": dom["alg_GB"] * 1e9, "avg_ms_per_forward": dom["ms"]},
+        "verify": verify,
+    }
+    emit(result, args)
     if world > 1:
         dist.destroy_process_group()
+
+
+def run_emulated(args, dev):
+    """bench.py --emulate 2,4,8: the COMPUTE half of the multi-GPU scaling model, measured on one GPU.  For every world size N and
+    every rank r the sharded forward of rank r runs here with dist.EmulatedPeers: the row ranges are RowShards.balanced_bounds',
+    every collective is a local fill of the same bytes with the rows an unsharded forward produced (so rank r's output must equal
+    the unsharded rows: checked), and ops' per-launch events give the rank's kernel time.  Three forms: all-gather exchange with
+    the narrow / the wide layer 1 on the prescribed products-shaped graph, and the overlapped halo exchange on a clustered graph
+    whose ids were shuffled and restored by the label-propagation partitioner."""
+    from glnn_amd import data, ops
+    from glnn_amd import dist as gdist
+    from glnn_amd.graph import FullNeighborLoader
+    from glnn_amd.models import Model
+    worlds = [int(v) for v in args.emulate.split(",") if v]
+    n_full = int(data.SHAPES[GRAPH]["n"] * args.scale)
+    torch.manual_seed(0)
+    teacher = Model(dict(model_name="SAGE", num_layers=3, feat_dim=SAGE_DIMS[0], hidden_dim=SAGE_DIMS[1], label_dim=SAGE_DIMS[-1], dropout_ratio=0.5,
+                         norm_type="batch", device=dev))
+    teacher.eval()
+    enc = teacher.encoder
+    steps, out = max(1, args.steps), {}
+    forms = [("allgather-narrow", "products", dict(exchange="allgather", l1="narrow")), ("allgather-wide", "products", dict(exchange="allgather", l1="wide")),
+             ("halo-lp", "clustered", dict(exchange="halo"))]
+    graphs = {}
+    for form, gkind, cfg in forms:
+        if gkind not in graphs:
+            graphs.clear()
+            torch.cuda.empty_cache()
+            if gkind == "products":
+                g = data.make_graph(GRAPH, seed=0, device=dev, scale=args.scale)
+                prep = None
+            else:
+                g0 = data.make_clustered_graph(n_full, 50.5, communities=64, p_in=0.95, seed=0, device=dev, shuffle_ids=True)
+                t0 = time.perf_counter()
+                perm = data.locality_order(g0, seed=0)
+                g = data.relabel(g0, perm)
+                torch.cuda.synchronize()
+                prep = time.perf_counter() - t0
+                del g0, perm
+            feats = ops.as_feat(torch.randn(g.n_dst, SAGE_DIMS[0], device=dev))
+            with torch.no_grad():
+                truth, want = gdist.record_truth(enc, g, feats, ops)
+                loader = FullNeighborLoader(g, 4096)
+                for _ in range(2):
+                    teacher.inference(loader, feats)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    teacher.inference(loader, feats)
+                torch.cuda.synchronize()
+                one_gpu_ms = 1e3 * (time.perf_counter() - t0) / steps
+            graphs[gkind] = (g, feats, truth, want, one_gpu_ms, prep)
+        g, feats, truth, want, one_gpu_ms, prep = graphs[gkind]
+        n, nnz = g.n_dst, g.num_edges()
+        res = {"graph": ("products-shaped power-law multigraph, random node order" if gkind == "products" else
+                         "community-structured graph (64 communities, 0.95 of the edges inside), node ids shuffled, then renumbered by data.locality_order"),
+               "nodes": n, "nnz": nnz, "one_gpu_forward_ms": one_gpu_ms, "partition_seconds": prep, "worlds": {}}
+        for N in worlds:
+            bounds = gdist.RowShards.balanced_bounds(g.indptr, N)
+            ranks = []
+            for r in range(N):
+                sh = gdist.RowShards(n, N, r, chunks=4, bounds=bounds)
+                peers = gdist.EmulatedPeers(N, r, truth=truth, full_graph=g if cfg["exchange"] == "halo" else None)
+                shard = g.row_range(sh.lo, sh.hi)
+                if cfg["exchange"] == "halo":
+                    t = gdist.HaloShardedTeacher(enc, shard, sh, ops, group=peers, overlap=True)
+                else:
+                    t = gdist.ShardedTeacher(enc, shard, sh, ops, group=peers, widening_exchange=cfg["l1"])
+                with torch.no_grad():
+                    t.forward(feats)                       # warm-up (buffers, relabelled columns, packed weights)
+                    timing, peers.events = [], []
+                    gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+                    torch.cuda.synchronize()
+                    ops.set_timing(timing)
+                    t0 = time.perf_counter()
+                    for _ in range(steps):
+                        y = t.forward(feats)
+                    torch.cuda.synchronize()
+                    wall = 1e3 * (time.perf_counter() - t0) / steps
+                    ops.set_timing(None)
+                kms = kernel_breakdown(timing, steps)
+                fill = sum(s_.elapsed_time(e_) for _, _, s_, e_ in peers.events) / steps
+                c = want.shape[1]
+                diff = float((y[:, :c] - want[sh.lo:sh.hi, :c]).abs().max()) if sh.rows else 0.0
+                ranks.append({"rank": r, "rows": sh.rows, "nnz": int(shard.num_edges()), "wall_ms": wall, "kernel_ms": sum(kms.values()), "fill_ms": fill,
+                              "GB_received": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / steps, "kernels": kms,
+                              "halo_rows": getattr(getattr(t, "plan", None), "n_halo", None), "max_abs_diff_vs_unsharded": diff})
+                del t, peers, shard, y
+                torch.cuda.empty_cache()
+            kmax = max(x_["kernel_ms"] for x_ in ranks)
+            gb = max(x_["GB_received"] for x_ in ranks)
+            link = [1e3 * gb / max(1, N - 1) / rt for rt in XGMI_LINK_GBS]       # the N-1 peers send over N-1 links in parallel
+            res["worlds"][str(N)] = {
+                "max_kernel_ms": kmax, "mean_kernel_ms": float(np.mean([x_["kernel_ms"] for x_ in ranks])), "max_GB_received_per_rank": gb,
+                "modelled_link_ms": link, "forward_ms_exchange_hidden": max(kmax, link[1]), "forward_ms_exchange_exposed": kmax + link[0],
+                "speedup_vs_one_gpu": [one_gpu_ms / (kmax + link[0]), one_gpu_ms / max(kmax, link[1])],
+                "verified": all(x_["max_abs_diff_vs_unsharded"] <= 1e-4 for x_ in ranks), "ranks": ranks}
+        out[form] = res
+    result = {"metric": "per-rank kernel time of the N-rank sharded teacher forward, every rank emulated on ONE GPU (compute half of the scaling model)",
+              "value": None, "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": 1, "ms_per_step": None, "higher_is_better": False, "scaling": "strong",
+              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": f"{GRAPH}-shaped SAGE teacher forward, ranks of N = {worlds} emulated (dist.EmulatedPeers, truth fills)", "scale": args.scale,
+                         "link_GBps_assumed": list(XGMI_LINK_GBS)},
+              "verified": all(w["verified"] for f in out.values() for w in f["worlds"].values()),
+              "scale_model": out}
+    emit(result, args)
+
+
+def emit(result, args):
+    """Print the long object first (one line, prefixed so that it is not mistaken for THE line), write it to the detail file, then
+    ONE compact JSON line (<= 4 KB) last: the driver's record keeps only the tail of stdout."""
+    path = args.detail_file
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    if path:
+        try:
+            with open(path, "w") as f:
+                json.dump(result, f)
+        except OSError:
+            path = None
+    print("DETAIL " + json.dumps(result), flush=True)
+    print(json.dumps(compact(result, path)), flush=True)
+
+
+def _short(v, n=160):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+
+
+def compact(r, detail_path):
+    """The contract keys + the headline numbers of every object; long prose, per-launch lists and sweeps stay in the DETAIL line."""
+    c = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data", "verified", "rccl_ranks", "backend")}
+    cfg = r.get("config", {})
+    c["config"] = {k: _short(v, 200) for k, v in cfg.items() if k in ("workload", "nodes", "nnz", "edges_aggregated_per_step", "scale", "exchange",
+                                                                       "layer1_exchange", "partition", "parallelism", "rows_per_gpu", "nnz_per_gpu",
+                                                                       "nodes_total", "shards", "rank_timed", "link_GBps_assumed")}
+    v = r.get("verify")
+    if v:
+        c["verify"] = {k: v[k] for k in ("max_abs_diff_vs_unfused_aggregate_first", "max_abs_diff_vs_unsharded", "layer1_conservation_rel_err_fp64",
+                                         "tolerance", "repeat_forward_bit_equal") if k in v}
+        if "launches" in v:
+            c["verify"]["max_abs_diff_vs_fp64"] = max([l["max_abs_diff_vs_fp64"] for l in v["launches"]] or [0.0])
+    rf = r.get("roofline")
+    if rf:
+        c["roofline"] = {k: _short(rf.get(k), 120) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                              "avg_launch_ms", "algorithmic_bytes_per_launch_sum", "avg_ms_per_forward") if k in rf}
+        if rf.get("traffic") is not None:
+            c["roofline"]["traffic_source"] = "static: " + PMC_FILE
+        if "hbm_bytes_estimated" in rf:
+            h = rf["hbm_bytes_estimated"]
+            c["roofline"]["hbm_frac_bracket"] = [h["frac_of_peak_lower"], h["frac_of_peak_upper"]]
+        if "all_aggregation_launches" in rf:
+            c["roofline"]["launches"] = [{"d": l["d"], "ms": l["avg_ms"], "GBps": l["GBps"]} for l in rf["all_aggregation_launches"]]
+            c["roofline"]["dense_ms"] = rf.get("dense_projection_ms_per_forward")
+    for key in ("roofline_reordered", "roofline_clustered"):
+        if key in r:
+            c[key] = {"edges_per_s": r[key]["edges_per_s"], "ms_per_step": r[key]["ms_per_step"], "frac": r[key]["frac"]}
+    if "layers" in r:
+        c["layers"] = [{k: _short(l.get(k), 60) for k in ("layer", "bound", "ms", "achieved", "unit", "frac", "GB_received_per_rank", "emulated_fill_ms",
+                                                           "modelled_link_ms") if l.get(k) is not None} for l in r["layers"]]
+        c["per_forward"] = {k: r["per_forward"][k] for k in ("wall_ms", "kernel_ms", "emulated_fill_ms", "GB_received_per_rank")}
+    st = r.get("student")
+    if st:
+        c["student"] = {"metric": _short(st["metric"], 90), "value": st["value"], "unit": st["unit"], "ms_per_step": st["ms_per_step"], "steps": st["steps"],
+                        "tflops": st["tflops"], "frac_of_fp32_mfma_peak": st["frac_of_fp32_mfma_peak"]}
+    if "students_small" in r:
+        c["students_small"] = {s_["student"]: round(s_["ms_per_step"], 4) for s_ in r["students_small"]}
+    if "teacher_training" in r:
+        c["teacher_training"] = {"steps_per_s": r["teacher_training"]["value"], "ms_per_step": r["teacher_training"]["ms_per_step"]}
+    cb = r.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 200),
+                             "student_steps_per_s": cb["student_steps_per_s"], "student_threads": cb["student_threads_best"]}
+    if r.get("exchange"):
+        c["exchange"] = {k: r["exchange"][k] for k in ("GB_received_per_rank_per_forward", "collectives_per_forward")}
+    if "scale_model" in r:
+        c["scale_model"] = {f: {"one_gpu_ms": o["one_gpu_forward_ms"],
+                                **{N: {"max_kernel_ms": w["max_kernel_ms"], "GB": w["max_GB_received_per_rank"], "link_ms": w["modelled_link_ms"],
+                                       "speedup": w["speedup_vs_one_gpu"]} for N, w in o["worlds"].items()}} for f, o in r["scale_model"].items()}
+    c["detail"] = "the preceding stdout line (prefix 'DETAIL ')" + (f" and {os.path.relpath(detail_path, ROOT)}" if detail_path else "")
+    return c
 
 
 def cpu_baseline(sd, dev, scale, budget):

@@ -163,6 +163,18 @@ def make_uniform_graph(n, avg_deg, seed=0, device="cpu"):
     return csr_from_edges(src, dst, n)
 
 
+def make_xl_shard(rows, avg_deg, n_total, seed=0, device="cpu"):
+    """One rank's destination rows of the synthetic-XL graph (BASELINE configs[4]: 100 M nodes / 2 B edges over 8 ranks = 12.5 M
+    rows and 250 M in-edges per rank): `rows` destinations, rows * avg_deg in-edges whose sources are uniform over ALL n_total
+    nodes (global ids), generated on `device` from a seeded counter RNG -- the graph never crosses PCIe."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    nnz = int(rows * avg_deg)
+    dst = torch.randint(0, rows, (nnz,), generator=gen, device=device)
+    src = torch.randint(0, n_total, (nnz,), generator=gen, device=device)
+    return csr_from_edges(src, dst, rows, n_total)
+
+
 def make_node_data(name, seed=0, device="cpu", scale=1.0, n=None):
     """feats ~ N(0,1) fp32, labels uniform int64, teacher out_t = log_softmax(N(0,1)), index split."""
     sh = SHAPES[name]

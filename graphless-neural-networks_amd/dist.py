@@ -89,6 +89,121 @@ def _count(out_block):
     EXCHANGE_STATS["floats_received"] += out_block.numel()
 
 
+class EmulatedPeers:
+    """In-process stand-in for the process group of a `world`-rank job: THIS process plays rank `rank`, the peers do not run.
+    Pass it as `group=` to ShardedTeacher / HaloShardedTeacher / HaloPlan (with RowShards(n, world, rank, ...)): every collective
+    of this module then writes -- with local device copies -- the same number of bytes into the same places the real transport
+    would, so that one GPU can time rank r's kernels of the N-rank forward (bench.py --emulate N, --workload xl).  Two sources:
+      truth[tag]  the full [n, d] activation a boundary exchanges, natural node order, taken from an UNSHARDED forward
+                  (`record_truth`): the peers' rows are the real ones and the emulated rank's output equals the unsharded rows;
+      no truth    the peers' slots are filled with copies of this rank's own slab (right volume, made-up values): the
+                  synthetic-XL shard, whose unsharded forward no single GPU can hold.
+    Tags: ("agg", l) the aggregate of widening layer l, ("y", l) the output of layer l, ("hw", l) the projected rows of
+    narrowing layer l.  `full_graph` (all rows, global ids) lets HaloPlan derive what the peers would request from this rank.
+    `events` collects (tag, bytes, start, end) device events of the fills when the tensors live on a GPU."""
+
+    def __init__(self, world, rank, truth=None, full_graph=None):
+        self.world, self.rank = int(world), int(rank)
+        self.truth = truth or {}
+        self.full_graph = full_graph
+        self.events = None          # set to a list to time the fills
+
+    def _timed(self, tag, nbytes, like):
+        if self.events is None or not like.is_cuda:
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        return (tag, nbytes, s)
+
+    def _done(self, rec):
+        if rec is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append(rec + (e,))
+
+    def fill_slots(self, base, mine, shards, tag, rows_per_slot, row_offset):
+        """The all-gather of one [world * rows_per_slot, ld] block `base` whose slot `rank` (= `mine`) is filled: slot p receives
+        rank p's rows [row_offset, row_offset + rows_per_slot) of its own range (clipped to the range)."""
+        t = self.truth.get(tag)
+        rec = self._timed(tag, (shards.world - 1) * mine.numel() * 4, base)
+        my_nr = max(0, min(shards.rows - row_offset, rows_per_slot))         # valid rows of `mine` (the rest of the slot is padding)
+        for p in range(shards.world):
+            if p == shards.rank:
+                continue
+            dst = base[p * rows_per_slot:(p + 1) * rows_per_slot]
+            lo = shards.bounds[p] + row_offset
+            nr = max(0, min(shards.bounds[p + 1] - lo, rows_per_slot))
+            if nr == 0:
+                continue
+            if t is not None:
+                dst[:nr, :t.shape[1]].copy_(t[lo:lo + nr])
+            elif my_nr == 0:
+                dst[:nr].zero_()
+            elif nr <= my_nr:
+                dst[:nr].copy_(mine[:nr])
+            else:                      # the peer's range is longer than mine: repeat my rows
+                dst[:nr].copy_(mine[torch.arange(nr, device=mine.device) % my_nr])
+        self._done(rec)
+
+    def peer_requests(self, shards):
+        """Per peer p: the sorted node ids inside THIS rank's range that p's rows reference (what p's HaloPlan would ask for)."""
+        g = self.full_graph
+        if g is None:
+            raise RuntimeError("EmulatedPeers: the halo plan of an emulated rank needs full_graph (all rows, global ids)")
+        out = []
+        for p in range(shards.world):
+            if p == shards.rank:
+                out.append(torch.empty(0, dtype=torch.int64, device=g.indices.device))
+                continue
+            e0, e1 = int(g.indptr[shards.bounds[p]]), int(g.indptr[shards.bounds[p + 1]])
+            u = torch.unique(g.indices[e0:e1].long())
+            out.append(u[(u >= shards.lo) & (u < shards.hi)])
+        return out
+
+    def fill_halo(self, out, send, tag, ids):
+        """The halo all-to-all: `out` [n_halo, w] receives the rows of node ids `ids` (ascending = grouped by owner)."""
+        t = self.truth.get(tag)
+        rec = self._timed(tag, out.numel() * 4, out)
+        if out.shape[0]:
+            if t is not None:
+                out[:, :t.shape[1]].copy_(t[ids])
+            elif send.shape[0]:
+                out.copy_(send[torch.arange(out.shape[0], device=out.device) % send.shape[0]])
+            else:
+                out.zero_()
+        self._done(rec)
+
+
+def _emu(group):
+    return group if isinstance(group, EmulatedPeers) else None
+
+
+def record_truth(encoder, graph, x, be):
+    """The unsharded layer-wise forward of `encoder` (SAGE, eval) over the whole `graph`, keeping what the sharded forms put on
+    the wire: {("agg", l) | ("hw", l) | ("y", l): [n, d]} for EmulatedPeers(truth=...), and the logits.  Stand-alone aggregation +
+    GEMM per layer (no fused kernel), project-first when the layer narrows -- the same arithmetic the sharded layers use."""
+    truth = {}
+    L = encoder.num_layers
+    n = graph.n_dst
+    h = be.as_feat(x)
+    for l, layer in enumerate(encoder.layers):
+        w = layer.fc_neigh.weight
+        es, eh, relu = encoder._tail(l)
+        d_out, d_in = w.shape
+        if d_in > d_out:
+            hw = be.gemm(h, w)
+            truth[("hw", l)] = hw
+            h = be.spmm(graph.indptr, graph.indices, hw, n, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=relu)
+        else:
+            agg = be.spmm(graph.indptr, graph.indices, h, n, be.AGG_SAGE_GCN)
+            if l < L - 1 and 2 * d_in <= d_out:
+                truth[("agg", l)] = agg
+            h = be.gemm(agg, w, ep_scale=es, ep_shift=eh, relu=relu)
+        if l < L - 1:
+            truth[("y", l)] = h
+    return truth, h
+
+
 def _storage_rows(buf):
     """The contiguous [rows, ld] tensor behind a feature view [rows, d] (ld = row stride >= d)."""
     if buf.is_contiguous():
@@ -96,16 +211,19 @@ def _storage_rows(buf):
     return torch.as_strided(buf, (buf.shape[0], buf.stride(0)), (buf.stride(0), 1))
 
 
-def all_gather_rows(buf, shards, group=None):
+def all_gather_rows(buf, shards, group=None, tag=None):
     """In-place all-gather of the [n_pad, d] feature buffer `buf` (row stride ld) whose slot [rank*rpr, (rank+1)*rpr) this
     rank has filled.  The collective runs on the contiguous padded storage, whole rows including the [d, ld) padding
     columns, so that every rank's slab is ONE contiguous block.  RCCL: the in-place form (send buffer = this rank's slab of
     the receive buffer, ncclAllGather's documented sendbuff == recvbuff + rank * sendcount case) -- no staging copy."""
-    if shards.world == 1 and not FORCE_COLLECTIVES:
+    if shards.world == 1 and not FORCE_COLLECTIVES and not _emu(group):
         return buf
     base = _storage_rows(buf)
     mine = base[shards.slot:shards.slot + shards.rpr]
     _count(base)
+    if _emu(group):
+        group.fill_slots(base, mine, shards, tag, shards.rpr, 0)
+        return buf
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(base, mine, group=group)
     else:   # gloo (CPU tests): list form
@@ -116,10 +234,13 @@ def all_gather_rows(buf, shards, group=None):
     return buf
 
 
-def _all_gather_block(out_block, mine, shards, group):
+def _all_gather_block(out_block, mine, shards, group, tag=None, chunk=0):
     """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot inside it (in place).
     Returns a callable that makes the current stream wait for it."""
     _count(out_block)
+    if _emu(group):
+        group.fill_slots(out_block, mine, shards, tag, shards.cr, chunk * shards.cr)
+        return lambda: None
     if dist.get_backend(group) == "nccl":
         work = dist.all_gather_into_tensor(out_block, mine, group=group, async_op=True)
         return work.wait
@@ -229,7 +350,7 @@ class ShardedTeacher:
             p0 = (c * sh.world + sh.rank) * sh.cr
             if nr > 0:
                 be.spmm(g.indptr[off:off + nr + 1], idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=self._chunk_self(x, layout, c))
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("agg", l), c))
         y = self._full_buffer(("ycm", l), d_out, x.device)
         for c in range(sh.chunks):
             works[c]()
@@ -259,7 +380,7 @@ class ShardedTeacher:
                 else:
                     agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("y", l), c))
         for wk in works:
             wk()
         return y
@@ -274,7 +395,7 @@ class ShardedTeacher:
         tail1, tail2 = enc._tail(l), enc._tail(l + 1)
         d_mid, d_out = w1.shape[0], w2.shape[0]
         last = l + 1 == enc.num_layers - 1
-        y_own = self._own(("y", l), d_mid, x.device)
+        y_own = None      # (fallback branch only: the fused launch never writes layer l's rows; own rows, not an n_pad-row buffer)
         hw = self._full_buffer(("hwcm", l + 1), d_out, x.device)          # chunk-major [C][P][cr]
         base = _storage_rows(hw)
         span = sh.world * sh.cr
@@ -292,10 +413,14 @@ class ShardedTeacher:
                     be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
                                   want_out=False)
                 else:
+                    if y_own is None:
+                        if ("y_own", l) not in self._bufs:
+                            self._bufs[("y_own", l)] = be.feat_empty(sh.rows, d_mid, x.device)
+                        y_own = self._bufs[("y_own", l)]
                     agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
                     be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
                     be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group))
+            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("hw", l + 1), c))
         out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l + 1), d_out, x.device)
         for wk in works:
             wk()
@@ -330,7 +455,7 @@ class ShardedTeacher:
                 hw = self._full_buffer(("hw", l), d_out, x.device)
                 for off, nr, sl in self._pieces(layout):
                     be.gemm(x[sl], w, out=hw[sh.slot + off:sh.slot + off + nr])
-                all_gather_rows(hw, sh, self.group)
+                all_gather_rows(hw, sh, self.group, ("hw", l))
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l), d_out, x.device)
                 be.spmm(g.indptr, self._cols("own"), hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                         out=out, x_self=hw[sh.slot:sh.slot + sh.rows])
@@ -352,7 +477,7 @@ class ShardedTeacher:
                     agg = self._full_buffer(("agg", l), d_in, x.device)
                     (_, _, sl), = self._pieces(layout)
                     be.spmm(g.indptr, self._cols(layout), x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.slot:sh.slot + sh.rows], x_self=x[sl])
-                    all_gather_rows(agg, sh, self.group)
+                    all_gather_rows(agg, sh, self.group, ("agg", l))
                     y_full = self._full_buffer(("y", l), d_out, x.device)
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)
                     x, layout = y_full, "own"
@@ -374,7 +499,7 @@ class ShardedTeacher:
                 if dims[l + 1][0] > dims[l + 1][1]:
                     x, complete = buf, False          # the next (narrowing) layer projects its own rows only: no exchange
                 else:
-                    x, complete = all_gather_rows(buf, sh, self.group), True
+                    x, complete = all_gather_rows(buf, sh, self.group, ("y", l)), True
                 layout = "own"
             l += 1
         return y_own
@@ -397,9 +522,15 @@ class HaloPlan:
         owner = torch.searchsorted(b[1:], remote, right=True)
         self.recv_counts = torch.bincount(owner, minlength=sh.world).tolist()        # rows I receive from each rank
         self.n_halo = int(remote.numel())
-        send_counts = _all_to_all_counts(self.recv_counts, sh, dev, group)
+        self.remote = remote                                                         # halo row i holds node remote[i]
+        if _emu(group):                       # the peers do not run: derive their requests from the full graph
+            req = group.peer_requests(sh)
+            send_counts = [int(r.numel()) for r in req]
+            wanted = torch.cat(req)
+        else:
+            send_counts = _all_to_all_counts(self.recv_counts, sh, dev, group)
+            wanted = _all_to_all_rows(remote.unsqueeze(1).contiguous(), self.recv_counts, send_counts, sh, group).squeeze(1)
         self.send_counts = send_counts                                               # rows each rank wants from me
-        wanted = _all_to_all_rows(remote.unsqueeze(1).contiguous(), self.recv_counts, send_counts, sh, group).squeeze(1)
         if wanted.numel() and (int(wanted.min()) < sh.lo or int(wanted.max()) >= sh.hi):
             raise RuntimeError("HaloPlan: a peer asked for rows this rank does not own")
         self.send_rows = (wanted - sh.lo).contiguous()                               # local row offsets, grouped by requesting rank
@@ -447,7 +578,7 @@ def _all_to_all_counts(counts, shards, dev, group):
     return [int(gathered[r][shards.rank]) for r in range(shards.world)]
 
 
-def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None):
+def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None, tag=None, ids=None):
     """Variable all-to-all of whole rows: `send` [sum(send_counts), w] grouped by destination rank -> [sum(recv_counts), w]
     grouped by source rank.  RCCL: one all_to_all_single with split sizes; gloo (CPU tests): pairwise isend / irecv."""
     n_recv = int(sum(recv_counts))
@@ -455,6 +586,9 @@ def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None):
         out = torch.empty((n_recv, send.shape[1]), dtype=send.dtype, device=send.device)
     EXCHANGE_STATS["collectives"] += 1
     EXCHANGE_STATS["floats_received"] += (n_recv - int(recv_counts[shards.rank])) * send.shape[1]
+    if _emu(group):
+        group.fill_halo(out, send, tag, ids)
+        return out
     if shards.world == 1 and not FORCE_COLLECTIVES:
         out.copy_(send)
         return out
@@ -482,13 +616,16 @@ def _all_to_all_rows(send, send_counts, recv_counts, shards, group, out=None):
     return out
 
 
-def _all_to_all_rows_async(send, send_counts, recv_counts, shards, group, out):
+def _all_to_all_rows_async(send, send_counts, recv_counts, shards, group, out, tag=None, ids=None):
     """_all_to_all_rows started without waiting for it: returns a callable that completes `out` (RCCL: the collective runs on
     the communicator's stream, the callable makes the current stream wait for it; gloo: the isend / irecv requests are posted
     here and reaped by the callable)."""
     n_recv = int(sum(recv_counts))
     EXCHANGE_STATS["collectives"] += 1
     EXCHANGE_STATS["floats_received"] += (n_recv - int(recv_counts[shards.rank])) * send.shape[1]
+    if _emu(group):
+        group.fill_halo(out, send, tag, ids)
+        return lambda: None
     if shards.world == 1 and not FORCE_COLLECTIVES:
         out.copy_(send)
         return lambda: None
@@ -545,21 +682,21 @@ class HaloShardedTeacher:
             self._bufs[k] = self.be.feat_empty(self.plan.rows + self.plan.n_halo, d, device, zero=True)
         return self._bufs[k]
 
-    def _exchange(self, buf):
+    def _exchange(self, buf, tag=None):
         """Fill the halo rows of the local buffer `buf` (own rows valid) from their owners."""
         pl, be = self.plan, self.be
         base = _storage_rows(buf)
         own = base[:pl.rows]
         send = _storage_rows(be.gather_rows(buf[:pl.rows], pl.send_rows)) if hasattr(be, "gather_rows") else own[pl.send_rows]
-        _all_to_all_rows(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, out=base[pl.rows:])
+        _all_to_all_rows(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, out=base[pl.rows:], tag=tag, ids=pl.remote)
         return buf
 
-    def _exchange_async(self, own, dst):
+    def _exchange_async(self, own, dst, tag=None):
         """Start filling dst[rows:] (halo rows) from the owners' rows of `own` ([rows, d] view of a local buffer); returns finish()."""
         pl, be = self.plan, self.be
         base = _storage_rows(dst)
         send = _storage_rows(be.gather_rows(own, pl.send_rows)) if hasattr(be, "gather_rows") else _storage_rows(own)[pl.send_rows]
-        return _all_to_all_rows_async(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, base[pl.rows:])
+        return _all_to_all_rows_async(send.contiguous(), pl.send_counts, pl.recv_counts, self.sh, self.group, base[pl.rows:], tag=tag, ids=pl.remote)
 
     def _aggregate_two_pass(self, key, own, d, finish, tail=(None, None, False), out=None):
         """SAGE-"gcn" mean of the own rows from an input whose halo rows are still in flight into buffer `key2` = [P | halo]:
@@ -595,13 +732,13 @@ class HaloShardedTeacher:
                 hw = self._local(("hw", l), d_out, x.device)
                 be.gemm(own, w, out=hw[:pl.rows])
                 key2 = ("hw2", l)
-                fin = self._exchange_async(hw[:pl.rows], self._local(key2, d_out, x.device))
+                fin = self._exchange_async(hw[:pl.rows], self._local(key2, d_out, x.device), ("hw", l))
                 nxt = None if last else self._local(("y", l), d_out, x.device)
                 out = self._aggregate_two_pass(key2, hw[:pl.rows], d_out, fin, tail, out=None if last else nxt[:pl.rows])
                 full, cols, own, pending = None, pl.cols, out, None
                 if not last:
                     if not dims[l + 1][0] > dims[l + 1][1]:
-                        pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device)))
+                        pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device), ("y", l)))
                 continue
             # aggregate-first layers need the mean of the own rows over ALL their edges
             widening = not last and 2 * d_in <= d_out
@@ -615,7 +752,7 @@ class HaloShardedTeacher:
             else:
                 raise RuntimeError("HaloShardedTeacher: internal error, an aggregating layer needs its halo rows")
             if widening:                          # exchange the narrow aggregate, project own rows meanwhile, halo rows after
-                fin = self._exchange_async(a_buf[:pl.rows], a_buf)
+                fin = self._exchange_async(a_buf[:pl.rows], a_buf, ("agg", l))
                 nxt = self._local(("y", l), d_out, x.device)
                 be.gemm(a_buf[:pl.rows], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=nxt[:pl.rows])
                 fin()
@@ -629,7 +766,7 @@ class HaloShardedTeacher:
             if not last:
                 own, full, cols = nxt[:pl.rows], None, pl.cols
                 if not dims[l + 1][0] > dims[l + 1][1]:      # the next layer aggregates these rows: start their exchange now
-                    pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device)))
+                    pending = (("y2", l), self._exchange_async(own, self._local(("y2", l), d_out, x.device), ("y", l)))
         return out
 
     def forward(self, x_full):
@@ -651,7 +788,7 @@ class HaloShardedTeacher:
             if d_in > d_out:                                   # narrowing: project own rows, exchange d_out-wide rows, aggregate
                 hw = self._local(("hw", l), d_out, x.device)
                 be.gemm(x_self, w, out=hw[:pl.rows])
-                self._exchange(hw)
+                self._exchange(hw, ("hw", l))
                 out = be.feat_empty(pl.rows, d_out, x.device) if last else self._local(("y", l), d_out, x.device)[:pl.rows]
                 be.spmm(g.indptr, pl.cols, hw, pl.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out,
                         x_self=hw[:pl.rows])
@@ -661,7 +798,7 @@ class HaloShardedTeacher:
             elif not last and 2 * d_in <= d_out:               # widening: exchange the narrow aggregate, project own + halo rows
                 agg = self._local(("agg", l), d_in, x.device)
                 be.spmm(g.indptr, cols, x, pl.rows, be.AGG_SAGE_GCN, out=agg[:pl.rows], x_self=x_self)
-                self._exchange(agg)
+                self._exchange(agg, ("agg", l))
                 nxt = self._local(("y", l), d_out, x.device)
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=nxt)
                 x, cols, x_self, complete = nxt, pl.cols, nxt[:pl.rows], True
@@ -678,7 +815,7 @@ class HaloShardedTeacher:
                 if dims[l + 1][0] > dims[l + 1][1]:
                     complete = False                           # the next (narrowing) layer projects its own rows only
                 else:
-                    self._exchange(nxt)
+                    self._exchange(nxt, ("y", l))
                     complete = True
                 x, cols, x_self = nxt, pl.cols, nxt[:pl.rows]
         return out

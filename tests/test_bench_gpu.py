@@ -22,7 +22,18 @@ def _run(cmd, env=None):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]                  # THE line is the last one ...
+    assert len(lines[0]) <= 4096, len(lines[0])                            # ... and fits the tail the driver's record keeps
+    compact = json.loads(lines[0])
+    detail = [ln for ln in r.stdout.splitlines() if ln.startswith("DETAIL {")]
+    assert len(detail) == 1
+    out = json.loads(detail[0][len("DETAIL "):])
+    for k in REQUIRED:                                                     # the compact line carries the contract keys with the same values
+        if k != "config":
+            assert compact[k] == out[k], k
+    assert compact["config"]["workload"] and compact.get("verified") == out.get("verified")
+    out["_compact"] = compact
+    return out
 
 
 def test_bench_single_gpu_line():
@@ -45,6 +56,12 @@ def test_bench_single_gpu_line():
     assert cb["student_threads_best"] >= 1 and len(cb["student_thread_sweep"]) >= 1 and cb["teacher_reps"] >= 3
     rc = out["roofline_clustered"]
     assert rc["edges_per_s"] > 0 and "communities" in rc["graph"]
+    c = out["_compact"]      # what the driver's record keeps: the verdict of the self-check, the roofline, both baselines, the student figure
+    assert c["verified"] is True and c["verify"]["max_abs_diff_vs_unfused_aggregate_first"] <= 1e-4
+    assert c["roofline"]["frac"] == rf["frac"] and c["roofline"]["peak"] == 8000.0 and len(c["roofline"]["hbm_frac_bracket"]) == 2
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] == cb["value"] and c["cpu_baseline"]["cores"] == cb["cores"]
+    assert c["student"]["frac_of_fp32_mfma_peak"] == out["student"]["frac_of_fp32_mfma_peak"] and c["student"]["ms_per_step"] > 0
+    assert c["teacher_training"]["steps_per_s"] == tt["value"] and set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"}
 
 
 @pytest.mark.parametrize("extra", [[], ["--student-global-bn"]])
@@ -89,3 +106,41 @@ def test_bench_halo_exchange_with_partitioner_two_ranks():
     assert out["config"]["partition_seconds"] > 0
     full = 4e-9 * out["config"]["nodes"] * 148 / 2          # what one rank would receive from the other under the all-gather
     assert out["exchange"]["GB_received_per_rank_per_forward"] < 0.8 * full, (out["exchange"], full)
+
+
+@pytest.mark.parametrize("l1", ["narrow", "wide"])
+def test_bench_xl_is_a_three_layer_forward_with_emulated_peers(l1):
+    """--workload xl (BASELINE configs[4]) at a shrunken shard: one rank of the 8-way run, all three layers through ShardedTeacher with
+    dist.EmulatedPeers; one object per layer; every launch of a verification forward checked against torch fp64 on a row sample."""
+    out = _run([sys.executable, "bench.py", "--workload", "xl", "--scale", "0.002", "--steps", "2", "--warmup", "1", "--layer1-exchange", l1])
+    assert out["verified"] is True and out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["shards"] == 8 and cfg["rank_timed"] == 4 and cfg["nodes_total"] == 8 * cfg["rows_per_gpu"] and cfg["nnz_per_gpu"] == 20 * cfg["rows_per_gpu"]
+    names = [l["layer"][0] for l in out["layers"]]
+    assert names == (["1", "1", "2", "3", "3"] if l1 == "wide" else ["1", "1", "1", "2", "3", "3"])
+    hbm = [l for l in out["layers"] if l.get("bound") == "hbm"]
+    assert len(hbm) == 3 and all(l["ms"] > 0 and l["achieved"] > 0 for l in hbm)
+    v = out["verify"]
+    assert v["repeat_forward_bit_equal"] and all(l["max_abs_diff_vs_fp64"] <= 1e-4 for l in v["launches"]) and len(v["launches"]) >= 8
+    assert all(l.get("row_range_relaunch_bit_equal", True) for l in v["launches"])
+    pf = out["per_forward"]
+    r4 = lambda d: (d + 3) // 4 * 4
+    n_pad = 8 * -(-cfg["rows_per_gpu"] // 4) * 4
+    want = 4e-9 * n_pad * ((256 if l1 == "wide" else 128) + r4(47))
+    assert abs(pf["GB_received_per_rank"] - want) < 1e-6 * max(1.0, want) + 1e-9, (pf, want)
+    assert len(out["_compact"]["layers"]) == len(out["layers"])
+
+
+def test_bench_emulate_measures_every_rank_of_the_scaling_model():
+    """--emulate 2,4: every rank of the 2- and 4-rank sharded forward timed on this one GPU with truth fills; every emulated rank's
+    output equals the unsharded rows; the halo form on the re-partitioned clustered graph receives less than the all-gather."""
+    out = _run([sys.executable, "bench.py", "--emulate", "2,4", "--scale", "0.02", "--steps", "2"])
+    sm = out["scale_model"]
+    assert set(sm) == {"allgather-narrow", "allgather-wide", "halo-lp"} and out["verified"] is True
+    for form, o in sm.items():
+        assert set(o["worlds"]) == {"2", "4"} and o["one_gpu_forward_ms"] > 0
+        for N, w in o["worlds"].items():
+            assert w["verified"] and len(w["ranks"]) == int(N) and w["max_kernel_ms"] > 0
+            assert sum(r["rows"] for r in w["ranks"]) == o["nodes"] and sum(r["nnz"] for r in w["ranks"]) == o["nnz"]
+    assert sm["halo-lp"]["worlds"]["4"]["max_GB_received_per_rank"] < sm["allgather-narrow"]["worlds"]["4"]["max_GB_received_per_rank"]
+    assert sm["allgather-wide"]["worlds"]["4"]["max_GB_received_per_rank"] > sm["allgather-narrow"]["worlds"]["4"]["max_GB_received_per_rank"]

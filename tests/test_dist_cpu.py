@@ -396,3 +396,95 @@ def test_stat_exchange_hook_world2_gloo():
             n = nn
         np.testing.assert_allclose(mean, z.mean(0), atol=1e-6)
         np.testing.assert_allclose(m2 / n, z.var(0), atol=1e-6)
+
+
+def _emu_setup(n, dims, seed, clustered=False):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from glnn_amd import data
+    from glnn_amd.graph import CSRGraph
+    from glnn_amd.models import SAGE
+    from graphgen import random_graph
+    import torch.nn.functional as F
+    if clustered:
+        g = data.make_clustered_graph(n, 10, communities=16, p_in=0.95, seed=seed)
+    else:
+        indptr, indices = random_graph(n, 9, seed=seed, power=0.5, isolated=3, hub=200)
+        g = CSRGraph(torch.from_numpy(indptr), torch.from_numpy(indices), n)
+    torch.manual_seed(seed)
+    enc = SAGE(len(dims) - 1, dims[0], dims[1], dims[-1], 0.5, F.relu, "batch")
+    with torch.no_grad():
+        for bn in enc.norms:
+            bn.running_mean.uniform_(-.3, .3); bn.running_var.uniform_(.5, 1.5); bn.weight.uniform_(.5, 1.5); bn.bias.uniform_(-.2, .2)
+    enc.eval()
+    x = torch.from_numpy(np.random.RandomState(seed).standard_normal((n, dims[0])).astype(np.float32))
+    return g, enc, x
+
+
+@pytest.mark.parametrize("world,n,dims,chunks,balanced,widening", [
+    (2, 1001, [12, 16, 16, 5], 1, False, "narrow"), (4, 1003, [8, 24, 24, 6], 3, True, "narrow"), (8, 1001, [8, 24, 24, 6], 2, True, "narrow"),
+    (4, 1003, [8, 24, 24, 6], 4, True, "wide"), (2, 90, [6, 16, 5], 4, False, "wide"), (4, 640, [12, 16, 16, 5], 2, False, "narrow")])
+def test_emulated_rank_equals_unsharded_rows(world, n, dims, chunks, balanced, widening):
+    """dist.EmulatedPeers (bench.py --emulate N / --workload xl): ONE process plays rank r of an N-rank job, every collective is a
+    local fill of the same bytes.  With the truth of an unsharded forward as the peers' data, every emulated rank's output equals
+    the unsharded rows and the bytes "received" are exactly the real exchange's; without truth (peers' slots = copies of the own
+    slab, the synthetic-XL mode) the same launches run over the same volume."""
+    from glnn_amd import dist as gdist
+    g, enc, x = _emu_setup(n, dims, 5)
+    be = OracleBackend()
+    with torch.no_grad():
+        truth, want = gdist.record_truth(enc, g, x, be)
+    bounds = gdist.RowShards.balanced_bounds(g.indptr, world) if balanced else None
+    r4 = lambda d: (d + 3) // 4 * 4
+    L = len(dims) - 1
+    per_node = 0
+    for l in range(L):
+        d_in, d_out = dims[l], dims[l + 1]
+        if d_in > d_out:
+            per_node += r4(d_out)
+        elif l < L - 1 and 2 * d_in <= d_out and widening == "narrow":
+            per_node += r4(d_in)
+        elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
+            per_node += r4(d_out)
+    covered = np.zeros(n, bool)
+    for rank in range(world):
+        sh = gdist.RowShards(n, world, rank, chunks=chunks, bounds=bounds)
+        for use_truth in (True, False):
+            peers = gdist.EmulatedPeers(world, rank, truth=truth if use_truth else None)
+            gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+            with torch.no_grad():
+                y = gdist.ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, group=peers, widening_exchange=widening).forward(x)
+            assert gdist.EXCHANGE_STATS["floats_received"] == sh.n_pad * per_node
+            assert tuple(y.shape) == (sh.rows, dims[-1]) and bool(torch.isfinite(y).all())
+            if use_truth:
+                np.testing.assert_allclose(y.numpy(), want[sh.lo:sh.hi].numpy(), atol=1e-4, rtol=0)
+                covered[sh.lo:sh.hi] = True
+    assert covered.all()
+
+
+@pytest.mark.parametrize("world,dims,overlap", [(2, [12, 16, 16, 5], False), (4, [8, 24, 24, 6], True), (4, [16, 16, 16, 4], True),
+                                                (8, [8, 24, 6], False)])
+def test_emulated_rank_halo_equals_unsharded_rows(world, dims, overlap):
+    """The halo form under dist.EmulatedPeers: the peers' requests are derived from the full graph (what their HaloPlan would send),
+    the halo rows come from the truth of the unsharded forward -> equal rows, and the plan's send lists equal what a real peer asks
+    for (checked against HaloPlans built for the peers themselves)."""
+    from glnn_amd import dist as gdist
+    n = 1600
+    g, enc, x = _emu_setup(n, dims, 7, clustered=True)
+    be = OracleBackend()
+    with torch.no_grad():
+        truth, want = gdist.record_truth(enc, g, x, be)
+    bounds = gdist.RowShards.balanced_bounds(g.indptr, world)
+    plans = []
+    for rank in range(world):
+        sh = gdist.RowShards(n, world, rank, bounds=bounds)
+        peers = gdist.EmulatedPeers(world, rank, truth=truth, full_graph=g)
+        t = gdist.HaloShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, group=peers, overlap=overlap)
+        with torch.no_grad():
+            y = t.forward(x)
+        np.testing.assert_allclose(y.numpy(), want[sh.lo:sh.hi].numpy(), atol=1e-4, rtol=0)
+        plans.append((sh, t.plan))
+    for sh, pl in plans:            # rows rank r sends to p == rows p receives from r
+        for p, (shp, plp) in enumerate(plans):
+            assert pl.send_counts[p] == plp.recv_counts[sh.rank]
+        assert pl.n_send == sum(plp.recv_counts[sh.rank] for _, plp in plans)

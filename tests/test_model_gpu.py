@@ -978,49 +978,32 @@ def test_full_size_products_teacher_forward_vs_oracle():
     assert torch.equal(p2_c[:, :47], p2_f[:, :47])
 
 
-def test_full_size_xl_shard_properties():
-    """BASELINE configs[4] at FULL size on one GPU: one rank's shard of the 100 M-node / 2 B-edge graph = 12.5 M destination
-    rows with 250 M in-edges whose sources are drawn over ALL 100 M nodes, gathering from the replicated 100 M x 128 fp32
-    feature matrix (51.2 GB, resident: an MI355X holds 288 GB) -- the locality the real 8-GPU run has, not that of a
-    12.5 M-row source matrix.  Size-independent checks: the conservation identity
-        sum_v (deg_v + 1) * out[v]  ==  sum_u outdeg_u * x[u]  +  sum_{v in shard} x[v]      (fp64)
-    and bit-equality of a row-range relaunch."""
-    from glnn_amd import ops
-    from glnn_amd.graph import CSRGraph
-    rows, deg, d, world, rank = 12_500_000, 20, 128, 8, 3
-    n_total = rows * world
-    lo_shard = rank * rows
-    gen = torch.Generator(device=DEV); gen.manual_seed(7)
-    dst = torch.randint(0, rows, (rows * deg,), generator=gen, device=DEV)
-    src = torch.randint(0, n_total, (rows * deg,), generator=gen, device=DEV)
-    order = torch.argsort(dst)
-    indices = src[order].to(torch.int32)
-    indptr = torch.zeros(rows + 1, dtype=torch.int64, device=DEV)
-    torch.cumsum(torch.bincount(dst, minlength=rows), 0, out=indptr[1:])
-    outdeg = torch.bincount(src, minlength=n_total).double()
-    del dst, src, order
-    g = CSRGraph(indptr, indices, rows, n_total)
-    assert g.num_edges() == 250_000_000 and int(indices.max()) > 7 * rows          # sources really span the 100 M rows
-    x = torch.empty(n_total, d, device=DEV)
-    for s0 in range(0, n_total, 1 << 23):                    # 51.2 GB, filled in slabs
-        x[s0:s0 + (1 << 23)].normal_(generator=gen)
-    x_self = x[lo_shard:lo_shard + rows]
-    out = ops.spmm(g.indptr, g.indices, x, rows, ops.AGG_SAGE_GCN, x_self=x_self)
-    indeg = g.in_degrees().double()
-    lhs = torch.zeros(d, dtype=torch.float64, device=DEV)
-    rhs = torch.zeros(d, dtype=torch.float64, device=DEV)
-    step = 1 << 21                                           # fp64 reductions in slabs (bounded temporaries)
-    for s0 in range(0, rows, step):
-        sl = slice(s0, s0 + step)
-        lhs += ((indeg[sl] + 1).unsqueeze(1) * out[sl].double()).sum(0)
-        rhs += x_self[sl].double().sum(0)
-    for s0 in range(0, n_total, step):
-        sl = slice(s0, s0 + step)
-        rhs += (outdeg[sl].unsqueeze(1) * x[sl].double()).sum(0)
-    assert float((lhs - rhs).abs().max() / rhs.abs().max().clamp(min=1)) < 1e-4
-    lo, hi = 5_000_000, 5_400_000
-    part = ops.spmm(g.indptr[lo:hi + 1], g.indices, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x_self[lo:hi])
-    assert torch.equal(part, out[lo:hi])
+def test_full_size_xl_teacher_forward_properties():
+    """BASELINE configs[4] at FULL size on one GPU, as a TEACHER FORWARD (reference models.py:121-148): rank 4 of the 8-rank run --
+    12.5 M destination rows with 250 M in-edges whose sources are drawn over ALL 100 M nodes -- through all three layers of
+    glnn_amd.dist.ShardedTeacher (128-256-256-47, BN eval) with the peers emulated (dist.EmulatedPeers: every all-gather a local
+    fill of the same bytes, so the layer-2 kernel gathers from a 102 GB hidden buffer and layer 3 from the 19 GB projected one, as
+    a rank of the real run does).  `bench.py --workload xl` IS that run; its self-check holds, for every launch of a verification
+    forward, size-independent properties: a sample of rows recomputed independently in torch fp64 from the launch's own inputs
+    (<= 1e-4), stand-alone aggregations re-launched as a row range (bit-equal) and held to the fp64 conservation identity
+    sum_v (deg_v + 1) mean_v == sum_u edges_out(u) x_u + sum_v x_self_v over ALL their rows; a repeated forward is bit-identical."""
+    import json, os, subprocess, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "xl", "--steps", "3", "--warmup", "1"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("DETAIL {")][0][len("DETAIL "):])
+    cfg = out["config"]
+    assert cfg["rows_per_gpu"] == 12_500_000 and cfg["nnz_per_gpu"] == 250_000_000 and cfg["nodes_total"] == 100_000_000 and cfg["rank_timed"] == 4
+    assert out["verified"] is True and out["verify"]["repeat_forward_bit_equal"] and out["verify"]["finite"]
+    launches = out["verify"]["launches"]
+    assert len(launches) == 16                       # 4 chunks x (aggregate, replicated projection, fused + chained, layer-3 aggregate)
+    for l in launches:
+        assert l["max_abs_diff_vs_fp64"] <= 1e-4, l
+        if l["launch"].startswith("spmm"):
+            assert l["row_range_relaunch_bit_equal"] and l["conservation_rel_err_fp64_all_rows"] < 1e-5, l
+    assert [l["layer"][0] for l in out["layers"]] == ["1", "1", "1", "2", "3", "3"]
+    assert abs(out["per_forward"]["GB_received_per_rank"] - 4e-9 * 100_000_000 * (128 + 48)) < 1e-3
 
 
 # ------------------------------------------------------------------------------------------- driver loops
