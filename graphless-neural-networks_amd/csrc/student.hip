@@ -992,6 +992,38 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   float* __restrict__ m = a.m[t];
   float* __restrict__ v = a.v[t];
   const AdamSrc sr = t < a.nsrc ? a.src[t] : AdamSrc{nullptr, 0, 0, 0};
+  const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+  // one element: the update itself (identical in the scalar and the float4 walk)
+  auto update = [&](float gi, float pi, float& mi, float& vi) -> float {
+    if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+    mi = mi + (gi - mi) * omb1;                                  // exp_avg.lerp_(grad, 1-beta1)
+    vi = fmaf(gi * gi, omb2, vi * a.beta2);                      // mul_(beta2).addcmul_(g,g,1-beta2)
+    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+    return pi - a.step_size * (mi / denom);
+  };
+  // float4 walk: a plain gradient (no partials to fold), every array 16-byte aligned, a multiple of 4 elements -- the weight matrices of
+  // the wide students (MLP3w8: 4.2 M of the 4.5 M parameters): 7 streams of 16 bytes per lane instead of 4 (30 -> 2x us at 126 MB)
+  const bool vec = sr.nslab == 0 && (n & 3) == 0 &&
+                   (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+    float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      const float4 gg = g4[i];
+      float4 pp = p4[i], mm = m4[i], vv = v4[i];
+      pp.x = update(gg.x, pp.x, mm.x, vv.x);
+      pp.y = update(gg.y, pp.y, mm.y, vv.y);
+      pp.z = update(gg.z, pp.z, mm.z, vv.z);
+      pp.w = update(gg.w, pp.w, mm.w, vv.w);
+      m4[i] = mm;
+      v4[i] = vv;
+      p4[i] = pp;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float gi;
     if (sr.nslab == 0) {
@@ -1018,14 +1050,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
       if (sr.lanes4) gi = (l[0] + l[1]) + (l[2] + l[3]);
       g[i] = gi;                     // the gradient itself stays observable (p.grad)
     }
-    const float pi = p[i];
-    if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-    const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);          // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = fmaf(gi * gi, 1.f - a.beta2, v[i] * a.beta2);  // mul_(beta2).addcmul_(g,g,1-beta2)
+    float mi = m[i], vi = v[i];
+    const float pn = update(gi, p[i], mi, vi);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    p[i] = pi - a.step_size * (mi / denom);
+    p[i] = pn;
   }
 }
 
