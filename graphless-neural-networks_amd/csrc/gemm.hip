@@ -793,6 +793,12 @@ inline bool pipe_enabled() {
   return !(e && e[0] == '0');
 }
 
+// GLNN_GEMM_ROWPANEL=0 keeps short reductions on the tiled kernels (A/B runs, bit-identity tests)
+inline bool rowpanel_enabled() {
+  const char* e = getenv("GLNN_GEMM_ROWPANEL");
+  return !(e && e[0] == '0');
+}
+
 constexpr size_t pipe_lds_bytes(int sa, int sb) {
   return 2 * (size_t)((sa == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE) + (sb == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE));
 }
@@ -1515,6 +1521,12 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
   if (!fast && !defer_splits && !b_layout && g.a_vec && lda >= ((k + 3) & ~3) && !g.b_vec && !a_scale && !row_scale) {
     const int rc = glnn::gemm_lat(a, lda, a_rows, nullptr, nullptr, 0.f, 0u, m, k, b, ldb, 0, n, ep_shift, c, ldc, nullptr, nullptr, nullptr, stream,
                                   nullptr, 0, ep_scale, relu);
+    if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+  }
+  // a short reduction over many rows (k <= 128: a projection of feature / aggregate rows): persistent workgroups with the weight panel
+  // resident in LDS (gemm_rowpanel.hip) instead of one workgroup per output tile with 3-4 k-tiles each
+  if (fast && !defer_splits && !b_layout && !a_rows && !a_scale && !row_scale && rowpanel_enabled()) {
+    const int rc = glnn::gemm_rowpanel(a, lda, m, k, b, ldb, n, ep_scale, ep_shift, relu, c, ldc, stream);
     if (rc != GLNN_ERR_UNSUPPORTED) return rc;
   }
   // latency regime: fewer than 64 tiles of 128 x (128|64) -> 64 x 64 tiles, four times the workgroups, a quarter of the

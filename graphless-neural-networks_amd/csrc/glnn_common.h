@@ -159,6 +159,11 @@ int gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, cons
                         uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, float* workspace,
                         int64_t workspace_floats, int* splits, void* stream);
 
+// gemm_rowpanel.hip: C = epi(A . W^T) for short reductions (k <= 128) over many rows -- persistent workgroups that keep a 128-column
+// panel of W in LDS and walk row tiles of A; bit-identical to the tiled kernels.  GLNN_ERR_UNSUPPORTED = nothing launched.
+int gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* ep_scale,
+                  const float* ep_shift, int relu, float* c, int64_t ldc, void* stream);
+
 // mlp_lat.hip: the latency form of a student layer (m <= ~1k rows, k <= 256): C = A' * B + bias in 32-row tiles whose four waves split
 // K, with the reduction that used to be the next launch as epilogue.  GLNN_ERR_UNSUPPORTED = not launched, use the tiled kernels.
 struct LatStats {      // BatchNorm1d training statistics of C + finalize (arguments as bn_stats)

@@ -40,7 +40,7 @@ namespace {
 #define GLNN_LONG_ROW 128
 #endif
 #ifndef GLNN_LONG_BLOCK_ROWS
-#define GLNN_LONG_BLOCK_ROWS 4096
+#define GLNN_LONG_BLOCK_ROWS 512
 #endif
 #ifndef GLNN_LONG_BLOCK_CAP
 #define GLNN_LONG_BLOCK_CAP 512
@@ -756,7 +756,11 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self; a.self_rows = self_rows;
     a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
     a.relu = relu; a.out = out + c0; a.ldo = ldo;
-    int64_t n_long = n_dst / GLNN_LONG_BLOCK_ROWS;       // workgroups in the long-row role
+    // workgroups in the long-row role: one per 512-row scan chunk, at most GLNN_LONG_BLOCK_CAP.  (Until round 4: n_dst / 4096 -- right
+    // for a whole graph, where it hits the cap, but a row SHARD of a power-law graph keeps the graph's hub rows: rank r of 8 launches
+    // 76 k-row chunks of the products graph whose rows of degree > 128 hold 20 % of the edges, and 18 workgroups gathered them while
+    // the other 2,400 had long finished -- 5.1 ms for an eighth of the 8.8 ms whole-graph launch, profiles/scale_model_r04_a.json)
+    int64_t n_long = (n_dst + GLNN_LONG_BLOCK_ROWS - 1) / GLNN_LONG_BLOCK_ROWS;
     if (n_long < 1) n_long = 1;
     if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
     a.n_long_blocks = (int)n_long;

@@ -239,6 +239,52 @@ def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(fo
     np.testing.assert_allclose(outs[0][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, (m if form == "tn" else k) / 512) ** 0.5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("m,k,n,epi", [(5000, 100, 256, True), (4096, 100, 2048, True), (100003, 128, 256, False), (2049, 36, 96, True),
+                                         (70001, 64, 300, True), (2048, 124, 130, False), (9000, 40, 128, True)])
+def test_rowpanel_gemm_equals_the_tiled_kernels_bit_for_bit(m, k, n, epi, monkeypatch):
+    """K3r (csrc/gemm_rowpanel.hip): short reductions over many rows -- persistent workgroups, the weight panel resident in LDS, row
+    tiles walked with a cross-tile software pipeline, all global traffic through per-tile buffer descriptors.  Same k order as the
+    tiled kernels -> identical bits; ragged last row tile, column panels past n, k tails inside the last k-group (k % 8 == 4), a
+    padded output (ldc > n) whose padding must stay untouched; and closeness to the fp64 product."""
+    from glnn_amd import ops
+    r = np.random.RandomState(m + k + n)
+    a = ops.as_feat(dev(r.standard_normal((m, k)).astype(np.float32)))
+    w = dev((r.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    es = dev(r.uniform(0.5, 1.5, n).astype(np.float32)) if epi else None
+    eh = dev(r.standard_normal(n).astype(np.float32)) if epi else None
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_GEMM_ROWPANEL", mode)
+        out = ops.feat_empty(m, n, DEV)
+        base = torch.as_strided(out, (m, out.stride(0)), (out.stride(0), 1))
+        base.fill_(-7.0)
+        ops.gemm(a, w, ep_scale=es, ep_shift=eh, relu=epi, out=out)
+        outs.append(base.clone())
+    assert torch.equal(outs[0], outs[1])
+    if outs[0].shape[1] > n:
+        assert float((outs[0][:, n:] + 7.0).abs().max()) == 0.0          # padding columns: not written by either path
+    want = a[:, :k].double() @ w.double().t()
+    if epi:
+        want = torch.relu(want * es.double() + eh.double())
+    np.testing.assert_allclose(outs[0][:, :n].cpu().numpy(), want.cpu().numpy(), atol=TOL, rtol=1e-5)
+
+
+def test_aggregation_of_a_row_shard_keeps_the_hub_rows_busy():
+    """A row SHARD of a power-law graph keeps the graph's hub rows: the long-row role of spmm_csr_kernel gets one workgroup per 512-row
+    scan chunk (round 4; it was n_dst / 4096, which left 18 workgroups with a fifth of the edges of a 76 k-row products shard).  Same
+    sums as before -- deterministic LDS fold -- so a shard's rows equal the whole-graph launch bit for bit, for several shard sizes."""
+    from glnn_amd import ops
+    n, d = 40000, 100
+    indptr, indices = random_graph(n, 20, seed=3, power=0.8, isolated=5, hub=9000)
+    x = dev(np.random.RandomState(3).standard_normal((n, d)).astype(np.float32))
+    ip, ix = g2d(indptr, indices)
+    full = ops.spmm(ip, ix, x, n, ops.AGG_SAGE_GCN)
+    np.testing.assert_allclose(full.cpu().numpy(), to.sage_gcn_agg(indptr, indices, x.cpu().numpy()), atol=TOL, rtol=0)
+    for lo, hi in ((0, 513), (1000, 6000), (20000, 40000), (39000, 40000)):
+        part = ops.spmm(ip[lo:hi + 1], ix, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x[lo:hi])
+        assert torch.equal(part, full[lo:hi])
+
+
 def test_gemm_transpose_detecting():
     # A = I (padded) against an ASYMMETRIC B catches swapped C layouts
     from glnn_amd import ops
