@@ -994,12 +994,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   const AdamSrc sr = t < a.nsrc ? a.src[t] : AdamSrc{nullptr, 0, 0, 0};
   const float omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
   // one element: the update itself (identical in the scalar and the float4 walk)
+  // (every contraction pinned by hand: left to the compiler, the scalar walk got mul + add for the lerp and the float4 walk a packed
+  //  fma -- two roundings of the same update, and the one-call step (folding, scalar) no longer equalled the two-call step bit for bit)
   auto update = [&](float gi, float pi, float& mi, float& vi) -> float {
+#pragma clang fp contract(off)
     if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-    mi = mi + (gi - mi) * omb1;                                  // exp_avg.lerp_(grad, 1-beta1)
+    mi = fmaf(gi - mi, omb1, mi);                                // exp_avg.lerp_(grad, 1-beta1)
     vi = fmaf(gi * gi, omb2, vi * a.beta2);                      // mul_(beta2).addcmul_(g,g,1-beta2)
     const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-    return pi - a.step_size * (mi / denom);
+    return fmaf(-a.step_size, mi / denom, pi);
   };
   // float4 walk: a plain gradient (no partials to fold), every array 16-byte aligned, a multiple of 4 elements -- the weight matrices of
   // the wide students (MLP3w8: 4.2 M of the 4.5 M parameters): 7 streams of 16 bytes per lane instead of 4 (30 -> 2x us at 126 MB)
