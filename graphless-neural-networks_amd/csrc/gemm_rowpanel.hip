@@ -42,7 +42,7 @@ struct RpArgs {
 
 __device__ __forceinline__ float4 rp_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int KG>                 // k-groups of 8: 8 (KG - 1) < k <= 8 KG, k % 4 == 0
+template <int KG>                 // k-groups of 8: 8 (KG - 1) < k <= 8 KG, k % 4 == 0; KG >= 5 (the side work is spread over k-groups 0 .. 4)
 __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs g) {
   constexpr int KP = 8 * KG;
   constexpr int KS = KP + 4;      // LDS row stride (floats): KS / 4 odd -> the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs 
       // ---- side work, in the shadow of the MFMAs (this wave's and its SIMD neighbour's) ----
       if (kg == 0) load_tile(CUR, tile + 2 * stride);            // tile it+2: requested more than a tile ahead, into staging set CUR
       if (kg >= 1 && kg < 5) store_quarter(acc[CUR ^ 1], prev, kg - 1);
-      if (kg == 6) store_tile_lds(CUR ^ 1, CUR ^ 1);             // tile it+1 (requested during tile it-1): staging set CUR^1 -> the other buffer
+      if (kg == (KG > 6 ? 6 : KG - 1)) store_tile_lds(CUR ^ 1, CUR ^ 1);   // tile it+1 (requested during tile it-1): staging set CUR^1 -> the other buffer
       // (all unconditional: behind the walk's end the loads are out of range and the LDS write goes to a buffer nobody reads)
       __builtin_amdgcn_sched_barrier(0);                         // keep the side work of a k-group with its MFMAs
       af = an; bf = bn;
