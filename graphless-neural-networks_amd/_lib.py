@@ -62,7 +62,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -92,7 +92,7 @@ class MlpStepDesc(ctypes.Structure):
                  ("sync_send", c_vp), ("sync_recv", c_vp), ("sync_rows", c_vp), ("sync_counters", c_vp),
                  ("act", _F), ("ld_act", c_i64 * MLP_MAX_LAYERS), ("xb", c_vp), ("ld_xb", c_i64),
                  ("grad_ready", GRAD_READY_FN), ("grad_ready_ctx", c_vp),
-                 ("aux_stream", c_vp), ("ev_main", c_vp), ("ev_aux", c_vp), ("dz2", c_vp), ("ld_dz2", c_i64)])
+                 ("dz2", c_vp), ("ld_dz2", c_i64)])
 
 
 SAGE_MAX_LAYERS = 8
@@ -115,8 +115,7 @@ class SageStepDesc(ctypes.Structure):
                 ("x", c_vp), ("ldx", c_i64), ("x_rows", c_i64), ("labels", c_vp), ("label_rows", c_vp),
                 ("dlogits", c_vp), ("ld_dlogits", c_i64), ("dagg", c_vp), ("ld_dagg", c_i64), ("dh", c_vp), ("ld_dh", c_i64),
                 ("ws_bn", c_vp), ("ws_bn_floats", c_i64), ("ws_tn", c_vp), ("ws_tn_floats", c_i64), ("ws_gemm", c_vp), ("ws_gemm_floats", c_i64),
-                ("ws_loss", c_vp), ("ws_loss_floats", c_i64), ("loss_out", c_vp), ("loss_accum", c_vp),
-                ("aux_stream", c_vp), ("ev_fork", c_vp), ("ev_join", c_vp)]
+                ("ws_loss", c_vp), ("ws_loss_floats", c_i64), ("loss_out", c_vp), ("loss_accum", c_vp)]
 
 
 _lib = None
@@ -149,6 +148,8 @@ def lib():
         h.glnn_layernorm_bwd_workspace_floats.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
+        h.glnn_reload_options.argtypes = []
+        h.glnn_reload_options.restype = None
         if h.glnn_abi_version() != ABI_VERSION:
             raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
         for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc)):

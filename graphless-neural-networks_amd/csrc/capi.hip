@@ -1,5 +1,7 @@
 // Error state, device query and the K7 row gather / scatter of libglnn_hip.so.
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "glnn_common.h"
 
@@ -10,6 +12,36 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- the library's ONLY read of the environment (see glnn::Options) ----
+static long long env_ll(const char* name, long long dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+static void load_options(Options& o) {
+  o.gemm_pipe = (int)env_ll("GLNN_GEMM_PIPE", 1);
+  o.gemm_rowpanel = (int)env_ll("GLNN_GEMM_ROWPANEL", 1);
+  o.gemm_lat = (int)env_ll("GLNN_GEMM_LAT", 1);
+  o.gemm_tn_lat = (int)env_ll("GLNN_GEMM_TN_LAT", 1);
+  o.gemm_tn_lat_splits = (int)env_ll("GLNN_GEMM_TN_LAT_SPLITS", 8);
+  o.lat_bn_bwd = (int)env_ll("GLNN_STUDENT_LAT_BN_BWD", 1);
+  o.bn_bwd_one_launch = (int)env_ll("GLNN_BN_BWD_ONE_LAUNCH", 1);
+  o.narrow_bwd = (int)env_ll("GLNN_STUDENT_NARROW_BWD", 1);
+  o.narrow_bwd_min = env_ll("GLNN_STUDENT_NARROW_BWD_MIN", 1ll << 20);
+  o.narrow_wgrad = (int)env_ll("GLNN_STUDENT_NARROW_WGRAD", 1);
+  o.pad_w0 = (int)env_ll("GLNN_STUDENT_PAD_W0", 1);
+  o.slab_consumers = (int)env_ll("GLNN_STUDENT_SLAB_CONSUMERS", 1);
+  o.defer_stats = (int)env_ll("GLNN_STUDENT_DEFER_STATS", 1);
+  o.batched_wgrad = (int)env_ll("GLNN_STUDENT_BATCHED_WGRAD", 1);
+  o.fuse_apply = (int)env_ll("GLNN_STUDENT_FUSE_APPLY", 1);
+  o.adam_folds = (int)env_ll("GLNN_STUDENT_ADAM_FOLDS", 1);
+}
+static Options g_opts;
+static std::once_flag g_opts_once;
+const Options& opts() {
+  std::call_once(g_opts_once, [] { load_options(g_opts); });
+  return g_opts;
 }
 }  // namespace glnn
 
@@ -49,7 +81,13 @@ int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, 
 
 }  // namespace
 
-extern "C" int glnn_abi_version(void) { return 6; }
+extern "C" int glnn_abi_version(void) { return 7; }
+
+// test / A-B hook: re-read the GLNN_* switches (glnn::Options).  Not for concurrent use with other calls into the library.
+extern "C" void glnn_reload_options(void) {
+  (void)glnn::opts();
+  glnn::load_options(glnn::g_opts);
+}
 
 extern "C" const char* glnn_last_error(void) { return glnn::g_err; }
 

@@ -788,16 +788,10 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
 }
 
 // GLNN_GEMM_PIPE=0 keeps every shape on the compiler-scheduled kernels (A/B runs, tests/test_kernels_gpu.py)
-inline bool pipe_enabled() {
-  const char* e = getenv("GLNN_GEMM_PIPE");      // read per call: the tests flip it inside one process
-  return !(e && e[0] == '0');
-}
+inline bool pipe_enabled() { return glnn::opts().gemm_pipe != 0; }
 
 // GLNN_GEMM_ROWPANEL=0 keeps short reductions on the tiled kernels (A/B runs, bit-identity tests)
-inline bool rowpanel_enabled() {
-  const char* e = getenv("GLNN_GEMM_ROWPANEL");
-  return !(e && e[0] == '0');
-}
+inline bool rowpanel_enabled() { return glnn::opts().gemm_rowpanel != 0; }
 
 constexpr size_t pipe_lds_bytes(int sa, int sb) {
   return 2 * (size_t)((sa == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE) + (sb == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE));
@@ -836,11 +830,6 @@ struct GemmTnArgs {
   int splits; int64_t rows_per_split;
   int a_vec; int b_vec;
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
-  // ABN (gemm_tn_tile_t<.., ABN = true>): the A operand is dz = BatchNorm/ReLU/dropout BACKWARD of (a = da, az = z), applied in the operand
-  // loads -- dz is never written.  S1 / S2 = column sums of dy, dy * xhat: an_parts partials an_stride floats apart (bn_bwd_partial's).
-  const float* az; int64_t ldaz; const float* an_gamma; const float* an_mean; const float* an_rstd; const float* an_scale; const float* an_shift;
-  const float* an_p1; const float* an_p2; int an_parts; int64_t an_stride; float an_inv_rows; uint32_t an_thr; uint32_t an_seed; float an_dscale;
-  float* an_dgamma; float* an_dbeta; float* an_cs;      // outputs: dgamma = S2, dbeta = S1; an_cs[split][ka] = column sums of dz over the split's rows
 };
 
 template <int BNT>
@@ -980,7 +969,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const GemmArgs g) 
 // is EXACTLY the NT kernel's (conflict-free ds_read_b128 fragments, 4 MFMAs per read).
 // Thread map: tid -> (rg: rows 4rg..4rg+3 of the 32-row k-tile, cg: columns 4cg..4cg+3), interleaved (below).
 // ---------------------------------------------------------------------------------------------
-template <int BMT, int BNT, int XF, bool ROWS, bool ABN = false>
+template <int BMT, int BNT, int XF, bool ROWS>
 __device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx, const int by, const int bz) {
   constexpr int MI = BMT / 64;
   constexpr int NT = BNT / 64;
@@ -1011,38 +1000,6 @@ __device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx
     sc4 = ld4g(g.b_scale + b_col);
     sh4 = ld4g(g.b_shift + b_col);
   }
-  // ABN: per-column constants of this thread's four A columns.  S1 / S2: every thread sums the same partials in the same (ascending)
-  // order, eight float4 pairs in flight per batch
-  float4 n_grs = zero4(), n_c1 = zero4(), n_c2 = zero4(), n_mu = zero4(), n_rs = zero4(), n_sc = zero4(), n_sf = zero4();
-  float4 z_reg[4];
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-  if (ABN && a_active) {
-    float4 S1 = zero4(), S2 = zero4();
-    for (int k0 = 0; k0 < g.an_parts; k0 += 8) {
-      float4 t1[8], t2[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + u < g.an_parts ? k0 + u : g.an_parts - 1;
-        t1[u] = ld4g(g.an_p1 + (int64_t)k * g.an_stride + a_col);
-        t2[u] = ld4g(g.an_p2 + (int64_t)k * g.an_stride + a_col);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k0 + u < g.an_parts) {
-          S1.x += t1[u].x; S1.y += t1[u].y; S1.z += t1[u].z; S1.w += t1[u].w;
-          S2.x += t2[u].x; S2.y += t2[u].y; S2.z += t2[u].z; S2.w += t2[u].w;
-        }
-    }
-    const float4 gm = ld4g(g.an_gamma + a_col);
-    n_mu = ld4g(g.an_mean + a_col); n_rs = ld4g(g.an_rstd + a_col); n_sc = ld4g(g.an_scale + a_col); n_sf = ld4g(g.an_shift + a_col);
-    n_grs = make_float4(gm.x * n_rs.x, gm.y * n_rs.y, gm.z * n_rs.z, gm.w * n_rs.w);
-    n_c1 = make_float4(S1.x * g.an_inv_rows, S1.y * g.an_inv_rows, S1.z * g.an_inv_rows, S1.w * g.an_inv_rows);
-    n_c2 = make_float4(S2.x * g.an_inv_rows, S2.y * g.an_inv_rows, S2.z * g.an_inv_rows, S2.w * g.an_inv_rows);
-    if (by == 0 && bz == 0 && rg == 0) {               // (a clamped column group rewrites its neighbour's values with the same numbers)
-      *reinterpret_cast<float4*>(g.an_dbeta + a_col) = S1;
-      *reinterpret_cast<float4*>(g.an_dgamma + a_col) = S2;
-    }
-  }
   float4 a_reg[4], b_reg[4];
   int64_t mt_cur = 0;
   int64_t src_row[4];        // ROWS: gathered source rows of the NEXT B loads, fetched one tile ahead (no dependent load in the loop)
@@ -1064,7 +1021,6 @@ __device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx
     if (mrow > g.m - 1) mrow = g.m - 1;
     if (p < 4) {
       if (a_active) a_reg[r] = ld4g(g.a + mrow * g.lda + a_col);
-      if (ABN && a_active) z_reg[r] = ld4g(g.az + mrow * g.ldaz + a_col);
     } else if (b_active) {
       if (ROWS) {
         b_reg[r] = ld4g(g.b + src_row[r] * g.ldb + b_col);
@@ -1085,23 +1041,6 @@ __device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx
   auto prep_row = [&](int r) {
     const bool in = mt_cur + 4 * rg + r < mend;        // rows past this split's end are reduction terms: zero them
     float4 a = in ? a_reg[r] : zero4();
-    if (ABN && a_active) {                             // da -> dz: bn_dy_s + bn_dz of student.hip, element by element
-      const uint32_t row = (uint32_t)(mt_cur + 4 * rg + r), c = (uint32_t)a_col;
-      const float4 z = z_reg[r];
-      float d[4] = {a_reg[r].x, a_reg[r].y, a_reg[r].z, a_reg[r].w};
-      const float zz[4] = {z.x, z.y, z.z, z.w}, sc[4] = {n_sc.x, n_sc.y, n_sc.z, n_sc.w}, sf[4] = {n_sf.x, n_sf.y, n_sf.z, n_sf.w};
-      const float gr[4] = {n_grs.x, n_grs.y, n_grs.z, n_grs.w}, c1[4] = {n_c1.x, n_c1.y, n_c1.z, n_c1.w}, c2[4] = {n_c2.x, n_c2.y, n_c2.z, n_c2.w};
-      const float mu[4] = {n_mu.x, n_mu.y, n_mu.z, n_mu.w}, rs[4] = {n_rs.x, n_rs.y, n_rs.z, n_rs.w};
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        float dav = d[t];
-        if (g.an_thr) dav = glnn::drop_keep(g.an_seed, g.an_thr, row, c + t) ? dav * g.an_dscale : 0.f;
-        const float dy = fmaf(zz[t], sc[t], sf[t]) > 0.f ? dav : 0.f;
-        d[t] = in ? glnn::bn_dz(gr[t], dy, c1[t], zz[t], mu[t], rs[t], c2[t]) : 0.f;
-        cs[t] += d[t];
-      }
-      a = make_float4(d[0], d[1], d[2], d[3]);
-    }
     av[r][0] = a.x; av[r][1] = a.y; av[r][2] = a.z; av[r][3] = a.w;
     if (b_active) {
       float4 b = b_reg[r];
@@ -1218,25 +1157,11 @@ __device__ __forceinline__ void gemm_tn_tile_t(const GemmTnArgs& g, const int bx
         if (col < g.nb && row < g.ka) cbase[(int64_t)row * g.ldc + col] = acc[i][j][r];
       }
   }
-  if (ABN && g.an_cs && by == 0) {                     // column sums of dz over this split's rows: the eight row groups of a column, fixed order
-    __syncthreads();                                   // (the operand tiles are dead)
-    if (a_active) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) smem[rg * BMT + 4 * cg + t] = cs[t];
-    }
-    __syncthreads();
-    if (tid < BMT) {
-      const float v = ((smem[tid] + smem[BMT + tid]) + (smem[2 * BMT + tid] + smem[3 * BMT + tid])) +
-                      ((smem[4 * BMT + tid] + smem[5 * BMT + tid]) + (smem[6 * BMT + tid] + smem[7 * BMT + tid]));
-      const int col = i0 + tid;
-      if (col < g.ka) g.an_cs[(int64_t)bz * g.ka + col] = v;          // ka % 4 == 0 (host check): a slot < ka was summed by an unclamped group
-    }
-  }
 }
 
-template <int BMT, int BNT, int XF, bool ROWS, bool ABN = false>
+template <int BMT, int BNT, int XF, bool ROWS>
 __global__ __launch_bounds__(256) void gemm_tn_kernel_t(const GemmTnArgs g) {
-  gemm_tn_tile_t<BMT, BNT, XF, ROWS, ABN>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+  gemm_tn_tile_t<BMT, BNT, XF, ROWS>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ONE launch for several independent weight gradients (the deferred dW_l of a small-batch student step, mlp_step.hip): the blocks of
@@ -1683,6 +1608,12 @@ __global__ void split_reduce_multi_kernel(const FoldMultiArgs fm) {
 
 // The plan glnn_gemm_tn_f32 makes for a "small" problem (64 x 64 tiles, the reduction split until ~1024 workgroups exist), or false
 // if the problem would not take that path there.  `avail` = workspace floats the split slabs may use.
+// ONE definition of "the weight gradient takes the 64 x 64 latency tiles", shared by glnn::gemm_tn and the batched plan below (they must
+// agree: the batched launch promises the per-problem plan of the single call)
+static inline bool tn_small_regime(bool fast, int tiles128, bool pipe_shape, int64_t m, int ka) {
+  return fast && tiles128 <= 64 && !(pipe_shape && m >= 2048) && !(m >= 8192 && ka >= 1024);
+}
+
 static bool tn_small_plan(int64_t m, int ka, int nb, int64_t lda, int64_t ldb, const float* a, const float* b, const float* b_scale,
                           const float* b_shift, const int64_t* b_rows, int64_t avail, int* gi, int* gj, int* splits, int64_t* rps) {
   const bool a_vec = (lda % 4 == 0) && glnn::aligned16(a), b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
@@ -1691,7 +1622,7 @@ static bool tn_small_plan(int64_t m, int ka, int nb, int64_t lda, int64_t ldb, c
   const int bnt = nb > 64 ? 128 : 64;
   const int gi0 = (ka + BM - 1) / BM, gj0 = (nb + bnt - 1) / bnt;
   const bool pipe_shape = fast && bnt == 128 && !b_scale && !b_rows && pipe_enabled() && (lda > ldb ? lda : ldb) < (1 << 20);
-  if (!(fast && gi0 * gj0 <= 64 && !(pipe_shape && m >= 2048))) return false;
+  if (!tn_small_regime(fast, gi0 * gj0, pipe_shape, m, ka)) return false;
   *gi = (ka + 63) / 64; *gj = (nb + 63) / 64;
   int sp = 1;
   const int64_t slab = (int64_t)ka * nb;
@@ -1775,80 +1706,6 @@ int gemm_tn_batch(const TnProblem* pr, int n, float* workspace, int64_t workspac
 }
 }  // namespace glnn
 
-// dW = dz^T . b where dz = BatchNorm / ReLU / dropout backward of (da, z) is applied in the A operand loads (GemmTnArgs ABN): the first
-// hidden layer's dz has no other consumer than this product (+ the column sums behind its bias gradient, + dgamma / dbeta, all emitted
-// here), so the apply pass and its 2 x rows x ka floats of traffic disappear.  64 x 64 tiles, the reduction split over up to 1024
-// workgroups; slabs / column-sum partials are left in the workspace for `defer` / `defer_colsum` (fused Adam) or folded here.
-int glnn::gemm_tn_bn(const float* da, int64_t ldda, int64_t m, int ka, const glnn::TnBnA& bn, const float* b, int64_t ldb, int nb, float* c,
-                     int64_t ldc, float* col_sum, float* workspace, int64_t workspace_floats, void* stream, glnn::GradFold* defer,
-                     glnn::GradFold* defer_colsum, int64_t* used_floats) {
-  if (!da || !b || !c || !bn.z || !bn.gamma || !bn.mean || !bn.rstd || !bn.a_scale || !bn.a_shift || !bn.p1 || !bn.p2 || !bn.dgamma || !bn.dbeta ||
-      bn.nparts < 1 || m < 1 || ka < 4 || nb < 1 || !workspace)
-    return GLNN_ERR_UNSUPPORTED;
-  const int64_t nbp = (nb + 3) & ~3;
-  if (ka % 4 || ldda % 4 || bn.ldz % 4 || ldb % 4 || ldda < ka || bn.ldz < ka || ldb < nbp || ldc < nb || bn.pstride % 4 || !glnn::aligned16(da) ||
-      !glnn::aligned16(bn.z) || !glnn::aligned16(b) || !glnn::aligned16(bn.gamma) || !glnn::aligned16(bn.mean) || !glnn::aligned16(bn.rstd) ||
-      !glnn::aligned16(bn.a_scale) || !glnn::aligned16(bn.a_shift) || !glnn::aligned16(bn.p1) || !glnn::aligned16(bn.p2) ||
-      !glnn::aligned16(bn.dgamma) || !glnn::aligned16(bn.dbeta) || bn.drop_p < 0.f || bn.drop_p >= 1.f)
-    return GLNN_ERR_UNSUPPORTED;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  GemmTnArgs g = {};
-  g.a = da; g.lda = ldda; g.m = m; g.ka = ka; g.b = b; g.ldb = ldb; g.nb = nb; g.a_vec = 1; g.b_vec = 1;
-  g.drop_thr = 0u; g.drop_seed = 0u; g.drop_scale = 1.f;
-  g.az = bn.z; g.ldaz = bn.ldz; g.an_gamma = bn.gamma; g.an_mean = bn.mean; g.an_rstd = bn.rstd; g.an_scale = bn.a_scale; g.an_shift = bn.a_shift;
-  g.an_p1 = bn.p1; g.an_p2 = bn.p2; g.an_parts = bn.nparts; g.an_stride = bn.pstride; g.an_inv_rows = 1.0f / (float)m;
-  g.an_thr = glnn::drop_threshold(bn.drop_p); g.an_seed = bn.drop_seed; g.an_dscale = 1.0f / (1.0f - bn.drop_p);
-  g.an_dgamma = bn.dgamma; g.an_dbeta = bn.dbeta;
-  // 64 x 128 tiles when b is wider than 64 columns: every column tile re-reads (and re-transforms) da and z
-  const bool wide = nb > 64;
-  const int gi = (ka + 63) / 64, gj = wide ? (nb + 127) / 128 : (nb + 63) / 64;
-  const int64_t slab = (int64_t)ka * nb;
-  int splits = ((wide ? 512 : 1024) + gi * gj - 1) / (gi * gj);
-  const int64_t max_by_rows = (m + 2 * BK - 1) / (2 * BK);
-  if (splits > max_by_rows) splits = (int)max_by_rows;
-  if (splits > 64) splits = 64;
-  while (splits > 1 && (int64_t)splits * slab + (int64_t)splits * ka > workspace_floats) --splits;
-  if ((int64_t)splits * ka > workspace_floats) return GLNN_ERR_UNSUPPORTED;
-  int64_t rps = (m + splits - 1) / splits;
-  rps = (rps + BK - 1) / BK * BK;
-  splits = (int)((m + rps - 1) / rps);
-  g.splits = splits; g.rows_per_split = rps;
-  float* ws_partial = workspace;
-  float* ws_cs = workspace + (splits > 1 ? (((int64_t)splits * slab + 3) & ~(int64_t)3) : 0);
-  if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
-  g.an_cs = col_sum ? ws_cs : nullptr;
-  constexpr size_t smem_s = sizeof(float) * 2 * (64 * LDS_K + 64 * LDS_K), smem_w = sizeof(float) * 2 * (64 * LDS_K + 128 * LDS_K);
-  static int cfg = 1, cfg_w = 1;
-  if (wide) {
-    if (cfg_w > 0) cfg_w = set_smem(gemm_tn_kernel_t<64, 128, 0, false, true>, smem_w);
-    if (cfg_w != GLNN_OK) return cfg_w;
-    hipLaunchKernelGGL((gemm_tn_kernel_t<64, 128, 0, false, true>), dim3(gi, gj, splits), dim3(256), smem_w, st, g);
-  } else {
-    if (cfg > 0) cfg = set_smem(gemm_tn_kernel_t<64, 64, 0, false, true>, smem_s);
-    if (cfg != GLNN_OK) return cfg;
-    hipLaunchKernelGGL((gemm_tn_kernel_t<64, 64, 0, false, true>), dim3(gi, gj, splits), dim3(256), smem_s, st, g);
-  }
-  int rc = glnn::check_launch("glnn::gemm_tn_bn");
-  if (rc != GLNN_OK) return rc;
-  if (used_floats) *used_floats = (splits > 1 ? (((int64_t)splits * slab + 3) & ~(int64_t)3) : 0) + (col_sum ? (int64_t)splits * ka : 0);
-  if (defer) *defer = {c, nullptr, 0, 0, 0};
-  if (defer_colsum) *defer_colsum = {col_sum, nullptr, 0, 0, 0};
-  if (splits > 1) {
-    if (defer && ldc == nb) {
-      *defer = {c, ws_partial, splits, 0, slab};
-    } else {
-      int blocks = (int)((slab + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(split_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws_partial, slab, splits, c, ldc, ka, nb);
-    }
-  }
-  if (col_sum) {
-    if (defer_colsum) *defer_colsum = {col_sum, ws_cs, splits, 0, (int64_t)ka};
-    else hipLaunchKernelGGL(colsum_stage2, dim3((ka + 255) / 256), dim3(256), 0, st, ws_cs, splits, ka, col_sum);
-  }
-  return glnn::check_launch("glnn::gemm_tn_bn(fold)");
-}
-
 extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                                 const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                                 uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream) {
@@ -1889,7 +1746,7 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   // unless the reduction is long enough for the pipelined kernel's deeper k-loop to pay (>= 2048 rows)
   // -- nor when a WIDE a is streamed over many rows (penn94's GCN: 4814 x 64 over 41554 rows, 0.8 GB): 64-column tiles read 256-byte
   // pieces of 19 KB rows (1.45 TB/s), 128-column tiles 2.2 TB/s (552 -> 369 us)
-  const bool small = fast && gi * gj <= 64 && !(pipe_shape && m >= 2048) && !(m >= 8192 && ka >= 1024);
+  const bool small = tn_small_regime(fast, gi * gj, pipe_shape, m, ka);
   if (small) { bnt = 64; gi = (ka + 63) / 64; gj = (nb + 63) / 64; }
   // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
   int splits = 1;

@@ -15,6 +15,30 @@ struct PendingFolds;
 
 void set_error(const char* fmt, ...);
 
+// Process-wide switches between SUPPORTED forms of the same arithmetic (every form is held to the same results by the tests: the
+// switches exist for those tests and for A/B timing).  Read from the environment ONCE, at the first call into the library
+// (capi.hip: the library's only getenv); glnn_reload_options() re-reads them (tests flip a switch between two runs in one process).
+// All default to the shipping form.
+struct Options {
+  int gemm_pipe;            // GLNN_GEMM_PIPE=0: every GEMM on the compiler-scheduled kernels (no hand-scheduled main loop)
+  int gemm_rowpanel;        // GLNN_GEMM_ROWPANEL=0: short reductions stay on the tiled kernels
+  int gemm_lat;             // GLNN_GEMM_LAT=0: small batches keep the tiled GEMM + separate reduction launches (mlp_lat.hip off)
+  int gemm_tn_lat;          // GLNN_GEMM_TN_LAT=0: the small step's weight gradients as the batched tiled launch
+  int gemm_tn_lat_splits;   // GLNN_GEMM_TN_LAT_SPLITS (8): 1 = unsplit reduction (bit-identical to the two-call step)
+  int lat_bn_bwd;           // GLNN_STUDENT_LAT_BN_BWD=0: input gradient and BatchNorm backward as separate tiled launches
+  int bn_bwd_one_launch;    // GLNN_BN_BWD_ONE_LAUNCH=0: BatchNorm backward as partial + apply launches
+  int narrow_bwd;           // GLNN_STUDENT_NARROW_BWD=0: the classifier's input gradient is always written
+  int64_t narrow_bwd_min;   // GLNN_STUDENT_NARROW_BWD_MIN (1 << 20): rows x hidden width from which it is recomputed instead
+  int narrow_wgrad;         // GLNN_STUDENT_NARROW_WGRAD=0: the classifier's weight gradient stays a gemm_tn launch
+  int pad_w0;               // GLNN_STUDENT_PAD_W0=0: wide unaligned first layers stay on the unaligned-W latency kernel
+  int slab_consumers;       // GLNN_STUDENT_SLAB_CONSUMERS=0: split-K partials are folded by a launch, not by their consumer
+  int defer_stats;          // GLNN_STUDENT_DEFER_STATS=0: small-step BatchNorm statistics finalised by the producing launch
+  int batched_wgrad;        // GLNN_STUDENT_BATCHED_WGRAD=0: small-step weight gradients one launch per layer
+  int fuse_apply;           // GLNN_STUDENT_FUSE_APPLY=0: the first hidden layer's BatchNorm-backward apply stays its own launch
+  int adam_folds;           // GLNN_STUDENT_ADAM_FOLDS=0: gradient partials are folded before Adam, not by it
+};
+const Options& opts();
+
 inline int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 inline int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -91,7 +115,6 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
 // da = dl[rows, k] . w[k, h] (w rows ldw apart: a Linear's [out = k, in = h] weight), k <= 64: see bn_bwd_*_sk in student.hip
-struct BnPartials { const float* p1; const float* p2; int nparts; int64_t pstride; };
 struct NarrowProduct {
   const float* dl; int64_t lddl; int k; const float* w; int64_t ldw;
   // optional (both or dw_ws alone): the first pass also leaves the narrow layer's OWN gradients as row-chunk partials -- dw_ws[chunk][k][h]
@@ -102,9 +125,7 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
                 void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0,
-                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr, struct BnPartials* partial_only = nullptr);
-// partial_only: launch the FIRST pass only and describe its S1 / S2 partials (in `workspace`: keep it until they are consumed); dz, dgamma,
-// dbeta, dz_col_sum are NOT written (glnn::gemm_tn_bn finishes the job inside a weight-gradient GEMM)
+                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr);
 // prod: the input gradient da is NOT in memory (da / ldda ignored): both passes recompute da = dl . w on the matrix cores; BatchNorm
 // two-launch form only (GLNN_ERR_UNSUPPORTED with nothing launched otherwise)
 // defer_colsum: (one-launch form only) dz_col_sum is NOT written; *defer_colsum describes the per-chunk partials left in `workspace`
@@ -139,16 +160,6 @@ int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t wo
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,
             const float* b_shift, float drop_p, uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace,
             int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0);
-// gemm.hip: c[ka, nb] = dz^T . b with dz = the BatchNorm / ReLU / dropout backward of (da, z) evaluated in the operand loads (never written);
-// p1 / p2 = the per-row-chunk sums of dy and dy * xhat (bn_bwd_partial: glnn::bn_relu_bwd with `partial_only`).  Also emits dgamma, dbeta
-// and, with col_sum, the column sums of dz (the bias gradient in front of the norm).  GLNN_ERR_UNSUPPORTED = nothing launched.
-struct TnBnA {
-  const float* z; int64_t ldz; const float* gamma; const float* mean; const float* rstd; const float* a_scale; const float* a_shift;
-  const float* p1; const float* p2; int nparts; int64_t pstride; float drop_p; uint32_t drop_seed; float* dgamma; float* dbeta;
-};
-int gemm_tn_bn(const float* da, int64_t ldda, int64_t m, int ka, const TnBnA& bn, const float* b, int64_t ldb, int nb, float* c, int64_t ldc,
-               float* col_sum, float* workspace, int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum,
-               int64_t* used_floats);
 // student.hip: glnn_adam_step_f32 whose gradient reads fold the pending partial sums (and store the folded gradient); grads_host =
 // host copy of the `grads` pointer table (how a pending fold finds its tensor); pending may be NULL
 int adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,

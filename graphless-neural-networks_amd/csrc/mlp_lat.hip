@@ -645,11 +645,6 @@ __global__ void tile_chunk_sum_kernel(const float* __restrict__ ws, int nchunks,
   out[col] = s;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
 __global__ __launch_bounds__(256) void bn_finalize_tiles_kernel(const BnFinArgs a) { bn_finalize_columns<false>(a, blockIdx.x); }
 
 
@@ -676,9 +671,8 @@ int glnn::gemm_lat(const float* a, int64_t lda, const int64_t* a_rows, const flo
                    uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, const float* bias, float* c,
                    int64_t ldc, const LatStats* pend, const LatStats* st, const LatLoss* ls, void* stream, float* a_copy, int64_t ld_copy,
                    const float* ep_scale, int relu) {
-  const int enabled = env_int("GLNN_GEMM_LAT", 1);            // read per call: tests and A/B runs toggle it between steps
-  static const int max_m = env_int("GLNN_GEMM_LAT_MAX_M", 1024), max_k = env_int("GLNN_GEMM_LAT_MAX_K", 256);
-  static const int max_n = env_int("GLNN_GEMM_LAT_MAX_N", 512);
+  const int enabled = glnn::opts().gemm_lat;
+  constexpr int max_m = 1024, max_k = 256, max_n = 512;      // the latency regime (sweeps of rounds 2-3)
   // W[n, k] whose rows are not float4-addressable (a feature width that is not a multiple of 4: cora's 1433) would take the guarded
   // generic GEMM (206 us for 140 x 128 x 1433): here it is loaded dword by dword, and K may be as deep as it comes
   const bool b_vec = b_layout || (ldb % 4 == 0 && glnn::aligned16(b));
@@ -757,8 +751,8 @@ int glnn::bn_finalize_tiles(const LatStats& st, int64_t m, int n, void* stream) 
 // defer + workspace (the fused Adam launch follows): long reductions are ALSO split over workgroups so that a wave runs one 8-group
 // chunk; the slabs go to the workspace and defer[p] tells Adam how to fold them (k ascending).
 int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer, float* workspace, int64_t workspace_floats) {
-  if (!env_int("GLNN_GEMM_TN_LAT", 1) || n < 1 || n > kTnLatMax) return GLNN_ERR_UNSUPPORTED;
-  static const int max_dim = env_int("GLNN_GEMM_TN_LAT_MAX_DIM", 256);
+  if (!glnn::opts().gemm_tn_lat || n < 1 || n > kTnLatMax) return GLNN_ERR_UNSUPPORTED;
+  constexpr int max_dim = 256;
   TnLatArgs a = {};
   a.n = n;
   int blocks = 0;
@@ -781,9 +775,9 @@ int glnn::gemm_tn_lat(const TnProblem* pr, int n, void* stream, GradFold* defer,
     g.splits = 1; g.slab = 0;
     if (defer) defer[p] = {q.c, nullptr, 0, 0, 0};
     const int64_t slab = (int64_t)q.ka * q.nb;
-    const int gpw_target = env_int("GLNN_GEMM_TN_LAT_GPW", kGroups);
+    const int gpw_target = kGroups;
     int sp = (groups + 4 * gpw_target - 1) / (4 * gpw_target);
-    const int max_sp = env_int("GLNN_GEMM_TN_LAT_SPLITS", 8);        // read per call: 1 = the unsplit form (bit-identical to the two-call step)
+    const int max_sp = glnn::opts().gemm_tn_lat_splits;               // 1 = the unsplit form (bit-identical to the two-call step)
     if (sp > max_sp) sp = max_sp;
     if (defer && workspace && sp > 1 && q.ldc == q.nb) {
       ws_off = (ws_off + 3) & ~(int64_t)3;
@@ -822,9 +816,8 @@ int glnn::lat_dgrad_bn_bwd(const float* dz_up, int64_t ld_up, int64_t m, int k, 
                            const float* gamma, const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                            uint32_t drop_seed, float* da, int64_t ldda, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                            float* workspace, int64_t workspace_floats, void* stream, GradFold* defer_colsum, int skip_apply) {
-  const int max_m = env_int("GLNN_LAT_BN_BWD_MAX_M", 1024);
-  const int max_n = env_int("GLNN_LAT_BN_BWD_MAX_N", 1024), max_k = env_int("GLNN_LAT_BN_BWD_MAX_K", 1024);
-  if (!env_int("GLNN_GEMM_LAT", 1) || !env_int("GLNN_STUDENT_LAT_BN_BWD", 1)) return GLNN_ERR_UNSUPPORTED;
+  constexpr int max_m = 1024, max_n = 1024, max_k = 1024;
+  if (!glnn::opts().gemm_lat || !glnn::opts().lat_bn_bwd) return GLNN_ERR_UNSUPPORTED;
   if (!(dz_up && w && z && gamma && mean && rstd && a_scale && a_shift && da && dz && dgamma && dbeta && workspace)) return GLNN_ERR_UNSUPPORTED;
   if (m < 1 || m > max_m || k < 4 || k > max_k || n < 4 || n > max_n || n % 4) return GLNN_ERR_UNSUPPORTED;
   const int kpad = (k + 3) & ~3;

@@ -59,20 +59,17 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   }
   const float* a_scale = nullptr;
   const float* a_shift = nullptr;
-  const char* nbe = getenv("GLNN_STUDENT_NARROW_BWD");              // "0": always write the classifier's input gradient (A/B runs, tests)
-  const bool narrow_bwd = !(nbe && nbe[0] == '0');
-  const char* nme = getenv("GLNN_STUDENT_NARROW_BWD_MIN");
-  const int64_t narrow_min = nme ? atoll(nme) : (1ll << 20);          // rows x hidden width from which the recomputing form is used
-  const char* nwe = getenv("GLNN_STUDENT_NARROW_WGRAD");            // "0": the classifier's weight gradient stays a gemm_tn launch
-  const bool narrow_wgrad = !(nwe && nwe[0] == '0');
+  const glnn::Options& opt = glnn::opts();                            // switches between equal-result forms (tests, A/B): read once per process
+  const bool narrow_bwd = opt.narrow_bwd != 0;                        // 0: always write the classifier's input gradient
+  const int64_t narrow_min = opt.narrow_bwd_min;                      // rows x hidden width from which the recomputing form is used
+  const bool narrow_wgrad = opt.narrow_wgrad != 0;                    // 0: the classifier's weight gradient stays a gemm_tn launch
   // Will the backward take the classifier's weight AND bias gradient out of the BatchNorm backward's first pass (bn_bwd_partial_wg_sk, see
   // the loop below)?  Then the loss kernel need not sum the bias gradient: it runs its 1024-workgroup form without the last-workgroup fold
   // (products MLP, B = 4096: 17 -> 7 us) and leaves the loss scalar to Adam.  The conditions mirror the backward's; should it fall back
   // after all, gemm_tn computes the column sums (fused_bias = false asks it to).
   bool expect_wg = false;
   if (L >= 2 && narrow_bwd && narrow_wgrad && grp == nullptr && d->batchnorm == 1 && d->dims[L] <= 64 && m > 1024 &&
-      (int64_t)m * d->dims[L - 1] >= narrow_min && !d->act[L - 2] && !d->grad_ready && (m + 127) / 128 <= 64 &&
-      !(d->aux_stream && d->ev_main && d->ev_aux && d->dz2)) {
+      (int64_t)m * d->dims[L - 1] >= narrow_min && !d->act[L - 2] && !d->grad_ready && (m + 127) / 128 <= 64) {
     const int64_t chunks = (m + 127) / 128;
     const int64_t need = ((chunks * d->dims[L] * d->dims[L - 1] + 3) & ~(int64_t)3) + ((chunks * d->dims[L] + 3) & ~(int64_t)3);
     expect_wg = need <= d->ws_tn_floats && d->dims[L - 1] % 4 == 0 && d->ld_dlogits % 4 == 0 && d->ld_dlogits >= d->dims[L] &&
@@ -83,12 +80,9 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const bool fused_bias = cnt && !expect_wg && d->dims[L] <= 64 && d->ws_loss_floats >= 256 * 65;
   bool loss_done = false;
   int logit_slabs = 0;
-  const char* pwe = getenv("GLNN_STUDENT_PAD_W0");                  // "0": wide unaligned first layers stay on the unaligned-W latency kernel
-  const bool pad_w0 = !(pwe && pwe[0] == '0');
-  const char* sce = getenv("GLNN_STUDENT_SLAB_CONSUMERS");
-  const bool slab_consumers = !(sce && sce[0] == '0');
-  const char* dfe = getenv("GLNN_STUDENT_DEFER_STATS");
-  const bool defer_stats = !(dfe && dfe[0] == '0');
+  const bool pad_w0 = opt.pad_w0 != 0;                                // 0: wide unaligned first layers stay on the unaligned-W latency kernel
+  const bool slab_consumers = opt.slab_consumers != 0;
+  const bool defer_stats = opt.defer_stats != 0;
   glnn::LatStats pend = {}, next = {};
   bool have_pend = false;
   for (int l = 0; l < L; ++l) {
@@ -220,27 +214,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
                               nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream,
                               loss_cnt, fused_bias ? d->gb[L - 1] : nullptr,
                               logit_slabs ? d->ws_gemm : nullptr, logit_slabs, logit_slabs ? d->b[L - 1] : nullptr, pf));
-  // ---- backward ----
-  // Two streams when the host provides them (glnn_mlp_step_desc.aux_stream): the critical path dz_l -> input gradient ->
-  // activation backward -> dz_{l-1} stays on `stream`; the weight gradients go to the aux stream.  dz_l alternates between
-  // d->dz and d->dz2 so that a weight gradient can still read dz_l while dz_{l-1} is being written.
-  const bool two = d->aux_stream && d->ev_main && d->ev_aux && d->dz2 && grp == nullptr && L >= 2;
-  hipStream_t s_main = reinterpret_cast<hipStream_t>(stream);
-  hipStream_t s_aux = two ? reinterpret_cast<hipStream_t>(d->aux_stream) : s_main;
-  hipEvent_t ev_main = reinterpret_cast<hipEvent_t>(d->ev_main), ev_aux = reinterpret_cast<hipEvent_t>(d->ev_aux);
-  void* wstream = two ? d->aux_stream : stream;            // where the weight gradients are issued
-  bool aux_used = false;
-#define GLNN_HIP_TRY(expr)                                                                                   \
-  do {                                                                                                        \
-    const hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_mlp_fwd_bwd_f32: %s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-  if (two) GLNN_REQUIRE(d->ld_dz2 >= d->ld_dz, "glnn_mlp_fwd_bwd_f32: ld_dz2 must be >= ld_dz");
+  // ---- backward ----  (one stream: a two-stream form -- weight gradients on a second HIP stream -- was measured slower and lives in
+  //      experiments/two_stream_backward.md since round 4)
   // Small-batch steps (sync counters on, one rank, no hooks, <= 3 layers): the weight gradients are NOT on the backward's critical
   // path, so they are collected and issued at the end as ONE gemm launch + ONE fold launch (glnn::gemm_tn_batch: same tile code, same
   // split plan, same fold order -> the same bits) instead of one gemm + one fold per layer: 4 launches fewer per 3-layer step
-  // (arxiv MLP 0.127 -> 0.10x ms).  dz_l then has to outlive the loop: it alternates between d->dz and d->dz2 as in the two-stream form.
-  const char* dwe = getenv("GLNN_STUDENT_BATCHED_WGRAD");
+  // (arxiv MLP 0.127 -> 0.10x ms).  dz_l then has to outlive the loop: it alternates between d->dz and d->dz2.
   // (both batched kernels want every product inside glnn_gemm_tn_f32's 64 x 64 regime -- <= 64 tiles of 128 x 128|64 -- or they fall back
   //  to one gemm + one fold launch per layer: penn94's 4814 x 256 first layer.  Decide that here and keep the folds for Adam instead.)
   bool batch_shapes = true;
@@ -248,7 +227,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     const int ti = (d->dims[l + 1] + 127) / 128, tj = d->dims[l] > 64 ? (d->dims[l] + 127) / 128 : 1;
     batch_shapes = batch_shapes && ti * tj <= 64;
   }
-  const bool defer = batch_shapes && !(dwe && dwe[0] == '0') && cnt && !two && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
+  const bool defer = batch_shapes && opt.batched_wgrad && cnt && grp == nullptr && !d->grad_ready && d->dz2 && d->ld_dz2 >= d->ld_dz && L <= 3 &&
                      m <= 1024 && fused_bias && !layernorm;      // (larger batches: neither batched kernel takes them -- per layer, folds left to Adam)      // (the last layer's bias gradient must come from the loss kernel: the batched launch has no column sums)
   glnn::TnProblem deferred[GLNN_MLP_MAX_LAYERS];
   int n_deferred = 0;
@@ -257,15 +236,9 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   // one-call form with the latency kernels its apply pass rides in that product's operand loads (TnProblem::bn_z) -- one launch less
   struct { const float* z; int64_t ldz; const float* gamma; const float* mean; const float* rstd; float* ws; int64_t ws_floats; int64_t mt;
            float* dgamma; float* dbeta; float* colsum; float* dz_out; int64_t ld_out; } unapplied = {};
-  const char* fae = getenv("GLNN_STUDENT_FUSE_APPLY");
-  const bool fuse_apply = !(fae && fae[0] == '0') && pf && defer;
-  // large batches: the FIRST hidden layer's dz has one consumer, the first layer's weight gradient -- only the first pass of its
-  // BatchNorm backward is launched (S1 / S2 partials), the rest is applied in that GEMM's operand loads (glnn::gemm_tn_bn)
-  // -- OPT-IN (GLNN_STUDENT_FUSE_APPLY_BIG=1): measured break-even on MLP3w8 (41 us against 20 + 22 us for the apply pass + the pipelined
-  // product: the transform keeps the 64 x 128-tile kernel off the hand-scheduled main loop) and slower on 512-wide students
-  const char* fbe = getenv("GLNN_STUDENT_FUSE_APPLY_BIG");
-  const bool fuse_big = fbe && fbe[0] == '1';
-  struct { bool on; glnn::BnPartials bp; uint32_t seed; float* dz_out; int64_t ld_out; float* wsb; int64_t wsb_floats; } big0 = {};
+  const bool fuse_apply = opt.fuse_apply && pf && defer;
+  // (large batches: the same idea -- the first layer's weight gradient applying the BatchNorm backward in its operand loads -- was
+  //  measured break-even on MLP3w8 and slower on 512-wide students; experiments/gemm_tn_bn.md)
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -296,54 +269,34 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       // layers' gradients) with its own workspace -- ws_gemm is idle during the backward
       // (earlier layers' slabs wait in ws_tn for Adam; if what is left cannot hold a few slabs of this product it would run unsplit --
       //  4 workgroups for vk_class' 512 x 100 over 6754 rows -- so it takes the idle ws_gemm and folds at once instead)
-      const bool cramped = pf && !two && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[1] * d->dims[0] &&
+      const bool cramped = pf && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[1] * d->dims[0] &&
                            d->ws_gemm_floats > d->ws_tn_floats - tn_off;
-      const bool fold_later = pf && !two && !cramped && tn_off < d->ws_tn_floats;
-      float* ws0 = (two || cramped) ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
-      const int64_t ws0_floats = (two || cramped) ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
+      const bool fold_later = pf && !cramped && tn_off < d->ws_tn_floats;
+      float* ws0 = cramped ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
+      const int64_t ws0_floats = cramped ? d->ws_gemm_floats : d->ws_tn_floats - (fold_later ? tn_off : 0);
       glnn::GradFold fw = {}, fc = {};
       int64_t used = 0;
-      int rc0 = GLNN_ERR_UNSUPPORTED;
-      if (big0.on) {
-        const glnn::TnBnA bn = {d->z[0], d->ldz[0], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0], d->a_shift[0], big0.bp.p1, big0.bp.p2,
-                                big0.bp.nparts, big0.bp.pstride, p, big0.seed, d->ggamma[0], d->gbeta[0]};
-        rc0 = glnn::gemm_tn_bn(d->da, d->ld_da, m, d->dims[1], bn, pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, d->dims[0], d->gw[0],
-                               d->dims[0], d->gb[0], ws0, ws0_floats, stream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used);
-        if (rc0 == GLNN_ERR_UNSUPPORTED) {               // (alignment): finish the BatchNorm backward the plain way, then the plain product
-          GLNN_TRY(glnn::bn_relu_bwd(d->da, d->ld_da, d->z[0], d->ldz[0], m, d->dims[1], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0],
-                                     d->a_shift[0], p, big0.seed, big0.dz_out, big0.ld_out, d->ggamma[0], d->gbeta[0], d->gb[0], big0.wsb,
-                                     big0.wsb_floats, stream, nullptr, nullptr));
-          dz = big0.dz_out; ld_dz = big0.ld_out;
-        }
-      }
-      if (rc0 == GLNN_ERR_UNSUPPORTED)
-        rc0 = glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
+      const int rc0 = glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
                             nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
                             d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
                             fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
       GLNN_TRY(rc0);
       if (fold_later) {
-        if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
-        if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
+        GLNN_REQUIRE(pf->n + 2 <= glnn::kMaxGradFolds, "glnn_mlp_train_step_f32: too many pending gradient folds");   // (gemm_tn skipped its own fold launch)
+        if (fw.nslab > 0) pf->e[pf->n++] = fw;
+        if (fc.nslab > 0) pf->e[pf->n++] = fc;
         if (fw.nslab > 0 || fc.nslab > 0) tn_off += (used + 3) & ~(int64_t)3;
       }
       if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, 0, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer 0)");
       break;
     }
     const uint32_t seed = p > 0.f ? drop_seeds[l - 1] : 0u;
-    // an MFMA-bound input gradient (>= 8 GFLOP) goes first and alone; the weight gradient follows it on the aux stream and
-    // overlaps the memory-bound kernels behind it.  A small one (the last layer's rank-C product) runs next to its weight gradient.
-    const bool big_dgrad = 2.0 * (double)m * d->dims[l + 1] * d->dims[l] >= 8e9;
-    if (two && !big_dgrad) {
-      GLNN_HIP_TRY(hipEventRecord(ev_main, s_main));             // dz_l is complete
-      GLNN_HIP_TRY(hipStreamWaitEvent(s_aux, ev_main, 0));
-    }
     // before the fused Adam launch (pf) a split reduction keeps its slabs -- and the column sums behind the last layer's bias gradient
     // their first-stage partials -- for Adam to fold: every layer then gets its own part of ws_tn (tn_off)
     auto weight_gradient = [&]() -> int {
-      const bool cramped = pf && !two && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[l + 1] * d->dims[l] &&
+      const bool cramped = pf && tn_off > 0 && d->ws_tn_floats - tn_off < 8ll * d->dims[l + 1] * d->dims[l] &&
                            d->ws_gemm_floats > d->ws_tn_floats - tn_off;      // see the first layer's product above
-      const bool fold_later = pf && !two && !cramped && tn_off < d->ws_tn_floats;
+      const bool fold_later = pf && !cramped && tn_off < d->ws_tn_floats;
       glnn::GradFold fw = {}, fc = {};
       int64_t used = 0;
       float* wsp = cramped ? d->ws_gemm : d->ws_tn + (fold_later ? tn_off : 0);
@@ -352,24 +305,24 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       int rc;
       if (d->act[l - 1])
         rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->act[l - 1], d->ld_act[l - 1], nullptr, nullptr, nullptr, 0.f, 0u,
-                           d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
+                           d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, stream, fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
       else
         rc = glnn::gemm_tn(dz, ld_dz, m, d->dims[l + 1], d->z[l - 1], d->ldz[l - 1], nullptr, d->a_scale[l - 1], d->a_shift[l - 1],
-                           p, seed, d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, wstream, fold_later ? &fw : nullptr,
+                           p, seed, d->dims[l], d->gw[l], d->dims[l], colsum, wsp, wsf, stream, fold_later ? &fw : nullptr,
                            fold_later ? &fc : nullptr, &used, d->ws_tn_floats);   // hidden layers get their bias gradient from glnn_bn_relu_bwd_f32 below
       if (rc == GLNN_OK && fold_later) {
-        if (fw.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fw;
-        if (fc.nslab > 0 && pf->n < glnn::kMaxGradFolds) pf->e[pf->n++] = fc;
+        GLNN_REQUIRE(pf->n + 2 <= glnn::kMaxGradFolds, "glnn_mlp_train_step_f32: too many pending gradient folds");   // (gemm_tn skipped its own fold launch)
+        if (fw.nslab > 0) pf->e[pf->n++] = fw;
+        if (fc.nslab > 0) pf->e[pf->n++] = fc;
         if (fw.nslab > 0 || fc.nslab > 0) tn_off += (used + 3) & ~(int64_t)3;
       }
       return rc;
     };
     int da_slabs = 0;
     auto input_gradient = [&]() -> int {
-      // ws_gemm is idle during the backward (two-stream form: the first layer's weight gradient borrows it, and never overlaps this
-      // call): deep, skinny input gradients (B = 512, 1024 wide: 128 tiles x 32 dependent k-tiles) may split their reduction
-      const bool ws_free = !two;
-      if (cnt && !two) {
+      // ws_gemm is idle during the backward: deep, skinny input gradients (B = 512, 1024 wide: 128 tiles x 32 dependent k-tiles) may
+      // split their reduction
+      if (cnt) {
         const int rc = glnn::gemm_lat(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
                                       nullptr, d->da, d->ld_da, nullptr, nullptr, nullptr, stream);
         if (rc != GLNN_ERR_UNSUPPORTED) return rc;
@@ -382,22 +335,14 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         }
       }
       return glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, m, d->dims[l + 1], d->w[l], d->dims[l], 1, d->dims[l],
-                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, ws_free ? d->ws_gemm : nullptr, ws_free ? d->ws_gemm_floats : 0, stream);
+                           nullptr, nullptr, nullptr, 0, d->da, d->ld_da, d->ws_gemm, d->ws_gemm_floats, stream);
     };
-    if (two && big_dgrad) {
-      GLNN_TRY(input_gradient());
-      GLNN_HIP_TRY(hipEventRecord(ev_main, s_main));             // dz_l complete AND the MFMA-bound GEMM in front of us done
-      GLNN_HIP_TRY(hipStreamWaitEvent(s_aux, ev_main, 0));
-    }
-    // before the activation backward below overwrites the buffer dz_{l+1} lived in, the weight gradient that reads it (issued
-    // on the aux stream one layer ago) must be done; the wait is enqueued BEFORE this layer's weight gradient re-records ev_aux
-    if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));
-    const bool alt = (two || defer) && ((L - 1 - l) & 1);            // alternate: dz of the layer above is still needed (aux stream / deferred dW)
+    const bool alt = defer && ((L - 1 - l) & 1);            // alternate: dz of the layer above is still needed (deferred dW)
     float* dz_out = alt ? d->dz2 : d->dz;
     const int64_t ld_out = alt ? d->ld_dz2 : d->ld_dz;
     // a NARROW layer behind (the classifier) and a large batch: its input gradient is never written -- both BatchNorm backward passes
     // recompute da = dz . W on the matrix cores (student.hip, bn_bwd_*_sk; they read dz while dz_out is written: distinct buffers only)
-    const bool narrow = narrow_bwd && !two && grp == nullptr && d->batchnorm == 1 && !layernorm && d->dims[l + 1] <= 64 &&
+    const bool narrow = narrow_bwd && grp == nullptr && d->batchnorm == 1 && !layernorm && d->dims[l + 1] <= 64 &&
                         (int64_t)m * d->dims[l] >= narrow_min && dz != dz_out;
     // ... and its first pass, holding dz and act(z) on chip, also leaves the narrow layer's own weight / bias gradient as row-chunk
     // partials in ws_tn (bn_bwd_partial_wg_sk) instead of a gemm_tn launch that re-reads z: folded by Adam, or by chunk_sum launches
@@ -406,12 +351,11 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     const bool wg_colsum = l == L - 1 && !fused_bias;
     bool narrow_wg = narrow && narrow_wgrad && !defer && !d->act[l - 1] && !d->grad_ready && wg_chunks <= 64 && tn_off + wg_need <= d->ws_tn_floats;
     if (!defer && !narrow_wg) GLNN_TRY(weight_gradient());
-    if (two) { GLNN_HIP_TRY(hipEventRecord(ev_aux, s_aux)); aux_used = true; }
-    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, wstream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
+    if (d->grad_ready) GLNN_REQUIRE(d->grad_ready(d->grad_ready_ctx, l, stream) == 0, "glnn_mlp_fwd_bwd_f32: grad_ready hook failed (layer %d)", l);
     // small batches: input gradient + BatchNorm backward as two launches with no wait between workgroups (mlp_lat.hip: the column
     // partial sums come out of the GEMM's epilogue, an apply kernel folds them in its prologue); each layer has its own slice of ws_bn
     bool lat_bn = false;
-    if (cnt && !two && d->batchnorm == 1 && grp == nullptr && L >= 2) {
+    if (cnt && d->batchnorm == 1 && grp == nullptr && L >= 2) {
       const int64_t per = d->ws_bn_floats / (L - 1) / 4 * 4;
       glnn::GradFold cf = {};
       bool skip = fuse_apply && l == 1 && (pregather || !idx);              // gemm_tn_lat's conditions: plain B operands, every dim <= 256
@@ -439,9 +383,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     float* wg_dw = narrow_wg ? d->ws_tn + tn_off : nullptr;
     float* wg_db = (narrow_wg && wg_colsum) ? wg_dw + ((wg_chunks * d->dims[l + 1] * d->dims[l] + 3) & ~(int64_t)3) : nullptr;
     const glnn::NarrowProduct np = {dz, ld_dz, d->dims[l + 1], d->w[l], d->dims[l], wg_dw, wg_db};
-    bool need_da = !(two && big_dgrad);
-    if (narrow) need_da = false;
-    if (need_da) GLNN_TRY(input_gradient());
+    if (!narrow) GLNN_TRY(input_gradient());
     if (layernorm) {
       GLNN_TRY(glnn_layernorm_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->beta[l - 1],
                                       d->mean[l - 1], d->rstd[l - 1], 1, p, seed, dz_out, ld_out, d->ggamma[l - 1], d->gbeta[l - 1],
@@ -456,18 +398,6 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       const bool dc = pf && grp == nullptr && L >= 2 && (d->ws_bn_floats / (L - 1) / 4 * 4) >= need_l && pf->n < glnn::kMaxGradFolds;
       if (dc) { wsb_floats = d->ws_bn_floats / (L - 1) / 4 * 4; wsb = d->ws_bn + (l - 1) * wsb_floats; }
       glnn::GradFold* cfp = dc ? &cf : nullptr;
-      if (fuse_big && l == 1 && !narrow && !two && grp == nullptr && !defer && !d->grad_ready && da_slabs == 0 && (pregather || !idx) &&
-          (int64_t)m * d->dims[1] >= (1ll << 20)) {
-        rc = glnn::bn_relu_bwd(d->da, d->ld_da, d->z[0], d->ldz[0], m, d->dims[1], d->gamma[0], d->mean[0], d->rstd[0], d->a_scale[0],
-                               d->a_shift[0], p, seed, dz_out, ld_out, d->ggamma[0], d->gbeta[0], nullptr, wsb, wsb_floats, stream, nullptr,
-                               nullptr, 1, 0, nullptr, nullptr, &big0.bp);
-        if (rc == GLNN_OK) {
-          big0.on = true; big0.seed = seed; big0.dz_out = dz_out; big0.ld_out = ld_out; big0.wsb = wsb; big0.wsb_floats = wsb_floats;
-          dz = dz_out; ld_dz = ld_out;                    // (not written: the l == 0 product reads da / z instead)
-          continue;
-        }
-        if (rc != GLNN_ERR_UNSUPPORTED) return rc;
-      }
       if (narrow) {
         rc = glnn::bn_relu_bwd(nullptr, 0, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->mean[l - 1],
                                d->rstd[l - 1], d->a_scale[l - 1], d->a_shift[l - 1], p, seed, dz_out, ld_out, d->ggamma[l - 1],
@@ -508,11 +438,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     dz = dz_out;
     ld_dz = ld_out;
   }
-  if (two && aux_used) GLNN_HIP_TRY(hipStreamWaitEvent(s_main, ev_aux, 0));      // join: `stream` continues behind every weight gradient
-#undef GLNN_HIP_TRY
   glnn::GradFold gf[GLNN_MLP_MAX_LAYERS + 2];
   bool tn_done = false;
-  if (defer && glnn::gemm_tn_lat(deferred, n_deferred, stream, pf ? gf : nullptr, d->ws_tn, d->ws_tn_floats) == GLNN_OK) {
+  int rc_lat = GLNN_ERR_UNSUPPORTED;
+  if (defer) rc_lat = glnn::gemm_tn_lat(deferred, n_deferred, stream, pf ? gf : nullptr, d->ws_tn, d->ws_tn_floats);
+  if (rc_lat != GLNN_OK && rc_lat != GLNN_ERR_UNSUPPORTED) return rc_lat;        // a real launch error is not a reason to fall back
+  if (rc_lat == GLNN_OK) {
     // every weight gradient of the step from one launch of the latency kernel; with Adam next, its reduction slabs are folded there
     tn_done = true;
     if (pf)
@@ -564,8 +495,7 @@ extern "C" int glnn_mlp_train_step_f32(const glnn_mlp_step_desc* d, const float*
   GLNN_REQUIRE(adam && adam->params && adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->sizes && adam->grads_host,
                "glnn_mlp_train_step_f32: the Adam descriptor is incomplete");
   glnn::PendingFolds pf = {};
-  const char* e = getenv("GLNN_STUDENT_ADAM_FOLDS");
-  const bool folds = !(e && e[0] == '0') && adam->num_tensors <= 32;
+  const bool folds = glnn::opts().adam_folds && adam->num_tensors <= 32;
   GLNN_TRY(mlp_fwd_bwd_impl(d, feats, ldx, idx, m, kind, labels, target_logp, ldt, target_rows, lamb, drop_seeds, stream, folds ? &pf : nullptr));
   return glnn::adam_step(adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq, adam->sizes, adam->num_tensors, adam->max_size,
                          adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay, adam->step, adam->grads_host,

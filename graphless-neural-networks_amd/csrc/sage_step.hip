@@ -28,22 +28,13 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
   }
   GLNN_REQUIRE(L == 1 || (d->dagg && d->dh), "glnn_sage_fwd_bwd_f32: backward scratch missing");
 
-  // the transposed blocks + 1/(deg+1) of the backward: on the aux stream, under the forward, when the caller provides one
-  const bool side = d->aux_stream && d->ev_fork && d->ev_join && L > 1;
+  // the transposed block + 1/(deg+1) of a layer's backward are built right in front of it (building them on a second stream under the
+  // forward was measured equal and removed in round 4)
   auto transposes = [&](int l, void* st) -> int {
     const glnn_sage_layer& y = d->layer[l];
     GLNN_TRY(glnn_csr_transpose(y.indptr, y.indices, y.n_dst, y.n_src, y.nnz, 1, y.t_indptr, y.t_indices, y.tr_ws, y.tr_ws_bytes, st));
     return glnn_degrees_f32(y.indptr, nullptr, y.n_dst, y.n_src, 0, GLNN_DEG_INV_PLUS1, y.inv_deg, nullptr, st);
   };
-  if (side) {
-    hipStream_t sm = reinterpret_cast<hipStream_t>(stream), sa = reinterpret_cast<hipStream_t>(d->aux_stream);
-    hipEvent_t ef = reinterpret_cast<hipEvent_t>(d->ev_fork), ej = reinterpret_cast<hipEvent_t>(d->ev_join);
-    if (hipEventRecord(ef, sm) != hipSuccess || hipStreamWaitEvent(sa, ef, 0) != hipSuccess)
-      return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fwd_bwd_f32: fork to the aux stream failed");
-    for (int l = L - 1; l >= 1; --l) GLNN_TRY(transposes(l, d->aux_stream));      // in the order the backward consumes them
-    if (hipEventRecord(ej, sa) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fwd_bwd_f32: hipEventRecord(ev_join) failed");
-  }
-  bool joined = !side;
   // ---- forward -----------------------------------------------------------------------------------------------------
   for (int l = 0; l < L; ++l) {
     const glnn_sage_layer& y = d->layer[l];
@@ -80,12 +71,7 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     // dagg = dz W ;  dh = (A^T + I_dst)(dagg / (deg + 1)) over the transposed block
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_out, y.w, d_in, 1, d_in, nullptr, nullptr, nullptr, 0,
                            d->dagg, d->ld_dagg, nullptr, 0, stream));
-    if (!side) GLNN_TRY(transposes(l, stream));
-    if (!joined) {
-      if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(d->ev_join), 0) != hipSuccess)
-        return glnn::fail(GLNN_ERR_HIP, "glnn_sage_fwd_bwd_f32: join with the aux stream failed");
-      joined = true;
-    }
+    GLNN_TRY(transposes(l, stream));
     GLNN_TRY(glnn_spmm_csr_f32(y.t_indptr, y.t_indices, y.n_src, y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, nullptr, y.inv_deg, nullptr,
                                0, nullptr, nullptr, nullptr, 0, d->dh, d->ld_dh, stream));
     const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh

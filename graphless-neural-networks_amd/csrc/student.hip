@@ -1260,12 +1260,8 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                       float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu,
-                      int da_slabs, glnn::GradFold* defer_colsum, const glnn::NarrowProduct* prod, glnn::BnPartials* partial_only) {
+                      int da_slabs, glnn::GradFold* defer_colsum, const glnn::NarrowProduct* prod) {
   if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
-  if (partial_only) {                                    // first pass only (S1 / S2 partials): the caller's GEMM applies the rest in its operand loads
-    if (!gamma || g || prod || da_slabs > 1 || !relu) return GLNN_ERR_UNSUPPORTED;
-    counters = nullptr;
-  }
   if (prod) {                                            // da = dl . w, recomputed by both passes (bn_bwd_*_sk): two-launch BatchNorm form only
     if (!gamma || g || da_slabs > 1 || prod->k < 1 || prod->k > 64 || !prod->dl || !prod->w || prod->lddl < prod->k || prod->ldw < h ||
         (prod->lddl | prod->ldw | h) % 4 != 0 || !glnn::aligned16(prod->dl) || !glnn::aligned16(prod->w) ||    // float4 staging loads
@@ -1300,8 +1296,7 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid((h + 63) / 64, nchunks);
   a.p1 = a.ws1; a.p2 = a.ws2; a.nparts = nchunks; a.pstride = h; a.local_part = -1; a.rows_total = nullptr;
-  const char* ol = getenv("GLNN_BN_BWD_ONE_LAUNCH");          // "0": keep partial + apply as two launches (A/B runs, tests)
-  const bool one_launch = !(ol && ol[0] == '0');
+  const bool one_launch = glnn::opts().bn_bwd_one_launch != 0;       // 0: keep partial + apply as two launches (A/B runs, tests)
   if (gamma && !g && !prereduce && a.counters && one_launch && (int64_t)grid.x * grid.y <= fused_grid_limit() && grid.x <= 256) {
     GLNN_REQUIRE(mean && rstd && a_scale && a_shift && dgamma && dbeta, "glnn_bn_relu_bwd_f32: BN path needs stats and outputs");
     // co-resident grid: partial -> wait -> apply in one launch
@@ -1333,10 +1328,6 @@ int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz
     } else if (prereduce) {
       fold_chunks(a.ws1, a.ws2, nchunks, h, totals, st);
       a.p1 = totals; a.p2 = totals + h; a.nparts = 1; a.pstride = 0;
-    }
-    if (partial_only) {
-      *partial_only = {a.p1, a.p2, a.nparts, a.pstride};
-      return glnn::check_launch("glnn_bn_relu_bwd_f32(partial)");
     }
     if (prod) launch_bn_bwd_sk(true, grid, st, a);
     else if (a.dthr) hipLaunchKernelGGL((bn_bwd_apply<true, true>), grid, dim3(256), 0, st, a);

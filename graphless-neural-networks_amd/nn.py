@@ -6,7 +6,6 @@
 Parameter names follow dgl 0.6.1 so that a reference `model.pth` loads: SAGEConv.fc_neigh.{weight,bias}
 (weight [out,in], xavier_uniform gain=relu; no fc_self for "gcn"), GraphConv.{weight [in,out] xavier_uniform,
 bias zeros}.  Only what the reference constructs is implemented; anything else raises."""
-import os
 
 import torch
 import torch.nn as nn
@@ -15,7 +14,7 @@ from . import ops
 from .autograd import GraphConvFn, SpmmFn, graphconv_fwd, linear_fn
 
 
-FUSED_SAGE_MAX_IN = int(os.environ.get("GLNN_FUSED_SAGE_MAX_IN", "256"))   # aggregate-first layers with d_in, d_out <= 256 take the single-launch K1F kernel.  Interleaved
+FUSED_SAGE_MAX_IN = 256   # aggregate-first layers with d_in, d_out <= 256 take the single-launch K1F kernel.  Interleaved
                           # A/B on one MI355X, products shape (scripts/ab_fused.py): 100->256 10.6 vs 12.5 ms,
                           # 128->256 11.4 vs 12.2 ms, 256->256 23.6 vs 25.1 ms (fused vs aggregation + GEMM)
 

@@ -92,46 +92,67 @@ def feat_empty(n, d, device, zero=False):
     return buf[:, :d]
 
 
+_RANDPERM_LOCK = __import__("threading").Lock()
+
+
 def randperm_cpu(n):
     """torch.randperm(n) from the global CPU generator (what the reference draws its mini-batches with, train_and_eval.py:66), issued
     with ONE intra-op thread: the CPU kernel is a serial shuffle, so the permutation is the same for any thread count
     (scripts/probe_randperm.py), but with the 128-thread pool of a GPU host awake the 0.3 ms job took 7-17 ms -- as long as the 177
-    optimiser steps of an ogbn-arxiv pass."""
-    k = torch.get_num_threads()
-    if k <= 1:
-        return torch.randperm(n)
-    torch.set_num_threads(1)
+    optimiser steps of an ogbn-arxiv pass.  Side effect, by design: torch's process-global intra-op thread count is 1 for the ~0.3 ms of
+    the call (serialised by a lock; a CPU op running concurrently in another thread of the host program sees one thread meanwhile)."""
+    with _RANDPERM_LOCK:
+        k = torch.get_num_threads()
+        if k <= 1:
+            return torch.randperm(n)
+        torch.set_num_threads(1)
+        try:
+            return torch.randperm(n)
+        finally:
+            torch.set_num_threads(k)
+
+
+_PADDED = []            # [(weakref to the source tensor, (version, data_ptr, strides), padded copy)], most recent first, <= 2 live entries
+
+
+def _pad_key(t):
     try:
-        return torch.randperm(n)
-    finally:
-        torch.set_num_threads(k)
+        ver = t._version
+    except RuntimeError:          # tensors created under torch.inference_mode() have no version counter: never cached
+        return None
+    return (ver, t.data_ptr(), tuple(t.stride()), tuple(t.shape))
 
 
-_PADDED = []            # [(weakref to the source tensor, its _version, padded copy)], most recent first, <= 2 entries
+def clear_pad_cache():
+    """Drop the padded copies as_feat remembers (they are only ever handed out for the very same, unmodified source tensor)."""
+    _PADDED.clear()
 
 
 def as_feat(t):
     """Return t itself if its layout suits the float4 kernels, else a padded copy.
     The copy of a LARGE matrix is remembered while the very same tensor object is passed again unmodified (identity + torch's in-place
-    version counter): the reference hands the same `feats` to every epoch's train / evaluate call, and re-padding penn94's 41554 x 4814
-    features (0.8 GB: a zero fill and a copy) cost 0.4 ms of every 1.8 ms GCN epoch.  The result of a padding call is READ-ONLY for the
-    caller (it may be handed out again); every call site in this package only reads it."""
+    version counter + data pointer and strides): the reference hands the same `feats` to every epoch's train / evaluate call, and re-padding
+    a wide unaligned feature matrix (cora 1433, citeseer 3703 columns) was a zero fill and a copy per call.  Writes that bypass the version
+    counter -- raw-pointer writes by this library's own kernels, `.data` assignments -- are NOT seen: such tensors are never inputs of
+    as_feat in this package (parameters skip the cache through requires_grad).  Entries whose source died are evicted on every call.
+    The result of a padding call is READ-ONLY for the caller (it may be handed out again); every call site in this package only reads it."""
     _mat(t, "as_feat")
     if t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
         return t
-    big = t.numel() >= (1 << 20) and not t.requires_grad
-    if big:
-        for i, (ref, ver, pad) in enumerate(_PADDED):
-            if ref() is t and ver == t._version and pad.shape == t.shape and pad.device == t.device:
+    _PADDED[:] = [e for e in _PADDED if e[0]() is not None]
+    key = _pad_key(t) if (t.numel() >= (1 << 20) and not t.requires_grad) else None
+    if key is not None:
+        for i, (ref, k, pad) in enumerate(_PADDED):
+            if ref() is t and k == key and pad.device == t.device:
                 if i:
                     _PADDED.insert(0, _PADDED.pop(i))
                 return pad
     out = feat_empty(t.shape[0], t.shape[1], t.device, zero=True)
     out.copy_(t)
-    if big:
+    if key is not None:
         import weakref
-        _PADDED[:] = [e for e in _PADDED if e[0]() is not None and e[0]() is not t][:1]
-        _PADDED.insert(0, (weakref.ref(t), t._version, out))
+        _PADDED[:] = [e for e in _PADDED if e[0]() is not t][:1]
+        _PADDED.insert(0, (weakref.ref(t), key, out))
     return out
 
 
@@ -232,9 +253,12 @@ _DEFAULT_WS = {}
 
 
 def _default_ws(device):
-    """One lazily allocated 64 MB split-K workspace per device for callers that pass none (stream-ordered reuse: one stream per device)."""
-    key = str(device)
+    """One lazily allocated 64 MB split-K workspace per (device, stream) for callers that pass none: the partials of two GEMMs issued
+    on different streams of one device must not share a buffer (reuse on ONE stream is ordered)."""
+    key = (str(device), int(_stream().value or 0))
     if key not in _DEFAULT_WS:
+        if len(_DEFAULT_WS) >= 8:
+            _DEFAULT_WS.clear()                        # a pathological number of streams: start over rather than grow without bound
         _DEFAULT_WS[key] = torch.empty(1 << 24, dtype=torch.float32, device=device)
     return _DEFAULT_WS[key]
 
@@ -258,10 +282,8 @@ def gemm(a, w, w_is_kn=False, a_rows=None, a_scale=None, a_shift=None, row_scale
     _mat(out, "gemm out")
     if w.stride(0) % 4 and w.numel() <= (1 << 22) and (w_is_kn or k < 4 or n > 512 or m >= 1024):
         w = as_feat(w)                              # weights whose rows are not float4-addressable and that the unaligned-W latency kernel does not
-                                                    # take, or takes badly: [k, n] with n % 4 != 0 (the 2 classes of pokec / penn94), [n, k] with k < 4
-                                                    # (their input gradient), or thousands of rows of A (penn94's 4814-feature first layer over all
-                                                    # 41,554 nodes in evaluate: 3.65 ms at 28 TF on 32-row tiles) -- padded rows (remembered by
-                                                    # as_feat while the weight is unchanged), then the tiled kernels
+                                                    # take, or takes badly ([k, n] with n % 4 != 0, [n, k] with k < 4, or thousands of rows of A):
+                                                    # a padded copy per call (nn.Parameters are never cached by as_feat), then the tiled kernels
     if workspace is None and m * n <= (1 << 22) and k >= 2048:
         workspace = _default_ws(a.device)          # lets a deep, narrow product split its reduction (see gemm.hip)
     with _Timed("gemm", m=m, k=k, n=n):

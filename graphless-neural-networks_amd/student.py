@@ -153,19 +153,7 @@ class StudentEngine:
         # GEMM of csrc/mlp_lat.hip) get the buffer filled by the first layer's GEMM itself; the rest keep the gather in the operand loads
         pg = os.environ.get("GLNN_STUDENT_PREGATHER", "auto")
         self.xb = ops.feat_empty(B, self.dims[0], dev) if pg == "1" or (pg == "auto" and ((B >= 2048 and self.dims[0] > 64) or (B <= 1024 and self.dims[0] <= 256))) else None
-        # two-stream backward (glnn_mlp_step_desc.aux_stream): the weight-gradient GEMMs on a second HIP stream, meant to run under
-        # the memory-bound activation backward of the layers in front.  It does not pay on this part: the pipelined GEMM holds every
-        # CU with one 4-wave workgroup that owns the whole register file, so a kernel on the other stream gets no wave slot until
-        # the GEMM's workgroups retire (rocprofv3 trace: bn_bwd_partial 13 -> 238 us next to the 2048 x 2048 weight gradient), and a
-        # cross-queue event costs 8-12 us.  Kept behind GLNN_STUDENT_TWO_STREAMS=1 for A/B runs.
-        ts = os.environ.get("GLNN_STUDENT_TWO_STREAMS", "auto")
-        self.aux_stream = self.ev_main = self.ev_aux = self.dz2 = None
-        if self.L >= 2 and ts == "1":       # OPT-IN: measured slower (MLP3w8 0.995 -> 1.089 ms, scripts/ab_student_streams.py) -- see DESIGN.md section 3
-            self.aux_stream = torch.cuda.Stream(device=dev)
-            self.ev_main, self.ev_aux = torch.cuda.Event(), torch.cuda.Event()
-            for ev in (self.ev_main, self.ev_aux):
-                ev.record()                                   # (torch creates the hipEvent_t lazily at the first record)
-            self.dz2 = ops.feat_empty(B, hmax, dev)
+        self.dz2 = None
         if self.dz2 is None and self.sync_counters is not None and self.L <= 3:
             self.dz2 = ops.feat_empty(B, hmax, dev)      # small steps defer their weight gradients to ONE batched launch (mlp_step.hip): dz_l must outlive the loop
         self.loss_out = torch.zeros(1, **f32)
@@ -251,8 +239,6 @@ class StudentEngine:
             d.xb, d.ld_xb = ptr(self.xb), self.xb.stride(0)
         if self.sync_counters is not None and max(self.dims) <= 64 * (_lib.MLP_COUNTERS - 1):
             d.sync_counters = ptr(self.sync_counters)
-        if self.aux_stream is not None:
-            d.aux_stream, d.ev_main, d.ev_aux = self.aux_stream.cuda_stream, self.ev_main.cuda_event, self.ev_aux.cuda_event
         if self.dz2 is not None:
             d.dz2, d.ld_dz2 = ptr(self.dz2), self.dz2.stride(0)
         return d

@@ -28,7 +28,6 @@ synchronisation:
 The engine works IN PLACE on the Model's parameters / BatchNorm buffers and on the torch optimizer's state tensors, exactly
 like glnn_amd.student.StudentEngine, so state_dict(), early-stopping snapshots and optimizer.state_dict() keep working."""
 import ctypes
-import os
 
 import torch
 import torch.nn as nn
@@ -122,15 +121,6 @@ class TeacherEngine:
         self.loss_out = torch.zeros(1, **f32)
         self.loss_accum = torch.zeros(1, **f32)
         self._sage_desc = self._arena = self._arena_stream = None      # step_sage: persistent descriptor and scratch arena
-        # step_sage can build the transposed blocks of the backward on a second HIP stream under the forward (glnn_sage_step_desc.aux_stream).
-        # OPT-IN: measured without effect (engine-only step 0.46 vs 0.47 ms; 12-epoch runs land in the same 1450 / 1550 / 1690 steps/s
-        # modes with and without it -- DESIGN.md section 3, TeacherEngine)
-        self.aux_stream = self.ev_fork = self.ev_join = None
-        if os.environ.get("GLNN_TEACHER_AUX_STREAM", "0") == "1" and torch.device(self.dev).type == "cuda":
-            self.aux_stream = torch.cuda.Stream(device=self.dev)
-            self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
-            for ev in (self.ev_fork, self.ev_join):
-                ev.record()                                   # (torch creates the hipEvent_t lazily at the first record)
         self.ws_loss = torch.empty(1024, **f32)
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.grad_sync = None
@@ -177,6 +167,21 @@ class TeacherEngine:
 
     # ------------------------------------------------------------------------------------------ GraphSAGE on blocks
     @torch.no_grad()
+    def _sage_signature(self, enc):
+        """Everything the persistent glnn_sage_step_desc captured once: the data pointers of every parameter, gradient buffer and BatchNorm
+        buffer, and the scalars baked into it.  A step whose signature differs rebuilds the descriptor (only the weight / bias
+        pointers used to be compared, so a replaced norm module or a changed dropout left the C call on stale or freed pointers)."""
+        ptr = lambda t: None if t is None else t.data_ptr()
+        sig = [float(enc.dropout.p), len(enc.layers)]
+        for l, layer in enumerate(enc.layers):
+            w, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+            sig += [ptr(w), ptr(b), ptr(self.grad(w)), ptr(self.grad(b))]
+            if l != len(enc.layers) - 1 and self.bn:
+                bn = enc.norms[l]
+                sig += [ptr(bn.weight), ptr(bn.bias), ptr(self.grad(bn.weight)), ptr(self.grad(bn.bias)), ptr(bn.running_mean), ptr(bn.running_var),
+                        ptr(bn.num_batches_tracked), bn.eps, bn.momentum]
+        return sig + [ptr(self.ws_loss), ptr(self.loss_out), ptr(self.loss_accum)]
+
     def step_sage(self, blocks, feats, labels, output_nodes, lamb=1.0, input_nodes=None):
         """One optimisation step on a batch of sampled blocks (blocks[0] outermost).  `feats` is the GLOBAL feature matrix:
         when blocks[0] carries global source ids (glnn_amd.graph.NodeDataLoader) its aggregation gathers from it directly,
@@ -212,6 +217,7 @@ class TeacherEngine:
         if d is None:
             d = self._sage_desc = _lib.SageStepDesc()
             self._sage_dims = [enc.layers[0].fc_neigh.weight.shape[1]] + [lay.fc_neigh.weight.shape[0] for lay in enc.layers]
+            self.p = float(enc.dropout.p)
             d.num_layers, d.batchnorm, d.dropout_p = L, 1 if self.bn else 0, self.p
             for i, v in enumerate(self._sage_dims):
                 d.dims[i] = v
@@ -226,9 +232,10 @@ class TeacherEngine:
                     y.running_mean, y.running_var, y.nbt = ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked)
             d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
             d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
-            self._sage_static = [(ptr(layer.fc_neigh.weight), ptr(layer.fc_neigh.bias)) for layer in enc.layers]
-        elif any(st != (ptr(layer.fc_neigh.weight), ptr(layer.fc_neigh.bias)) for st, layer in zip(self._sage_static, enc.layers)):
-            self._sage_desc = None                          # the parameters were re-allocated (load_state_dict keeps them; .to() does not)
+            self._sage_static = self._sage_signature(enc)
+        elif self._sage_static != self._sage_signature(enc):
+            self._sage_desc = None                          # something the descriptor captured was replaced (load_state_dict keeps the
+                                                            # tensors; .to(), a new norm module, a changed dropout / eps / momentum do not)
             self.step_count -= 1
             return self.step_sage(blocks, feats, labels, output_nodes, lamb, input_nodes)
         dims = self._sage_dims
@@ -289,8 +296,6 @@ class TeacherEngine:
         d.labels, d.label_rows = ptr(labels), ptr(output_nodes)
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
-        if self.aux_stream is not None:
-            d.aux_stream, d.ev_fork, d.ev_join = self.aux_stream.cuda_stream, self.ev_fork.cuda_event, self.ev_join.cuda_event
         keep = [x]                                              # alive until the call below is queued (same-stream reuse is ordered)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         if rc != 0:

@@ -45,6 +45,9 @@ GLNN_API int glnn_device_info(int* cu_count, int* xcd_count, char* arch_buf, int
 /* sizeof of the descriptor structs below as THIS build sees them (0 = glnn_mlp_step_desc, 1 = glnn_sage_step_desc,
  * 2 = glnn_sage_layer, 3 = glnn_adam_desc; -1 otherwise): lets a binding in another language check its mirror of the layout at load time. */
 GLNN_API int64_t glnn_struct_bytes(int which);
+/* The library reads its GLNN_* environment switches (csrc/glnn_common.h, glnn::Options: choices between supported, equal-result
+ * forms of a launch sequence, for tests and A/B timing) ONCE, at the first call.  This re-reads them; not for concurrent use. */
+GLNN_API void glnn_reload_options(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2  CSR neighbour aggregation (SpMM with an implicit all-ones adjacency, multi-edges kept).
@@ -331,18 +334,9 @@ typedef struct glnn_mlp_step_desc {
    * Return 0 on success.  NULL = no call. */
   int (*grad_ready)(void* ctx, int layer, void* stream);
   void* grad_ready_ctx;
-  /* optional two-stream backward (ABI 5; all NULL = everything on `stream`).  The backward's critical path is
-   *   dz_l -> input gradient GEMM -> BatchNorm/ReLU/dropout backward -> dz_{l-1} -> ...
-   * and the weight-gradient GEMMs hang off it: with aux_stream (a second HIP stream), ev_main / ev_aux (two hipEvent_t created by
-   * the host, timing disabled) and dz2 (a second [max_batch, ld_dz2] gradient buffer: dz_l alternates between dz and dz2, so the
-   * weight gradient of layer l can still read dz_l while the backward of layer l-1 writes dz_{l-1}) the weight-gradient GEMM of
-   * layer l is issued on aux_stream -- behind the layer's input-gradient GEMM when that one is MFMA-bound, next to it
-   * otherwise -- and runs under the memory-bound BatchNorm backward, the first layer's weight gradient and the small kernels of
-   * the layers in front (MLP3w8, B=4096: backward 0.69 -> 0.58 ms).  grad_ready(layer) is then called with aux_stream (the
-   * stream that orders gw[layer]); the call returns with `stream` waiting for everything issued on aux_stream. */
-  void* aux_stream;
-  void* ev_main;
-  void* ev_aux;
+  /* optional second [max_batch, ld_dz2] gradient buffer (ABI 7: the aux_stream / ev_main / ev_aux fields of the two-stream backward
+   * of ABI 5-6 are gone -- measured slower, removed): small steps collect their weight gradients and issue them as ONE launch at the
+   * end of the backward; dz_l then alternates between dz and dz2 so that it outlives the loop. */
   float* dz2;
   int64_t ld_dz2;
 } glnn_mlp_step_desc;
@@ -417,11 +411,6 @@ typedef struct glnn_sage_step_desc {
   float* ws_bn; int64_t ws_bn_floats; float* ws_tn; int64_t ws_tn_floats; float* ws_gemm; int64_t ws_gemm_floats;
   float* ws_loss; int64_t ws_loss_floats;
   float* loss_out; float* loss_accum;
-  /* optional (ABI 6; all NULL = everything on `stream`): the transposed blocks + 1/(deg+1) vectors the BACKWARD needs depend only on
-   * the blocks, so they are built on aux_stream (hipStream_t) while the forward runs on `stream`: ev_fork is recorded on `stream` at
-   * entry, ev_join on aux_stream behind the last transpose; `stream` waits for ev_join before the first transposed aggregation
-   * (hipEvent_t, both created by the caller).  ~12 launches of ~5 us leave the step's critical path. */
-  void* aux_stream; void* ev_fork; void* ev_join;
 } glnn_sage_step_desc;
 
 GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream);

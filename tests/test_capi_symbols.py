@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in fns:
         assert hasattr(h, name), f"{name} declared in include/glnn_hip.h but not exported"
     h.glnn_abi_version.restype = ctypes.c_int
-    assert h.glnn_abi_version() == 6
+    assert h.glnn_abi_version() == 7
     h.glnn_last_error.restype = ctypes.c_char_p
     assert h.glnn_last_error() is not None
 
@@ -42,7 +42,7 @@ def test_binding_table_matches_header():
     for name, argtypes in _lib.SIGNATURES.items():
         assert name in fns, name
         assert len(argtypes) == fns[name], f"{name}: binding has {len(argtypes)} args, header {fns[name]}"
-    assert set(fns) - set(_lib.SIGNATURES) == {"glnn_last_error"}
+    assert set(fns) - set(_lib.SIGNATURES) == {"glnn_last_error", "glnn_reload_options"}
     glnn_amd.lib()
 
 
@@ -139,3 +139,25 @@ def test_cross_workgroup_publishes_drain_their_stores_before_the_counter_update(
             assert any(l.startswith("s_barrier") for l in region), name
             checked += 1
     assert checked >= 8, checked      # loss, bn statistics, bn backward (partial / fused), column sums; the latency GEMM's epilogues
+
+
+def test_library_reads_the_environment_in_one_place():
+    """The GLNN_* switches (glnn::Options) are read ONCE, by one function of csrc/capi.hip; no kernel launcher calls getenv
+    (round 3 had 14 per-call reads on the hot launch paths)."""
+    import glob
+    hits = {}
+    for f in glob.glob(os.path.join(ROOT, "graphless-neural-networks_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h")):
+            n = len(re.findall(r"\bgetenv\s*\(", open(f).read()))
+            if n:
+                hits[os.path.basename(f)] = n
+    assert hits == {"capi.hip": 1}, hits
+
+
+def test_reload_options_follows_the_environment(monkeypatch):
+    from glnn_amd import _lib
+    h = _lib.lib()
+    monkeypatch.setenv("GLNN_GEMM_PIPE", "0")
+    h.glnn_reload_options()            # (no way to read a switch back through the C ABI: the GPU tests observe the effect)
+    monkeypatch.delenv("GLNN_GEMM_PIPE")
+    h.glnn_reload_options()

@@ -39,44 +39,6 @@ def test_spmm_sage_gcn_vs_oracle(d):
         assert float(base[:, d:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("d,mode", [(47, "sage"), (64, "sage"), (100, "sage"), (128, "sum"), (256, "sage"), (200, "sage")])
-def test_group_per_row_aggregation_kernel_vs_oracle(d, mode, monkeypatch):
-    """The opt-in group-per-row form of the aggregation (GLNN_SPMM_GPR=1: batches of 32 rows per wave, one lane group per row,
-    indices and self rows prefetched a row ahead, rows dealt inside the wave) against the oracle: empty rows, hub rows that the
-    long-row role keeps, multi-edges, a ragged last batch, an epilogue (bias + ReLU); and a self-row indirection."""
-    from glnn_amd import ops
-    monkeypatch.setenv("GLNN_SPMM_GPR", "1")
-    monkeypatch.setenv("GLNN_SPMM_GPR_MIN_ROWS", "0")
-    n = 3001
-    indptr, indices = random_graph(n, 14, seed=d + 1, power=0.6, isolated=9, hub=2500)
-    x = np.random.RandomState(d).standard_normal((n, d)).astype(np.float32)
-    ip, ix = g2d(indptr, indices)
-    if mode == "sage":
-        want = to.sage_gcn_agg(indptr, indices, x)
-        got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN)
-    else:
-        want = to.spmm_sum(indptr, indices, x)
-        got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SUM)
-    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0 if mode == "sage" else 1e-5)    # (unnormalised sums of 2500 terms)
-    if mode == "sage":
-        bias = np.random.RandomState(1).standard_normal(d).astype(np.float32)
-        got = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN, ep_shift=dev(bias), relu=True)
-        np.testing.assert_allclose(got.cpu().numpy(), np.maximum(want + bias, 0), atol=TOL, rtol=0)
-        # block form: destinations = the first 1000 rows, self rows through an index list into another matrix
-        rows = np.random.RandomState(2).permutation(n)[:1000].astype(np.int64)
-        xs = np.random.RandomState(3).standard_normal((n, d)).astype(np.float32)
-        got = ops.spmm(ip[:1001], ix, dev(x), 1000, ops.AGG_SAGE_GCN, x_self=dev(xs), self_rows=dev(rows))
-        s = to.spmm_sum(indptr[:1001], indices, x, n_dst=1000)
-        deg = (indptr[1:1001] - indptr[:1000]).astype(np.float32)[:, None]
-        np.testing.assert_allclose(got.cpu().numpy(), (s + xs[rows]) / (deg + 1), atol=TOL, rtol=0)
-    # and against the default (wave-per-row) kernel
-    monkeypatch.setenv("GLNN_SPMM_GPR", "0")
-    ref = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN if mode == "sage" else ops.AGG_SUM)
-    monkeypatch.setenv("GLNN_SPMM_GPR", "1")
-    again = ops.spmm(ip, ix, dev(x), n, ops.AGG_SAGE_GCN if mode == "sage" else ops.AGG_SUM)
-    assert float((ref - again).abs().max() / ref.abs().max().clamp(min=1)) <= 2e-5
-
-
 def test_spmm_known_answers_on_gpu():
     from glnn_amd import ops
     src = np.array([0, 2, 2, 3, 1]); dst = np.array([1, 1, 1, 3, 0])

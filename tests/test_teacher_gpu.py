@@ -360,38 +360,6 @@ def test_train_sage_on_device_built_blocks_vs_oracle_and_global_gather():
         np.testing.assert_allclose(g_gpu.cpu().numpy(), g_ref, atol=1e-5, rtol=1e-4, err_msg=pname)
 
 
-def test_sage_step_with_transposes_on_the_aux_stream_is_bit_identical(monkeypatch):
-    """glnn_sage_step_desc.aux_stream / ev_fork / ev_join (opt-in, GLNN_TEACHER_AUX_STREAM=1): the transposed blocks of the backward are
-    built on a second HIP stream while the forward runs -- same kernels, same data, so three steps end in the same parameters bit for bit."""
-    from glnn_amd import ops
-    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
-    from glnn_amd.models import Model
-    from glnn_amd.teacher import TeacherEngine
-    n, dims = 20000, [40, 64, 64, 9]
-    indptr, indices = random_graph(n, 10, seed=9, power=0.6, hub=5000, isolated=30)
-    rs = np.random.RandomState(9)
-    fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
-    ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
-    g = _graph(indptr, indices)
-    batches = list(NodeDataLoader(g, torch.arange(1536), MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=False, seed=5))
-    states = []
-    for aux in ("0", "1"):
-        monkeypatch.setenv("GLNN_TEACHER_AUX_STREAM", aux)
-        torch.manual_seed(2)
-        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=0.3,
-                           norm_type="batch", device=DEV))
-        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
-        model.train()
-        eng = TeacherEngine(model, opt)
-        assert (eng.aux_stream is not None) == (aux == "1")
-        for input_nodes, output_nodes, blocks in batches:
-            eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
-        torch.cuda.synchronize()
-        states.append([t.detach().clone() for t in model.state_dict().values()] + [eng.loss_out.clone()])
-    for a, b in zip(*states):
-        assert torch.equal(a, b)
-
-
 def test_autograd_surface_matches_the_engine():
     """Callers that differentiate Model.forward themselves (loss.backward() as in the reference's loops) get the same
     gradients as the engine: both run the same HIP kernels."""
