@@ -3,7 +3,7 @@ target of the SQ counter pass in scripts/rowpanel_pmc.sh."""
 import os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from glnn_amd import ops
+from glnn_amd import _lib, ops
 dev = "cuda:0"
 shapes = [("products replicated projection", 2449029, 100, 256), ("teacher-training layer 0", 500000, 100, 256), ("student first layer", 4096, 100, 2048),
           ("xl chunk (1/10)", 2500000, 128, 256)]
@@ -13,8 +13,9 @@ for what, m, k, n in shapes:
     es, eh = torch.rand(n, device=dev) + 0.5, torch.randn(n, device=dev)
     out = ops.feat_empty(m, n, dev)
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "2", "0"):
         os.environ["GLNN_GEMM_ROWPANEL"] = mode
+        _lib.lib().glnn_reload_options()
         for _ in range(3):
             ops.gemm(a, w, ep_scale=es, ep_shift=eh, relu=True, out=out)
         ts = []
@@ -24,5 +25,7 @@ for what, m, k, n in shapes:
             ts.append(s.elapsed_time(e))
         res[mode] = statistics.median(ts)
     fl = 2.0 * m * k * n
-    print(f"{what:34s} m={m:8d} k={k:3d} n={n:4d}  rowpanel {res['1'] * 1e3:9.1f} us = {fl / res['1'] / 1e9:6.1f} TF   tiled {res['0'] * 1e3:9.1f} us = {fl / res['0'] / 1e9:6.1f} TF", flush=True)
+    print(f"{what:34s} m={m:8d} k={k:3d} n={n:4d}  rowpanel {res['1'] * 1e3:9.1f} us = {fl / res['1'] / 1e9:6.1f} TF   workgroup-tile form {res['2'] * 1e3:9.1f} us = "
+          f"{fl / res['2'] / 1e9:6.1f} TF   tiled {res['0'] * 1e3:9.1f} us = {fl / res['0'] / 1e9:6.1f} TF", flush=True)
 os.environ["GLNN_GEMM_ROWPANEL"] = "1"
+_lib.lib().glnn_reload_options()
