@@ -187,168 +187,6 @@ __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// K3r, wave-private form (k <= 112): NO barrier in the walk.  The SQ counters of the form above show its waves parked 21 % of their
-// cycles (profiles/r04_rowpanel_sq.txt: SQ_WAIT_ANY) -- the per-tile workgroup barrier and the LDS latency all eight waves then pay
-// at once.  Here a workgroup shares only its W panel (64 columns, loaded once, ONE barrier); every wave owns a private LDS tile of
-// 32 rows and walks its OWN sequence of 32-row tiles of A: stage registers -> private tile (LDS operations of one wave are ordered:
-// no barrier, no wait) -> request the next tile -> 2 x 4 KG MFMAs on two independent accumulators (two 32-column blocks), with the
-// previous tile's 32 stores leaving from a second accumulator pair in the first k-groups.  Two waves per SIMD drift apart freely, so
-// one's staging / store phase lies under the other's MFMAs.  Same k order per output element: bit-identical to the form above.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRwRows = 32;       // rows of A per wave tile
-constexpr int kRwCols = 64;       // columns of W per workgroup
-constexpr int kRwWaves = 8;
-
-template <int KG>
-__global__ __launch_bounds__(64 * kRwWaves) void gemm_rowpanel_wave_kernel(const RpArgs g) {
-  constexpr int KP = 8 * KG;
-  constexpr int KS = KP + 4;
-  constexpr int NP = (kRwRows * (KP / 4) + 63) / 64;       // float4 per lane and tile (upper bound: kv <= KP / 4)
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Wp = lds;                                         // [64][KS]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* At = lds + kRwCols * KS + wave * (kRwRows * KS);  // this wave's [32][KS]
-  const int li = lane & 31, kk = lane >> 5;
-  const int n0 = blockIdx.y * kRwCols;
-  const int kv = g.k >> 2;
-
-  constexpr uint32_t kOob = 0x80000000u;
-  uint32_t a_voff[NP];
-  int a_loff[NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q) {
-    const int f = lane + 64 * q;
-    const int row = f / kv, c = f - row * kv;
-    const bool on = f < kRwRows * kv;
-    a_voff[q] = on ? (uint32_t)((row * g.lda + 4 * c) * 4) : kOob;
-    a_loff[q] = on ? (kRwCols + wave * kRwRows + row) * KS + 4 * c           // (offsets from `lds`)
-                   : (kRwCols + kRwWaves * kRwRows) * KS + 4 * tid;         // idle pieces write a private dummy slot behind the tiles
-  }
-  const int64_t wtiles = (g.m + kRwRows - 1) / kRwRows;
-  auto rows_of = [&](int64_t tile) -> int64_t {
-    const int64_t left = g.m - tile * kRwRows;
-    return left < 0 ? 0 : (left > kRwRows ? kRwRows : left);
-  };
-  auto a_rsrc = [&](int64_t tile) {
-    const int64_t v = rows_of(tile);
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a) + tile * kRwRows * g.lda, 0, v > 0 ? (int)(((v - 1) * g.lda + g.k) * 4) : 0,
-                                             0x00020000);
-  };
-  auto c_rsrc = [&](int64_t tile) {
-    const int64_t v = rows_of(tile);
-    return __builtin_amdgcn_make_buffer_rsrc(g.c + tile * kRwRows * g.ldc, 0, v > 0 ? (int)(((v - 1) * g.ldc + g.n) * 4) : 0, 0x00020000);
-  };
-  float4 stage[NP];
-  auto load_tile = [&](int64_t tile) {
-    const __amdgpu_buffer_rsrc_t rs = a_rsrc(tile);
-#pragma unroll
-    for (int q = 0; q < NP; ++q) stage[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, a_voff[q], 0, 0));
-  };
-  auto store_tile_lds = [&]() {
-#pragma unroll
-    for (int q = 0; q < NP; ++q) *reinterpret_cast<float4*>(lds + a_loff[q]) = stage[q];
-  };
-
-  // ---- prologue: zero behind k, W panel -> LDS (all waves), one barrier ----
-  if (g.k < KP) {
-    for (int r = tid; r < kRwCols + kRwWaves * kRwRows; r += 64 * kRwWaves)
-      *reinterpret_cast<float4*>(lds + r * KS + g.k) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int f = tid; f < kRwCols * kv; f += 64 * kRwWaves) {
-    const int row = f / kv, c = f - row * kv;
-    int ng = n0 + row;
-    if (ng > g.n - 1) ng = g.n - 1;
-    *reinterpret_cast<float4*>(Wp + row * KS + 4 * c) = rp_ld4(g.w + (int64_t)ng * g.ldw + 4 * c);
-  }
-  const int64_t first = (int64_t)blockIdx.x * kRwWaves + wave, stride = (int64_t)gridDim.x * kRwWaves;
-  const int64_t n_my = first < wtiles ? (wtiles - first + stride - 1) / stride : 0;
-  load_tile(first);                                        // (out of range = zeros, if this wave has no tile)
-  __syncthreads();
-  if (n_my == 0) return;
-
-  const int col0 = n0 + li, col1 = n0 + 32 + li;
-  const bool ok0 = col0 < g.n, ok1 = col1 < g.n;
-  const float es0 = (ok0 && g.ep_scale) ? g.ep_scale[col0] : 1.f, eh0 = (ok0 && g.ep_shift) ? g.ep_shift[col0] : 0.f;
-  const float es1 = (ok1 && g.ep_scale) ? g.ep_scale[col1] : 1.f, eh1 = (ok1 && g.ep_shift) ? g.ep_shift[col1] : 0.f;
-  const uint32_t c_voff0 = ok0 ? (uint32_t)((4 * kk * g.ldc + col0) * 4) : kOob;
-  const uint32_t c_voff1 = ok1 ? (uint32_t)((4 * kk * g.ldc + col1) * 4) : kOob;
-  const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
-  const float* ap = At + li * KS + kk * 4;
-  const float* bp0 = Wp + li * KS + kk * 4;
-  const float* bp1 = Wp + (32 + li) * KS + kk * 4;
-
-  rp_f32x16 acc[2][2];                                     // [set][column block]
-  auto store_eighth = [&](const rp_f32x16 (&av)[2], const __amdgpu_buffer_rsrc_t rs, int e) {      // e = 0..7: block e >> 2, rows 4 (e & 3) ..
-    const int b = e >> 2, q0 = e & 3;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float v = fmaf(av[b][4 * q0 + t], b ? es1 : es0, b ? eh1 : eh0);
-      if (g.relu) v = fmaxf(v, 0.f);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, b ? c_voff1 : c_voff0, (uint32_t)(8 * q0 + t) * ldc4, 0);
-    }
-  };
-
-  auto tile_step = [&](auto cur_, int64_t it) {
-    constexpr int CUR = decltype(cur_)::value;
-    const int64_t tile = first + it * stride;
-    const __amdgpu_buffer_rsrc_t prev = c_rsrc(it > 0 ? tile - stride : wtiles);       // size 0 at the walk's start: stores dropped
-    store_tile_lds();                                      // stage (tile `it`, requested a tile ago) -> the private LDS tile
-    load_tile(tile + stride);                              // tile it+1 -> stage (out of range behind the walk's end)
-    float4 af = rp_ld4(ap), bf0 = rp_ld4(bp0), bf1 = rp_ld4(bp1);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[CUR][0][r] = 0.f; acc[CUR][1][r] = 0.f; }
-#pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-      float4 an = af, bn0 = bf0, bn1 = bf1;
-      if (kg + 1 < KG) {
-        an = rp_ld4(ap + (kg + 1) * 8);
-        bn0 = rp_ld4(bp0 + (kg + 1) * 8);
-        bn1 = rp_ld4(bp1 + (kg + 1) * 8);
-      }
-      acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf0.x, acc[CUR][0], 0, 0, 0);
-      acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf1.x, acc[CUR][1], 0, 0, 0);
-      acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf0.y, acc[CUR][0], 0, 0, 0);
-      acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf1.y, acc[CUR][1], 0, 0, 0);
-      acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf0.z, acc[CUR][0], 0, 0, 0);
-      acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf1.z, acc[CUR][1], 0, 0, 0);
-      acc[CUR][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf0.w, acc[CUR][0], 0, 0, 0);
-      acc[CUR][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf1.w, acc[CUR][1], 0, 0, 0);
-      if (kg < 4) { store_eighth(acc[CUR ^ 1], prev, 2 * kg); store_eighth(acc[CUR ^ 1], prev, 2 * kg + 1); }
-      __builtin_amdgcn_sched_barrier(0);
-      af = an; bf0 = bn0; bf1 = bn1;
-    }
-  };
-  for (int64_t it = 0; it < n_my; it += 2) {
-    tile_step(std::integral_constant<int, 0>{}, it);
-    if (it + 1 < n_my) tile_step(std::integral_constant<int, 1>{}, it + 1);
-  }
-  const int64_t last = n_my - 1;
-  const __amdgpu_buffer_rsrc_t rl = c_rsrc(first + last * stride);
-  if (last & 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) store_eighth(acc[1], rl, e);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) store_eighth(acc[0], rl, e);
-  }
-}
-
-template <int KG>
-int launch_rowpanel_wave(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
-  constexpr size_t smem = sizeof(float) * ((size_t)(kRwCols + kRwWaves * kRwRows) * (8 * KG + 4) + 4 * 64 * kRwWaves);   // + dummy slots
-  static_assert(smem <= 160 * 1024, "LDS");
-  static int configured = 0;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpanel_wave_kernel<KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return glnn::fail(GLNN_ERR_HIP, "gemm_rowpanel: hipFuncSetAttribute(max dynamic LDS=%zu) failed", smem);
-    configured = 1;
-  }
-  hipLaunchKernelGGL(gemm_rowpanel_wave_kernel<KG>, dim3((unsigned)grid_x, (unsigned)panels), dim3(64 * kRwWaves), smem, st, g);
-  return glnn::check_launch("glnn_gemm_f32(rowpanel, wave-private)");
-}
-
 template <int KG>
 int launch_rowpanel(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
   constexpr size_t smem = sizeof(float) * ((size_t)(kRpCols + 2 * kRpRows) * (8 * KG + 4) + 4 * kRpThreads);      // + the idle pieces' dummy slots
@@ -377,30 +215,6 @@ int glnn::gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const flo
   g.c = c; g.ldc = ldc; g.tiles = (m + kRpRows - 1) / kRpRows;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int kg = (k + 7) / 8;
-  if (kg <= 14 && glnn::opts().gemm_rowpanel != 2) {
-    // wave-private form: 64-column panels, 8 independent walkers per workgroup, 32-row tiles (LDS: 64 + 8 x 32 rows of k + 4 floats)
-    g.tiles = (m + kRwRows - 1) / kRwRows;
-    const int panels = (n + kRwCols - 1) / kRwCols;
-    if (panels > 65535) return GLNN_ERR_UNSUPPORTED;
-    int64_t gx = 256 / panels;                              // one workgroup per CU; the panels of a row strip on one XCD (grid_x % 8 == 0)
-    if (gx < 8) gx = 8;
-    gx &= ~(int64_t)7;
-    while (gx > 8 && g.tiles < 2 * gx * kRwWaves) gx -= 8;
-    if (g.tiles < 2 * gx * kRwWaves) return GLNN_ERR_UNSUPPORTED;      // fewer than two tiles per wave: the panel load does not pay
-    switch (kg) {
-      case 5: return launch_rowpanel_wave<5>(g, (int)gx, panels, st);
-      case 6: return launch_rowpanel_wave<6>(g, (int)gx, panels, st);
-      case 7: return launch_rowpanel_wave<7>(g, (int)gx, panels, st);
-      case 8: return launch_rowpanel_wave<8>(g, (int)gx, panels, st);
-      case 9: return launch_rowpanel_wave<9>(g, (int)gx, panels, st);
-      case 10: return launch_rowpanel_wave<10>(g, (int)gx, panels, st);
-      case 11: return launch_rowpanel_wave<11>(g, (int)gx, panels, st);
-      case 12: return launch_rowpanel_wave<12>(g, (int)gx, panels, st);
-      case 13: return launch_rowpanel_wave<13>(g, (int)gx, panels, st);
-      case 14: return launch_rowpanel_wave<14>(g, (int)gx, panels, st);
-      default: return GLNN_ERR_UNSUPPORTED;
-    }
-  }
   const int panels = (n + kRpCols - 1) / kRpCols;
   if (panels > 65535) return GLNN_ERR_UNSUPPORTED;
   // one workgroup per CU (the W panel + two A buffers take 108-132 KB of the CU's 160 KB LDS): 256 workgroups in all, the `panels`

@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...);
 // All default to the shipping form.
 struct Options {
   int gemm_pipe;            // GLNN_GEMM_PIPE=0: every GEMM on the compiler-scheduled kernels (no hand-scheduled main loop)
-  int gemm_rowpanel;        // GLNN_GEMM_ROWPANEL=0: short reductions stay on the tiled kernels; 2: the workgroup-tile form for every k <= 128
+  int gemm_rowpanel;        // GLNN_GEMM_ROWPANEL=0: short reductions stay on the tiled kernels
   int gemm_lat;             // GLNN_GEMM_LAT=0: small batches keep the tiled GEMM + separate reduction launches (mlp_lat.hip off)
   int gemm_tn_lat;          // GLNN_GEMM_TN_LAT=0: the small step's weight gradients as the batched tiled launch
   int gemm_tn_lat_splits;   // GLNN_GEMM_TN_LAT_SPLITS (8): 1 = unsplit reduction (bit-identical to the two-call step)

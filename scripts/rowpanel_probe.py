@@ -13,7 +13,7 @@ for what, m, k, n in shapes:
     es, eh = torch.rand(n, device=dev) + 0.5, torch.randn(n, device=dev)
     out = ops.feat_empty(m, n, dev)
     res = {}
-    for mode in ("1", "2", "0"):
+    for mode in ("1", "0"):
         os.environ["GLNN_GEMM_ROWPANEL"] = mode
         _lib.lib().glnn_reload_options()
         for _ in range(3):
@@ -25,7 +25,7 @@ for what, m, k, n in shapes:
             ts.append(s.elapsed_time(e))
         res[mode] = statistics.median(ts)
     fl = 2.0 * m * k * n
-    print(f"{what:34s} m={m:8d} k={k:3d} n={n:4d}  rowpanel {res['1'] * 1e3:9.1f} us = {fl / res['1'] / 1e9:6.1f} TF   workgroup-tile form {res['2'] * 1e3:9.1f} us = "
-          f"{fl / res['2'] / 1e9:6.1f} TF   tiled {res['0'] * 1e3:9.1f} us = {fl / res['0'] / 1e9:6.1f} TF", flush=True)
+    print(f"{what:34s} m={m:8d} k={k:3d} n={n:4d}  rowpanel {res['1'] * 1e3:9.1f} us = {fl / res['1'] / 1e9:6.1f} TF   "
+          f"tiled {res['0'] * 1e3:9.1f} us = {fl / res['0'] / 1e9:6.1f} TF", flush=True)
 os.environ["GLNN_GEMM_ROWPANEL"] = "1"
 _lib.lib().glnn_reload_options()

@@ -215,14 +215,14 @@ def test_rowpanel_gemm_equals_the_tiled_kernels_bit_for_bit(m, k, n, epi, monkey
     es = dev(r.uniform(0.5, 1.5, n).astype(np.float32)) if epi else None
     eh = dev(r.standard_normal(n).astype(np.float32)) if epi else None
     outs = []
-    for mode in ("1", "2", "0"):       # 1 = shipping choice (wave-private walkers for k <= 112), 2 = the workgroup-tile form for every k, 0 = tiled kernels
+    for mode in ("1", "0"):            # the row-panel kernel | the tiled kernels
         monkeypatch.setenv("GLNN_GEMM_ROWPANEL", mode)
         out = ops.feat_empty(m, n, DEV)
         base = torch.as_strided(out, (m, out.stride(0)), (out.stride(0), 1))
         base.fill_(-7.0)
         ops.gemm(a, w, ep_scale=es, ep_shift=eh, relu=epi, out=out)
         outs.append(base.clone())
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    assert torch.equal(outs[0], outs[1])
     if outs[0].shape[1] > n:
         assert float((outs[0][:, n:] + 7.0).abs().max()) == 0.0          # padding columns: not written by either path
     want = a[:, :k].double() @ w.double().t()
