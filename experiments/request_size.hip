@@ -81,6 +81,52 @@ __global__ __launch_bounds__(512) void gather_kernel(const int32_t* __restrict__
   if (on) out[(wave * 64 + lane) % (1 << 20)] = acc.x + acc.y + acc.z + acc.w;
 }
 
+// SPLIT LAYOUT probe: a D-column row stored as a 128-byte-aligned MAIN part (`dm` columns, pitch ldm: whole lines only) + a small
+// TAIL part (d - dm columns, pitch ldt) in a second, compact array that can stay in the 256 MB Infinity Cache: does a line served by the
+// Infinity Cache cost as much as one from HBM?  MODE 0 = both parts, 1 = main part only (upper bound), 2 = tail part only.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(512) void gather_split_kernel(const int32_t* __restrict__ idx, int64_t n_edges, const float* __restrict__ xm, int ldm, int dm,
+                                                            const float* __restrict__ xt, int ldt, int d, float* __restrict__ out) {
+  constexpr int G = 64 / LPR, U = 8;
+  const int lane = threadIdx.x & 63, g = lane / LPR, c4 = (lane % LPR) * 4;
+  const bool in_main = c4 < dm, on = c4 < d && (MODE == 0 || (MODE == 1) == in_main);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t e0 = wave * (G * U); e0 + G * U <= n_edges; e0 += n_waves * (G * U)) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = idx[e0 + u * G + g];
+      const float* p = in_main ? xm + row * ldm + c4 : xt + row * ldt + (c4 - dm);
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (on) v[u] = ld4p<0>(p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < U; ++u) { asm volatile("" : "+v"(v[u])); acc += v[u]; }
+  }
+  if (on) out[(wave * 64 + lane) % (1 << 20)] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int LPR, int MODE>
+void run_split(const char* what, const int32_t* idx, int64_t n_edges, const float* xm, int ldm, int dm, const float* xt, int ldt, int d, float* out) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(a, 0);
+    hipLaunchKernelGGL((gather_split_kernel<LPR, MODE>), dim3(4096), dim3(512), 0, 0, idx, n_edges, xm, ldm, dm, xt, ldt, d, out);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  printf("split d=%3d main %3d cols (pitch %3d) + tail (pitch %2d) mode=%d  %-30s %8.3f ms  %6.2f G rows/s\n", d, dm, ldm, ldt, MODE, what, best,
+         (double)n_edges / best / 1e6);
+  fflush(stdout);
+}
+
 template <int LPR, int BODY, int TAIL>
 float run(const char* what, const int32_t* idx, int64_t n_edges, const float* x, int ld, int d, float* out) {
   hipEvent_t a, b;
@@ -129,5 +175,21 @@ int main() {
   run<32, 5, 5>("nt sc0 sc1", idx, n_edges, x, 100, 100, out);
   run<32, 0, 5>("plain, tail nt sc0 sc1", idx, n_edges, x, 100, 100, out);
   run<32, 0, 7>("plain, tail 4 x dword", idx, n_edges, x, 100, 100, out);
+  // ---- split layout, products-sized row range (2.45 M rows: the tail arrays are 39 MB / 157 MB) ----
+  {
+    const int64_t n_small = 2'449'029;
+    std::vector<int32_t> h2(n_edges);
+    for (auto& v : h2) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int32_t)(s % (uint64_t)n_small); }
+    (void)hipMemcpy(idx, h2.data(), n_edges * 4, hipMemcpyHostToDevice);
+    float* xt = x + n_small * 128;                           // behind the main part (pitch <= 128)
+    run<32, 0, 0>("plain pitch 400, 2.45 M rows", idx, n_edges, x, 100, 100, out);
+    run_split<32, 0>("96 + 4", idx, n_edges, x, 96, 96, xt, 4, 100, out);
+    run_split<32, 1>("96 only (bound)", idx, n_edges, x, 96, 96, xt, 4, 100, out);
+    run_split<32, 2>("tail 4 only", idx, n_edges, x, 96, 96, xt, 4, 100, out);
+    run<16, 0, 0>("plain pitch 192, 2.45 M rows", idx, n_edges, x, 48, 47, out);
+    run_split<16, 0>("32 + 16", idx, n_edges, x, 32, 32, xt, 16, 47, out);
+    run_split<16, 1>("32 only (bound)", idx, n_edges, x, 32, 32, xt, 16, 47, out);
+    run_split<16, 2>("tail 16 only", idx, n_edges, x, 32, 32, xt, 16, 47, out);
+  }
   return 0;
 }
