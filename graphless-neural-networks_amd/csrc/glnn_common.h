@@ -170,6 +170,11 @@ int gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, cons
                         uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n, float* workspace,
                         int64_t workspace_floats, int* splits, void* stream);
 
+// spmm.hip: the SAGE-"gcn" aggregation over rows stored as pre-activations z, the hidden layer's tail applied in the gather
+struct SourceTail { const float* scale; const float* shift; float drop_p; uint32_t drop_seed; };      // scale / shift NULL: no affine (norm "none")
+int spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* z, int64_t ldz, int d,
+                  const SourceTail& tail, float* out, int64_t ldo, void* stream);
+
 // gemm_rowpanel.hip: C = epi(A . W^T) for short reductions (k <= 128) over many rows -- persistent workgroups that keep a 128-column
 // panel of W in LDS and walk row tiles of A; bit-identical to the tiled kernels.  GLNN_ERR_UNSUPPORTED = nothing launched.
 int gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* ep_scale,

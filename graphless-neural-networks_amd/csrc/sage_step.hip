@@ -23,7 +23,6 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
                  "glnn_sage_fwd_bwd_f32: layer %d: null pointer or bad block sizes", l);
     GLNN_REQUIRE(l == 0 || y.n_src == d->layer[l - 1].n_dst, "glnn_sage_fwd_bwd_f32: block %d has %lld sources, block %d %lld destinations",
                  l, (long long)y.n_src, l - 1, (long long)d->layer[l - 1].n_dst);
-    GLNN_REQUIRE(l == L - 1 || y.h, "glnn_sage_fwd_bwd_f32: hidden layer %d needs its activation buffer", l);
     GLNN_REQUIRE(l == 0 || (y.t_indptr && y.t_indices && y.inv_deg && y.tr_ws), "glnn_sage_fwd_bwd_f32: layer %d needs the transpose buffers", l);
   }
   GLNN_REQUIRE(L == 1 || (d->dagg && d->dh), "glnn_sage_fwd_bwd_f32: backward scratch missing");
@@ -43,16 +42,24 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     const int64_t ld_src = l == 0 ? d->ldx : d->layer[l - 1].ldh;
     const int64_t n_src = l == 0 ? d->x_rows : y.n_src;
     // (sum_{u->v} h[u] + h_dst[v]) / (deg + 1); the outermost block may gather from the global matrix (self_rows)
-    GLNN_TRY(glnn_spmm_csr_f32(y.indptr, y.indices, y.n_dst, n_src, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, nullptr, src, ld_src,
-                               l == 0 ? y.self_rows : nullptr, nullptr, nullptr, 0, y.agg, y.ld_agg, stream));
+    if (l > 0 && !d->layer[l - 1].h) {
+      // the hidden layer in front left only z: its tail (BatchNorm affine, ReLU, dropout) is evaluated in this layer's gather
+      const glnn_sage_layer& pv = d->layer[l - 1];
+      const glnn::SourceTail tail = {d->batchnorm ? pv.a_scale : nullptr, d->batchnorm ? pv.a_shift : nullptr, p, pv.drop_seed};
+      GLNN_TRY(glnn::spmm_csr_tail(y.indptr, y.indices, y.n_dst, n_src, pv.z, pv.ldz, d_in, tail, y.agg, y.ld_agg, stream));
+    } else {
+      GLNN_TRY(glnn_spmm_csr_f32(y.indptr, y.indices, y.n_dst, n_src, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, nullptr, src, ld_src,
+                                 l == 0 ? y.self_rows : nullptr, nullptr, nullptr, 0, y.agg, y.ld_agg, stream));
+    }
     GLNN_TRY(glnn_gemm_f32(y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_in, y.w, d_in, 0, d_out, nullptr, nullptr, y.b, 0,
                            y.z, y.ldz, d->ws_gemm, d->ws_gemm_floats, stream));
     if (l == L - 1) break;
     if (d->batchnorm)
       GLNN_TRY(glnn::bn_stats(y.z, y.ldz, y.n_dst, d_out, y.gamma, y.beta, d->bn_eps, d->bn_momentum, y.running_mean, y.running_var, y.nbt,
                               y.mean, y.rstd, y.a_scale, y.a_shift, d->ws_bn, d->ws_bn_floats, stream, nullptr));
-    GLNN_TRY(glnn_act_fwd_f32(y.z, y.ldz, y.n_dst, d_out, d->batchnorm ? y.a_scale : nullptr, d->batchnorm ? y.a_shift : nullptr, p,
-                              y.drop_seed, y.h, y.ldh, stream));
+    if (y.h)          // h = tail(z) materialised (optional: with h == NULL the next layer's gather evaluates the tail itself)
+      GLNN_TRY(glnn_act_fwd_f32(y.z, y.ldz, y.n_dst, d_out, d->batchnorm ? y.a_scale : nullptr, d->batchnorm ? y.a_shift : nullptr, p,
+                                y.drop_seed, y.h, y.ldh, stream));
   }
   // ---- loss + dlogits (labels indexed by the batch's output nodes) ----------------------------------------------------
   const glnn_sage_layer& top = d->layer[L - 1];

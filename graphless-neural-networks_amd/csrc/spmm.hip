@@ -67,7 +67,37 @@ struct SpmmArgs {
   int64_t ldo;
   int n_long_blocks;
   int rows_per_block;           // rows a row-role workgroup pulls from its ticket (8 waves x 1..kRowsPerWave rows)
+  // XF kernels only: every gathered row and every self row is  drop(relu(z * xf_scale + xf_shift))  of the stored row z -- the tail of the
+  // hidden layer in front (BatchNorm affine, ReLU, counter-based dropout keyed by the SOURCE row id), evaluated in the gather instead of
+  // being written by a pass of its own (glnn_act_fwd_f32's arithmetic, element for element)
+  int xf_on; const float* xf_scale; const float* xf_shift; uint32_t xf_thr; uint32_t xf_seed; float xf_dscale;
 };
+
+// per-lane constants of the source transform: the lane's four columns
+struct XfCols { float s[4], h[4]; uint32_t thr, seed; float dscale; int col; bool affine; };
+__device__ __forceinline__ XfCols load_xf_cols(const SpmmArgs& a, int col4) {
+  XfCols x;
+  x.thr = a.xf_thr; x.seed = a.xf_seed; x.dscale = a.xf_dscale; x.col = col4; x.affine = a.xf_scale != nullptr;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bool ok = x.affine && col4 + t < a.d;
+    x.s[t] = ok ? a.xf_scale[col4 + t] : 1.f;
+    x.h[t] = ok ? a.xf_shift[col4 + t] : 0.f;
+  }
+  return x;
+}
+__device__ __forceinline__ float4 xf_apply(const XfCols& x, float4 v, uint32_t row) {
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float y = x.affine ? fmaf(o[t], x.s[t], x.h[t]) : o[t];
+    y = fmaxf(y, 0.f);
+    if (x.thr) y = glnn::drop_keep(x.seed, x.thr, row, (uint32_t)(x.col + t)) ? y * x.dscale : 0.f;
+    asm volatile("" : "+v"(y));        // the ROUNDED tail value is what gets summed (act_fwd stored it): no fma of y * dscale into the row sum
+    o[t] = y;
+  }
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -119,11 +149,11 @@ __device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
 // Sum of x[indices[e], col4..col4+3] over the edges e in [e0,e1) that belong to this wave:
 // 64-edge chunks  e0 + 64*(wave_id + k*n_waves).  Returns the total in every lane of group 0
 // (lanes < LPR); other lanes hold partial garbage.
-template <int LPR, int U, bool CS>
+template <int LPR, int U, bool CS, bool XF = false>
 __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ indices, int64_t e0, int64_t e1,
                                                   int wave_id, int n_waves, const float* __restrict__ x,
                                                   int64_t ldx, int col4, bool col_ok,
-                                                  const float* __restrict__ col_scale, int lane) {
+                                                  const float* __restrict__ col_scale, int lane, const XfCols& xf) {
   constexpr int G = 64 / LPR;
   const int g = lane / LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -136,6 +166,7 @@ __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ in
     for (int j = 0; j < cnt; j += G * U) {
       float4 v[U];
       float s[U];
+      int srcs[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ei = j + u * G + g;
@@ -148,7 +179,13 @@ __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ in
         if (CS) s[u] = (G == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cs), ei & 63))
                                 : __shfl(my_cs, ei & 63);
         const bool ok = (ei < cnt) && col_ok;
+        srcs[u] = ok ? src : -1;
         v[u] = ok ? ld4(x + (int64_t)src * ldx + col4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (XF) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (srcs[u] >= 0) v[u] = xf_apply(xf, v[u], (uint32_t)srcs[u]);      // (absent edges stay exact zeros)
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) acc = CS ? fma4(s[u], v[u], acc) : add4(acc, v[u]);
@@ -175,12 +212,14 @@ __device__ __forceinline__ EpCols load_ep_cols(const SpmmArgs& a, int col4) {
   return e;
 }
 
-template <int MODE>
-__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep) {
+template <int MODE, bool XF = false>
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep,
+                                           const XfCols& xf) {
   float4 y;
   if (MODE == GLNN_AGG_SAGE_GCN) {
     const int64_t sr = a.self_rows ? a.self_rows[v] : v;
-    const float4 s = ld4(a.x_self + sr * a.ld_self + col4);
+    float4 s = ld4(a.x_self + sr * a.ld_self + col4);
+    if (XF) s = xf_apply(xf, s, (uint32_t)sr);
     const float dp1 = (float)deg + 1.0f;
     y = mean4(acc, s, dp1);
   } else {
@@ -203,8 +242,9 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
 }
 
 // ---- long-row role: scan a strided share of the rows, whole workgroup per long row (deterministic LDS fold) ----
-template <int LPR, int U, int MODE, bool CS>
-__device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int wave, int col4, bool col_ok, const EpCols& ep) {
+template <int LPR, int U, int MODE, bool CS, bool XF = false>
+__device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int wave, int col4, bool col_ok, const EpCols& ep,
+                                               const XfCols& xf) {
   __shared__ int64_t s_rows[kBlock];
   __shared__ int s_count;
   __shared__ float4 s_part[kWavesPerBlock][64];
@@ -225,22 +265,22 @@ __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int 
     for (int i = 0; i < n_found; ++i) {
       const int64_t v = s_rows[i];
       const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
-      float4 acc = wave_gather_sum<LPR, U, CS>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok,
-                                               a.col_scale, lane);
+      float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok,
+                                                   a.col_scale, lane, xf);
       if (lane < LPR) s_part[wave][lane] = acc;
       __syncthreads();
       if (wave == 0 && lane < LPR && col_ok) {
         float4 t = s_part[0][lane];
 #pragma unroll
         for (int w = 1; w < kWavesPerBlock; ++w) t = add4(t, s_part[w][lane]);
-        finish_row<MODE>(a, v, e1 - e0, t, col4, ep);
+        finish_row<MODE, XF>(a, v, e1 - e0, t, col4, ep, xf);
       }
       __syncthreads();
     }
   }
 }
 
-template <int LPR, int U, int MODE, bool CS>
+template <int LPR, int U, int MODE, bool CS, bool XF = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
   // rows wider than 256 floats (raw cora / citeseer features): blockIdx.y = the 256-column tile of this workgroup -- one launch instead
   // of one per tile (14 for citeseer's 3703 features)
@@ -258,9 +298,11 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
   const int col4 = c * 4;
   const bool col_ok = col4 < a.d;
   const EpCols ep = load_ep_cols(a, col_ok ? col4 : 0);
+  XfCols xf = {};                                     // (registers; dead code when !XF)
+  if (XF) xf = load_xf_cols(a, col_ok ? col4 : 0);
 
   if ((int)blockIdx.x < a.n_long_blocks) {
-    long_rows_role<LPR, U, MODE, CS>(a, lane, wave, col4, col_ok, ep);
+    long_rows_role<LPR, U, MODE, CS, XF>(a, lane, wave, col4, col_ok, ep, xf);
     return;
   }
 
@@ -282,8 +324,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     const int64_t deg = e1 - e0;
     if (deg > kLongRow) continue;
-    float4 acc = wave_gather_sum<LPR, U, CS>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane);
-    if (lane < LPR && col_ok) finish_row<MODE>(a, v, deg, acc, col4, ep);
+    float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
+    if (lane < LPR && col_ok) finish_row<MODE, XF>(a, v, deg, acc, col4, ep, xf);
   }
 }
 
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
       const int64_t deg = e1 - e0;
       deferred = deg > kLongRow;
       if (!deferred) {
-        const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, nullptr, lane);
+        const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
         if (lane < LPR && col_ok) {
           const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
           const float dp1 = (float)deg + 1.0f;
@@ -370,7 +412,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     if (v >= a.n_dst) break;
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     if (e1 - e0 <= kLongRow) continue;
-    const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane);
+    const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
     // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
     if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
     __syncthreads();
@@ -507,7 +549,9 @@ template <int LPR, int U>
 int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1) {
   const bool cs = a.col_scale != nullptr;
   const dim3 g(grid, col_tiles);
-  if (mode == GLNN_AGG_SAGE_GCN) {
+  if (mode == GLNN_AGG_SAGE_GCN && a.xf_on) {
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false, true>), g, dim3(kBlock), 0, st, a);
+  } else if (mode == GLNN_AGG_SAGE_GCN) {
     hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), g, dim3(kBlock), 0, st, a);
   } else if (cs) {
     hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SUM, true>), g, dim3(kBlock), 0, st, a);
@@ -542,11 +586,11 @@ __global__ void int_to_float_kernel(float* p, int64_t n, int transform) {
 
 }  // namespace
 
-extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
-                                 const float* x, int64_t ldx, int d, int mode, const float* row_scale,
-                                 const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
-                                 const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
-                                 void* stream) {
+static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                     const float* x, int64_t ldx, int d, int mode, const float* row_scale,
+                     const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                     const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
+                     void* stream, const glnn::SourceTail* tail) {
   if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
   GLNN_REQUIRE(indptr && x && out, "glnn_spmm_csr_f32: null pointer");   // indices may be NULL iff the graph has no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
@@ -569,6 +613,10 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
   // column tiles of <= 256 floats (64 lanes x float4); wider rows (raw cora / citeseer features) take ONE launch whose blockIdx.y is the
   // tile (the kernel shifts its pointers): `wide` runs this loop body once with the whole width
   const bool wide = d > 256 && (d + 255) / 256 <= 65535;
+  if (tail) {
+    GLNN_REQUIRE(mode == GLNN_AGG_SAGE_GCN && d <= 256, "glnn::spmm_csr_tail: SAGE_GCN rows of <= 256 floats only");
+    GLNN_REQUIRE((tail->scale == nullptr) == (tail->shift == nullptr) && tail->drop_p >= 0.f && tail->drop_p < 1.f, "glnn::spmm_csr_tail: bad tail");
+  }
   for (int c0 = 0; c0 < d; c0 += (wide ? d : 256)) {
     const int dt = wide ? 256 : ((d - c0) < 256 ? (d - c0) : 256);
     SpmmArgs a;
@@ -578,6 +626,10 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     a.x_self = x_self ? x_self + c0 : nullptr; a.ld_self = ld_self; a.self_rows = self_rows;
     a.ep_scale = ep_scale ? ep_scale + c0 : nullptr; a.ep_shift = ep_shift ? ep_shift + c0 : nullptr;
     a.relu = relu; a.out = out + c0; a.ldo = ldo;
+    a.xf_on = tail ? 1 : 0;
+    a.xf_scale = tail ? tail->scale : nullptr; a.xf_shift = tail ? tail->shift : nullptr;
+    a.xf_thr = tail ? glnn::drop_threshold(tail->drop_p) : 0u; a.xf_seed = tail ? tail->drop_seed : 0u;
+    a.xf_dscale = tail ? 1.0f / (1.0f - tail->drop_p) : 1.f;
     // workgroups in the long-row role: one per 512-row scan chunk, at most GLNN_LONG_BLOCK_CAP.  (Until round 4: n_dst / 4096 -- right
     // for a whole graph, where it hits the cap, but a row SHARD of a power-law graph keeps the graph's hub rows: rank r of 8 launches
     // 76 k-row chunks of the products graph whose rows of degree > 128 hold 20 % of the edges, and 18 workgroups gathered them while
@@ -607,6 +659,23 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
     if (rc != GLNN_OK) return rc;
   }
   return GLNN_OK;
+}
+
+extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                 const float* x, int64_t ldx, int d, int mode, const float* row_scale,
+                                 const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                                 const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
+                                 void* stream) {
+  return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, row_scale, col_scale, x_self, ld_self, self_rows, ep_scale, ep_shift, relu,
+                   out, ldo, stream, nullptr);
+}
+
+// SAGE-"gcn" aggregation of rows that exist only as pre-activations z: every gathered / self row is tail(z) = drop(relu(z * scale +
+// shift)) evaluated in the gather (glnn_sage_fwd_bwd_f32: the hidden layers' h = tail(z) is never written)
+int glnn::spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* z, int64_t ldz, int d,
+                        const glnn::SourceTail& tail, float* out, int64_t ldo, void* stream) {
+  return spmm_impl(indptr, indices, n_dst, n_src, z, ldz, d, GLNN_AGG_SAGE_GCN, nullptr, nullptr, z, ldz, nullptr, nullptr, nullptr, 0, out, ldo,
+                   stream, &tail);
 }
 
 extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,

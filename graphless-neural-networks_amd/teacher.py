@@ -28,6 +28,7 @@ synchronisation:
 The engine works IN PLACE on the Model's parameters / BatchNorm buffers and on the torch optimizer's state tensors, exactly
 like glnn_amd.student.StudentEngine, so state_dict(), early-stopping snapshots and optimizer.state_dict() keep working."""
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -122,6 +123,10 @@ class TeacherEngine:
         self.loss_accum = torch.zeros(1, **f32)
         self._sage_desc = self._arena = self._arena_stream = None      # step_sage: persistent descriptor and scratch arena
         self.ws_loss = torch.empty(1024, **f32)
+        # step_sage: the hidden layers' h = dropout(relu(norm(z))) is NOT written -- the next layer's aggregation applies that tail to the z
+        # rows it gathers (glnn::spmm_csr_tail; same arithmetic per element, so the step is bit-identical to the materialised form, one pass
+        # over the layer's activations and its buffer less).  GLNN_TEACHER_GATHER_TAIL=0 (read here, once) keeps the act_fwd launches.
+        self.gather_tail = os.environ.get("GLNN_TEACHER_GATHER_TAIL", "1") != "0"
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.grad_sync = None
 
@@ -251,7 +256,10 @@ class TeacherEngine:
                 y.agg, y.ld_agg = A.take(4 * n_dst * r4(dims[l])), r4(dims[l])
                 y.z, y.ldz = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
                 if l != L - 1:
-                    y.h, y.ldh = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
+                    if self.gather_tail:
+                        y.h, y.ldh = None, 0
+                    else:
+                        y.h, y.ldh = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
                     max_rows, max_hidden = max(max_rows, n_dst), max(max_hidden, dims[l + 1])
                     if self.bn:
                         y.mean, y.rstd, y.a_scale, y.a_shift = (A.take(4 * dims[l + 1]) for _ in range(4))

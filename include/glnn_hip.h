@@ -393,7 +393,8 @@ typedef struct glnn_sage_layer {
   float* w; float* b; float* gw; float* gb;
   float* gamma; float* beta; float* ggamma; float* gbeta; float* running_mean; float* running_var; int64_t* nbt;
   float* mean; float* rstd; float* a_scale; float* a_shift;
-  float* agg; int64_t ld_agg; float* z; int64_t ldz; float* h; int64_t ldh;
+  float* agg; int64_t ld_agg; float* z; int64_t ldz; float* h; int64_t ldh;      /* h may be NULL (hidden layers): the tail of z is then
+                                                                                   * applied inside the next layer's aggregation, never written */
   int64_t* t_indptr; int32_t* t_indices; float* inv_deg; void* tr_ws; int64_t tr_ws_bytes;
   uint32_t drop_seed;
 } glnn_sage_layer;

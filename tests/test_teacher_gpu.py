@@ -637,3 +637,43 @@ def test_sage_and_gcn_teachers_on_random_shapes_vs_oracle(seed):
         if edge2 < 3e-7:
             break
         np.testing.assert_allclose(prm.grad.cpu().numpy(), gr, atol=2e-5 * max(1.0, gmax2), rtol=1e-4, err_msg=f"{tag} gcn {pname} edge={edge2:.2e}")
+
+
+@pytest.mark.parametrize("norm,p,full", [("batch", 0.3, False), ("none", 0.5, False), ("batch", 0.0, False), ("batch", 0.4, True)])
+def test_sage_step_tail_in_the_gather_is_bit_identical_to_the_materialised_tail(norm, p, full, monkeypatch):
+    """glnn_sage_layer.h == NULL (round 4, the default of TeacherEngine): a hidden layer's h = dropout(relu(norm(z))) is not written, the
+    next layer's aggregation applies that tail to every z row it gathers (glnn::spmm_csr_tail -- hub rows through the long-row role,
+    self rows, rows gathered many times) with act_fwd's arithmetic element for element: three optimiser steps end in the same
+    parameters, BatchNorm buffers and loss bit for bit as with GLNN_TEACHER_GATHER_TAIL=0 (the act_fwd launches)."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    n, dims = 20000, [40, 64, 64, 9]
+    indptr, indices = random_graph(n, 10, seed=9, power=0.6, hub=5000, isolated=30)
+    rs = np.random.RandomState(9)
+    fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
+    ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
+    g = _graph(indptr, indices)
+    if full:      # full neighbourhoods: the 5000-edge hub row is a destination of the inner blocks -> the long-row role applies the tail too
+        batches = list(NodeDataLoader(g, torch.arange(768), MultiLayerFullNeighborSampler(3), batch_size=256, shuffle=False, seed=5))
+        assert max(int(b.in_degrees().max()) for b in batches[0][2][1:]) > 128
+    else:
+        batches = list(NodeDataLoader(g, torch.arange(1536), MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=False, seed=5))
+    states = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_TEACHER_GATHER_TAIL", mode)
+        torch.manual_seed(2)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type=norm, device=DEV))
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        assert eng.gather_tail == (mode == "1")
+        for input_nodes, output_nodes, blocks in batches:
+            eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+        torch.cuda.synchronize()
+        states.append([t.detach().clone() for t in model.state_dict().values()] + [eng.loss_out.clone()])
+    diffs = [float((a.double() - b.double()).abs().max()) for a, b in zip(*states)]
+    assert all(torch.equal(a, b) for a, b in zip(*states)), diffs
+    assert bool(torch.isfinite(states[0][-1]).all())
