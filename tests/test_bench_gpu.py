@@ -144,3 +144,18 @@ def test_bench_emulate_measures_every_rank_of_the_scaling_model():
             assert sum(r["rows"] for r in w["ranks"]) == o["nodes"] and sum(r["nnz"] for r in w["ranks"]) == o["nnz"]
     assert sm["halo-lp"]["worlds"]["4"]["max_GB_received_per_rank"] < sm["allgather-narrow"]["worlds"]["4"]["max_GB_received_per_rank"]
     assert sm["allgather-wide"]["worlds"]["4"]["max_GB_received_per_rank"] > sm["allgather-narrow"]["worlds"]["4"]["max_GB_received_per_rank"]
+
+
+def test_bench_xl_two_ranks_driver_launch_line():
+    """--workload xl under the driver's launch line with 2 ranks (both on cuda:0 over gloo: test-only knobs): every rank generates its own
+    shard, the input is replicated, the exchanges are REAL collectives (no emulation), weak scaling; every launch of the verification
+    forward holds on both ranks."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2", "--workload", "xl", "--scale", "0.002", "--steps", "2", "--warmup", "1"],
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["verified"] is True
+    cfg = out["config"]
+    assert cfg["shards"] == 2 and cfg["nodes_total"] == 2 * cfg["rows_per_gpu"] and "EMULATED" not in cfg["parallelism"]
+    assert out["per_forward"]["emulated_fill_ms"] is None and out["per_forward"]["collectives"] == 8
+    assert abs(out["value"] - 2 * 3 * cfg["nnz_per_gpu"] * 2 / (out["ms_per_step"] * 2e-3)) < 1e-3 * out["value"]
