@@ -696,9 +696,9 @@ class CheckedBackend:
         return out
 
     def sage_fused(self, indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
-                   w_next=None, out_next=None, want_out=True):
+                   w_next=None, out_next=None, want_out=True, tile_order=None):
         res = self.be.sage_fused(indptr, indices, x, n_dst, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out, x_self=x_self,
-                                 w_packed=w_packed, w_next=w_next, out_next=out_next, want_out=want_out)
+                                 w_packed=w_packed, w_next=w_next, out_next=out_next, want_out=want_out, tile_order=tile_order)
         if n_dst:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)

@@ -21,7 +21,7 @@ SIGNATURES = {
     "glnn_packed_weight_floats": [c_int, c_int],
     "glnn_pack_weight_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp],
     "glnn_sage_fused_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
-                            c_i64, c_vp, c_int, c_vp, c_i64, c_vp],
+                            c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp, c_i64, c_vp],

@@ -357,6 +357,7 @@ struct FusedArgs {
   // optional chained projection: out2 = epi(...) @ W2^T for the NEXT layer when that layer projects first (in > out): the
   // hidden rows go from the MFMA accumulators through LDS into a second MFMA pass and never reach HBM
   const float* w2_packed; int d_out2; int kgroups2; float* out2; int64_t ldo2;
+  const int32_t* tile_order;                            // optional permutation of the tile ids (heaviest tiles first)
 };
 
 template <int LPR, int U, int RT>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
   const bool col_ok = col4 < a.d_in;
   const int kpad = a.kgroups * 8;
   const int lda = kpad + 4;
-  const int64_t row0 = (int64_t)blockIdx.x * kFusedRows;
+  const int64_t row0 = (int64_t)(a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x) * kFusedRows;
 
   // ---- phase A: the 8 waves pull rows of the tile from an LDS ticket (degrees vary by 100x: a static
   //      4-rows-per-wave split leaves most waves idle at the barrier behind the heaviest one) ---------
@@ -718,7 +719,8 @@ extern "C" int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int 
 extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
                                    int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
                                    int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
-                                   int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, void* stream) {
+                                   int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
+                                   void* stream) {
   if (n_dst == 0) return GLNN_OK;
   GLNN_REQUIRE(indptr && x && x_self && w_packed && (out || w2_packed), "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
   GLNN_REQUIRE(!w2_packed || (out2 && d_out2 >= 1 && d_out2 <= 256 && ldo2 >= d_out2 && glnn::aligned16(w2_packed)),
@@ -735,6 +737,7 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   a.ld_self = ld_self; a.w_packed = w_packed; a.d_out = d_out; a.kgroups = (d_in + 7) / 8; a.ep_scale = ep_scale;
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
   a.w2_packed = w2_packed; a.d_out2 = w2_packed ? d_out2 : 0; a.kgroups2 = w2_packed ? (d_out + 7) / 8 : 0; a.out2 = out2; a.ldo2 = ldo2;
+  a.tile_order = tile_order;
   // one 32-row sub-tile per workgroup (RT = 1).  RT = 2 (64-row tiles, every W fragment load feeding two MFMA chains) was measured
   // 1.5x slower in round 1 -- big workgroups drain badly -- and its instantiations were removed in round 3
   constexpr int rt = 1;

@@ -284,6 +284,16 @@ class ShardedTeacher:
             self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
         return self._bufs[k]
 
+    def _tile_order(self, off, nr):
+        """Heaviest-tile-first order of the fused launch over own rows [off, off + nr) (cached; None without a HIP backend): a shard's
+        chunk launch is short, and the graph's hub rows should start first, not wherever their ids put them."""
+        if not hasattr(self.be, "fused_tile_order") or nr < 4096:
+            return None
+        k = ("order", off, nr)
+        if k not in self._col_cache:
+            self._col_cache[k] = self.be.fused_tile_order(self.g.indptr[off:off + nr + 1], nr)
+        return self._col_cache[k]
+
     def _cols(self, layout):
         """Column indices of the shard's edges for a source matrix in `layout` (one-time relabelling, cached)."""
         if layout == "nat" or (layout == "own" and self.sh.uniform):
@@ -330,7 +340,8 @@ class ShardedTeacher:
         for off, nr, sl in self._pieces(layout):
             ip = g.indptr[off:off + nr + 1]            # absolute offsets into the one indices array
             if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
-                be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr], x_self=x[sl])
+                be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr], x_self=x[sl],
+                              tile_order=self._tile_order(off, nr))
             else:
                 agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl])
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
@@ -376,7 +387,8 @@ class ShardedTeacher:
                 ip = g.indptr[off:off + nr + 1]
                 xs = self._chunk_self(x, layout, c)
                 if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
-                    be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs)
+                    be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
+                                  tile_order=self._tile_order(off, nr))
                 else:
                     agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
@@ -411,7 +423,7 @@ class ShardedTeacher:
                 if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256 and d_out <= 256:
                     # aggregate + project + tail + the NEXT layer's projection in one launch: layer l's rows never reach HBM
                     be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
-                                  want_out=False)
+                                  want_out=False, tile_order=self._tile_order(off, nr))
                 else:
                     if y_own is None:
                         if ("y_own", l) not in self._bufs:

@@ -95,6 +95,16 @@ class CSRGraph:
             self._cache["inv1"] = ops.degrees(self.indptr, None, self.n_dst, self.n_src, 0, want_out=False, transform=ops.DEG_INV_PLUS1)[0]
         return self._cache["inv1"]
 
+    def fused_tile_order(self):
+        """The 32-row tiles of a fused aggregate + project launch over ALL destination rows, heaviest row first (cached int32 permutation;
+        None on graphs too small for it to matter): hub rows of a power-law graph start first (ops.sage_fused(tile_order=...))."""
+        if self.n_dst < 4096 or not self.indptr.is_cuda:
+            return None
+        if "tile_order" not in self._cache:
+            from . import ops
+            self._cache["tile_order"] = ops.fused_tile_order(self.indptr, self.n_dst)
+        return self._cache["tile_order"]
+
     def has_zero_in_degree(self):
         """dgl GraphConv's `(graph.in_degrees() == 0).any()` check, evaluated once per graph."""
         if "zero_in" not in self._cache:

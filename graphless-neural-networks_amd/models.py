@@ -240,7 +240,7 @@ class SAGE(nn.Module):
                         # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
                         _, projected = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale,
                                                       ep_shift=ep_shift, relu=relu, x_self=x[:n], w_next=nxt.fc_neigh.weight,
-                                                      want_out=False)
+                                                      want_out=False, tile_order=g.fused_tile_order())
                         y = x                                                    # (not read: the next layer consumes `projected`)
                     else:
                         y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)

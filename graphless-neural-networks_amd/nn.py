@@ -58,8 +58,9 @@ class SAGEConv(nn.Module):
                             ep_shift=shift, relu=relu)
         if self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256:
             # aggregation + projection + epilogue in one launch: the aggregated rows never reach HBM
+            order = graph.fused_tile_order() if n_dst == graph.n_dst else None
             return ops.sage_fused(graph.indptr, graph.indices, h_src, n_dst, w, ep_scale=ep_scale, ep_shift=shift, relu=relu,
-                                  x_self=h_dst, w_packed=w_packed)
+                                  x_self=h_dst, w_packed=w_packed, tile_order=order)
         agg = ops.spmm(graph.indptr, graph.indices, h_src, n_dst, ops.AGG_SAGE_GCN)
         return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu)
 

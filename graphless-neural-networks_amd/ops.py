@@ -204,8 +204,19 @@ def pack_weight(w):
     return wp
 
 
+def fused_tile_order(indptr, n_dst):
+    """The 32-row tiles of a fused launch over rows [0, n_dst) of `indptr`, heaviest row first (stable): int32 permutation for
+    sage_fused(tile_order=...).  One-time index arithmetic per graph / row range (cache it)."""
+    deg = (indptr[1:n_dst + 1] - indptr[:n_dst])
+    tiles = (n_dst + 31) // 32
+    pad = tiles * 32 - n_dst
+    if pad:
+        deg = torch.cat([deg, deg.new_zeros(pad)])
+    return torch.argsort(deg.view(tiles, 32).amax(1), descending=True, stable=True).to(torch.int32)
+
+
 def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
-               w_next=None, out_next=None, want_out=True):
+               w_next=None, out_next=None, want_out=True, tile_order=None):
     """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256).
     w_next [d_out2, d_out]: also returns (.. , out @ w_next.T) -- the projection of the NEXT layer when it projects first;
     with want_out=False the hidden rows themselves are not written at all (returns (None, projected))."""
@@ -216,6 +227,8 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
     d_out = w.shape[0]
     if w.shape[1] != d_in:
         raise ValueError("sage_fused: weight must be [d_out, d_in]")
+    if tile_order is not None and (tile_order.dtype != torch.int32 or not tile_order.is_contiguous() or tile_order.numel() != (n_dst + 31) // 32):
+        raise ValueError("sage_fused: tile_order must be a contiguous int32 permutation of the ceil(n_dst / 32) tile ids")
     if w_packed is None:
         w_packed = pack_weight(w)
     if out is None and (want_out or w_next is None):
@@ -231,7 +244,7 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
         rc = _lib.lib().glnn_sage_fused_f32(_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d_in, _p(x_self), _ld(x_self),
                                             _p(w_packed), d_out, _p(_vec(ep_scale, d_out, "ep_scale")),
                                             _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out) if out is not None else 0,
-                                            _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _stream())
+                                            _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _p(tile_order), _stream())
     _lib.check(rc, "glnn_sage_fused_f32")
     return out if w_next is None else (out, out_next)
 

@@ -100,7 +100,10 @@ GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, 
                                  const float* x_self, int64_t ld_self, const float* w_packed,
                                  int d_out, const float* ep_scale, const float* ep_shift, int relu,
                                  float* out, int64_t ldo, const float* w2_packed, int d_out2,
-                                 float* out2, int64_t ldo2, void* stream);
+                                 float* out2, int64_t ldo2, const int32_t* tile_order, void* stream);
+/* tile_order (optional, ceil(n_dst / 32) entries: a permutation of the 32-row tile ids): workgroup i takes tile tile_order[i].  A caller
+ * that sorts the tiles by their heaviest row (descending in-degree) starts the hub rows of a power-law graph first instead of wherever
+ * their ids put them -- what matters for SHORT launches (a row shard's chunk: one 8 k-edge hub row is 100 us of a 0.7 ms launch). */
 
 /* in_deg[v] = t(indptr[v+1]-indptr[v]); out_deg[u] = t(#edges with source u), as floats, t = `transform`:
  *   GLNN_DEG_RAW          the degree itself            g.in_degrees() / g.out_degrees()
