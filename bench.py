@@ -80,7 +80,8 @@ def alg_bytes(nnz, n_dst, d, d_out=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100, help="timed teacher forwards (default 100: a >= 3 s timed region at ~38 ms each)")
+    ap.add_argument("--steps", type=int, default=None, help="timed teacher forwards (default 100: a >= 3 s timed region at ~33 ms each; "
+                    "--workload xl: 10 rank-forwards of ~170 ms; --emulate: 3 per emulated rank)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "halo"],
                     help="N > 1: per-layer all-gather of every rank's rows (default) or halo exchange of only the referenced remote rows")
@@ -126,6 +127,8 @@ def main():
                          "shuffled ids re-partitioned by label propagation: the compute half of DESIGN.md section 6's scaling model, measured")
     ap.add_argument("--detail-file", default=None, help="also write the long detail object to this file (default: gpurun_out/bench_detail.json when that directory exists)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.emulate else (10 if args.workload == "xl" else 100)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)          # `python bench.py --gpus N` by itself: spawn the N ranks (one per GPU) and relay their line
@@ -971,7 +974,9 @@ def run_emulated(args, dev):
                 torch.cuda.empty_cache()
             kmax = max(x_["kernel_ms"] for x_ in ranks)
             gb = max(x_["GB_received"] for x_ in ranks)
-            link = [1e3 * gb / max(1, N - 1) / rt for rt in XGMI_LINK_GBS]       # the N-1 peers send over N-1 links in parallel
+            # per link: an all-gather's count includes the own slab (N slabs, N-1 of them arrive, one per link); a halo exchange's does not
+            per_link = gb / N if cfg["exchange"] == "allgather" else gb / max(1, N - 1)
+            link = [1e3 * per_link / rt for rt in XGMI_LINK_GBS]                 # the N-1 peers send over N-1 links in parallel
             res["worlds"][str(N)] = {
                 "max_kernel_ms": kmax, "mean_kernel_ms": float(np.mean([x_["kernel_ms"] for x_ in ranks])), "max_GB_received_per_rank": gb,
                 "modelled_link_ms": link, "forward_ms_exchange_hidden": max(kmax, link[1]), "forward_ms_exchange_exposed": kmax + link[0],
