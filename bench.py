@@ -824,13 +824,25 @@ def run_xl(args, rank, world, dev, barrier):
     wide = args.layer1_exchange == "wide"
     layers = []
 
-    def agg_layer(name, key, d, d_written, what):
+    def xl_traffic(pmc_key):
+        """HBM bytes per forward of one layer's launches: a constant from the committed PMC passes of this command (profiles/pmc_traffic_xl.json,
+        scripts/pmc_xl.sh: per-launch mean x the chunk launches), valid for the full-size shard with 4 chunks only; else None."""
+        if args.scale != 1.0 or sh.chunks != 4 or shards_n != 8:
+            return None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_xl.json")) as f:
+                return 4 * json.load(f)["per_launch_bytes"][pmc_key]["total"]
+        except Exception:
+            return None
+
+    def agg_layer(name, key, d, d_written, what, pmc_key=None):
         t = ms.get(key)
         if t is None:
             return
         b = alg_bytes(nnz, rows, d, d_written)
         layers.append({"layer": name, "kernel": what, "bound": "hbm", "ms": t, "alg_GB": b / 1e9, "achieved": b / t / 1e6, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": b / t / 1e6 / HBM_PEAK_GBS, "Gedges_per_s": nnz / t / 1e6})
+                       "unit": "GB/s", "frac": b / t / 1e6 / HBM_PEAK_GBS, "Gedges_per_s": nnz / t / 1e6,
+                       "traffic": xl_traffic(pmc_key) if pmc_key else None})
 
     def gemm_layer(name, key, m, k, n):
         t = ms.get(key)
@@ -852,13 +864,15 @@ def run_xl(args, rank, world, dev, barrier):
         agg_layer("1 aggregate+project (own rows)", f"sage_fused d={d0}->{d1}", d0, d1, f"sage_fused_kernel<LPR={lanes_per_row(d0)}>")
         exchange_layer("1 exchange (256-wide output)", "y0", d1)
     else:
-        agg_layer("1 aggregate (own rows)", f"spmm d={d0}", d0, None, f"spmm_csr_kernel<LPR={lanes_per_row(d0)},U={SPMM_U},SAGE_GCN>")
+        agg_layer("1 aggregate (own rows)", f"spmm d={d0}", d0, None, f"spmm_csr_kernel<LPR={lanes_per_row(d0)},U={SPMM_U},SAGE_GCN>",
+                  f"spmm_csr_kernel<LPR={lanes_per_row(d0)},U={SPMM_U},SAGE_GCN>")
         exchange_layer("1 exchange (128-wide aggregate)", "agg0", d0)
         gemm_layer("1 projection (replicated: ALL rows on every rank)", f"gemm k={d0} n={d1}", sh.n_pad, d0, d1)
     agg_layer("2 aggregate+project+chained 256->47 (own rows)", f"sage_fused d={d1}->{d2}->{c}", d1, c,
-              f"sage_fused_kernel<LPR=64> (only the 47 chained floats per row are written)")
+              f"sage_fused_kernel<LPR=64> (only the 47 chained floats per row are written)", f"sage_fused_kernel<LPR=64,U={SPMM_U}>")
     exchange_layer("3 exchange (47-wide projected rows)", "hw2", c)
-    agg_layer("3 aggregate (own rows)", f"spmm d={c}", c, None, f"spmm_csr_kernel<LPR={lanes_per_row(c)},U={SPMM_U},SAGE_GCN>")
+    agg_layer("3 aggregate (own rows)", f"spmm d={c}", c, None, f"spmm_csr_kernel<LPR={lanes_per_row(c)},U={SPMM_U},SAGE_GCN>",
+              f"spmm_csr_kernel<LPR={lanes_per_row(c)},U={SPMM_U},SAGE_GCN>")
     kernel_ms = sum(ms.values())
     fill_total = sum(fill_ms.values())
     dom = max((l for l in layers if l.get("bound") == "hbm"), key=lambda l: l["ms"])
@@ -877,7 +891,8 @@ def run_xl(args, rank, world, dev, barrier):
                         "GB_received_per_rank": exch_gb, "collectives": n_coll, "kernels": ms},
         "layers": layers,
         "roofline": {"bound": "hbm", "kernel": f"{dom['kernel']} (layer {dom['layer']})", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": dom["frac"], "traffic": None, "algorithmic_bytes_per_launch_sum": dom["alg_GB"] * 1e9, "avg_ms_per_forward": dom["ms"]},
+                     "frac": dom["frac"], "traffic": dom.get("traffic"), "algorithmic_bytes_per_launch_sum": dom["alg_GB"] * 1e9, "avg_ms_per_forward": dom["ms"],
+                     "traffic_source": None if dom.get("traffic") is None else "static: profiles/pmc_traffic_xl.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"},
         "verify": verify,
     }
     emit(result, args)
