@@ -574,7 +574,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#define GLNN_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_))
+// (accumulators in arch VGPRs: the blocked accumulation below adds them up with VALU instructions; AGPR accumulators + accvgpr
+//  reads / writes measured 1.2 % slower on the 4096 x 2048 x 2048 products)
+#define GLNN_MFMA(ACC_, A_, B_) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC_) : "v"(A_), "v"(B_))
 #define GLNN_DS_READ(DST_, ADDR_, OFF_) \
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_) : "memory")
 #define GLNN_DS_READ2ST64(DST_, ADDR_, OFF0_, OFF1_) \
@@ -624,6 +626,10 @@ template <> struct PipeOp<KROW> {
 //             feed outputs that are never stored)
 //   kext      k extent from the origin.  ROWK operands need kext == 32 nk (a k tail inside a row is not out of range);
 //             KROW operands may end inside the last k-tile: those rows lie behind the descriptor's end and read as 0
+#ifndef GLNN_PIPE_BLOCK_TILES
+#define GLNN_PIPE_BLOCK_TILES 8
+#endif
+constexpr int PIPE_BLOCK_TILES = GLNN_PIPE_BLOCK_TILES;      // k-tiles (of 32) per accumulation block: a power of two >= 2
 template <int SA, int SB>
 __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int64_t ext_a, const float* b0, int64_t ldb, int64_t ext_b,
                                               int64_t kext, int nk, f32x16 (&acc)[2][2]) {
@@ -701,6 +707,13 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   }
   PipeOp<SA> fa[2];                      // fragments, double-buffered by k-group parity
   PipeOp<SB> fb[2];
+  f32x16 tot[2][2];                      // sum of the finished blocks (see kloop)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
 
   // the DS reads of k-group KG out of LDS buffer BUF into fragment set PAR; R = 0 .. NR-1 selects one instruction
   auto frag_read = [&](auto buf_, auto kg_, auto par_, auto r_) {
@@ -779,10 +792,30 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     for (int kt = 0; kt < nk; kt += 2) {
       ktile(std::integral_constant<int, 0>{}, ph_, soff_a(kt + 2), soff_b(kt + 2));
       ktile(std::integral_constant<int, 1>{}, ph_, soff_a(kt + 3), soff_b(kt + 3));
+      // blocked accumulation: the MFMA chain of an output element is cut every PIPE_BLOCK_TILES k-tiles (256 k) and its partial sum
+      // moved into `tot` by VALU adds -- 32 v_pk_add + 32 v_mov_b64 per wave and block.  fp32 rounding noise of a 4096 x K x 2048
+      // product against fp64 (scripts/gemm_noise.py, rms relative): one chain 5.7e-7 / 8.1e-7 / 1.15e-6 at K = 1024 / 2048 / 4096
+      // (= rocBLAS), blocked 2.9e-7 at every K (numpy's blocked sgemm: 3.4 - 3.8e-7), for +0.3 .. 2 % time.  A uniform, rarely
+      // taken branch; nothing but acc / tot is touched inside (the staged loads and fragment reads in flight keep their registers)
+      if (__builtin_expect(((kt + 2) & (PIPE_BLOCK_TILES - 1)) == 0 && kt + 2 < nk, 0)) {
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // XDL write -> VALU read: 18 wait states
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            tot[i][j] += acc[i][j];
+            acc[i][j] = 0.f;
+          }
+        asm volatile("s_nop 4" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));                // VALU write -> XDL SrcC read
+      }
     }
     // drain: loads / fragment reads of the tiles past the end are in flight; the accumulators are read by VALU next (XDL
     // write -> VALU read needs 18 wait states the compiler cannot see behind the asm)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = tot[i][j] + acc[i][j];
   };
   kloop(std::integral_constant<int, 2>{});
 }

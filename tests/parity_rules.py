@@ -75,8 +75,9 @@ def has_gauge(g):
     return g.norm == "batch" and g.wd == 0
 
 
-# post-training outputs: |impl - ref_fp64| <= 3 x the reference's own fp32-to-fp64 distance, taken over its TWO fp32 draws.
-ANCHOR_FACTOR = 3.0
+# post-training outputs: |impl - ref_fp64| <= 2 x the reference's own fp32-to-fp64 distance, taken over its TWO fp32 draws
+# (3 x until round 4: the pipelined GEMMs now accumulate in blocks of 256 k, see csrc/gemm.hip pipe_mainloop).
+ANCHOR_FACTOR = 2.0
 
 
 def _anchor(g, which):
@@ -90,12 +91,13 @@ def check_eval_out(g, out):
     keys f64.*, tests/golden/make_student_golden.py).  The fixtures hold TWO draws of the reference's fp32 rounding noise
     around that fp64 result -- the plain fp32 run and the run from initial weights moved by one ulp; on MLP3w8 they sit 9.2e-3 /
     3.4e-2 (max) and 9.5e-4 / 3.4e-3 (mean) away from it: one ulp decides the sign of Adam's first steps on zero-gradient
-    entries.  An implementation must stay within 3 x the larger draw, max and mean, never tighter than the 1e-4 bar.
-    Measured (scripts/anchor_ratios.py, ratio to the plain fp32 run's distance): numpy oracle 0.2-2.0 x, HIP 0.3-3.2 x (mean on
-    MLP3w8: 3.0e-3, i.e. 0.88 x the perturbed reference's 3.4e-3); HIP is the noisier fp32 of the three on the wide students
-    (fp32 MFMA accumulates its reduction sequentially, MKL blocks it), not a biased one: per-step losses, step-1 gradients
-    and eval at identical state all hold 1e-4.  Round 2 used 4 x the fp32 self-noise against the reference's FP32 outputs
-    (0.14 max on MLP3w8); this anchor is 0.10 there and, unlike self-noise, is a distance to a fixed, better answer."""
+    entries.  An implementation must stay within 2 x the larger draw, max and mean, never tighter than the 1e-4 bar.
+    Measured in round 4 (scripts/anchor_ratios.py, ratio to the larger draw): HIP 0.25 - 0.94 x on the BatchNorm students (MLP3w8:
+    max 0.48 x, mean 0.88 x -- 3.0e-3 against the perturbed reference's 3.4e-3; against the plain fp32 run alone that is 3.2 x, which
+    says how far apart the reference's own two draws are, not how noisy the GEMMs are: it did not move when the pipelined GEMMs'
+    rounding noise dropped 2.8 - 3.9 x to below numpy's, scripts/gemm_noise.py), 1.1 - 1.8 x on the four fixtures whose distances are
+    1e-7 .. 3e-6, i.e. decided by the 1e-4 floor.  Per-step losses, step-1 gradients and eval at identical state all hold 1e-4.
+    Round 2 used 4 x the fp32 self-noise against the reference's FP32 outputs (0.14 max on MLP3w8), round 3 a factor of 3 here."""
     d = np.abs(g.view(np.asarray(out)).astype(np.float64) - np.asarray(g.z["f64.eval_out"], np.float64))
     tol_max, tol_mean = max(TOL, ANCHOR_FACTOR * _anchor(g, 0)), max(TOL / 5, ANCHOR_FACTOR * _anchor(g, 1))
     assert d.max() <= tol_max, ("eval max", d.max(), tol_max)

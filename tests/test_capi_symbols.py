@@ -69,9 +69,11 @@ def test_ops_refuse_cpu_tensors():
 
 def test_pipelined_gemm_loops_contain_no_vector_alu_and_no_register_copies(tmp_path):
     """gemm_kernel_pipe / gemm_tn_kernel_pipe issue their operand loads from inline asm: the compiler does not know those loads are
-    in flight, so any register copy (or other VALU instruction) it placed between the prologue barrier and the final drain would
-    read registers that have not been written yet.  Checked on the ISA hipcc generates for gfx950 (also the performance contract:
-    no vector-ALU work between the MFMAs)."""
+    in flight, so any register copy (or other VALU instruction) it placed on a staging / fragment register between the prologue
+    barrier and the final drain would read registers that have not been written yet.  Checked on the ISA hipcc generates for gfx950
+    (also the performance contract: no vector-ALU work between the MFMAs of the main loop body).  The only VALU work in that region
+    is the out-of-line block that moves the accumulators into the block totals every 8 k-tiles (round 4): it may touch nothing but
+    accumulator / total registers."""
     import re, shutil, subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -84,23 +86,43 @@ def test_pipelined_gemm_loops_contain_no_vector_alu_and_no_register_copies(tmp_p
     text = out.read_text()
     kernels = re.findall(r"^(_ZN[^\n:]*gemm_(?:tn_)?kernel_pipe[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
     assert len(kernels) == 3, [k for k, _ in kernels]
+
+    def vregs(operand_text):
+        regs = set()
+        for lo, hi in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+            regs.update(range(int(lo), int(hi) + 1))
+        regs.update(int(r) for r in re.findall(r"\bv(\d+)\b", operand_text))
+        return regs
+
     for name, body in kernels:
         lines = body.split("\n")
         first_barrier = next(i for i, l in enumerate(lines) if "s_barrier" in l)
         last_drain = max(i for i, l in enumerate(lines) if "s_nop 15" in l)
-        region = [l.split(";")[0].strip() for l in lines[first_barrier + 1:last_drain]]
         assert sum("Loop Header" in l for l in lines) == 1
         head = next(i for i, l in enumerate(lines) if "Loop Header" in l)
         label = lines[head].split(":")[0].strip()
         back = next(i for i, l in enumerate(lines) if i > head and "s_cbranch" in l and label in l)
+        assert first_barrier < head < back < last_drain
         loop = [l.split(";")[0].strip() for l in lines[head + 1:back]]
-        # inside the loop: no vector-ALU instruction on vector registers at all
+        # inside the main loop body: no vector-ALU instruction on vector registers at all
         valu = [l for l in loop if re.match(r"v_(?!mfma)", l) and re.search(r"\b[va]\[?\d", l)]
         assert not valu, (name, valu[:5])
         assert sum(l.startswith("v_mfma_f32_32x32x2") for l in loop) == 128      # two k-tiles per iteration
-        # around it (prologue barrier .. drain): no register-to-register copies
-        copies = [l for l in region if l.startswith(("v_mov", "v_accvgpr_read", "v_accvgpr_mov"))]
-        assert not copies, (name, copies[:5])
+        # the registers with asynchronous writers: destinations of the asm loads / LDS reads, sources of the LDS writes
+        busy = set()
+        for l in loop:
+            if l.startswith(("buffer_load", "ds_read")):
+                busy |= vregs(l.split(",")[0])
+            elif l.startswith("ds_write"):
+                busy |= vregs(l.split(",")[1])
+        assert len(busy) >= 32 + 16
+        # prologue barrier .. drain, outside the loop body: VALU only on other registers (the accumulators and their block totals)
+        region = [l.split(";")[0].strip() for l in lines[first_barrier + 1:head] + lines[back + 1:last_drain]]
+        side = [l for l in region if re.match(r"v_(?!mfma)", l)]
+        assert side, name
+        clash = [l for l in side if vregs(l) & busy]
+        assert not clash, (name, clash[:5])
+        assert sum(l.startswith("v_pk_add_f32") for l in side) == 32, name
 
 
 def test_cross_workgroup_publishes_drain_their_stores_before_the_counter_update(tmp_path):

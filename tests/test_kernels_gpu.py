@@ -191,11 +191,16 @@ def test_gemm_vs_oracle(m, k, n, kn):
                                         ("tn", 4096, 2048, 2048), ("tn", 320, 200, 130), ("tn", 8192, 256, 256), ("tn", 64, 129, 257),
                                         ("tn", 2080, 130, 100), ("tn", 2077, 256, 256), ("tn", 60001, 256, 128), ("tn", 4096, 2048, 100),
                                         ("tn", 2049, 129, 65), ("tn", 2064, 128, 128), ("tn", 2144, 130, 100), ("tn", 4128, 256, 256),
-                                        ("nt", 300, 96, 200), ("kn", 200, 32, 132), ("kn", 2100, 160, 256), ("nt", 5000, 224, 384)])
+                                        ("nt", 300, 96, 200), ("kn", 200, 32, 132), ("kn", 2100, 160, 256), ("nt", 5000, 224, 384),
+                                        ("tn", 256, 130, 100), ("tn", 200, 256, 256), ("tn", 96, 2048, 300), ("nt", 700, 256, 260),
+                                        ("nt", 4096, 4096, 2048), ("kn", 1000, 1024, 512), ("nt", 260, 288, 130), ("nt", 200, 544, 256)])
 def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(form, m, k, n, monkeypatch):
     """gemm_kernel_pipe / gemm_tn_kernel_pipe (hand-scheduled main loop, buffer loads, plain operands, K % 32 == 0) keep the tiles,
-    the k order and the MFMA order of gemm_kernel_fast / gemm_tn_kernel_t: same bits, ragged tiles, epilogues and splits included.
-    For "tn" (m, k, n) = (reduction rows, ka, nb)."""
+    the k order and the MFMA order of gemm_kernel_fast / gemm_tn_kernel_t: same bits, ragged tiles, epilogues and splits included --
+    for reductions of up to 256 terms.  Longer ones are accumulated in blocks of 256 k by the pipelined kernels (round 4: one MFMA
+    chain over K = 2048 - 4096 carried 2.2 - 3.1 x the rounding noise of the oracle's blocked sgemm): there the two paths must agree
+    to rounding, both must sit within the fp64 product's tolerance, and from 1024 terms on the pipelined result must be the closer
+    one by a clear margin (rms error <= 0.75 x).  For "tn" (m, k, n) = (reduction rows, ka, nb)."""
     from glnn_amd import ops
     r = np.random.RandomState(m + k + n)
     outs = []
@@ -220,12 +225,19 @@ def test_pipelined_gemm_kernels_equal_the_compiler_scheduled_ones_bit_for_bit(fo
             outs.append(ops.gemm(a, w, w_is_kn=(form == "kn"), row_scale=rs, ep_scale=es, ep_shift=eh, relu=True).clone())
     # the weight-gradient launcher picks other tiles / reduction splits for few-tile outputs over >= 2048 rows when the pipelined
     # kernel is available: a different summation order across splits, so only closeness can be asked there
-    same_order = not (form == "tn" and m >= 2048 and ((k + 127) // 128) * ((n + 127) // 128) <= 64)
+    red = m if form == "tn" else k              # terms per output element
+    same_order = red <= 256 and not (form == "tn" and m >= 2048 and ((k + 127) // 128) * ((n + 127) // 128) <= 64)
     if same_order:
         assert torch.equal(outs[0], outs[1])
     else:
-        np.testing.assert_allclose(outs[1][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, m / 512) ** 0.5, rtol=1e-5)
-    np.testing.assert_allclose(outs[0][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, (m if form == "tn" else k) / 512) ** 0.5, rtol=1e-5)
+        np.testing.assert_allclose(outs[1][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, red / 512) ** 0.5, rtol=1e-5)
+    np.testing.assert_allclose(outs[0][:, :want.shape[1]].cpu().numpy(), want.cpu().numpy(), atol=TOL * max(1.0, red / 512) ** 0.5, rtol=1e-5)
+    unsplit = not (form == "tn" and ((k + 127) // 128) * ((n + 127) // 128) <= 64)
+    if red >= 1024 and unsplit:      # (split reductions are blocked by their splits on both paths)
+        full = want.shape[0] * want.shape[1] >= 2048 * 2048          # enough tiles that the launcher does not split K: the pipelined kernel runs
+        if full or not torch.equal(outs[0], outs[1]):
+            e = [float((o[:, :want.shape[1]].double() - want).pow(2).mean().sqrt()) for o in outs]
+            assert e[0] <= 0.75 * e[1], e
 
 
 @pytest.mark.parametrize("m,k,n,epi", [(5000, 100, 256, True), (4096, 100, 2048, True), (100003, 128, 256, False), (2049, 36, 96, True),
