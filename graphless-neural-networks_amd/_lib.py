@@ -51,6 +51,7 @@ SIGNATURES = {
     "glnn_sample_neighbors": [c_vp, c_vp, c_vp, c_i64, c_int, c_u32, c_vp, c_vp, c_vp],
     "glnn_block_workspace_bytes": [c_i64, c_i64],
     "glnn_block_build": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp],
+    "glnn_block_build_ids": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_int, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "glnn_csr_transpose_workspace_bytes": [c_i64, c_i64],
     "glnn_csr_transpose": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_gather_rows_f32": [c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp],
@@ -62,7 +63,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)

@@ -152,9 +152,27 @@ struct BlockArgs {
   int32_t* gindices;            // out [nnz_cap] global ids (optional)
   int64_t* input_nodes;         // out [ns + nnz_cap]
   int64_t* counts;              // out device [2]: nnz, n_src
-  int* keys; int* seed_pos; int* first_pos; int* local_of_slot; unsigned mask;    // hash table (4 arrays of mask+1)
+  int* keys; int* pos; unsigned mask;    // hash table: keys + one position word per slot (mask+1 entries each)
   int* slot_of_edge;            // [nnz_cap]
+  int direct;                   // 1: `pos` is indexed by the node id itself (n_nodes entries, no keys array, no probing)
 };
+
+// The position word of a node (one per table slot, 0x7F-filled = absent) goes through three stages, all orderable by atomicMin:
+//   insert     destination i of the block writes i (< ns); in-edge e writes ns + e  ->  min = the destination index if the node is a
+//              destination, else ns + its FIRST edge position (ns + nnz_cap < 2^30: bit 30 is clear in every such value);
+//   scan       edge e is a first occurrence of a new source iff pos == ns + e; its dense local id replaces the word with bit 30 set
+//              (never equal to any ns + e', so the other edges of that node keep reading "not first");
+//   relabel    local id = pos & 0x3FFFFFFF for both kinds.
+// One random access per edge and pass (round 4; before: seed_pos / first_pos / local_of_slot, two per edge and pass).
+constexpr int kLocalBit = 1 << 30;
+
+// table slot of a node id: the id itself in direct mode (a small id universe: one atomicMin per edge instead of a CAS chain plus
+// an atomicMin, and tables of n_nodes instead of 2..4x the frontier entries), else the open-addressing insert
+template <bool DIRECT>
+__device__ __forceinline__ int slot_of(const BlockArgs& a, int key) {
+  if (DIRECT) return key;
+  return ht_insert(a.keys, a.mask, key);
+}
 
 struct RowCount {
   BlockArgs a;
@@ -172,7 +190,7 @@ struct WriteIndptr {
   }
 };
 
-template <bool FULL>
+template <bool FULL, bool DIRECT>
 __global__ __launch_bounds__(256) void block_insert_kernel(const BlockArgs a) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (FULL) {
@@ -182,23 +200,23 @@ __global__ __launch_bounds__(256) void block_insert_kernel(const BlockArgs a) {
     if (i >= a.ns) return;
     const int64_t v = a.seeds[i];
     if (lane == 0) {
-      const int slot = ht_insert(a.keys, a.mask, (int)v);
-      atomicMin(&a.seed_pos[slot], (int)i);
+      const int slot = slot_of<DIRECT>(a, (int)v);
+      atomicMin(&a.pos[slot], (int)i);
       a.input_nodes[i] = v;
     }
     const int64_t g0 = a.g_indptr[v], cnt = a.g_indptr[v + 1] - g0, e0 = a.indptr[i];
     for (int64_t k = lane; k < cnt && e0 + k < a.nnz_cap; k += 64) {       // (counts[0] reports the true nnz: the caller checks it against nnz_cap)
       const int key = a.g_indices[g0 + k];
-      const int slot = ht_insert(a.keys, a.mask, key);
-      atomicMin(&a.first_pos[slot], (int)(e0 + k));
+      const int slot = slot_of<DIRECT>(a, key);
+      atomicMin(&a.pos[slot], (int)(a.ns + e0 + k));
       a.slot_of_edge[e0 + k] = slot;
       if (a.gindices) a.gindices[e0 + k] = key;
     }
   } else {
     if (t < a.ns) {
       const int64_t v = a.seeds[t];
-      const int slot = ht_insert(a.keys, a.mask, (int)v);
-      atomicMin(&a.seed_pos[slot], (int)t);
+      const int slot = slot_of<DIRECT>(a, (int)v);
+      atomicMin(&a.pos[slot], (int)t);
       a.input_nodes[t] = v;
       return;
     }
@@ -208,8 +226,8 @@ __global__ __launch_bounds__(256) void block_insert_kernel(const BlockArgs a) {
     if (i >= a.ns || k >= a.smp_cnt[i]) return;
     const int64_t e = a.indptr[i] + k;
     const int key = a.smp_src[i * a.fanout + k];
-    const int slot = ht_insert(a.keys, a.mask, key);
-    atomicMin(&a.first_pos[slot], (int)e);
+    const int slot = slot_of<DIRECT>(a, key);
+    atomicMin(&a.pos[slot], (int)(a.ns + e));
     a.slot_of_edge[e] = slot;
     if (a.gindices) a.gindices[e] = key;
   }
@@ -219,8 +237,7 @@ struct FirstSeen {           // 1 iff edge e is the first occurrence of a node t
   BlockArgs a;
   __device__ int operator()(int64_t e) const {
     if (e >= a.indptr[a.ns]) return 0;
-    const int slot = a.slot_of_edge[e];
-    return (a.first_pos[slot] == (int)e && a.seed_pos[slot] == kFill32) ? 1 : 0;
+    return a.pos[a.slot_of_edge[e]] == (int)(a.ns + e) ? 1 : 0;
   }
 };
 struct AssignLocal {
@@ -228,8 +245,8 @@ struct AssignLocal {
   __device__ void operator()(int64_t e, long long ex, int flag) const {
     if (flag) {
       const int slot = a.slot_of_edge[e];
-      a.local_of_slot[slot] = (int)(a.ns + ex);
-      a.input_nodes[a.ns + ex] = a.keys[slot];
+      a.pos[slot] = (int)(a.ns + ex) | kLocalBit;
+      a.input_nodes[a.ns + ex] = a.direct ? slot : a.keys[slot];
     }
   }
 };
@@ -241,9 +258,7 @@ __global__ __launch_bounds__(256) void block_relabel_kernel(const BlockArgs a, c
     a.counts[1] = a.ns + *n_new;
   }
   if (e >= a.indptr[a.ns]) return;
-  const int slot = a.slot_of_edge[e];
-  const int sp = a.seed_pos[slot];
-  a.indices[e] = (sp != kFill32) ? sp : a.local_of_slot[slot];
+  a.indices[e] = a.pos[a.slot_of_edge[e]] & (kLocalBit - 1);
 }
 
 __global__ void block_empty_counts_kernel(int64_t* counts, int64_t* indptr, int64_t ns) {
@@ -334,13 +349,13 @@ extern "C" int64_t glnn_block_workspace_bytes(int64_t ns, int64_t nnz_cap) {
   uint64_t cap = 64;
   while (cap < (uint64_t)(2 * (ns + nnz_cap))) cap <<= 1;
   const int64_t scan_words = (ns + kScanTile - 1) / kScanTile + (nnz_cap + kScanTile - 1) / kScanTile + 2;
-  return (int64_t)(4 * cap * sizeof(int)) + nnz_cap * (int64_t)sizeof(int) + scan_words * 8 + 64;
+  return (int64_t)(2 * cap * sizeof(int)) + nnz_cap * (int64_t)sizeof(int) + scan_words * 8 + 64;
 }
 
-extern "C" int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds, int64_t ns,
-                                const int32_t* smp_src, const int32_t* smp_cnt, int fanout, int64_t nnz_cap,
-                                int64_t* indptr, int32_t* indices, int32_t* gindices, int64_t* input_nodes, int64_t* counts,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+static int block_build_impl(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds, int64_t ns,
+                            const int32_t* smp_src, const int32_t* smp_cnt, int fanout, int64_t nnz_cap,
+                            int64_t* indptr, int32_t* indices, int32_t* gindices, int64_t* input_nodes, int64_t* counts,
+                            int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream) {
   GLNN_REQUIRE(ns >= 0 && nnz_cap >= 0, "glnn_block_build: negative size");
   GLNN_REQUIRE(counts && indptr, "glnn_block_build: null counts/indptr");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -363,36 +378,61 @@ extern "C" int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indice
                "glnn_block_build: workspace needs %lld bytes, 8-byte aligned", (long long)glnn_block_workspace_bytes(ns, nnz_cap));
   uint64_t cap = 64;
   while (cap < (uint64_t)(2 * (ns + nnz_cap))) cap <<= 1;
+  // direct mode: every node id is < n_nodes and the id universe is no larger than the hash table's two arrays -- the positions are indexed by
+  // the id itself (n_nodes entries: they fit the same workspace), one atomicMin per edge instead of CAS chain + atomicMin, and the
+  // 0x7F fill covers n_nodes words instead of 2 cap (the widest block of a products batch: 8 M-slot tables -> a 2.45 M-entry one)
+  const bool direct = n_nodes > 0 && (uint64_t)n_nodes <= 2 * cap && n_nodes < kFill32;
+  const uint64_t tab = direct ? (uint64_t)((n_nodes + 1) & ~(int64_t)1) : cap;      // entries per table (even: the arrays behind stay 8-byte aligned)
   const int64_t b1 = (ns + kScanTile - 1) / kScanTile, b2 = (nnz_cap + kScanTile - 1) / kScanTile;
-  // layout: [status1 b1][status2 b2][ticket1, ticket2 (one 8-byte word)][n_new (8 bytes)] | keys, seed_pos, first_pos | -- 0x7F-filled up to here
-  //         local_of_slot | slot_of_edge
+  // layout: [status1 b1][status2 b2][ticket1, ticket2 (one 8-byte word)][n_new (8 bytes)] | (keys,) pos | -- 0x7F-filled up to here
+  //         slot_of_edge
   unsigned long long* status1 = reinterpret_cast<unsigned long long*>(workspace);
   unsigned long long* status2 = status1 + b1;
   int* tickets = reinterpret_cast<int*>(status2 + b2);
   int64_t* n_new = reinterpret_cast<int64_t*>(tickets + 2);
-  int* keys = reinterpret_cast<int*>(n_new + 1);
+  int* tables = reinterpret_cast<int*>(n_new + 1);
   BlockArgs a;
   a.g_indptr = g_indptr; a.g_indices = g_indices; a.seeds = seeds; a.ns = ns; a.smp_src = smp_src; a.smp_cnt = smp_cnt;
   a.fanout = fanout; a.nnz_cap = nnz_cap; a.indptr = indptr; a.indices = indices; a.gindices = gindices; a.input_nodes = input_nodes;
-  a.counts = counts; a.keys = keys; a.seed_pos = keys + cap; a.first_pos = keys + 2 * cap; a.local_of_slot = keys + 3 * cap;
-  a.mask = (unsigned)(cap - 1); a.slot_of_edge = keys + 4 * cap;
-  const size_t fill_bytes = (size_t)((b1 + b2 + 2) * 8) + 3 * cap * sizeof(int);
+  a.counts = counts; a.direct = direct ? 1 : 0;
+  a.keys = direct ? nullptr : tables;
+  a.pos = direct ? tables : tables + tab;
+  a.mask = (unsigned)(cap - 1); a.slot_of_edge = a.pos + tab;
+  const size_t fill_bytes = (size_t)((b1 + b2 + 2) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
   if (hipMemsetAsync(workspace, 0x7F, fill_bytes, st) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset failed");
   int rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
   if (rc != GLNN_OK) return rc;
-  if (full) {
-    const int64_t threads = ns * 64;
-    hipLaunchKernelGGL((block_insert_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
-  } else {
-    const int64_t threads = ns + ns * (int64_t)fanout;
-    hipLaunchKernelGGL((block_insert_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, a);
-  }
+  const int64_t threads = full ? ns * 64 : ns + ns * (int64_t)fanout;
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (full && direct) hipLaunchKernelGGL((block_insert_kernel<true, true>), grid, dim3(256), 0, st, a);
+  else if (full) hipLaunchKernelGGL((block_insert_kernel<true, false>), grid, dim3(256), 0, st, a);
+  else if (direct) hipLaunchKernelGGL((block_insert_kernel<false, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((block_insert_kernel<false, false>), grid, dim3(256), 0, st, a);
   rc = glnn::check_launch("glnn_block_build(insert)");
   if (rc != GLNN_OK) return rc;
   rc = launch_scan(FirstSeen{a}, nnz_cap, status2, tickets + 1, AssignLocal{a}, n_new, st, "glnn_block_build(scan first occurrences)");
   if (rc != GLNN_OK) return rc;
   hipLaunchKernelGGL(block_relabel_kernel, dim3((unsigned)((nnz_cap + 255) / 256)), dim3(256), 0, st, a, n_new);
   return glnn::check_launch("glnn_block_build(relabel)");
+}
+
+extern "C" int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds, int64_t ns,
+                                const int32_t* smp_src, const int32_t* smp_cnt, int fanout, int64_t nnz_cap,
+                                int64_t* indptr, int32_t* indices, int32_t* gindices, int64_t* input_nodes, int64_t* counts,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  return block_build_impl(g_indptr, g_indices, seeds, ns, smp_src, smp_cnt, fanout, nnz_cap, indptr, indices, gindices, input_nodes, counts,
+                          0, workspace, workspace_bytes, stream);
+}
+
+// ABI 8: the same with the size of the id universe (every seed / neighbour id < n_nodes; 0 = unknown).  When the universe is no larger
+// than the hash table would be, the tables are indexed by the id itself (see block_build_impl); results are identical.
+extern "C" int glnn_block_build_ids(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds, int64_t ns,
+                                    const int32_t* smp_src, const int32_t* smp_cnt, int fanout, int64_t nnz_cap,
+                                    int64_t* indptr, int32_t* indices, int32_t* gindices, int64_t* input_nodes, int64_t* counts,
+                                    int64_t n_nodes, void* workspace, int64_t workspace_bytes, void* stream) {
+  GLNN_REQUIRE(n_nodes >= 0, "glnn_block_build_ids: negative n_nodes");
+  return block_build_impl(g_indptr, g_indices, seeds, ns, smp_src, smp_cnt, fanout, nnz_cap, indptr, indices, gindices, input_nodes, counts,
+                          n_nodes, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t glnn_csr_transpose_workspace_bytes(int64_t n_src, int64_t nnz_out) {

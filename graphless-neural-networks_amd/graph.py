@@ -184,7 +184,8 @@ class FullNeighborLoader:
         for b in range(len(bounds) - 1):
             s, e = bounds[b], bounds[b + 1]
             output_nodes = torch.arange(s, e, device=g.device)
-            indptr, indices, _, input_nodes, nnz, n_src = ops.block_build(output_nodes, g.indptr, g.indices, nnz_cap=offs[b + 1] - offs[b])
+            indptr, indices, _, input_nodes, nnz, n_src = ops.block_build(output_nodes, g.indptr, g.indices, nnz_cap=offs[b + 1] - offs[b],
+                                                                          n_nodes=g.n_src)
             block = CSRGraph(indptr, indices, e - s, n_src)
             block._nnz = nnz
             yield input_nodes, output_nodes, [block]
@@ -234,10 +235,11 @@ class NodeDataLoader:
         if fanout is None:                                   # full neighbourhood: the edge count bounds the buffers
             deg_sum = int((g.indptr[seeds + 1] - g.indptr[seeds]).sum().item())
             indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, g.indptr, g.indices, nnz_cap=deg_sum,
-                                                                              want_global=want_global)
+                                                                              want_global=want_global, n_nodes=g.n_src)
         else:
             smp, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, fanout, rng_seed)
-            indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=want_global)
+            indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=want_global,
+                                                                              n_nodes=g.n_src)
         block = CSRGraph(indptr, indices, seeds.numel(), n_src)
         block._nnz = nnz
         if want_global:

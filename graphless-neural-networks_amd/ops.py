@@ -541,8 +541,9 @@ def _i32(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)[:int(n)]
 
 
-def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_cnt=None, nnz_cap=None, want_global=False):
-    """glnn_block_build: one 1-hop block over the destination nodes `seeds` (int64 device vector).
+def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_cnt=None, nnz_cap=None, want_global=False, n_nodes=0):
+    """glnn_block_build_ids: one 1-hop block over the destination nodes `seeds` (int64 device vector).  n_nodes: the size of the id
+    universe (every id < n_nodes) when known -- lets wide blocks index their tables by the id itself; 0 = unknown.
     Sampled mode: smp_src [ns, fanout] / smp_cnt [ns] from sample_neighbors.  Full-neighbour mode: the graph CSR and
     nnz_cap (an upper bound of the block's edge count).  Returns (indptr [ns+1], indices [nnz] local ids,
     gindices [nnz] global ids or None, input_nodes [n_src], nnz, n_src); ONE host read-back (the two counts)."""
@@ -568,10 +569,10 @@ def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_
     counts = torch.empty(2, dtype=torch.int64, device=dev)
     wsb = int(_lib.lib().glnn_block_workspace_bytes(ns, nnz_cap))
     ws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
-    rc = _lib.lib().glnn_block_build(_p(graph_indptr) if smp_src is None else None, _p(graph_indices) if smp_src is None else None,
-                                     _p(seeds), ns, _p(smp_src), _p(smp_cnt), fanout, nnz_cap, _p(indptr), _p(indices), _p(gindices),
-                                     _p(input_nodes), _p(counts), _p(ws), ws.numel() * 8, _stream())
-    _lib.check(rc, "glnn_block_build")
+    rc = _lib.lib().glnn_block_build_ids(_p(graph_indptr) if smp_src is None else None, _p(graph_indices) if smp_src is None else None,
+                                         _p(seeds), ns, _p(smp_src), _p(smp_cnt), fanout, nnz_cap, _p(indptr), _p(indices), _p(gindices),
+                                         _p(input_nodes), _p(counts), int(n_nodes), _p(ws), ws.numel() * 8, _stream())
+    _lib.check(rc, "glnn_block_build_ids")
     nnz, n_src = (int(v) for v in counts.tolist())          # the only host sync of the block
     if nnz > nnz_cap:
         raise _lib.GlnnError(f"block_build: the block has {nnz} edges, more than nnz_cap = {nnz_cap}")

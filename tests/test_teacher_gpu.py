@@ -77,8 +77,11 @@ def _first_appearance_block(seeds, rows):
     return np.asarray(indptr, np.int64), np.asarray(local, np.int32), np.asarray(input_nodes, np.int64)
 
 
+@pytest.mark.parametrize("known_ids", [False, True])
 @pytest.mark.parametrize("ns", [1, 37, 1000, 5000])
-def test_block_build_full_neighbourhood_equals_numpy(ns):
+def test_block_build_full_neighbourhood_equals_numpy(ns, known_ids):
+    """known_ids: the builder is told the size of the id universe (glnn_block_build_ids) and indexes its tables by the node id itself
+    whenever that universe is no larger than the frontier's hash table would be (here: ns >= 1000) -- identical blocks either way."""
     from glnn_amd import ops
     n = 6000
     indptr, indices = random_graph(n, 8, seed=5, power=0.7, hub=3000, isolated=20)
@@ -87,22 +90,24 @@ def test_block_build_full_neighbourhood_equals_numpy(ns):
     rows = [indices[indptr[v]:indptr[v + 1]] for v in seeds]
     w_ip, w_ix, w_in = _first_appearance_block(seeds, rows)
     g_ip, g_ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
-    ip, ix, gix, inp, nnz, n_src = ops.block_build(torch.from_numpy(seeds).to(DEV), g_ip, g_ix, nnz_cap=int(w_ip[-1]) + 11, want_global=True)
+    ip, ix, gix, inp, nnz, n_src = ops.block_build(torch.from_numpy(seeds).to(DEV), g_ip, g_ix, nnz_cap=int(w_ip[-1]) + 11, want_global=True,
+                                                   n_nodes=n if known_ids else 0)
     assert nnz == w_ip[-1] and n_src == len(w_in)
     assert np.array_equal(ip.cpu().numpy(), w_ip) and np.array_equal(ix.cpu().numpy(), w_ix) and np.array_equal(inp.cpu().numpy(), w_in)
     assert np.array_equal(gix.cpu().numpy(), np.concatenate(rows) if nnz else np.zeros(0, np.int32))
     assert np.array_equal(w_in[ix.cpu().numpy()], gix.cpu().numpy())          # local ids name the same nodes
 
 
+@pytest.mark.parametrize("known_ids", [False, True])
 @pytest.mark.parametrize("ns,fanout", [(512, 15), (7000, 10), (3, 1), (20000, 5)])
-def test_block_build_from_sampled_neighbours(ns, fanout):
+def test_block_build_from_sampled_neighbours(ns, fanout, known_ids):
     from glnn_amd import ops
     n = 30000
     indptr, indices = random_graph(n, 12, seed=9, power=0.6, hub=9000, isolated=50)
     g_ip, g_ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
     seeds = torch.from_numpy(np.random.RandomState(ns).permutation(n)[:ns].astype(np.int64)).to(DEV)
     smp, cnt = ops.sample_neighbors(g_ip, g_ix, seeds, fanout, 1234)
-    ip, ix, gix, inp, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=True)
+    ip, ix, gix, inp, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=True, n_nodes=n if known_ids else 0)
     smp_h, cnt_h = smp.cpu().numpy(), cnt.cpu().numpy()
     rows = [smp_h[i, :cnt_h[i]] for i in range(ns)]
     w_ip, w_ix, w_in = _first_appearance_block(seeds.cpu().numpy(), rows)
