@@ -30,6 +30,8 @@ SIGNATURES = {
     "glnn_softmax_loss_f32": [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_log_softmax_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "glnn_linear_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "glnn_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                           c_vp, c_vp, c_i64, c_vp],
     "glnn_bn_relu_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64,

@@ -36,6 +36,7 @@ static void load_options(Options& o) {
   o.batched_wgrad = (int)env_ll("GLNN_STUDENT_BATCHED_WGRAD", 1);
   o.fuse_apply = (int)env_ll("GLNN_STUDENT_FUSE_APPLY", 1);
   o.adam_folds = (int)env_ll("GLNN_STUDENT_ADAM_FOLDS", 1);
+  o.gemm_stats = (int)env_ll("GLNN_GEMM_STATS", 1);
 }
 static Options g_opts;
 static std::once_flag g_opts_once;

@@ -51,6 +51,10 @@ struct GemmArgs {
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;   // drop_thr == 0: no dropout
   int ksplits; int ktiles_per_split; float* ws;               // split-K (fast kernel): raw partials -> ws[z][m][n]
   int defer_fold;     // host side only: the split-K partials are folded (sum over z + epilogue) by the CONSUMER of C, not by a launch here
+  // gemm_kernel_pipe only (else NULL): per 128-row tile and column, mean / M2 of the stored values at st_*[tile_row * n + col] -- the first
+  // pass of the BatchNorm statistics over C taken from the accumulators (glnn::gemm_stats)
+  float* st_mean; float* st_m2;
+  int* st_done;       // host side only: set to 1 by the launcher when the kernel that writes them was chosen
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -830,6 +834,67 @@ constexpr size_t pipe_lds_bytes(int sa, int sb) {
   return 2 * (size_t)((sa == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE) + (sb == ROWK ? PipeOp<ROWK>::TILE : PipeOp<KROW>::TILE));
 }
 
+// Column statistics of one stored 128 x 128 tile (g.st_mean != NULL; no row scale, no relu): mean and M2 = sum (v - mean)^2 over the
+// tile's valid rows, two passes over the accumulators like bn_stats_stage1's two passes over memory, written for the tile row
+// m0 / 128.  A column's 128 values sit in 2 lanes (lane halves) x 2 waves (row halves) x 32 registers: shuffle, then LDS.
+__device__ __forceinline__ void pipe_tile_stats(const GemmArgs& g, const f32x16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn, int li, int kk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // free: every LDS write of the main loop is behind its last barrier
+  float* red = smem;                                                // [2 row halves][128 columns]
+  const int rows = (int)(g.m - m0 < 128 ? g.m - m0 : 128);
+  float v[2][2][16];
+  float s[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + li;
+    const bool col_ok = col < g.n;
+    const float es = (col_ok && g.ep_scale) ? g.ep_scale[col] : 1.f;
+    const float eh = (col_ok && g.ep_shift) ? g.ep_shift[col] : 0.f;
+    s[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+        v[j][i][r] = fmaf(acc[i][j][r], es, eh);                    // the stored value
+        s[j] += row < rows ? v[j][i][r] : 0.f;
+      }
+    s[j] += __shfl_xor(s[j], 32);
+  }
+  __syncthreads();
+  if (kk == 0) { red[wm * 128 + wn * 64 + li] = s[0]; red[wm * 128 + wn * 64 + 32 + li] = s[1]; }
+  __syncthreads();
+  float mean[2], q[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = wn * 64 + j * 32 + li;
+    mean[j] = (red[c] + red[128 + c]) / (float)rows;
+    q[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+        const float dv = v[j][i][r] - mean[j];
+        q[j] = row < rows ? fmaf(dv, dv, q[j]) : q[j];
+      }
+    q[j] += __shfl_xor(q[j], 32);
+  }
+  __syncthreads();
+  if (kk == 0) { red[wm * 128 + wn * 64 + li] = q[0]; red[wm * 128 + wn * 64 + 32 + li] = q[1]; }
+  __syncthreads();
+  if (wm == 0 && kk == 0) {
+    const int64_t base = (m0 / 128) * (int64_t)g.n;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = wn * 64 + j * 32 + li, col = n0 + c;
+      if (col < g.n) {
+        g.st_mean[base + col] = mean[j];
+        g.st_m2[base + col] = red[c] + red[128 + c];
+      }
+    }
+  }
+}
+
 // C = epi(A . W^T) (B_KN = false, W [n,k]) or epi(A . W) (B_KN = true, W [k,n]): plain A, K % 32 == 0, no split-K
 template <bool B_KN>
 __global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
@@ -848,6 +913,7 @@ __global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
   else
     pipe_mainloop<ROWK, ROWK>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + (int64_t)n0 * g.ldb, g.ldb, g.n - n0, g.k, g.k / BK, acc);
   store_tile<128, 128, 2, 2>(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
+  if (g.st_mean) pipe_tile_stats(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1405,9 +1471,11 @@ int launch_gemm(GemmArgs& g, bool fast, hipStream_t st) {
     const bool window = B_KN ? (g.lda < (1 << 21) && (int64_t)g.k * g.ldb < (1 << 28)) : (g.lda < (1 << 21) && g.ldb < (1 << 21));
     if (pipe_enabled() && !g.a_scale && g.ksplits == 1 && g.k % BK == 0 && !g.a_rows && window) {
       static int cfg_pipe = 1;
+      if (g.st_done) *g.st_done = 1;
       return launch_gemm_kernel(gemm_kernel_pipe<B_KN>, cfg_pipe, pipe_lds_bytes(ROWK, B_KN ? KROW : ROWK), g, BN, st, 128);
     }
   }
+  g.st_mean = g.st_m2 = nullptr;
   if (BKF != BK) g.ktiles_per_split *= BK / BKF;     // split bookkeeping is in units of the fast kernel's k-tiles
   if (!g.a_scale) return launch_gemm_kernel(gemm_kernel_fast<BMT, BN, B_KN, 0, BKF>, cfg[0], smem_fast, g, BN, st, BMT);
   if (!g.drop_thr) return launch_gemm_kernel(gemm_kernel_fast<BMT, BN, B_KN, 1, BKF>, cfg[1], smem_fast, g, BN, st, BMT);
@@ -1435,7 +1503,7 @@ int launch_gemm_small(GemmArgs& g, hipStream_t st) {
 static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,
                      const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k, const float* b, int64_t ldb, int b_layout, int n,
                      const float* row_scale, const float* ep_scale, const float* ep_shift, int relu, float* c,
-                     int64_t ldc, float* workspace, int64_t workspace_floats, void* stream, int* defer_splits) {
+                     int64_t ldc, float* workspace, int64_t workspace_floats, void* stream, int* defer_splits, glnn::ColStats* cs = nullptr) {
   GLNN_REQUIRE(a && b && c, "glnn_gemm_f32: null pointer");
   GLNN_REQUIRE(m >= 0 && k >= 1 && n >= 1, "glnn_gemm_f32: bad sizes m=%lld k=%d n=%d", (long long)m, k, n);
   GLNN_REQUIRE(lda >= k && ldc >= n, "glnn_gemm_f32: lda/ldc too small");
@@ -1455,6 +1523,11 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
   g.ksplits = 1; g.ktiles_per_split = (k + BK - 1) / BK; g.ws = nullptr; g.defer_fold = 0;
+  g.st_mean = g.st_m2 = nullptr; g.st_done = nullptr;
+  int tile_stats_done = 0;
+  if (cs && !relu && !row_scale && !defer_splits && cs->ws && cs->ws_floats >= 2 * ((m + BM - 1) / BM) * (int64_t)n) {
+    g.st_mean = cs->ws; g.st_m2 = cs->ws + ((m + BM - 1) / BM) * (int64_t)n; g.st_done = &tile_stats_done;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // fast path: all float4 loads legal and all-or-nothing at the k (and, for [k,n], n) boundary
   const bool fast = g.a_vec && g.b_vec && lda >= ((k + 3) & ~3) && ldb >= (((b_layout ? n : k) + 3) & ~3) &&
@@ -1484,7 +1557,7 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
   // a short reduction over many rows (k <= 128: a projection of feature / aggregate rows): persistent workgroups with the weight panel
   // resident in LDS (gemm_rowpanel.hip) instead of one workgroup per output tile with 3-4 k-tiles each
   if (fast && !defer_splits && !b_layout && !a_rows && !a_scale && !row_scale && rowpanel_enabled()) {
-    const int rc = glnn::gemm_rowpanel(a, lda, m, k, b, ldb, n, ep_scale, ep_shift, relu, c, ldc, stream);
+    const int rc = glnn::gemm_rowpanel(a, lda, m, k, b, ldb, n, ep_scale, ep_shift, relu, c, ldc, stream, cs);
     if (rc != GLNN_ERR_UNSUPPORTED) return rc;
   }
   // latency regime: fewer than 64 tiles of 128 x (128|64) -> 64 x 64 tiles, four times the workgroups, a quarter of the
@@ -1545,8 +1618,23 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
       }
     }
   }
-  if (n > 64) return b_layout ? launch_gemm<128, true>(g, fast, st) : launch_gemm<128, false>(g, fast, st);
-  return b_layout ? launch_gemm<64, true>(g, fast, st) : launch_gemm<64, false>(g, fast, st);
+  int rc;
+  if (n > 64) rc = b_layout ? launch_gemm<128, true>(g, fast, st) : launch_gemm<128, false>(g, fast, st);
+  else rc = b_layout ? launch_gemm<64, true>(g, fast, st) : launch_gemm<64, false>(g, fast, st);
+  if (rc == GLNN_OK && tile_stats_done) {
+    cs->ws_cnt = nullptr; cs->ws_mean = g.st_mean; cs->ws_m2 = g.st_m2;
+    cs->nparts = (int)((m + BM - 1) / BM); cs->chunk_rows = BM; cs->done = 1;
+  }
+  return rc;
+}
+
+// glnn_gemm_f32 with plain operands (C = A W^T + bias) that also leaves the first pass of C's column statistics when the kernel taking
+// the shape can (the row-panel kernel: per-workgroup triples; the pipelined kernel: per-tile mean / M2) -- see glnn::ColStats
+int glnn::gemm_stats(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* bias, float* c, int64_t ldc,
+                     float* workspace, int64_t workspace_floats, void* stream, glnn::ColStats* cs) {
+  if (cs) { cs->done = 0; cs->nparts = 0; cs->chunk_rows = 0; cs->ws_cnt = cs->ws_mean = cs->ws_m2 = nullptr; }
+  return gemm_impl(a, lda, nullptr, nullptr, nullptr, 0.f, 0u, m, k, w, ldw, 0, n, nullptr, nullptr, bias, 0, c, ldc, workspace, workspace_floats,
+                   stream, nullptr, cs);
 }
 
 extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,

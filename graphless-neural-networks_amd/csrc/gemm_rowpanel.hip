@@ -38,11 +38,14 @@ struct RpArgs {
   const float* ep_scale; const float* ep_shift; int relu;
   float* c; int64_t ldc;
   int64_t tiles;                  // ceil(m / 64)
+  // optional column statistics of C (BatchNorm training): workgroup (x, y) leaves, for each of its 128 columns, the count / mean / M2 of
+  // the rows it wrote at st_*[x * n + col] -- accumulated in registers along its walk, from the very values it stores
+  float* st_cnt; float* st_mean; float* st_m2;
 };
 
 __device__ __forceinline__ float4 rp_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-template <int KG>                 // k-groups of 8: 8 (KG - 1) < k <= 8 KG, k % 4 == 0; KG >= 5 (the side work is spread over k-groups 0 .. 4)
+template <int KG, bool STATS>     // k-groups of 8: 8 (KG - 1) < k <= 8 KG, k % 4 == 0; KG >= 5 (the side work is spread over k-groups 0 .. 4)
 __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs g) {
   constexpr int KP = 8 * KG;
   constexpr int KS = KP + 4;      // LDS row stride (floats): KS / 4 odd -> the 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots
@@ -130,12 +133,22 @@ __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs 
   const uint32_t ldc4 = (uint32_t)(g.ldc * 4);
 
   rp_f32x16 acc[2];
-  auto store_quarter = [&](const rp_f32x16& av, const __amdgpu_buffer_rsrc_t rs, int q0) {
+  // STATS: per lane, the sums of (v - shift) and (v - shift)^2 over the 16 values of its column it stores per tile; shift = the first value
+  // the lane stores (within a few sigma of the column mean: the one-pass variance loses a few bits, not the digits a zero shift would).
+  // `rows_ok` = valid rows of the stored tile counted from this lane's first row (rb*32 + 4*kk): only the matrix's ragged last tile masks.
+  float st_shift = 0.f, st_s1 = 0.f, st_s2 = 0.f;
+  auto store_quarter = [&](const rp_f32x16& av, const __amdgpu_buffer_rsrc_t rs, int q0, bool first, int rows_ok) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       float v = fmaf(av[4 * q0 + t], es, eh);
       if (g.relu) v = fmaxf(v, 0.f);
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, c_voff, (uint32_t)(8 * q0 + t) * ldc4, 0);
+      if (STATS) {
+        if (q0 == 0 && t == 0) st_shift = first ? v : st_shift;
+        const float dv = (8 * q0 + t < rows_ok) ? v - st_shift : 0.f;
+        st_s1 += dv;
+        st_s2 = fmaf(dv, dv, st_s2);
+      }
     }
   };
 
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs 
       acc[CUR] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[CUR], 0, 0, 0);
       // ---- side work, in the shadow of the MFMAs (this wave's and its SIMD neighbour's) ----
       if (kg == 0) load_tile(CUR, tile + 2 * stride);            // tile it+2: requested more than a tile ahead, into staging set CUR
-      if (kg >= 1 && kg < 5) store_quarter(acc[CUR ^ 1], prev, kg - 1);
+      if (kg >= 1 && kg < 5) store_quarter(acc[CUR ^ 1], prev, kg - 1, it == 1, it > 0 ? 64 : 0);   // (never the ragged tile; walk start: nothing to count)
       if (kg == (KG > 6 ? 6 : KG - 1)) store_tile_lds(CUR ^ 1, CUR ^ 1);   // tile it+1 (requested during tile it-1): staging set CUR^1 -> the other buffer
       // (all unconditional: behind the walk's end the loads are out of range and the LDS write goes to a buffer nobody reads)
       __builtin_amdgcn_sched_barrier(0);                         // keep the side work of a k-group with its MFMAs
@@ -178,26 +191,69 @@ __global__ __launch_bounds__(kRpThreads) void gemm_rowpanel_kernel(const RpArgs 
   // the last tile's stores
   const int64_t last = n_my - 1;
   const __amdgpu_buffer_rsrc_t rl = c_rsrc(first + last * stride);
+  const int rows_last = (int)rows_of(first + last * stride) - (rb * 32 + 4 * kk);      // may be <= 0: nothing of this lane's rows is valid
   if (last & 1) {
 #pragma unroll
-    for (int q0 = 0; q0 < 4; ++q0) store_quarter(acc[1], rl, q0);
+    for (int q0 = 0; q0 < 4; ++q0) store_quarter(acc[1], rl, q0, last == 0, rows_last);
   } else {
 #pragma unroll
-    for (int q0 = 0; q0 < 4; ++q0) store_quarter(acc[0], rl, q0);
+    for (int q0 = 0; q0 < 4; ++q0) store_quarter(acc[0], rl, q0, last == 0, rows_last);
+  }
+  if (STATS) {
+    // lane -> (count, mean, M2) of its values; the four holders of a column (2 lane halves x 2 row-block waves) are combined in double
+    // (Chan) by one thread per column.  Accumulator element r sits at row offset 8 (r >> 2) + (r & 3): count the valid ones of the last tile
+    int n_last = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) n_last += (8 * (r >> 2) + (r & 3) < rows_last) ? 1 : 0;
+    const float cnt = (float)(16 * (n_my - 1) + n_last);
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    const float mean_l = st_shift + st_s1 * inv;
+    const float m2_l = fmaxf(st_s2 - st_s1 * st_s1 * inv, 0.f);
+    // (the walk's last barrier is behind every LDS read: the buffers are free)
+    float* red = lds;                              // [3][8 waves][64 lanes]
+    red[wave * 64 + lane] = cnt;
+    red[512 + wave * 64 + lane] = mean_l;
+    red[1024 + wave * 64 + lane] = m2_l;
+    __syncthreads();
+    if (tid < kRpCols) {
+      const int cbk = tid >> 5, lik = tid & 31, colk = n0 + tid;
+      double n = 0.0, mu = 0.0, m2 = 0.0;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {                // (row block 0, half 0), (0, 1), (1, 0), (1, 1): rows ascending within a tile
+        const int src = (cbk * 2 + (h >> 1)) * 64 + lik + 32 * (h & 1);
+        const double nb = red[src], mb = red[512 + src], qb = red[1024 + src];
+        if (nb > 0.0) {
+          const double nt = n + nb, dl = mb - mu;
+          mu += dl * nb / nt;
+          m2 += qb + dl * dl * n * nb / nt;
+          n = nt;
+        }
+      }
+      if (colk < g.n) {
+        const int64_t o = (int64_t)blockIdx.x * g.n + colk;
+        g.st_cnt[o] = (float)n;
+        g.st_mean[o] = (float)mu;
+        g.st_m2[o] = (float)m2;
+      }
+    }
   }
 }
 
-template <int KG>
-int launch_rowpanel(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
+template <int KG, bool STATS>
+int launch_rowpanel_t(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
   constexpr size_t smem = sizeof(float) * ((size_t)(kRpCols + 2 * kRpRows) * (8 * KG + 4) + 4 * kRpThreads);      // + the idle pieces' dummy slots
   static int configured = 0;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpanel_kernel<KG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_rowpanel_kernel<KG, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return glnn::fail(GLNN_ERR_HIP, "gemm_rowpanel: hipFuncSetAttribute(max dynamic LDS=%zu) failed", smem);
     configured = 1;
   }
-  hipLaunchKernelGGL(gemm_rowpanel_kernel<KG>, dim3((unsigned)grid_x, (unsigned)panels), dim3(kRpThreads), smem, st, g);
+  hipLaunchKernelGGL((gemm_rowpanel_kernel<KG, STATS>), dim3((unsigned)grid_x, (unsigned)panels), dim3(kRpThreads), smem, st, g);
   return glnn::check_launch("glnn_gemm_f32(rowpanel)");
+}
+template <int KG>
+int launch_rowpanel(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
+  return g.st_mean ? launch_rowpanel_t<KG, true>(g, grid_x, panels, st) : launch_rowpanel_t<KG, false>(g, grid_x, panels, st);
 }
 
 }  // namespace
@@ -206,7 +262,7 @@ int launch_rowpanel(const RpArgs& g, int grid_x, int panels, hipStream_t st) {
 // 36 <= k <= 128 (k % 4 == 0) -- from k = 129 on the pipelined k loop of gemm.hip amortises its prologue -- and enough rows that every
 // workgroup walks >= 2 tiles of a full-chip grid.
 int glnn::gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* ep_scale,
-                        const float* ep_shift, int relu, float* c, int64_t ldc, void* stream) {
+                        const float* ep_shift, int relu, float* c, int64_t ldc, void* stream, glnn::ColStats* cs) {
   if (k < 36 || k > 128 || (k & 3) || m < 2048 || n < 96) return GLNN_ERR_UNSUPPORTED;
   if ((lda & 3) || (ldw & 3) || lda < k || ldw < k || ldc < n || !glnn::aligned16(a) || !glnn::aligned16(w)) return GLNN_ERR_UNSUPPORTED;
   if (lda >= (1 << 22) || ldc >= (1 << 22)) return GLNN_ERR_UNSUPPORTED;      // a 64-row tile must fit a 2 GiB buffer window
@@ -225,6 +281,13 @@ int glnn::gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const flo
   gx &= ~(int64_t)7;
   while (gx > 8 && g.tiles < 2 * gx) gx -= 8;
   if (g.tiles < 2 * gx) return GLNN_ERR_UNSUPPORTED;                            // too few tiles per workgroup to pay for the panel load
+  g.st_cnt = g.st_mean = g.st_m2 = nullptr;
+  if (cs && !relu && cs->ws && cs->ws_floats >= 3 * gx * (int64_t)n) {          // (statistics of an activated output are nobody's BatchNorm input)
+    g.st_cnt = cs->ws;
+    g.st_mean = cs->ws + gx * (int64_t)n;
+    g.st_m2 = cs->ws + 2 * gx * (int64_t)n;
+  }
+  const auto launch = [&]() -> int {
   switch (kg) {
     case 5: return launch_rowpanel<5>(g, (int)gx, panels, st);
     case 6: return launch_rowpanel<6>(g, (int)gx, panels, st);
@@ -240,4 +303,11 @@ int glnn::gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const flo
     case 16: return launch_rowpanel<16>(g, (int)gx, panels, st);
     default: return GLNN_ERR_UNSUPPORTED;
   }
+  };
+  const int rc = launch();
+  if (rc == GLNN_OK && g.st_mean) {
+    cs->ws_cnt = g.st_cnt; cs->ws_mean = g.st_mean; cs->ws_m2 = g.st_m2;
+    cs->nparts = (int)gx; cs->chunk_rows = 0; cs->done = 1;
+  }
+  return rc;
 }

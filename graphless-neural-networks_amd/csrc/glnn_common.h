@@ -36,6 +36,7 @@ struct Options {
   int batched_wgrad;        // GLNN_STUDENT_BATCHED_WGRAD=0: small-step weight gradients one launch per layer
   int fuse_apply;           // GLNN_STUDENT_FUSE_APPLY=0: the first hidden layer's BatchNorm-backward apply stays its own launch
   int adam_folds;           // GLNN_STUDENT_ADAM_FOLDS=0: gradient partials are folded before Adam, not by it
+  int gemm_stats;           // GLNN_GEMM_STATS=0: BatchNorm statistics always take their own first pass over the GEMM's output
 };
 const Options& opts();
 
@@ -100,10 +101,12 @@ struct BnGroup {
 };
 // `counters` (optional, device ints, all zero on entry, left zero on exit): with them the final fold of a two-stage reduction
 // is done by the last workgroup of the first stage instead of by a second launch (student.hip: last_workgroup()).
+struct ColStats;
 int bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps, float momentum,
              float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out, float* rstd_out,
              float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats, void* stream, const BnGroup* g,
-             int* counters = nullptr, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr);
+             int* counters = nullptr, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr, const ColStats* cs = nullptr);
+// cs (cs->done): the producing GEMM left the first-pass partials in `workspace` (glnn::gemm_stats): only the combine is launched
 // slabs / nslab (<= 8) / bias: z = sum of the split-K partial slabs of gemm_split_partials + bias, folded (and stored to z) by the
 // statistics kernel itself; one-launch form only (counters, single rank) -- otherwise GLNN_ERR_UNSUPPORTED with nothing launched
 int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind, const int64_t* labels, const int64_t* label_rows,
@@ -177,8 +180,20 @@ int spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, 
 
 // gemm_rowpanel.hip: C = epi(A . W^T) for short reductions (k <= 128) over many rows -- persistent workgroups that keep a 128-column
 // panel of W in LDS and walk row tiles of A; bit-identical to the tiled kernels.  GLNN_ERR_UNSUPPORTED = nothing launched.
+// BatchNorm statistics partials out of a GEMM's epilogue (round 4): the product kernel leaves, per column of C, partial (count,) mean
+// and M2 triples of the rows it wrote -- the statistics' first pass over C (bn_stats_stage1: one more read of C) is not launched.
+//   in   ws / ws_floats   where the partials may go (the BatchNorm workspace)
+//   out  done             1 = partials written: nparts of them, at ws_mean[p * n + col] / ws_m2[..] and, when chunk_rows == 0,
+//                         ws_cnt[..] (per-partial row counts); chunk_rows > 0: partial p covers rows [p * chunk_rows, ..)
+struct ColStats {
+  float* ws; int64_t ws_floats;
+  int done; int nparts; int chunk_rows; float* ws_cnt; float* ws_mean; float* ws_m2;
+};
 int gemm_rowpanel(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* ep_scale,
-                  const float* ep_shift, int relu, float* c, int64_t ldc, void* stream);
+                  const float* ep_shift, int relu, float* c, int64_t ldc, void* stream, ColStats* cs = nullptr);
+// glnn_gemm_f32 (plain A) + column statistics partials when the kernel that takes the shape can produce them (cs->done)
+int gemm_stats(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* bias, float* c, int64_t ldc,
+               float* workspace, int64_t workspace_floats, void* stream, ColStats* cs);
 
 // mlp_lat.hip: the latency form of a student layer (m <= ~1k rows, k <= 256): C = A' * B + bias in 32-row tiles whose four waves split
 // K, with the reduction that used to be the next launch as epilogue.  GLNN_ERR_UNSUPPORTED = not launched, use the tiled kernels.

@@ -163,7 +163,12 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
       else z_slabs = 0;
     }
-    if (lat != GLNN_OK)
+    // the tiled product of a BatchNorm layer with a plain operand: the kernel's epilogue leaves the first pass of the statistics
+    // (glnn::gemm_stats -> cs.done; bn_stats below then launches the combine only)
+    glnn::ColStats cs = {d->ws_bn, d->ws_bn_floats, 0, 0, 0, nullptr, nullptr, nullptr};
+    if (lat != GLNN_OK && !last && d->batchnorm == 1 && !rows && !a_scale && opt.gemm_stats)
+      GLNN_TRY(glnn::gemm_stats(src, ld_src, m, d->dims[l], w_l, ldw_l, d->dims[l + 1], d->b[l], out, ldo, wsg, wsg_floats, stream, &cs));
+    else if (lat != GLNN_OK)
       GLNN_TRY(glnn_gemm_f32(src, ld_src, rows, a_scale, a_shift, gp, gseed, m,
                              d->dims[l], w_l, ldw_l, 0, d->dims[l + 1], nullptr, nullptr, d->b[l], 0, out, ldo,
                              wsg, wsg_floats, stream));
@@ -182,7 +187,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         int rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,
                                 d->running_mean[l], d->running_var[l], d->nbt[l], d->mean[l], d->rstd[l], d->a_scale[l],
                                 d->a_shift[l], d->ws_bn, d->ws_bn_floats, stream, grp, cnt, z_slabs ? wsg : nullptr, z_slabs,
-                                z_slabs ? d->b[l] : nullptr);
+                                z_slabs ? d->b[l] : nullptr, cs.done ? &cs : nullptr);
         if (rc == GLNN_ERR_UNSUPPORTED && z_slabs) {          // not the one-launch form after all: fold with a launch, then the plain call
           GLNN_TRY(glnn::gemm_fold_partials(wsg, z_slabs, m, d->dims[l + 1], d->b[l], out, ldo, stream));
           rc = glnn::bn_stats(out, ldo, m, d->dims[l + 1], d->gamma[l], d->beta[l], d->bn_eps, d->bn_momentum,

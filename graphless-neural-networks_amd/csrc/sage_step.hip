@@ -51,12 +51,18 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
       GLNN_TRY(glnn_spmm_csr_f32(y.indptr, y.indices, y.n_dst, n_src, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, nullptr, src, ld_src,
                                  l == 0 ? y.self_rows : nullptr, nullptr, nullptr, 0, y.agg, y.ld_agg, stream));
     }
-    GLNN_TRY(glnn_gemm_f32(y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_in, y.w, d_in, 0, d_out, nullptr, nullptr, y.b, 0,
-                           y.z, y.ldz, d->ws_gemm, d->ws_gemm_floats, stream));
+    // hidden BatchNorm layers: the projection's epilogue leaves the first pass of the column statistics (glnn::ColStats)
+    glnn::ColStats cs = {d->ws_bn, d->ws_bn_floats, 0, 0, 0, nullptr, nullptr, nullptr};
+    if (l < L - 1 && d->batchnorm && glnn::opts().gemm_stats)
+      GLNN_TRY(glnn::gemm_stats(y.agg, y.ld_agg, y.n_dst, d_in, y.w, d_in, d_out, y.b, y.z, y.ldz, d->ws_gemm, d->ws_gemm_floats, stream, &cs));
+    else
+      GLNN_TRY(glnn_gemm_f32(y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_in, y.w, d_in, 0, d_out, nullptr, nullptr, y.b, 0,
+                             y.z, y.ldz, d->ws_gemm, d->ws_gemm_floats, stream));
     if (l == L - 1) break;
     if (d->batchnorm)
       GLNN_TRY(glnn::bn_stats(y.z, y.ldz, y.n_dst, d_out, y.gamma, y.beta, d->bn_eps, d->bn_momentum, y.running_mean, y.running_var, y.nbt,
-                              y.mean, y.rstd, y.a_scale, y.a_shift, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+                              y.mean, y.rstd, y.a_scale, y.a_shift, d->ws_bn, d->ws_bn_floats, stream, nullptr, nullptr, nullptr, 0, nullptr,
+                              cs.done ? &cs : nullptr));
     if (y.h)          // h = tail(z) materialised (optional: with h == NULL the next layer's gather evaluates the tail itself)
       GLNN_TRY(glnn_act_fwd_f32(y.z, y.ldz, y.n_dst, d_out, d->batchnorm ? y.a_scale : nullptr, d->batchnorm ? y.a_shift : nullptr, p,
                                 y.drop_seed, y.h, y.ldh, stream));

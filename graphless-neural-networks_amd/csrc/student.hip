@@ -1145,23 +1145,30 @@ static int run_exchange(const glnn::BnGroup* g, int64_t floats, void* stream, co
 int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta, float eps,
                    float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out,
                    float* rstd_out, float* a_scale_out, float* a_shift_out, float* workspace, int64_t workspace_floats,
-                   void* stream, const glnn::BnGroup* g, int* counters, const float* slabs, int nslab, const float* bias) {
+                   void* stream, const glnn::BnGroup* g, int* counters, const float* slabs, int nslab, const float* bias,
+                   const glnn::ColStats* cs) {
   GLNN_REQUIRE(z && a_scale_out && a_shift_out && workspace, "glnn_bn_stats_f32: null pointer");
+  if (cs && !(cs->done && nslab <= 0 && cs->ws == workspace)) cs = nullptr;
   if (nslab > 0 && !(slabs && nslab <= 8 && counters && !g)) return GLNN_ERR_UNSUPPORTED;       // nothing launched: fold first, call again
   GLNN_REQUIRE(rows >= 1 && h >= 1 && ldz >= h, "glnn_bn_stats_f32: bad sizes");
-  const int nchunks = (int)((rows + kBnRows - 1) / kBnRows);
-  const int64_t need_ws = 2ll * nchunks * h + (nchunks > 4 * kBnGroup ? 3ll * ((nchunks + kBnGroup - 1) / kBnGroup) * h : 0);
+  const bool tiles = cs && cs->chunk_rows > 0;          // the GEMM's partials cover fixed row chunks (same layout as stage 1's)
+  GLNN_REQUIRE(!tiles || cs->chunk_rows == kBnRows, "glnn_bn_stats_f32: tile partials must cover %d rows", kBnRows);
+  const int nchunks = (cs && !tiles) ? cs->nparts : (int)((rows + kBnRows - 1) / kBnRows);
+  const int64_t need_ws = (cs && !tiles ? 3ll : 2ll) * nchunks * h + (nchunks > 4 * kBnGroup ? 3ll * ((nchunks + kBnGroup - 1) / kBnGroup) * h : 0);
   GLNN_REQUIRE(workspace_floats >= need_ws, "glnn_bn_stats_f32: workspace needs >= %lld floats", (long long)need_ws);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  float* ws_mean = workspace;
-  float* ws_m2 = workspace + (int64_t)nchunks * h;
+  float* ws_mean = cs ? cs->ws_mean : workspace;
+  float* ws_m2 = cs ? cs->ws_m2 : workspace + (int64_t)nchunks * h;
   BnFinArgs a = {};
+  if (cs && !tiles) a.ws_cnt = cs->ws_cnt;               // partials with their own row counts (the row-panel kernel's workgroups)
   a.ws_mean = ws_mean; a.ws_m2 = ws_m2; a.nparts = nchunks; a.pstride = h; a.rows = rows; a.h = h; a.gamma = gamma; a.beta = beta;
   a.eps = eps; a.momentum = momentum; a.running_mean = running_mean; a.running_var = running_var; a.nbt = num_batches_tracked;
   a.mean_out = mean_out; a.rstd_out = rstd_out; a.a_scale = a_scale_out; a.a_shift = a_shift_out;
   const dim3 fgrid((h + 63) / 64);
   const SlabSrc src = {slabs, nslab, rows * (int64_t)h, bias, const_cast<float*>(z)};
-  if (counters && !g) {     // one launch: the last row-chunk workgroup of every column block finishes the statistics
+  if (cs) {
+    // first pass already done in the producing GEMM's epilogue
+  } else if (counters && !g) {     // one launch: the last row-chunk workgroup of every column block finishes the statistics
     const dim3 sgrid((h + 63) / 64, nchunks);
     if (nslab <= 0) hipLaunchKernelGGL(bn_stats_stage1<0>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
     else if (nslab <= 2) hipLaunchKernelGGL(bn_stats_stage1<2>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
@@ -1169,8 +1176,8 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
     else hipLaunchKernelGGL(bn_stats_stage1<8>, sgrid, dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, counters, src);
     return glnn::check_launch("glnn_bn_stats_f32");
   }
-  hipLaunchKernelGGL(bn_stats_stage1<0>, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr, src);
-  if (!g && nchunks > 4 * kBnGroup) {
+  if (!cs) hipLaunchKernelGGL(bn_stats_stage1<0>, dim3((h + 63) / 64, nchunks), dim3(256), 0, st, z, ldz, rows, h, ws_mean, ws_m2, a, (int*)nullptr, src);
+  if (!g && nchunks > 4 * kBnGroup && !(cs && !tiles)) {
     // thousands of row chunks (a 500k-row activation): combine groups of kBnGroup partial triples first (Chan's combine is
     // associative), then the group triples -- a single level walked ~1000 partials per lane (0.35 ms)
     const int ngroups = (nchunks + kBnGroup - 1) / kBnGroup;
@@ -1194,6 +1201,24 @@ int glnn::bn_stats(const float* z, int64_t ldz, int64_t rows, int h, const float
   }
   hipLaunchKernelGGL(bn_stats_stage2, fgrid, dim3(256), 0, st, a);
   return glnn::check_launch("glnn_bn_stats_f32");
+}
+
+// z = a W^T + bias, then the BatchNorm1d training statistics of z -- the Linear + BatchNorm head of a hidden layer (reference
+// models.py:43-47 / 110-114) with the statistics' first pass taken from the product kernel's epilogue whenever the kernel that takes
+// the shape can leave it (glnn::gemm_stats); otherwise exactly glnn_gemm_f32 followed by glnn_bn_stats_f32.
+extern "C" int glnn_linear_bn_stats_f32(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const float* bias,
+                                        float* z, int64_t ldz, const float* gamma, const float* beta, float eps, float momentum,
+                                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean_out,
+                                        float* rstd_out, float* a_scale_out, float* a_shift_out, float* ws_gemm, int64_t ws_gemm_floats,
+                                        float* ws_bn, int64_t ws_bn_floats, void* stream) {
+  GLNN_REQUIRE(a && w && z && ws_bn, "glnn_linear_bn_stats_f32: null pointer");
+  glnn::ColStats cs = {ws_bn, ws_bn_floats, 0, 0, 0, nullptr, nullptr, nullptr};
+  int rc;
+  if (glnn::opts().gemm_stats) rc = glnn::gemm_stats(a, lda, m, k, w, ldw, n, bias, z, ldz, ws_gemm, ws_gemm_floats, stream, &cs);
+  else rc = glnn_gemm_f32(a, lda, nullptr, nullptr, nullptr, 0.f, 0u, m, k, w, ldw, 0, n, nullptr, nullptr, bias, 0, z, ldz, ws_gemm, ws_gemm_floats, stream);
+  if (rc != GLNN_OK) return rc;
+  return glnn::bn_stats(z, ldz, m, n, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, rstd_out,
+                        a_scale_out, a_shift_out, ws_bn, ws_bn_floats, stream, nullptr, nullptr, nullptr, 0, nullptr, cs.done ? &cs : nullptr);
 }
 
 extern "C" int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h, const float* gamma, const float* beta,

@@ -389,6 +389,27 @@ def bn_stats(z, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=
     return mean, rstd, a_scale, a_shift
 
 
+def linear_bn_stats(a, w, bias, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, out=None):
+    """glnn_linear_bn_stats_f32: z = a w^T + bias and the BatchNorm1d training statistics of z, the statistics' first pass taken from
+    the product kernel's epilogue where that kernel can leave it.  Returns (z, mean, rstd, a_scale, a_shift)."""
+    _need_cuda(a, w, bias, gamma, beta, running_mean, running_var, nbt, out)
+    a = as_feat(a)
+    m, k = a.shape
+    n = w.shape[0]
+    if w.dim() != 2 or w.shape[1] < k or w.stride(1) != 1:
+        raise ValueError("linear_bn_stats: w must be [n, k] row-major")
+    z = feat_empty(m, n, a.device) if out is None else out
+    mean, rstd, a_scale, a_shift = (torch.empty(n, dtype=torch.float32, device=a.device) for _ in range(4))
+    nchunks = (m + 127) // 128
+    ws_bn = torch.empty(max(2 * nchunks * n + (3 * ((nchunks + 63) // 64) * n if nchunks > 256 else 0), 3 * 128 * n), dtype=torch.float32, device=a.device)
+    ws = _default_ws(a.device)
+    rc = _lib.lib().glnn_linear_bn_stats_f32(_p(a), _ld(a), m, k, _p(w), w.stride(0), n, _p(bias), _p(z), _ld(z), _p(gamma), _p(beta), eps, momentum,
+                                             _p(running_mean), _p(running_var), _p(nbt), _p(mean), _p(rstd), _p(a_scale), _p(a_shift),
+                                             _p(ws), ws.numel(), _p(ws_bn), ws_bn.numel(), _stream())
+    _lib.check(rc, "glnn_linear_bn_stats_f32")
+    return z, mean, rstd, a_scale, a_shift
+
+
 def bn_relu_bwd(da, z, gamma=None, mean=None, rstd=None, a_scale=None, a_shift=None, dz=None, dgamma=None,
                 dbeta=None, workspace=None, drop_p=0.0, drop_seed=0, dz_col_sum=None, relu=True):
     """K5 glnn_bn_relu_bwd_f32 (relu=False: glnn_bn_bwd_f32, the norm -> dropout tail of GCN.forward).  Returns (dz, dgamma,

@@ -146,7 +146,7 @@ class StudentEngine:
         # latency-bound steps keep the recompute (one launch fewer per hidden layer).
         mat = os.environ.get("GLNN_STUDENT_MATERIALIZE_ACT", "auto")
         self.act = [ops.feat_empty(B, self.dims[l + 1], dev)
-                    if self.ln or mat == "1" or (mat == "auto" and self.p > 0 and self._materialize_tail(l, B)) else None
+                    if self.ln or mat == "1" or (mat == "auto" and self._materialize_tail(l, B)) else None
                     for l in range(self.L - 1)]
         # feats[idx] copied once per step when the batch is long enough for the first layer's weight gradient to take the
         # pipelined kernel (>= 2048 reduction rows, > 64 feature columns); small batches (<= 1024 rows, <= 256 features: the latency
@@ -170,6 +170,10 @@ class StudentEngine:
         hidden layer: 1.18 -> 1.00 ms); round 3 from 2^19, which adds MLP3w4 at B = 512 (0.164 -> 0.158 ms, interleaved A/B).
         A tail that feeds only the narrow output layer (one column tile) stays recomputed: materialising it as well costs
         MLP3w8 0.8 %."""
+        if self.p <= 0:
+            # no hash to save, but a stored tail is a PLAIN operand: its consumers take the pipelined kernels (148 TF) instead of the
+            # operand-transform ones (127 TF forward, 117 TF weight gradient) -- MLP3w8 at B = 4096 without dropout: 1.02 -> 0.93 ms
+            return self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 21)
         return self.dims[l + 2] >= 512 and B * self.dims[l + 1] >= (1 << 19)
 
     def enable_batch_split(self, world, rank, group=None):

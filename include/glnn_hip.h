@@ -204,6 +204,18 @@ GLNN_API int glnn_bn_stats_f32(const float* z, int64_t ldz, int64_t rows, int h,
                                float* rstd_out, float* a_scale_out, float* a_shift_out,
                                float* workspace, int64_t workspace_floats, void* stream);
 
+/* ABI 8: z = a W^T + bias [m, n] followed by glnn_bn_stats_f32 on z -- Linear + BatchNorm1d statistics of a hidden layer (reference
+ * models.py:43-47, 110-114).  When the product runs on the row-panel kernel (k <= 128 over many rows) or the pipelined kernel
+ * (k % 32 == 0, plain operands, >= 64 output tiles) the statistics' first pass comes out of the product's epilogue (per-workgroup /
+ * per-tile count, mean, M2 of the stored values) and z is not read again; otherwise the two calls run as they are.  Plain operands
+ * only.  ws_bn: as glnn_bn_stats_f32, and >= 3 * 128 * n floats for the row-panel form.  GLNN_GEMM_STATS=0 forces the two-call form. */
+GLNN_API int glnn_linear_bn_stats_f32(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n,
+                                      const float* bias, float* z, int64_t ldz, const float* gamma, const float* beta,
+                                      float eps, float momentum, float* running_mean, float* running_var,
+                                      int64_t* num_batches_tracked, float* mean_out, float* rstd_out, float* a_scale_out,
+                                      float* a_shift_out, float* ws_gemm, int64_t ws_gemm_floats, float* ws_bn,
+                                      int64_t ws_bn_floats, void* stream);
+
 GLNN_API int glnn_bn_relu_bwd_f32(const float* da, int64_t ldda, const float* z, int64_t ldz,
                                   int64_t rows, int h, const float* gamma, const float* mean,
                                   const float* rstd, const float* a_scale, const float* a_shift,

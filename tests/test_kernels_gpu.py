@@ -487,6 +487,39 @@ def test_bn_stats_and_backward_vs_oracle(rows, h):
     np.testing.assert_allclose(dzsum.cpu().numpy(), (da * (z > 0)).astype(np.float64).sum(0), atol=2e-4 * max(1.0, rows / 4096), rtol=1e-5)
 
 
+@pytest.mark.parametrize("m,k,n", [(4096, 100, 2048), (5000, 100, 256), (70001, 128, 300), (2049, 36, 96), (100003, 64, 130),      # row-panel kernel
+                                   (4096, 2048, 2048), (9000, 256, 256), (8321, 160, 1100), (16385, 512, 257),                     # pipelined kernel
+                                   (300, 64, 200), (1000, 100, 64), (3000, 1024, 128)])                                            # neither: two-call form
+def test_linear_bn_stats_equals_the_two_call_form(m, k, n, monkeypatch):
+    """glnn_linear_bn_stats_f32: the BatchNorm statistics whose first pass comes out of the product kernel's epilogue -- the row-panel
+    kernel's per-workgroup (count, mean, M2) triples accumulated along its walk, the pipelined kernel's per-tile mean / M2 -- against
+    (a) the two-call form (GLNN_GEMM_STATS=0: same z bit for bit, statistics to rounding) and (b) float64 statistics of the stored z.
+    Ragged last row tiles, column panels past n, columns with a large offset mean (the one-pass variance's shift at work)."""
+    from glnn_amd import ops
+    r = np.random.RandomState(m + k + n)
+    a = ops.as_feat(dev(r.standard_normal((m, k)).astype(np.float32)))
+    w = dev((r.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    bias = dev((r.standard_normal(n) * 5).astype(np.float32))                 # |mean| / std up to ~15
+    gamma, beta = dev(r.uniform(.5, 1.5, n).astype(np.float32)), dev((r.standard_normal(n) * .2).astype(np.float32))
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_GEMM_STATS", mode)
+        rm, rv, nbt = dev(np.zeros(n, np.float32)), dev(np.ones(n, np.float32)), torch.tensor([0], device=DEV)
+        z, mean, rstd, a_sc, a_sh = ops.linear_bn_stats(a, w, bias, gamma, beta, rm, rv, nbt)
+        outs.append((z[:, :n].clone(), mean.clone(), rstd.clone(), a_sc.clone(), a_sh.clone(), rm, rv, int(nbt.item())))
+    assert torch.equal(outs[0][0], outs[1][0])
+    zd = outs[0][0].double()
+    mu, var = zd.mean(0), zd.var(0, unbiased=False)
+    for o in outs:
+        np.testing.assert_allclose(o[1].cpu().numpy(), mu.cpu().numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(o[2].cpu().numpy(), (1.0 / torch.sqrt(var + 1e-5)).cpu().numpy(), rtol=1e-5)
+        np.testing.assert_allclose(o[5].cpu().numpy(), (0.1 * mu).cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o[6].cpu().numpy(), (0.9 + 0.1 * zd.var(0, unbiased=True)).cpu().numpy(), rtol=1e-5)
+        assert o[7] == 1
+    for x, y in zip(outs[0][1:5], outs[1][1:5]):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("rows,h,relu,p", [(100, 48, True, 0.0), (513, 512, True, 0.3), (64, 2048, True, 0.0), (33, 2500, False, 0.2),
                                            (40, 70, False, 0.0), (1000, 1, True, 0.0), (7, 4096, True, 0.5)])
 def test_layernorm_forward_and_backward_vs_torch(rows, h, relu, p):
