@@ -195,18 +195,19 @@ def test_rccl_transport_branches_execute_on_one_rank():
     np.testing.assert_array_equal(recv, np.arange(24, dtype=np.float32))
 
 
-def _student_setup(dims, norm, dropout, dev, seed=3):
+def _student_setup(dims, norm, dropout, dev, seed=3, big=False):
     from glnn_amd.models import Model
     torch.manual_seed(seed)
     model = Model(dict(model_name="MLP", num_layers=len(dims) - 1, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1],
                        dropout_ratio=dropout, norm_type=norm, device=dev))
     opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
     g = torch.Generator().manual_seed(seed)
-    n = 3000
+    n = 30000 if big else 3000
     feats = torch.randn(n, dims[0], generator=g).to(dev)
     labels = torch.randint(0, dims[-1], (n,), generator=g).to(dev)
     out_t = torch.log_softmax(torch.randn(n, dims[-1], generator=g), 1).to(dev)
-    batches = [torch.randperm(n, generator=g)[:b].to(dev) for b in (512, 512, 300, 512)]     # 300: unequal, odd chunk tail
+    sizes = (24000, 24000, 20001, 24000) if big else (512, 512, 300, 512)                  # 300 / 20001: unequal, odd chunk tail
+    batches = [torch.randperm(n, generator=g)[:b].to(dev) for b in sizes]
     return model, opt, feats, labels, out_t, batches
 
 
@@ -214,7 +215,7 @@ def _run_student(model, opt, feats, labels, out_t, batches, world, rank, group_e
     from glnn_amd import ops
     from glnn_amd.student import StudentEngine
     model.train()
-    eng = StudentEngine(model, opt, 512)
+    eng = StudentEngine(model, opt, max(b.numel() for b in batches))
     if group_enabled:
         eng.enable_batch_split(world, rank)
     first_grads = None
@@ -237,35 +238,38 @@ def _run_student(model, opt, feats, labels, out_t, batches, world, rank, group_e
     return sd, first_grads, (eng.exchange.calls if eng.exchange else 0)
 
 
-def _student_worker(rank, world, port, dims, norm, q):
+def _student_worker(rank, world, port, dims, norm, q, big=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        setup = _student_setup(dims, norm, 0.0, "cuda:0")
+        setup = _student_setup(dims, norm, 0.0, "cuda:0", big=big)
         sd, grads, calls = _run_student(*setup, world, rank, True)
         q.put((rank, sd, grads, calls))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,norm", [([100, 256, 256, 47], "batch"), ([128, 192, 40], "batch"), ([50, 64, 64, 7], "none")])
-def test_student_batch_split_two_ranks_equals_single_gpu_step(dims, norm):
+@pytest.mark.parametrize("dims,norm,big", [([100, 256, 256, 47], "batch", False), ([128, 192, 40], "batch", False), ([50, 64, 64, 7], "none", False),
+                                           ([100, 512, 512, 47], "batch", True)])
+def test_student_batch_split_two_ranks_equals_single_gpu_step(dims, norm, big):
     """a batch split over ranks (uneven slices, global BatchNorm statistics through the exchange hook,
     summed gradients) must take the same optimisation steps as one GPU on the whole batch -- parameters, BN running
-    statistics and num_batches_tracked after 4 mixed NLL/KL steps."""
+    statistics and num_batches_tracked after 4 mixed NLL/KL steps.  big: batches of 24000 rows (14400 / 9600 per rank): the products run on
+    the row-panel and the pipelined kernels, whose epilogues leave the statistics' first pass as per-workgroup triples / per-tile partials
+    that the rank-level combine and exchange then start from (glnn::ColStats under a BnGroup)."""
     world = 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_student_worker, args=(r, world, port, dims, norm, q)) for r in range(world)]
+    procs = [ctx.Process(target=_student_worker, args=(r, world, port, dims, norm, q, big)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    want, want_grads, _ = _run_student(*_student_setup(dims, norm, 0.0, "cuda:0"), 1, 0, False)
+    want, want_grads, _ = _run_student(*_student_setup(dims, norm, 0.0, "cuda:0", big=big), 1, 0, False)
     n_bn = len(dims) - 2 if norm == "batch" else 0
     L = len(dims) - 1
 
@@ -288,6 +292,8 @@ def test_student_batch_split_two_ranks_equals_single_gpu_step(dims, norm):
                 assert sd[k] == want[k], k
             elif not gauge(k):
                 d = np.abs(sd[k].astype(np.float64) - want[k])
-                assert d.mean() <= 1e-5 and d.max() <= 0.01, (rank, k, d.mean(), d.max())      # max: one lr-sized Adam flip
+                # max: one lr-sized Adam flip.  big: gradients of 24000-row batches are an order smaller against the same fp32 summation
+                # noise, and Adam normalises them away: mean 6e-5 with AND without the statistics epilogues (GLNN_GEMM_STATS=0)
+                assert d.mean() <= (1e-4 if big else 1e-5) and d.max() <= 0.01, (rank, k, d.mean(), d.max())
     for k in want:            # the two ranks hold bit-identical models (same gathered sums, same order)
         np.testing.assert_array_equal(res[0][1][k], res[1][1][k], err_msg=k)
