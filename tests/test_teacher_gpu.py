@@ -125,6 +125,38 @@ def test_block_build_from_sampled_neighbours(ns, fanout, known_ids):
             avail.remove(int(u))                                               # multi-edge multiplicity is respected
 
 
+def test_products_scale_sampled_blocks_properties():
+    """The block builder at the products training configuration (B = 4096, fan-out 15 / 10 / 5 from the output layer inwards, 2.45 M nodes:
+    the two wide blocks index their position table by the node id, the first one probes a hash table), checked through properties that
+    need no CPU restatement: local ids name the sampled global ids, destinations come first and in order, sources are unique, new
+    sources appear in order of first occurrence, and the builder that is NOT told the id universe (hash tables throughout) returns
+    the same block bit for bit."""
+    from glnn_amd import data, ops
+    g = data.make_graph("ogbn-products", seed=0, device=DEV)
+    n = g.n_dst
+    seeds = torch.randperm(n, generator=torch.Generator().manual_seed(7))[:4096].to(DEV)
+    for level, fanout in enumerate((15, 10, 5)):
+        smp, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, fanout, 99 + level)
+        blocks = [ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=True, n_nodes=nn) for nn in (n, 0)]
+        ip, ix, gix, inp, nnz, n_src = blocks[0]
+        for a, b in zip(blocks[0][:4], blocks[1][:4]):
+            assert torch.equal(a, b)
+        assert blocks[0][4:] == blocks[1][4:]
+        ns = seeds.numel()
+        assert nnz == int(cnt.sum()) and torch.equal(ip[1:] - ip[:-1], cnt.long())
+        assert torch.equal(inp[:ns], seeds)                                        # destinations first, in order
+        assert torch.equal(inp[ix.long()], gix.long())                             # local ids name the sampled nodes
+        assert torch.unique(inp).numel() == n_src                                  # every source once
+        first = torch.full((n,), nnz, dtype=torch.int64, device=DEV)
+        first.scatter_reduce_(0, gix.long(), torch.arange(nnz, device=DEV), "amin")
+        new = inp[ns:]
+        assert bool((first[new][1:] > first[new][:-1]).all())                      # new sources in order of first appearance
+        is_dst = torch.zeros(n, dtype=torch.bool, device=DEV)
+        is_dst[seeds] = True
+        assert not bool(is_dst[new].any())
+        seeds = inp                                                                # the next (wider) block's destinations
+
+
 def test_full_neighbour_loader_chunks_map_back_to_the_graph():
     """The reference's dataloader_eval (train_and_eval.py:193-202) as glnn_amd.graph.FullNeighborLoader: chunks in node-id
     order, the chunk's destinations first among the block's sources, block edges = the graph's edges."""
