@@ -1015,14 +1015,20 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
     float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-      const float4 gg = g4[i];
-      float4 pp = p4[i], mm = m4[i], vv = v4[i];
+      // g, m, v are streamed once per step (126 MB for MLP3w8: nothing survives in L2 until the next step): non-temporal accesses,
+      // 28.6 -> 27.8 us; p is read again by the next forward
+      typedef float nt4 __attribute__((ext_vector_type(4)));
+      const nt4 g_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(g4) + i);
+      const nt4 m_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(m4) + i);
+      const nt4 v_ = __builtin_nontemporal_load(reinterpret_cast<const nt4*>(v4) + i);
+      const float4 gg = make_float4(g_.x, g_.y, g_.z, g_.w);
+      float4 pp = p4[i], mm = make_float4(m_.x, m_.y, m_.z, m_.w), vv = make_float4(v_.x, v_.y, v_.z, v_.w);
       pp.x = update(gg.x, pp.x, mm.x, vv.x);
       pp.y = update(gg.y, pp.y, mm.y, vv.y);
       pp.z = update(gg.z, pp.z, mm.z, vv.z);
       pp.w = update(gg.w, pp.w, mm.w, vv.w);
-      m4[i] = mm;
-      v4[i] = vv;
+      { const nt4 o = {mm.x, mm.y, mm.z, mm.w}; __builtin_nontemporal_store(o, reinterpret_cast<nt4*>(m4) + i); }
+      { const nt4 o = {vv.x, vv.y, vv.z, vv.w}; __builtin_nontemporal_store(o, reinterpret_cast<nt4*>(v4) + i); }
       p4[i] = pp;
     }
     return;
