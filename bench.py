@@ -18,8 +18,8 @@ per-launch HIP events recorded inside the timed region on the launch stream; "ro
 the same graph with its nodes renumbered by descending in-degree (SURVEY 8d allows a locality-ordered figure beside the
 random-order one; `value` stays the random-order number); and "cpu_baseline" (SURVEY 8d / BASELINE.md section 3): the
 teacher forward on the host cores -- this repo's OpenMP C restatement ("port": the reference's own dgl CPU path cannot
-run, dgl is not installed) with torch.sparse_csr @ X beside it as a second opinion, on a 0.5-scale graph whose feature
-matrices (0.49 / 1.25 GB) do not fit the host's last-level cache -- and the student step as the SAME SEQUENCE OF
+run, dgl is not installed) with torch.sparse_csr @ X beside it as a second opinion, on the full-size graph of the metric -- and
+the student step as the SAME SEQUENCE OF
 PyTorch CPU OPS the reference issues (nn.Linear / BatchNorm1d / relu / dropout / log_softmax / KLDivLoss / Adam,
 reference train_and_eval.py:74-85), thread count stated."""
 import argparse
@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.
 SAGE_DIMS = [100, 256, 256, 47]  # reference train.conf.yaml:196-204 (ogbn-products SAGE, hidden 256, BN)
 STUDENT = dict(name="MLP3w8", dims=[100, 2048, 2048, 47], batch=4096, dropout=0.2, lr=0.01, wd=0.0)   # :187-194
 GRAPH = "ogbn-products"
-CPU_SAMPLE_SCALE = 0.5
+CPU_SAMPLE_SCALE = 1.0            # the CPU baseline runs the metric's own configuration (full-size graph): ~15 s per forward on 128 threads
 SPMM_U = 8                        # in-flight gathers per lane group: GLNN_SPMM_U / GLNN_FUSED_U of csrc/spmm.hip
 # --workload arxiv = BASELINE.json configs[1] + [2]: ogbn-arxiv-shaped SAGE teacher forward (train.conf.yaml:170-177) and the
 # MLP3w4 student the reference's experiments/glnn_arxiv.sh uses (:149-154).  Features (87 MB) fit the 256 MB Infinity Cache,
@@ -108,9 +108,11 @@ def main():
     ap.add_argument("--shuffle-ids", action="store_true", help="--locality p: randomly permute the node ids of the clustered graph")
     ap.add_argument("--partition", default="none", choices=["none", "lp"],
                     help="N > 1: renumber the nodes with glnn_amd.data.locality_order (label propagation) before the row ranges are cut")
-    ap.add_argument("--layer1-exchange", default="narrow", choices=["narrow", "wide"],
+    ap.add_argument("--layer1-exchange", default="auto", choices=["auto", "narrow", "wide"],
                     help="N > 1, all-gather exchange: what the widening first layer (100 -> 256) puts on the wire -- its 100-wide aggregate "
-                         "(every rank projects all rows itself; default) or its 256-wide fused output (no replicated work, 2.56x the bytes)")
+                         "(every rank projects all rows itself) or its 256-wide fused output (no replicated work, 2.56x the bytes).  auto (default): "
+                         "both forms are timed on this job's transport before the timed region (3 forwards each) and the faster one runs; "
+                         "--workload xl and N = 1 treat auto as narrow")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed output ('verified' on the JSON line)")
     ap.add_argument("--no-clustered-leg", action="store_true", help="N = 1: skip roofline_clustered (the forward on a graph with communities)")
     ap.add_argument("--no-small-students", action="store_true", help="N = 1: skip students_small (the B = 512 arxiv students' step times)")
@@ -125,6 +127,9 @@ def main():
                          "one GPU (glnn_amd.dist.EmulatedPeers: each collective replaced by a local fill of the same bytes with the rows an unsharded "
                          "forward produced), for the all-gather exchange (narrow and wide layer 1) and the halo exchange on a clustered graph with "
                          "shuffled ids re-partitioned by label propagation: the compute half of DESIGN.md section 6's scaling model, measured")
+    ap.add_argument("--no-xl-leg", action="store_true", help="N = 1, products at scale 1.0: skip the 'xl' object (BASELINE configs[4]: one rank-forward "
+                    "of the synthetic 100M-node / 2B-edge graph, run as a child process of this one after the products legs)")
+    ap.add_argument("--no-arxiv-leg", action="store_true", help="N = 1, products at scale 1.0: skip the 'arxiv' object (BASELINE configs[1] + [2])")
     ap.add_argument("--detail-file", default=None, help="also write the long detail object to this file (default: gpurun_out/bench_detail.json when that directory exists)")
     args = ap.parse_args()
     if args.steps is None:
@@ -164,6 +169,8 @@ def main():
         torch.cuda.synchronize()
 
     if args.workload == "xl":
+        if args.layer1_exchange == "auto":      # (link-bound at this size by every estimate: the narrow aggregate)
+            args.layer1_exchange = "narrow"
         return run_xl(args, rank, world, dev, barrier)
     if args.emulate:
         if world != 1:
@@ -198,16 +205,41 @@ def main():
     teacher.eval()
     # N > 1: destination-row ranges cut by WORK (in-edges + 2 per row), not by row count
     shards = RowShards(n, world, rank, chunks=4 if world > 1 else 1, bounds=RowShards.balanced_bounds(g.indptr, world) if world > 1 else None)
-    ref_own = None
+    ref_own, link_probe, autotune = None, None, None
+    if world == 1 and args.layer1_exchange == "auto":
+        args.layer1_exchange = "narrow"
     if world > 1:
+        from glnn_amd.dist import probe_link as gdist_probe
         if not args.no_verify:      # the unsharded forward of this rank's rows, before the full graph is dropped: the sharded result
             with torch.no_grad():   # (whatever the transport did) must reproduce it
                 ref_own = teacher.inference(FullNeighborLoader(g, 4096), feats)[shards.lo:shards.hi].clone()
         shard_graph = g.row_range(shards.lo, shards.hi)
+        # what the transport delivers for the layer-1 payloads (narrow / wide slab of one rank): recorded, and the model's link rate
+        link_probe = {w_: gdist_probe(world, rank, shards.rpr * ((d_ + 3) // 4 * 4), dev) for w_, d_ in (("narrow", SAGE_DIMS[0]), ("wide", SAGE_DIMS[1]))}
         if args.exchange == "halo":
             sharded = HaloShardedTeacher(teacher.encoder, shard_graph, shards, ops, overlap=not args.no_halo_overlap)
         else:
+            if args.layer1_exchange == "auto":
+                # self-tuning: the driver passes no flags and the right form depends on a link rate nobody has measured -- so measure the
+                # forms themselves, on this transport, outside the timed region (max over ranks; identical decision on every rank)
+                autotune = {}
+                for form in ("narrow", "wide"):
+                    cand = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=form)
+                    with torch.no_grad():
+                        cand.forward(feats)
+                        barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(3):
+                            cand.forward(feats)
+                        barrier()
+                    tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    autotune[form] = 1e3 * float(tt.item())
+                    del cand
+                    torch.cuda.empty_cache()
+                args.layer1_exchange = min(autotune, key=autotune.get)
             sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
+        shard_rows, shard_nnz = shards.rows, int(shard_graph.num_edges())
         del g
         torch.cuda.empty_cache()
 
@@ -227,17 +259,27 @@ def main():
         teacher_forward()
     timing = []
     barrier()
-    if rank == 0 and world == 1:
-        ops.set_timing(timing)
+    ops.set_timing(timing)          # per-launch HIP events on every rank (N > 1: kernel time vs wall time = the exposed exchange)
     from glnn_amd import dist as gdist
     gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     out_timed = None
     for _ in range(args.steps):
         out_timed = teacher_forward()
+    ev1.record()                    # this rank's own end on its compute stream, before it waits for the others
     barrier()
     t_teacher = time.perf_counter() - t0
     ops.set_timing(None)
+    rank_diag = None
+    if world > 1:
+        kms = kernel_breakdown(timing, args.steps)
+        own_ms = ev0.elapsed_time(ev1) / args.steps
+        mine = {"rank": rank, "rows": shard_rows, "nnz": shard_nnz, "wall_ms": own_ms, "kernel_ms": sum(kms.values()),
+                "exchange_exposed_ms": own_ms - sum(kms.values()), "kernels": kms}
+        rank_diag = [None] * world
+        dist.all_gather_object(rank_diag, mine)
     verify = None
     if not args.no_verify:
         verify = verify_single(g, feats, teacher, out_timed, ops) if world == 1 else verify_sharded(out_timed, ref_own, dev, dist)
@@ -287,6 +329,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_student = float(tt.item())
     student_steps_per_s = world * k_student / t_student      # B-row batches processed per second, whole job
+    student_local_ms = None
+    if world > 1 and not args.student_global_bn:
+        # diagnostic, outside the timed region: the same step WITHOUT the gradient exchange (a second engine on a copy of the model: one
+        # C call per step, Adam fused) -- the difference to the timed step is what data parallelism costs per step (exposed all-reduce
+        # + the two-call form of the step), max over ranks
+        s2 = Model(dict(model_name=sd["name"], num_layers=3, feat_dim=sd["dims"][0], hidden_dim=sd["dims"][1], label_dim=sd["dims"][-1],
+                        dropout_ratio=sd["dropout"], norm_type="batch", device=dev))
+        s2.train()
+        e2 = StudentEngine(s2, torch.optim.Adam(s2.parameters(), lr=sd["lr"], weight_decay=sd["wd"]), sd["batch"])
+        k2 = min(k_student, 200)
+        for i in range(3):
+            e2.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k2):
+            e2.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+        torch.cuda.synchronize()
+        tt = torch.tensor([(time.perf_counter() - t0) / k2], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        student_local_ms = 1e3 * float(tt.item())
+        del s2, e2
 
     if rank != 0:
         if world > 1:
@@ -316,6 +379,13 @@ def main():
         "exchange": None if world == 1 else {
             "GB_received_per_rank_per_forward": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / args.steps,
             "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
+            "link_probe": link_probe, "link_GBps_measured": link_probe["narrow"]["per_link_GBps"] if link_probe else None,
+            "layer1_autotune_ms": autotune, "layer1_chosen": args.layer1_exchange if args.exchange == "allgather" else None,
+            "ranks": rank_diag,
+            "kernel_ms_max": max(r_["kernel_ms"] for r_ in rank_diag), "kernel_ms_mean": float(np.mean([r_["kernel_ms"] for r_ in rank_diag])),
+            "wall_ms_max": max(r_["wall_ms"] for r_ in rank_diag),
+            "exchange_exposed_ms_max": max(r_["exchange_exposed_ms"] for r_ in rank_diag),
+            "exchange_exposed_ms_mean": float(np.mean([r_["exchange_exposed_ms"] for r_ in rank_diag])),
             "what": (("all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
                       "with the aggregation; the projection is replicated and consumes chunks in arrival order)" if args.layer1_exchange == "narrow" else
                       "all-gathers: 256-wide fused output of layer 1 (chunked, overlapped with the aggregation; no replicated projection)")
@@ -331,6 +401,8 @@ def main():
                     "scaling": "weak",
                     "gradient_exchange": None if world == 1 else ("one all-reduce after the backward" if args.no_grad_overlap and not args.student_global_bn
                                                                   else "weight gradients >= 1 MB all-reduced from inside the backward (grad_ready hook), the rest after it"),
+                    "local_step_ms": student_local_ms,
+                    "dp_overhead_ms": None if student_local_ms is None else 1e3 * t_student / k_student - student_local_ms,
                     "gflop_per_step": 3 * 2 * sd["batch"] * sum(a * b for a, b in zip(sd["dims"][:-1], sd["dims"][1:])) / 1e9},
     }
     result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3      # per GPU
@@ -359,9 +431,39 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, dev, min(CPU_SAMPLE_SCALE, args.scale), 1.0 if args.scale >= 1.0 else 0.1)
 
+    # ---- BASELINE configs[1]+[2] and configs[4] on the same clock (N = 1, full-size products run): child processes of this one, after
+    #      this process has released its device memory (the XL rank-forward keeps 228 GB resident).  A failed leg is reported, not fatal.
+    if world == 1 and GRAPH == "ogbn-products" and args.scale == 1.0 and args.locality == 0:
+        del g, feats, labels, out_t, teacher, student, eng, opt, perm, loader, shards
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        if not args.no_arxiv_leg:
+            result["arxiv"] = child_leg("arxiv", ["--workload", "arxiv", "--steps", "200", "--warmup", "5", "--student-steps-per-step", "10", "--no-cpu-baseline",
+                                                   "--no-train-leg", "--no-small-students", "--reorder", "none"], 600)
+        if not args.no_xl_leg:
+            result["xl"] = child_leg("xl", ["--workload", "xl", "--steps", "5", "--warmup", "1"], 900)
+
     emit(result, args)
     if world > 1:
         dist.destroy_process_group()
+
+
+def child_leg(name, argv, timeout_s):
+    """Run `python bench.py <argv>` as a child process and return its DETAIL object (+ wall seconds); {"error": ...} if it failed."""
+    import subprocess
+    detail = os.path.join(ROOT, "gpurun_out", f"bench_detail_{name}.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.devnull
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--detail-file", detail], capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("DETAIL {")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"rc {p.returncode}: " + (p.stderr.strip().splitlines() or ["no output"])[-1][:300], "wall_s": time.perf_counter() - t0}
+        r = json.loads(lines[-1][len("DETAIL "):])
+        r["wall_s"] = time.perf_counter() - t0
+        return r
+    except Exception as e:      # timeout, unparsable output: the products line is still printed
+        return {"error": f"{type(e).__name__}: {e}"[:300], "wall_s": time.perf_counter() - t0}
 
 
 def self_launch(args):
@@ -1065,6 +1167,8 @@ def compact(r, detail_path):
     if st:
         c["student"] = {"metric": _short(st["metric"], 90), "value": st["value"], "unit": st["unit"], "ms_per_step": st["ms_per_step"], "steps": st["steps"],
                         "tflops": st["tflops"], "frac_of_fp32_mfma_peak": st["frac_of_fp32_mfma_peak"]}
+        if st.get("local_step_ms") is not None:
+            c["student"].update(local_step_ms=st["local_step_ms"], dp_overhead_ms=st["dp_overhead_ms"])
     if "students_small" in r:
         c["students_small"] = {s_["student"]: round(s_["ms_per_step"], 4) for s_ in r["students_small"]}
     if "teacher_training" in r:
@@ -1074,7 +1178,30 @@ def compact(r, detail_path):
         c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 200),
                              "student_steps_per_s": cb["student_steps_per_s"], "student_threads": cb["student_threads_best"]}
     if r.get("exchange"):
-        c["exchange"] = {k: r["exchange"][k] for k in ("GB_received_per_rank_per_forward", "collectives_per_forward")}
+        ex = r["exchange"]
+        c["exchange"] = {k: ex.get(k) for k in ("GB_received_per_rank_per_forward", "collectives_per_forward", "link_GBps_measured", "layer1_autotune_ms",
+                                                "layer1_chosen", "kernel_ms_max", "kernel_ms_mean", "wall_ms_max", "exchange_exposed_ms_max",
+                                                "exchange_exposed_ms_mean")}
+        if ex.get("link_probe"):
+            c["exchange"]["link_probe_GBps"] = {k: [round(v["per_link_GBps"], 2), round(v["received_GBps"], 2)] for k, v in ex["link_probe"].items()}
+        if ex.get("ranks"):       # per rank: [kernel ms, wall ms, exposed exchange ms]; per launch family: the slowest rank's ms
+            c["exchange"]["ranks"] = [[round(q["kernel_ms"], 3), round(q["wall_ms"], 3), round(q["exchange_exposed_ms"], 3)] for q in ex["ranks"]]
+            fam = {}
+            for q in ex["ranks"]:
+                for k, v in q["kernels"].items():
+                    fam[k] = max(fam.get(k, 0.0), v)
+            c["exchange"]["family_ms_max"] = {k: round(v, 3) for k, v in fam.items()}
+    x = r.get("xl")
+    if x:                      # BASELINE configs[4] on the same clock: one rank-forward of the synthetic 100M-node / 2B-edge graph (child process)
+        c["xl"] = {"error": _short(x["error"], 120)} if "error" in x else {
+            "ms": x["ms_per_step"], "Gedges_per_s_per_gpu": x["value"] / 1e9, "verified": x.get("verified"), "kernel_ms": x["per_forward"]["kernel_ms"],
+            "rows_per_gpu": x["config"]["rows_per_gpu"], "nnz_per_gpu": x["config"]["nnz_per_gpu"], "shards": x["config"]["shards"],
+            "layers": [{"ms": round(l["ms"], 3), "bound": l["bound"], "frac": round(l["frac"], 4)} for l in x["layers"] if "frac" in l], "wall_s": round(x["wall_s"], 1)}
+    x = r.get("arxiv")
+    if x:                      # BASELINE configs[1] + [2]: arxiv-shaped teacher forward + the MLP3w4 student step (child process)
+        c["arxiv"] = {"error": _short(x["error"], 120)} if "error" in x else {
+            "ms": x["ms_per_step"], "Gedges_per_s": x["value"] / 1e9, "verified": x.get("verified"), "student": x["student"]["metric"].split("(", 1)[-1].split(" ", 1)[0],
+            "student_ms": x["student"]["ms_per_step"], "nodes": x["config"]["nodes"], "nnz": x["config"]["nnz"], "wall_s": round(x["wall_s"], 1)}
     if "scale_model" in r:
         c["scale_model"] = {f: {"one_gpu_ms": o["one_gpu_forward_ms"],
                                 **{N: {"max_kernel_ms": w["max_kernel_ms"], "GB": w["max_GB_received_per_rank"], "link_ms": w["modelled_link_ms"],
@@ -1085,9 +1212,8 @@ def compact(r, detail_path):
 
 def cpu_baseline(sd, dev, scale, budget):
     """SURVEY 8(d) / BASELINE.md section 3 CPU baseline on this host's cores (bounded: ~30-60 s).
-    (i) teacher: the 3-layer SAGE forward of the metric on a 0.5-scale products-shaped graph (same generator and degree
-        profile; feature matrices 0.49 GB / 1.25 GB: larger than the host's last-level cache, so the gather is a DRAM
-        gather as at full scale), oracle/glnn_oracle.c with OpenMP on all host threads = kind "port" (the reference's own
+    (i) teacher: the 3-layer SAGE forward of the metric on the metric's own full-size products-shaped graph (scale 1.0: n 2,449,029 /
+        nnz 123,718,280; same generator as the GPU run), oracle/glnn_oracle.c with OpenMP on all host threads = kind "port" (the reference's own
         dgl CPU path cannot be timed: dgl is not installed); beside it torch.sparse_csr @ X for the layer-1 aggregation.
     (ii) student: the reference's loop body (train_and_eval.py:74-85) as the SAME PyTorch CPU ops it issues -- nn.Linear,
         nn.BatchNorm1d, relu, nn.Dropout, log_softmax, nn.KLDivLoss(batchmean, log_target), loss.backward(),
@@ -1111,7 +1237,7 @@ def cpu_baseline(sd, dev, scale, budget):
     ip, ix = g.indptr.numpy(), g.indices.numpy()
     to.sage_gcn_agg(ip, ix, x, threads=threads)                                    # page in / warm up
     rep_s = []
-    while len(rep_s) < 3:                                                          # three full forwards, the best one is reported
+    while len(rep_s) < (2 if scale >= 1.0 else 3):                                 # full forwards (two at full size), the best one is reported
         t0 = time.perf_counter()
         to.sage_inference(ip, ix, x, layers, norms, threads=threads)
         rep_s.append(time.perf_counter() - t0)

@@ -155,6 +155,8 @@ struct BlockArgs {
   int* keys; int* pos; unsigned mask;    // hash table: keys + one position word per slot (mask+1 entries each)
   int* slot_of_edge;            // [nnz_cap]
   int direct;                   // 1: `pos` is indexed by the node id itself (n_nodes entries, no keys array, no probing)
+  int n_nodes;                  // direct mode: size of the id universe
+  int* bad;                     // direct mode: set to 0 (from the 0x7F fill) by an id outside [0, n_nodes) -> counts[0] = -1
 };
 
 // The position word of a node (one per table slot, 0x7F-filled = absent) goes through three stages, all orderable by atomicMin:
@@ -170,7 +172,11 @@ constexpr int kLocalBit = 1 << 30;
 // an atomicMin, and tables of n_nodes instead of 2..4x the frontier entries), else the open-addressing insert
 template <bool DIRECT>
 __device__ __forceinline__ int slot_of(const BlockArgs& a, int key) {
-  if (DIRECT) return key;
+  if (DIRECT) {
+    if ((unsigned)key < (unsigned)a.n_nodes) return key;
+    *a.bad = 0;                 // an id outside the universe the caller promised: reported through counts[0], never indexed with
+    return 0;
+  }
   return ht_insert(a.keys, a.mask, key);
 }
 
@@ -254,7 +260,7 @@ struct AssignLocal {
 __global__ __launch_bounds__(256) void block_relabel_kernel(const BlockArgs a, const int64_t* n_new) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0) {
-    a.counts[0] = a.indptr[a.ns];
+    a.counts[0] = (a.direct && *a.bad == 0) ? -1 : a.indptr[a.ns];
     a.counts[1] = a.ns + *n_new;
   }
   if (e >= a.indptr[a.ns]) return;
@@ -384,21 +390,22 @@ static int block_build_impl(const int64_t* g_indptr, const int32_t* g_indices, c
   const bool direct = n_nodes > 0 && (uint64_t)n_nodes <= 2 * cap && n_nodes < kFill32;
   const uint64_t tab = direct ? (uint64_t)((n_nodes + 1) & ~(int64_t)1) : cap;      // entries per table (even: the arrays behind stay 8-byte aligned)
   const int64_t b1 = (ns + kScanTile - 1) / kScanTile, b2 = (nnz_cap + kScanTile - 1) / kScanTile;
-  // layout: [status1 b1][status2 b2][ticket1, ticket2 (one 8-byte word)][n_new (8 bytes)] | (keys,) pos | -- 0x7F-filled up to here
+  // layout: [status1 b1][status2 b2][ticket1, ticket2 (one 8-byte word)][n_new (8 bytes)][bad (8 bytes)] | (keys,) pos | -- 0x7F-filled up to here
   //         slot_of_edge
   unsigned long long* status1 = reinterpret_cast<unsigned long long*>(workspace);
   unsigned long long* status2 = status1 + b1;
   int* tickets = reinterpret_cast<int*>(status2 + b2);
   int64_t* n_new = reinterpret_cast<int64_t*>(tickets + 2);
-  int* tables = reinterpret_cast<int*>(n_new + 1);
+  int* bad = reinterpret_cast<int*>(n_new + 1);
+  int* tables = reinterpret_cast<int*>(n_new + 2);
   BlockArgs a;
   a.g_indptr = g_indptr; a.g_indices = g_indices; a.seeds = seeds; a.ns = ns; a.smp_src = smp_src; a.smp_cnt = smp_cnt;
   a.fanout = fanout; a.nnz_cap = nnz_cap; a.indptr = indptr; a.indices = indices; a.gindices = gindices; a.input_nodes = input_nodes;
-  a.counts = counts; a.direct = direct ? 1 : 0;
+  a.counts = counts; a.direct = direct ? 1 : 0; a.n_nodes = (int)(direct ? n_nodes : 0); a.bad = bad;
   a.keys = direct ? nullptr : tables;
   a.pos = direct ? tables : tables + tab;
   a.mask = (unsigned)(cap - 1); a.slot_of_edge = a.pos + tab;
-  const size_t fill_bytes = (size_t)((b1 + b2 + 2) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
+  const size_t fill_bytes = (size_t)((b1 + b2 + 3) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
   if (hipMemsetAsync(workspace, 0x7F, fill_bytes, st) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset failed");
   int rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
   if (rc != GLNN_OK) return rc;

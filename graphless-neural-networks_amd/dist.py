@@ -254,6 +254,51 @@ def _all_gather_block(out_block, mine, shards, group, tag=None, chunk=0):
     return finish
 
 
+def probe_link(world, rank, floats_per_rank, device, group=None, reps=3):
+    """Measure what an in-place all-gather of `floats_per_rank` floats per rank achieves on THIS job's transport (RCCL over xGMI on
+    the GPU box; gloo in the CPU / single-device tests): the figure the exchange forms of ShardedTeacher are priced with.  Every rank
+    receives world - 1 slabs, one from each peer (on MI355X: one xGMI link per peer, all links in parallel), so
+        per_link_GBps = slab bytes / time,     received_GBps = (world - 1) * slab bytes / time.
+    Collective; returns the same dict on every rank (times are the maximum over ranks)."""
+    import time as _time
+    m = max(1, int(floats_per_rank))
+    out = torch.empty(world * m, device=device)
+    mine = out[rank * m:(rank + 1) * m]
+    mine.fill_(float(rank))
+    nccl = dist.get_backend(group) == "nccl"
+
+    def once():
+        if nccl:
+            dist.all_gather_into_tensor(out, mine, group=group)
+        else:
+            tmp = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(tmp, mine.contiguous(), group=group)
+            for r, t in enumerate(tmp):
+                out[r * m:(r + 1) * m].copy_(t)
+
+    def sync():
+        if out.is_cuda:
+            torch.cuda.synchronize(device)
+
+    once()                                       # communicator set-up, buffer registration
+    sync()
+    dist.barrier(group=group)
+    times = []
+    for _ in range(reps):
+        sync()
+        t0 = _time.perf_counter()
+        once()
+        sync()
+        times.append(_time.perf_counter() - t0)
+    ok = bool((out.view(world, m)[:, 0] == torch.arange(world, device=device, dtype=out.dtype)).all())
+    t = torch.tensor([min(times), 0.0 if ok else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    sec = float(t[0].item())
+    slab = 4.0 * m
+    return {"slab_MB": slab / 1e6, "seconds": sec, "per_link_GBps": slab / sec / 1e9, "received_GBps": (world - 1) * slab / sec / 1e9,
+            "correct": float(t[1].item()) == 0.0, "reps": reps, "backend": dist.get_backend(group)}
+
+
 class ShardedTeacher:
     """SAGE layer-wise inference over a row-sharded graph.  `graph_shard` = full graph's rows [lo,hi)
     (glnn_amd.graph.CSRGraph.row_range), column indices global.

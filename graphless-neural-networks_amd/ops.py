@@ -595,6 +595,8 @@ def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_
                                          _p(input_nodes), _p(counts), int(n_nodes), _p(ws), ws.numel() * 8, _stream())
     _lib.check(rc, "glnn_block_build_ids")
     nnz, n_src = (int(v) for v in counts.tolist())          # the only host sync of the block
+    if nnz < 0:
+        raise _lib.GlnnError(f"block_build: a seed or neighbour id lies outside [0, n_nodes = {int(n_nodes)})")
     if nnz > nnz_cap:
         raise _lib.GlnnError(f"block_build: the block has {nnz} edges, more than nnz_cap = {nnz_cap}")
     return indptr, indices[:nnz], (gindices[:nnz] if want_global else None), input_nodes[:n_src], nnz, n_src

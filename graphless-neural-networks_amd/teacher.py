@@ -256,7 +256,7 @@ class TeacherEngine:
                 y.agg, y.ld_agg = A.take(4 * n_dst * r4(dims[l])), r4(dims[l])
                 y.z, y.ldz = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])
                 if l != L - 1:
-                    if self.gather_tail:
+                    if self.gather_tail and dims[l + 1] <= 256:      # (the tail-in-gather kernel holds a row in registers: d <= 256)
                         y.h, y.ldh = None, 0
                     else:
                         y.h, y.ldh = A.take(4 * n_dst * r4(dims[l + 1])), r4(dims[l + 1])

@@ -506,7 +506,8 @@ GLNN_API int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices,
                               int64_t workspace_bytes, void* stream);
 /* ABI 8: the same, told the size of the id universe (every seed and neighbour id is < n_nodes; 0 = unknown -> glnn_block_build).
  * When n_nodes is no larger than the two arrays of the frontier hash table (the wider blocks of a large batch), the positions are indexed by
- * the node id itself: one atomicMin per edge, no probing, a smaller fill.  Same workspace size, identical results. */
+ * the node id itself: one atomicMin per edge, no probing, a smaller fill.  Same workspace size, identical results.  Precondition: every id is in
+ * [0, n_nodes); an id outside is never used as an index -- counts[0] comes back as -1 (the block's outputs are then undefined). */
 GLNN_API int glnn_block_build_ids(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds,
                                   int64_t ns, const int32_t* smp_src, const int32_t* smp_cnt, int fanout,
                                   int64_t nnz_cap, int64_t* indptr, int32_t* indices, int32_t* gindices,

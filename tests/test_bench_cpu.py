@@ -31,7 +31,15 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
          "cpu_baseline": {"value": 2.5e7, "unit": "edges/s", "cores": 128, "kind": "port", "sample": long, "student_steps_per_s": 3.5,
                           "student_threads_best": 16, "student_thread_sweep": [{"threads": t} for t in range(50)]},
          "roofline_reordered": {"edges_per_s": 1.0, "ms_per_step": 1.0, "frac": 0.8, "kernel": long},
-         "roofline_clustered": {"edges_per_s": 1.0, "ms_per_step": 1.0, "frac": 1.0, "kernel": long}}
+         "roofline_clustered": {"edges_per_s": 1.0, "ms_per_step": 1.0, "frac": 1.0, "kernel": long},
+         # round 5: BASELINE configs[4] and configs[1]+[2] ride on the default line (child processes of the products run)
+         "xl": {"ms_per_step": 160.0, "value": 4.7e9, "verified": True, "per_forward": {"kernel_ms": 140.0}, "wall_s": 80.0, "verify": {"what": long},
+                "config": {"rows_per_gpu": 12500000, "nnz_per_gpu": 250000000, "shards": 8, "workload": long},
+                "layers": [{"layer": long, "kernel": long, "bound": "hbm", "ms": 24.0, "frac": 0.72}, {"layer": long, "GB_received_per_rank": 44.8},
+                           {"layer": long, "bound": "mfma", "ms": 56.0, "frac": 0.74}, {"layer": long, "bound": "hbm", "ms": 46.0, "frac": 0.73},
+                           {"layer": long, "GB_received_per_rank": 16.0}, {"layer": long, "bound": "hbm", "ms": 12.0, "frac": 0.55}]},
+         "arxiv": {"ms_per_step": 0.89, "value": 8.4e9, "verified": True, "wall_s": 15.0, "config": {"nodes": 169343, "nnz": 2484941, "workload": long},
+                   "student": {"metric": "student distill steps/s (MLP3w4 128-1024-1024-40, B=512 per rank, " + long, "ms_per_step": 0.135}}}
     c = bench.compact(r, None)
     line = json.dumps(c)
     assert len(line) <= 4096, len(line)
@@ -41,6 +49,11 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
     assert c["roofline"]["frac"] == 0.85 and c["roofline"]["hbm_frac_bracket"] == [0.6, 0.9] and len(c["roofline"]["launches"]) == 3
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 128 and c["student"]["frac_of_fp32_mfma_peak"] == 0.76
     assert set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"} and c["teacher_training"]["steps_per_s"] == 300.0
+    assert c["xl"]["ms"] == 160.0 and c["xl"]["verified"] is True and [l["frac"] for l in c["xl"]["layers"]] == [0.72, 0.74, 0.73, 0.55]
+    assert c["arxiv"]["student"] == "MLP3w4" and c["arxiv"]["student_ms"] == 0.135 and c["arxiv"]["Gedges_per_s"] == 8.4
+    r2 = dict(r, xl={"error": long, "wall_s": 1.0}, arxiv={"error": "rc 1: boom", "wall_s": 1.0})        # a failed leg is reported, the line survives
+    c2 = bench.compact(r2, None)
+    assert len(json.dumps(c2)) <= 4096 and "error" in c2["xl"] and c2["arxiv"]["error"] == "rc 1: boom" and c2["value"] == 1.0
 
 
 def test_checked_backend_catches_a_wrong_launch_and_accepts_right_ones():

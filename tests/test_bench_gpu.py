@@ -73,11 +73,35 @@ def test_bench_two_ranks_driver_launch_line(extra):
     assert REQUIRED <= out.keys()
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["student"]["global_batch"] == 2 * 4096
-    ex = out["exchange"]       # per forward: n_pad * (100 + 48) floats = the narrow sides only (layer 2 exchanges nothing)
+    ex = out["exchange"]       # per forward: n_pad * (100 + 48) floats = the narrow sides only (layer 2 exchanges nothing); wide: 256 + 48
     n_pad = -(-out["config"]["nodes"] // 8) * 8        # work-balanced (uneven) row ranges pad every slot to the longest range
-    assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * 148 < 0.15 * 4e-9 * n_pad * 148, ex
+    # round 5: the driver passes no flags -- the layer-1 exchange form is chosen by timing both forms on this transport, and the line says so
+    l1 = out["config"]["layer1_exchange"]
+    assert l1 in ("narrow", "wide") and ex["layer1_chosen"] == l1 and set(ex["layer1_autotune_ms"]) == {"narrow", "wide"}
+    assert ex["layer1_autotune_ms"][l1] == min(ex["layer1_autotune_ms"].values())
+    per_node = 148 if l1 == "narrow" else 256 + 48
+    assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * per_node < 0.15 * 4e-9 * n_pad * per_node, ex
     assert ex["collectives_per_forward"] == 8
     assert ("global" in out["student"]["batchnorm"]) == bool(extra)
+    # ... and the record can diagnose itself: the measured link rate, and per rank kernel time vs wall time = the exposed exchange
+    assert ex["link_GBps_measured"] > 0 and ex["link_probe"]["narrow"]["correct"] and ex["link_probe"]["wide"]["correct"]
+    assert ex["link_probe"]["wide"]["slab_MB"] > 2.4 * ex["link_probe"]["narrow"]["slab_MB"]
+    ranks = ex["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and sum(r["rows"] for r in ranks) == out["config"]["nodes"] and sum(r["nnz"] for r in ranks) == out["config"]["nnz"]
+    for r in ranks:
+        assert r["kernel_ms"] > 0 and r["wall_ms"] >= r["kernel_ms"] * 0.99 and abs(r["exchange_exposed_ms"] - (r["wall_ms"] - r["kernel_ms"])) < 1e-9
+        assert abs(sum(r["kernels"].values()) - r["kernel_ms"]) < 1e-6 and any(k.startswith("sage_fused") for k in r["kernels"])
+    assert ex["kernel_ms_max"] == max(r["kernel_ms"] for r in ranks) and ex["exchange_exposed_ms_max"] == max(r["exchange_exposed_ms"] for r in ranks)
+    c = out["_compact"]["exchange"]
+    assert c["layer1_chosen"] == l1 and len(c["ranks"]) == 2 and len(c["ranks"][0]) == 3 and c["link_GBps_measured"] == ex["link_GBps_measured"]
+    assert set(c["family_ms_max"]) == set().union(*[r["kernels"].keys() for r in ranks])
+    st = out["student"]
+    if extra:
+        assert st["local_step_ms"] is None and st["dp_overhead_ms"] is None
+    else:
+        assert st["local_step_ms"] > 0 and abs(st["dp_overhead_ms"] - (st["ms_per_step"] - st["local_step_ms"])) < 1e-9
+        assert out["_compact"]["student"]["dp_overhead_ms"] == st["dp_overhead_ms"]
+    assert len(json.dumps(out["_compact"])) <= 4096
 
 
 @pytest.mark.parametrize("l1", ["narrow", "wide"])

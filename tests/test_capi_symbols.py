@@ -131,6 +131,76 @@ def test_pipelined_gemm_loops_contain_no_vector_alu_and_no_register_copies(tmp_p
         assert sum(l.startswith("v_pk_add_f32") for l in side) == 32, name
 
 
+def test_wave_walk_gemm_loop_is_the_stated_slot_schedule_and_nothing_else(tmp_path):
+    """gemm_rowwalk_kernel (K3w, csrc/gemm_rowpanel.hip, round 5) keeps registers in flight across its whole walk -- A fragments requested a
+    tile ahead, W fragments a k-group ahead, accumulators in AGPRs -- all through inline asm the compiler cannot see into.  Checked on the
+    ISA hipcc generates for gfx950 (the development subset: K = 100 and K = 128 reductions, with and without ReLU):
+      * no spill, no scratch: a spilled register of this kernel would be copied while its load is still in flight;
+      * exactly ONE loop, whose body holds the stated schedule and nothing else: KG x 16 MFMAs, 4 KG ds_read_b128, KG buffer loads, 64
+        dword stores, 64 accumulator reads -- and outside the asm blocks only scalar bookkeeping and the 64 epilogue FMAs (+ 64 max with
+        ReLU): no compiler-placed s_waitcnt (it would be a wait for ALL loads: the software pipeline gone), no scalar / vector memory
+        instruction, no register copy;
+      * every MFMA of the loop reads its A operand from the rolling fragment registers and accumulates in AGPRs."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "graphless-neural-networks_amd", "csrc", "gemm_rowpanel.hip")
+    out = tmp_path / "rowpanel.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DGLNN_RP_DEV", f"-I{ROOT}/include",
+                    f"-I{ROOT}/graphless-neural-networks_amd/csrc", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, capture_output=True, timeout=900)
+    text = out.read_text()
+    kernels = re.findall(r"^(_ZN[^\n:]*gemm_rowwalk_kernelILi(\d+)ELb([01])E[^\n:]*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert sorted((int(kg), int(relu)) for _, kg, relu, _ in kernels) == [(13, 0), (13, 1), (16, 0), (16, 1)]
+    for name, kg, relu, body in kernels:
+        kg, relu = int(kg), int(relu)
+        meta = text[text.index(f".name:           {name}"):]
+        meta = meta[:meta.index(".wavefront_size")]
+        assert re.search(r"\.vgpr_spill_count:\s+0\b", meta) and re.search(r"\.sgpr_spill_count:\s+0\b", meta), name
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta), name
+        assert "scratch_" not in body, name
+        lines = body.split("\n")
+        # basic blocks in layout order: [label line, next label line); the walk's loop = the header block whose loop holds the MFMAs
+        # plus every block the compiler tagged "in Loop: Header=<that block>"
+        starts = [i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)] + [len(lines)]
+        blocks = [(lines[a0].split(":")[0].lstrip(".L"), lines[a0], lines[a0 + 1:a1]) for a0, a1 in zip(starts[:-1], starts[1:])]
+        loops = {}
+        for label, first, blk in blocks:
+            if "Loop Header" in first:
+                loops.setdefault(label, []).extend(blk)
+            m_ = re.search(r"in Loop: Header=(BB\d+_\d+)", first)
+            if m_:
+                loops.setdefault(m_.group(1), []).extend(blk)
+        walk = [v for v in loops.values() if any("v_mfma" in l for l in v)]
+        assert len(walk) == 1, (name, list(loops))
+        loop = walk[0]
+        inasm, asm_ops, other = False, [], []
+        for raw in loop:
+            if "#ASMSTART" in raw:
+                inasm = True
+                continue
+            if "#ASMEND" in raw:
+                inasm = False
+                continue
+            l = raw.split(";")[0].strip()
+            if not l or l.endswith(":") or l.startswith("."):
+                continue
+            (asm_ops if inasm else other).append(l)
+        count = lambda ops_, pre: sum(o.startswith(pre) for o in ops_)
+        assert count(asm_ops, "v_mfma_f32_32x32x2") == 16 * kg, (name, count(asm_ops, "v_mfma_f32_32x32x2"))
+        assert count(asm_ops, "ds_read_b128") == 4 * kg and count(asm_ops, "buffer_load_dwordx4") == kg, name
+        assert count(asm_ops, "buffer_store_dword") == 64 and count(asm_ops, "v_accvgpr_read_b32") == 64, name
+        # outside the asm blocks: scalar ALU / branches / s_nop, and the epilogue arithmetic -- nothing that waits, loads, stores or copies
+        bad = [o for o in other if not re.match(r"(s_(?!waitcnt|load|buffer|sleep|barrier)\w+|v_cmp_\w+|v_fma_f32|v_fmac_f32|v_max_f32\w*)\b", o)]
+        assert not bad, (name, bad[:8])
+        assert count(other, "v_fma") + count(other, "v_fmac") == 64 and count(other, "v_max_f32") == (64 if relu else 0), name
+        for o in asm_ops:
+            if o.startswith("v_mfma"):
+                a = [x.strip() for x in o.split(None, 1)[1].split(",")]
+                assert a[0].startswith("a[") and a[1].startswith("v") and a[2].startswith("v") and (a[3] == "0" or a[3] == a[0]), (name, o)
+
+
 def test_cross_workgroup_publishes_drain_their_stores_before_the_counter_update(tmp_path):
     """last_workgroup / bn_bwd_fused (csrc/student.hip) publish partial sums with write-through stores and then bump an arrival
     counter that workgroups on OTHER XCDs read.  A barrier alone does not wait for the write-through on gfx950 (the ISA used to be

@@ -254,14 +254,14 @@ def test_rowpanel_gemm_equals_the_tiled_kernels_bit_for_bit(m, k, n, epi, monkey
     es = dev(r.uniform(0.5, 1.5, n).astype(np.float32)) if epi else None
     eh = dev(r.standard_normal(n).astype(np.float32)) if epi else None
     outs = []
-    for mode in ("1", "0"):            # the row-panel kernel | the tiled kernels
+    for mode in ("1", "2", "0"):       # the wave-walk kernel (round 5) | the workgroup-tile kernel (round 4) | the tiled kernels
         monkeypatch.setenv("GLNN_GEMM_ROWPANEL", mode)
         out = ops.feat_empty(m, n, DEV)
         base = torch.as_strided(out, (m, out.stride(0)), (out.stride(0), 1))
         base.fill_(-7.0)
         ops.gemm(a, w, ep_scale=es, ep_shift=eh, relu=epi, out=out)
         outs.append(base.clone())
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
     if outs[0].shape[1] > n:
         assert float((outs[0][:, n:] + 7.0).abs().max()) == 0.0          # padding columns: not written by either path
     want = a[:, :k].double() @ w.double().t()
@@ -518,6 +518,27 @@ def test_linear_bn_stats_equals_the_two_call_form(m, k, n, monkeypatch):
         assert o[7] == 1
     for x, y in zip(outs[0][1:5], outs[1][1:5]):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,k,n", [(5000, 100, 256), (40000, 128, 128), (4096, 2048, 256)])
+def test_linear_bn_stats_of_columns_far_from_zero(m, k, n, monkeypatch):
+    """Columns with |mean| / std of several hundred: the statistics out of the product kernels' epilogues -- the wave-walk
+    kernel's per-tile sums around the tile's first value merged tile by tile (Chan), the pipelined kernel's two passes over its accumulators
+    -- keep the variance of the stored z to fp32 rounding, as the two-call form does."""
+    from glnn_amd import ops
+    r = np.random.RandomState(m + n)
+    a = ops.as_feat(dev(r.standard_normal((m, k)).astype(np.float32)))
+    w = dev((r.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    bias = dev((r.choice([-1.0, 1.0], n) * r.uniform(100, 400, n)).astype(np.float32))
+    gamma, beta = dev(np.ones(n, np.float32)), dev(np.zeros(n, np.float32))
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_GEMM_STATS", mode)
+        rm, rv, nbt = dev(np.zeros(n, np.float32)), dev(np.ones(n, np.float32)), torch.tensor([0], device=DEV)
+        z, mean, rstd, _, _ = ops.linear_bn_stats(a, w, bias, gamma, beta, rm, rv, nbt)
+        zd = z[:, :n].double()
+        mu, var = zd.mean(0), zd.var(0, unbiased=False)
+        np.testing.assert_allclose(mean.cpu().numpy(), mu.cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(rstd.cpu().numpy(), (1.0 / torch.sqrt(var + 1e-5)).cpu().numpy(), rtol=2e-4)
 
 
 @pytest.mark.parametrize("rows,h,relu,p", [(100, 48, True, 0.0), (513, 512, True, 0.3), (64, 2048, True, 0.0), (33, 2500, False, 0.2),
