@@ -113,6 +113,8 @@ def main():
                          "(every rank projects all rows itself) or its 256-wide fused output (no replicated work, 2.56x the bytes).  auto (default): "
                          "both forms are timed on this job's transport before the timed region (3 forwards each) and the faster one runs; "
                          "--workload xl and N = 1 treat auto as narrow")
+    ap.add_argument("--chunks", type=int, default=0, help="N > 1 / --emulate: chunks of the overlapped all-gather exchange (0 = 4, or chosen by the "
+                    "layer-1 autotune among 2, 4, 8)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed output ('verified' on the JSON line)")
     ap.add_argument("--no-clustered-leg", action="store_true", help="N = 1: skip roofline_clustered (the forward on a graph with communities)")
     ap.add_argument("--no-small-students", action="store_true", help="N = 1: skip students_small (the B = 512 arxiv students' step times)")
@@ -204,7 +206,7 @@ def main():
                          label_dim=SAGE_DIMS[-1], dropout_ratio=0.5, norm_type="batch", device=dev))
     teacher.eval()
     # N > 1: destination-row ranges cut by WORK (in-edges + 2 per row), not by row count
-    shards = RowShards(n, world, rank, chunks=4 if world > 1 else 1, bounds=RowShards.balanced_bounds(g.indptr, world) if world > 1 else None)
+    shards = RowShards(n, world, rank, chunks=(args.chunks or 4) if world > 1 else 1, bounds=RowShards.balanced_bounds(g.indptr, world) if world > 1 else None)
     ref_own, link_probe, autotune = None, None, None
     if world == 1 and args.layer1_exchange == "auto":
         args.layer1_exchange = "narrow"
@@ -221,23 +223,29 @@ def main():
         else:
             if args.layer1_exchange == "auto":
                 # self-tuning: the driver passes no flags and the right form depends on a link rate nobody has measured -- so measure the
-                # forms themselves, on this transport, outside the timed region (max over ranks; identical decision on every rank)
-                autotune = {}
+                # forms themselves (what layer 1 puts on the wire x how many chunks the overlapped exchange is cut into), on this
+                # transport, outside the timed region (max over ranks; identical decision on every rank)
+                autotune, best = {}, None
                 for form in ("narrow", "wide"):
-                    cand = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=form)
-                    with torch.no_grad():
-                        cand.forward(feats)
-                        barrier()
-                        t0 = time.perf_counter()
-                        for _ in range(3):
+                    for ch in ([args.chunks] if args.chunks else [2, 4, 8]):
+                        sh_c = RowShards(n, world, rank, chunks=ch, bounds=shards.bounds)
+                        cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form)
+                        with torch.no_grad():
                             cand.forward(feats)
-                        barrier()
-                    tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    autotune[form] = 1e3 * float(tt.item())
-                    del cand
-                    torch.cuda.empty_cache()
-                args.layer1_exchange = min(autotune, key=autotune.get)
+                            barrier()
+                            t0 = time.perf_counter()
+                            for _ in range(3):
+                                cand.forward(feats)
+                            barrier()
+                        tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        autotune[f"{form}/{ch}"] = 1e3 * float(tt.item())
+                        if best is None or autotune[f"{form}/{ch}"] < autotune[best]:
+                            best = f"{form}/{ch}"
+                        del cand, sh_c
+                        torch.cuda.empty_cache()
+                args.layer1_exchange, ch = best.split("/")
+                shards = RowShards(n, world, rank, chunks=int(ch), bounds=shards.bounds)
             sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
         shard_rows, shard_nnz = shards.rows, int(shard_graph.num_edges())
         del g
@@ -381,6 +389,7 @@ def main():
             "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
             "link_probe": link_probe, "link_GBps_measured": link_probe["narrow"]["per_link_GBps"] if link_probe else None,
             "layer1_autotune_ms": autotune, "layer1_chosen": args.layer1_exchange if args.exchange == "allgather" else None,
+            "chunks": shards.chunks,
             "ranks": rank_diag,
             "kernel_ms_max": max(r_["kernel_ms"] for r_ in rank_diag), "kernel_ms_mean": float(np.mean([r_["kernel_ms"] for r_ in rank_diag])),
             "wall_ms_max": max(r_["wall_ms"] for r_ in rank_diag),
@@ -775,9 +784,10 @@ class CheckedBackend:
         self.report.append({"launch": what, "max_abs_diff_vs_fp64": diff, **({} if exact is None else {"row_range_relaunch_bit_equal": exact})})
 
     def spmm(self, indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None, relu=False, out=None,
-             x_self=None, self_rows=None):
+             x_self=None, self_rows=None, **kw):
+        # (kw: the hub plan of the HIP backend.  The row-range relaunch below runs WITHOUT one: plan and no plan must agree bit for bit)
         out = self.be.spmm(indptr, indices, x, n_dst, mode, row_scale=row_scale, col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift,
-                           relu=relu, out=out, x_self=x_self, self_rows=self_rows)
+                           relu=relu, out=out, x_self=x_self, self_rows=self_rows, **kw)
         if n_dst and self_rows is None:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)
@@ -801,9 +811,9 @@ class CheckedBackend:
         return out
 
     def sage_fused(self, indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
-                   w_next=None, out_next=None, want_out=True, tile_order=None):
+                   w_next=None, out_next=None, want_out=True, tile_order=None, **kw):
         res = self.be.sage_fused(indptr, indices, x, n_dst, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out, x_self=x_self,
-                                 w_packed=w_packed, w_next=w_next, out_next=out_next, want_out=want_out, tile_order=tile_order)
+                                 w_packed=w_packed, w_next=w_next, out_next=out_next, want_out=want_out, tile_order=tile_order, **kw)
         if n_dst:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)
@@ -1061,7 +1071,7 @@ def run_emulated(args, dev):
             bounds = gdist.RowShards.balanced_bounds(g.indptr, N)
             ranks = []
             for r in range(N):
-                sh = gdist.RowShards(n, N, r, chunks=4, bounds=bounds)
+                sh = gdist.RowShards(n, N, r, chunks=args.chunks or 4, bounds=bounds)
                 peers = gdist.EmulatedPeers(N, r, truth=truth, full_graph=g if cfg["exchange"] == "halo" else None)
                 shard = g.row_range(sh.lo, sh.hi)
                 if cfg["exchange"] == "halo":
@@ -1069,7 +1079,8 @@ def run_emulated(args, dev):
                 else:
                     t = gdist.ShardedTeacher(enc, shard, sh, ops, group=peers, widening_exchange=cfg["l1"])
                 with torch.no_grad():
-                    t.forward(feats)                       # warm-up (buffers, relabelled columns, packed weights)
+                    for _ in range(2):
+                        t.forward(feats)                   # warm-up (buffers, relabelled columns, packed weights, hub plans, first launches)
                     timing, peers.events = [], []
                     gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
                     torch.cuda.synchronize()
@@ -1180,7 +1191,7 @@ def compact(r, detail_path):
     if r.get("exchange"):
         ex = r["exchange"]
         c["exchange"] = {k: ex.get(k) for k in ("GB_received_per_rank_per_forward", "collectives_per_forward", "link_GBps_measured", "layer1_autotune_ms",
-                                                "layer1_chosen", "kernel_ms_max", "kernel_ms_mean", "wall_ms_max", "exchange_exposed_ms_max",
+                                                "layer1_chosen", "chunks", "kernel_ms_max", "kernel_ms_mean", "wall_ms_max", "exchange_exposed_ms_max",
                                                 "exchange_exposed_ms_mean")}
         if ex.get("link_probe"):
             c["exchange"]["link_probe_GBps"] = {k: [round(v["per_link_GBps"], 2), round(v["received_GBps"], 2)] for k, v in ex["link_probe"].items()}

@@ -22,6 +22,12 @@ SIGNATURES = {
     "glnn_pack_weight_f32": [c_vp, c_i64, c_int, c_int, c_vp, c_vp],
     "glnn_sage_fused_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
                             c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp],
+    "glnn_hub_row_threshold": [],
+    "glnn_hub_segment_edges": [],
+    "glnn_spmm_csr_plan_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
+                               c_int, c_vp, c_i64, c_vp, c_vp],
+    "glnn_sage_fused_plan_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
+                                 c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp, c_i64, c_vp],
@@ -65,7 +71,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -77,6 +83,12 @@ class AdamDesc(ctypes.Structure):
                 ("sizes", ctypes.c_void_p), ("grads_host", ctypes.c_void_p), ("num_tensors", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("max_size", c_i64), ("lr", c_f32), ("beta1", c_f32), ("beta2", c_f32), ("eps", c_f32), ("weight_decay", c_f32),
                 ("reserved2", ctypes.c_int32), ("step", c_i64)]
+
+
+class HubPlanDesc(ctypes.Structure):
+    """glnn_hub_plan of include/glnn_hip.h (field for field)."""
+    _fields_ = [("rows", c_vp), ("seg_ptr", c_vp), ("n_hub", ctypes.c_int32), ("n_seg", ctypes.c_int32), ("slab", c_vp),
+                ("ld_slab", c_i64), ("slab_rows", c_i64)]
 
 
 class MlpStepDesc(ctypes.Structure):
@@ -155,7 +167,7 @@ def lib():
         h.glnn_reload_options.restype = None
         if h.glnn_abi_version() != ABI_VERSION:
             raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
-        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc)):
+        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc), (4, HubPlanDesc)):
             if h.glnn_struct_bytes(which) != ctypes.sizeof(mirror):
                 raise GlnnError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {h.glnn_struct_bytes(which)} in the library, "
                                 f"{ctypes.sizeof(mirror)} in this binding")

@@ -47,6 +47,25 @@ constexpr int kBlock = 512;              // 8 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kRowsPerWave = GLNN_ROWS_PER_WAVE;
 constexpr int kLongRow = GLNN_LONG_ROW;  // degree above which a whole workgroup takes the row
+// HUB rows (round 5): a row of more than kHubRow in-edges is summed SEGMENT BY SEGMENT -- kHubSeg = 512 edges, 64 per wave, the eight wave
+// partials folded as ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)), the segments added in ascending order -- so that its segments can be gathered
+// by different workgroups (hub_gather_kernel, one workgroup per segment, into a slab the row's consumer adds up) without changing a bit:
+// with or without a plan, fused or stand-alone launch of a whole graph, a chunk or a shard, a hub row's sum is the same number.
+// Why: a shard's chunk launch takes ~0.7 ms, one workgroup needs ~0.5 ms for a 17 k-edge row at D = 256 (scripts/hub_tail_probe.py).
+#ifndef GLNN_HUB_ROW
+#define GLNN_HUB_ROW 1024
+#endif
+constexpr int kHubRow = GLNN_HUB_ROW;
+constexpr int kHubSeg = 512;
+
+// the hub rows of one launch and where their segments' partial sums are (glnn_hub_plan of the C ABI, checked by the launcher)
+struct HubPlan {
+  const int64_t* rows;          // ascending row ids (relative to the launch's indptr), degree > kHubRow
+  const int32_t* seg_ptr;       // [n_hub + 1] first segment of each hub row; seg_ptr[n_hub] = number of segments
+  int n_hub;
+  float* slab;                  // [n_seg][ld_slab] partial sums, written by hub_gather_kernel
+  int64_t ld_slab;
+};
 
 struct SpmmArgs {
   const int64_t* indptr;
@@ -71,6 +90,7 @@ struct SpmmArgs {
   // hidden layer in front (BatchNorm affine, ReLU, counter-based dropout keyed by the SOURCE row id), evaluated in the gather instead of
   // being written by a pass of its own (glnn_act_fwd_f32's arithmetic, element for element)
   int xf_on; const float* xf_scale; const float* xf_shift; uint32_t xf_thr; uint32_t xf_seed; float xf_dscale;
+  HubPlan hub;                  // n_hub == 0: hub rows are summed by the row's own workgroup (same order, same bits)
 };
 
 // per-lane constants of the source transform: the lane's four columns
@@ -241,6 +261,80 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
   st4_stream(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
 }
 
+// ---- hub rows ---------------------------------------------------------------------------------------------------------
+// the eight wave partials of ONE segment -> its sum in lanes < LPR of wave 0 (other waves: garbage), through four LDS slots:
+// waves 4-7 park, waves 0-3 add theirs, wave 0 adds the four.  Two barriers; every wave of the workgroup must call it.
+template <int LPR>
+__device__ __forceinline__ float4 hub_fold8(float4 acc, float4 (*s_part)[64], int wave, int lane) {
+  if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
+  __syncthreads();
+  if (wave < 4 && lane < LPR) s_part[wave][lane] = add4(acc, s_part[wave][lane]);
+  __syncthreads();
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wave == 0 && lane < LPR) t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
+  return t;
+}
+// index of row v in the plan (uniform), -1 if absent
+__device__ __forceinline__ int hub_find(const HubPlan& h, int64_t v) {
+  int lo = 0, hi = h.n_hub - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int64_t r = h.rows[mid];
+    if (r == v) return mid;
+    if (r < v) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+// sum of a hub row's gathered source rows, valid in lanes < LPR of wave 0.  All 8 waves of the workgroup call it (uniform arguments).
+template <int LPR, int U, bool CS, bool XF>
+__device__ __forceinline__ float4 hub_row_sum(const HubPlan& h, const int32_t* __restrict__ indices, int64_t v, int64_t e0, int64_t e1,
+                                              const float* __restrict__ x, int64_t ldx, int col4, bool col_ok, const float* __restrict__ col_scale,
+                                              float4 (*s_part)[64], int wave, int lane, const XfCols& xf) {
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int hi = h.n_hub > 0 ? hub_find(h, v) : -1;
+  if (hi >= 0) {
+    // the segments were gathered by hub_gather_kernel: add them up in order
+    if (wave == 0 && lane < LPR && col_ok) {
+      const int s0 = h.seg_ptr[hi], s1 = h.seg_ptr[hi + 1];
+      for (int sg = s0; sg < s1; ++sg) t = add4(t, ld4(h.slab + (int64_t)sg * h.ld_slab + col4));
+    }
+    return t;
+  }
+  for (int64_t b = e0; b < e1; b += kHubSeg) {
+    const int64_t be = b + kHubSeg < e1 ? b + kHubSeg : e1;
+    const float4 acc = wave_gather_sum<LPR, U, CS, XF>(indices, b, be, wave, 8, x, ldx, col4, col_ok, col_scale, lane, xf);
+    const float4 sgm = hub_fold8<LPR>(acc, s_part, wave, lane);
+    t = add4(t, sgm);
+    __syncthreads();              // the slots are free again
+  }
+  return t;
+}
+
+// one workgroup per segment of a hub row: its partial sum -> slab[segment]
+template <int LPR, int U, bool CS, bool XF>
+__global__ __launch_bounds__(kBlock) void hub_gather_kernel(const SpmmArgs a) {
+  __shared__ float4 s_part[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col4 = (lane % LPR) * 4;
+  const bool col_ok = col4 < a.d;
+  XfCols xf = {};
+  if (XF) xf = load_xf_cols(a, col_ok ? col4 : 0);
+  const int sg = (int)blockIdx.x;
+  int lo = 0, hi = a.hub.n_hub - 1;                      // the hub row whose segment range holds sg: last h with seg_ptr[h] <= sg
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (a.hub.seg_ptr[mid] <= sg) lo = mid; else hi = mid - 1;
+  }
+  const int64_t v = a.hub.rows[lo];
+  const int64_t e0 = a.indptr[v] + (int64_t)(sg - a.hub.seg_ptr[lo]) * kHubSeg;
+  const int64_t e1r = a.indptr[v + 1];
+  const int64_t e1 = e0 + kHubSeg < e1r ? e0 + kHubSeg : e1r;
+  const float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, 8, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
+  const float4 t = hub_fold8<LPR>(acc, s_part, wave, lane);
+  if (wave == 0 && lane < LPR && col_ok) st4(a.hub.slab + (int64_t)sg * a.hub.ld_slab + col4, t);
+}
+
 // ---- long-row role: scan a strided share of the rows, whole workgroup per long row (deterministic LDS fold) ----
 template <int LPR, int U, int MODE, bool CS, bool XF = false>
 __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int wave, int col4, bool col_ok, const EpCols& ep,
@@ -265,6 +359,12 @@ __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int 
     for (int i = 0; i < n_found; ++i) {
       const int64_t v = s_rows[i];
       const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+      if (e1 - e0 > kHubRow) {      // (uniform: every wave reads the same row)
+        const float4 t = hub_row_sum<LPR, U, CS, XF>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, a.col_scale, s_part, wave, lane, xf);
+        if (wave == 0 && lane < LPR && col_ok) finish_row<MODE, XF>(a, v, e1 - e0, t, col4, ep, xf);
+        __syncthreads();
+        continue;
+      }
       float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok,
                                                    a.col_scale, lane, xf);
       if (lane < LPR) s_part[wave][lane] = acc;
@@ -358,6 +458,7 @@ struct FusedArgs {
   // hidden rows go from the MFMA accumulators through LDS into a second MFMA pass and never reach HBM
   const float* w2_packed; int d_out2; int kgroups2; float* out2; int64_t ldo2;
   const int32_t* tile_order;                            // optional permutation of the tile ids (heaviest tiles first)
+  HubPlan hub;                                          // n_hub == 0: hub rows are summed by the tile's own workgroup
 };
 
 template <int LPR, int U, int RT>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains
@@ -413,14 +514,15 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     if (v >= a.n_dst) break;
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     if (e1 - e0 <= kLongRow) continue;
-    const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
-    // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
-    if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
-    __syncthreads();
-    if (wave < 4 && lane < LPR) s_part[wave][lane] = add4(acc, s_part[wave][lane]);
-    __syncthreads();
+    float4 t;
+    if (e1 - e0 > kHubRow) {
+      t = hub_row_sum<LPR, U, false, false>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, nullptr, s_part, wave, lane, XfCols{});
+    } else {
+      // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
+      const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
+      t = hub_fold8<LPR>(acc, s_part, wave, lane);
+    }
     if (wave == 0 && lane < LPR && col4 < kpad) {
-      const float4 t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (col_ok) {
         const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
@@ -547,9 +649,23 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int64_t ldw, int
 }
 
 template <int LPR, int U>
-int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1) {
+int launch_hub_gather(const SpmmArgs& a, int mode, int n_seg, hipStream_t st) {
+  const bool cs = a.col_scale != nullptr;
+  const dim3 g((unsigned)n_seg);
+  if (mode == GLNN_AGG_SAGE_GCN && a.xf_on) hipLaunchKernelGGL((hub_gather_kernel<LPR, U, false, true>), g, dim3(kBlock), 0, st, a);
+  else if (cs) hipLaunchKernelGGL((hub_gather_kernel<LPR, U, true, false>), g, dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((hub_gather_kernel<LPR, U, false, false>), g, dim3(kBlock), 0, st, a);
+  return glnn::check_launch("glnn_spmm_csr_f32(hub segments)");
+}
+
+template <int LPR, int U>
+int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1, int hub_segs = 0) {
   const bool cs = a.col_scale != nullptr;
   const dim3 g(grid, col_tiles);
+  if (hub_segs > 0) {                    // the hub rows' segments first: one workgroup each, into the plan's slab
+    const int rc = launch_hub_gather<LPR, U>(a, mode, hub_segs, st);
+    if (rc != GLNN_OK) return rc;
+  }
   if (mode == GLNN_AGG_SAGE_GCN && a.xf_on) {
     hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false, true>), g, dim3(kBlock), 0, st, a);
   } else if (mode == GLNN_AGG_SAGE_GCN) {
@@ -587,11 +703,25 @@ __global__ void int_to_float_kernel(float* p, int64_t n, int transform) {
 
 }  // namespace
 
+// a caller's glnn_hub_plan -> the kernels' HubPlan (d = the row width the slab must hold); *n_seg = segments to gather (0: no plan)
+static int hub_plan_of(const glnn_hub_plan* plan, int d, HubPlan* h, int* n_seg, const char* who) {
+  h->rows = nullptr; h->seg_ptr = nullptr; h->n_hub = 0; h->slab = nullptr; h->ld_slab = 0;
+  *n_seg = 0;
+  if (!plan || plan->n_hub == 0) return GLNN_OK;
+  const int dpad = (d + 3) & ~3;
+  GLNN_REQUIRE(plan->n_hub > 0 && plan->n_seg >= plan->n_hub && plan->rows && plan->seg_ptr && plan->slab, "%s: incomplete hub plan", who);
+  GLNN_REQUIRE(plan->ld_slab % 4 == 0 && plan->ld_slab >= dpad && plan->slab_rows >= plan->n_seg && glnn::aligned16(plan->slab),
+               "%s: the hub plan's slab needs >= %d rows of >= %d floats (ld multiple of 4), 16-byte aligned", who, plan->n_seg, dpad);
+  h->rows = plan->rows; h->seg_ptr = plan->seg_ptr; h->n_hub = plan->n_hub; h->slab = plan->slab; h->ld_slab = plan->ld_slab;
+  *n_seg = plan->n_seg;
+  return GLNN_OK;
+}
+
 static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
                      const float* x, int64_t ldx, int d, int mode, const float* row_scale,
                      const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
                      const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
-                     void* stream, const glnn::SourceTail* tail) {
+                     void* stream, const glnn::SourceTail* tail, const glnn_hub_plan* plan = nullptr) {
   if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
   GLNN_REQUIRE(indptr && x && out, "glnn_spmm_csr_f32: null pointer");   // indices may be NULL iff the graph has no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
@@ -631,6 +761,11 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
     a.xf_scale = tail ? tail->scale : nullptr; a.xf_shift = tail ? tail->shift : nullptr;
     a.xf_thr = tail ? glnn::drop_threshold(tail->drop_p) : 0u; a.xf_seed = tail ? tail->drop_seed : 0u;
     a.xf_dscale = tail ? 1.0f / (1.0f - tail->drop_p) : 1.f;
+    int hub_segs = 0;
+    {
+      const int rch = hub_plan_of(d <= 256 ? plan : nullptr, d, &a.hub, &hub_segs, "glnn_spmm_csr_f32");      // (column-tiled rows: no plan)
+      if (rch != GLNN_OK) return rch;
+    }
     // workgroups in the long-row role: one per 512-row scan chunk, at most GLNN_LONG_BLOCK_CAP.  (Until round 4: n_dst / 4096 -- right
     // for a whole graph, where it hits the cap, but a row SHARD of a power-law graph keeps the graph's hub rows: rank r of 8 launches
     // 76 k-row chunks of the products graph whose rows of degree > 128 hold 20 % of the edges, and 18 workgroups gathered them while
@@ -652,11 +787,11 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
     const int grid = (int)(row_blocks + n_long);
     const int dv = (dt + 3) / 4;
     int rc;
-    if (dv <= 4) rc = launch_lpr<4, GLNN_SPMM_U>(a, mode, st, grid);
-    else if (dv <= 8) rc = launch_lpr<8, GLNN_SPMM_U>(a, mode, st, grid);
-    else if (dv <= 16) rc = launch_lpr<16, GLNN_SPMM_U>(a, mode, st, grid);
-    else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid);
-    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid, wide ? (d + 255) / 256 : 1);
+    if (dv <= 4) rc = launch_lpr<4, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
+    else if (dv <= 8) rc = launch_lpr<8, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
+    else if (dv <= 16) rc = launch_lpr<16, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
+    else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
+    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid, wide ? (d + 255) / 256 : 1, hub_segs);
     if (rc != GLNN_OK) return rc;
   }
   return GLNN_OK;
@@ -670,6 +805,18 @@ extern "C" int glnn_spmm_csr_f32(const int64_t* indptr, const int32_t* indices, 
   return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, row_scale, col_scale, x_self, ld_self, self_rows, ep_scale, ep_shift, relu,
                    out, ldo, stream, nullptr);
 }
+
+extern "C" int glnn_spmm_csr_plan_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                      const float* x, int64_t ldx, int d, int mode, const float* row_scale,
+                                      const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                                      const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
+                                      const glnn_hub_plan* plan, void* stream) {
+  return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, row_scale, col_scale, x_self, ld_self, self_rows, ep_scale, ep_shift, relu,
+                   out, ldo, stream, nullptr, plan);
+}
+
+extern "C" int glnn_hub_row_threshold(void) { return kHubRow; }
+extern "C" int glnn_hub_segment_edges(void) { return kHubSeg; }
 
 // SAGE-"gcn" aggregation of rows that exist only as pre-activations z: every gathered / self row is tail(z) = drop(relu(z * scale +
 // shift)) evaluated in the gather (glnn_sage_fwd_bwd_f32: the hidden layers' h = tail(z) is never written)
@@ -716,11 +863,11 @@ extern "C" int glnn_pack_weight_f32(const float* w, int64_t ldw, int d_out, int 
   return glnn::check_launch("glnn_pack_weight_f32");
 }
 
-extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
-                                   int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
-                                   int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
-                                   int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
-                                   void* stream) {
+static int sage_fused_impl(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
+                           int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
+                           int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
+                           int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
+                           const glnn_hub_plan* plan, void* stream) {
   if (n_dst == 0) return GLNN_OK;
   GLNN_REQUIRE(indptr && x && x_self && w_packed && (out || w2_packed), "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
   GLNN_REQUIRE(!w2_packed || (out2 && d_out2 >= 1 && d_out2 <= 256 && ldo2 >= d_out2 && glnn::aligned16(w2_packed)),
@@ -750,8 +897,41 @@ extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices
   const int dv = dpad / 4;
   // columns [4*LPR, kpad) must not exist: LPR*4 >= kpad is guaranteed by picking LPR from kpad (a multiple of 8)
   const int kv = a.kgroups * 2;      // float4 per padded row
+  int hub_segs = 0;
+  {
+    const int rch = hub_plan_of(plan, d_in, &a.hub, &hub_segs, "glnn_sage_fused_f32");
+    if (rch != GLNN_OK) return rch;
+  }
+  if (hub_segs > 0) {
+    // the hub rows' segments first (one workgroup each, the lane mapping of the fused launch: same sums as its own in-tile path)
+    SpmmArgs h = {};
+    h.indptr = indptr; h.indices = indices; h.n_dst = n_dst; h.x = x; h.ldx = ldx; h.d = d_in; h.hub = a.hub;
+    int rc;
+    if (kv <= 16 && dv <= 16) rc = launch_hub_gather<16, GLNN_FUSED_U>(h, GLNN_AGG_SUM, hub_segs, st);
+    else if (kv <= 32) rc = launch_hub_gather<32, GLNN_FUSED_U>(h, GLNN_AGG_SUM, hub_segs, st);
+    else rc = launch_hub_gather<64, GLNN_FUSED_U>(h, GLNN_AGG_SUM, hub_segs, st);
+    if (rc != GLNN_OK) return rc;
+  }
 #define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
   if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 1); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 1); else GLNN_FUSED_LAUNCH(64, 1);
 #undef GLNN_FUSED_LAUNCH
   return glnn::check_launch("glnn_sage_fused_f32");
+}
+
+extern "C" int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
+                                   int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
+                                   int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                   int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
+                                   void* stream) {
+  return sage_fused_impl(indptr, indices, n_dst, n_src, x, ldx, d_in, x_self, ld_self, w_packed, d_out, ep_scale, ep_shift, relu, out, ldo,
+                         w2_packed, d_out2, out2, ldo2, tile_order, nullptr, stream);
+}
+
+extern "C" int glnn_sage_fused_plan_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
+                                        int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
+                                        int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                        int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
+                                        const glnn_hub_plan* plan, void* stream) {
+  return sage_fused_impl(indptr, indices, n_dst, n_src, x, ldx, d_in, x_self, ld_self, w_packed, d_out, ep_scale, ep_shift, relu, out, ldo,
+                         w2_packed, d_out2, out2, ldo2, tile_order, plan, stream);
 }

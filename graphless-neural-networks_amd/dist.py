@@ -339,6 +339,30 @@ class ShardedTeacher:
             self._col_cache[k] = self.be.fused_tile_order(self.g.indptr[off:off + nr + 1], nr)
         return self._col_cache[k]
 
+    def _hub(self, off, nr):
+        """The hub plan of a launch over own rows [off, off + nr) (cached; None without hub rows / without a HIP backend): a shard keeps the
+        graph's hub rows, and a chunk launch is short -- their segments are gathered by one workgroup each (ops.HubPlan)."""
+        if not hasattr(self.be, "hub_plan"):
+            return None
+        k = ("hub", off, nr)
+        if k not in self._col_cache:
+            self._col_cache[k] = self.be.hub_plan(self.g.indptr[off:off + nr + 1], nr)
+        return self._col_cache[k]
+
+    def _kw(self, off, nr, fused=False, d_in=None):
+        """Launch extras of an aggregation over own rows [off, off + nr): hub plan (+ tile order for the fused kernel), HIP backend only.
+        The plan is used where it was measured to pay on the products shard (profiles/scale_model_r05*.json): every stand-alone
+        aggregation, and the fused kernel at d_in > 128 -- at 100 wide its heaviest-first tile order already hides the hub rows behind a
+        chunk launch, and the extra launch costs ~30 us per chunk."""
+        kw = {}
+        if not fused or (d_in is not None and d_in > 128):
+            hub = self._hub(off, nr)
+            if hub is not None:
+                kw["hub"] = hub
+        if fused:
+            kw["tile_order"] = self._tile_order(off, nr)
+        return kw
+
     def _cols(self, layout):
         """Column indices of the shard's edges for a source matrix in `layout` (one-time relabelling, cached)."""
         if layout == "nat" or (layout == "own" and self.sh.uniform):
@@ -386,9 +410,9 @@ class ShardedTeacher:
             ip = g.indptr[off:off + nr + 1]            # absolute offsets into the one indices array
             if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
                 be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr], x_self=x[sl],
-                              tile_order=self._tile_order(off, nr))
+                              **self._kw(off, nr, fused=True, d_in=d_in))
             else:
-                agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl])
+                agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl], **self._kw(off, nr))
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
 
     def _widening_layer_overlapped(self, l, x, layout, w, tail):
@@ -405,7 +429,8 @@ class ShardedTeacher:
             off, nr = sh.chunk_rows(c)
             p0 = (c * sh.world + sh.rank) * sh.cr
             if nr > 0:
-                be.spmm(g.indptr[off:off + nr + 1], idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=self._chunk_self(x, layout, c))
+                be.spmm(g.indptr[off:off + nr + 1], idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=self._chunk_self(x, layout, c),
+                        **self._kw(off, nr))
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("agg", l), c))
         y = self._full_buffer(("ycm", l), d_out, x.device)
         for c in range(sh.chunks):
@@ -433,9 +458,9 @@ class ShardedTeacher:
                 xs = self._chunk_self(x, layout, c)
                 if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
                     be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
-                                  tile_order=self._tile_order(off, nr))
+                                  **self._kw(off, nr, fused=True, d_in=d_in))
                 else:
-                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
+                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("y", l), c))
         for wk in works:
@@ -468,13 +493,13 @@ class ShardedTeacher:
                 if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256 and d_out <= 256:
                     # aggregate + project + tail + the NEXT layer's projection in one launch: layer l's rows never reach HBM
                     be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
-                                  want_out=False, tile_order=self._tile_order(off, nr))
+                                  want_out=False, **self._kw(off, nr, fused=True, d_in=w1.shape[1]))
                 else:
                     if y_own is None:
                         if ("y_own", l) not in self._bufs:
                             self._bufs[("y_own", l)] = be.feat_empty(sh.rows, d_mid, x.device)
                         y_own = self._bufs[("y_own", l)]
-                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs)
+                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
                     be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
                     be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
             works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("hw", l + 1), c))
@@ -485,7 +510,7 @@ class ShardedTeacher:
         idx_cm = self._cols("cm")
         for off, nr, sl in self._pieces("cm"):
             be.spmm(g.indptr[off:off + nr + 1], idx_cm, hw, nr, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=rl,
-                    out=out[off:off + nr], x_self=hw[sl])
+                    out=out[off:off + nr], x_self=hw[sl], **self._kw(off, nr))
         return out
 
     def forward(self, x_full):
@@ -515,7 +540,7 @@ class ShardedTeacher:
                 all_gather_rows(hw, sh, self.group, ("hw", l))
                 out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l), d_out, x.device)
                 be.spmm(g.indptr, self._cols("own"), hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
-                        out=out, x_self=hw[sh.slot:sh.slot + sh.rows])
+                        out=out, x_self=hw[sh.slot:sh.slot + sh.rows], **self._kw(0, sh.rows))
             elif not complete:
                 raise RuntimeError("ShardedTeacher: internal error, an aggregating layer needs every node's input row")
             elif multi and not last and 2 * d_in <= d_out and self.widening_exchange == "wide" and sh.chunks > 1 and not next_narrow:
@@ -533,7 +558,8 @@ class ShardedTeacher:
                 else:
                     agg = self._full_buffer(("agg", l), d_in, x.device)
                     (_, _, sl), = self._pieces(layout)
-                    be.spmm(g.indptr, self._cols(layout), x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.slot:sh.slot + sh.rows], x_self=x[sl])
+                    be.spmm(g.indptr, self._cols(layout), x, sh.rows, be.AGG_SAGE_GCN, out=agg[sh.slot:sh.slot + sh.rows], x_self=x[sl],
+                            **self._kw(0, sh.rows))
                     all_gather_rows(agg, sh, self.group, ("agg", l))
                     y_full = self._full_buffer(("y", l), d_out, x.device)
                     be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y_full)

@@ -105,6 +105,17 @@ class CSRGraph:
             self._cache["tile_order"] = ops.fused_tile_order(self.indptr, self.n_dst)
         return self._cache["tile_order"]
 
+    def hub_plan(self):
+        """ops.HubPlan over ALL destination rows (cached; None without hub rows or off the GPU): the rows of more than
+        glnn_hub_row_threshold() in-edges are gathered segment by segment by one workgroup each in front of an aggregation launch
+        (ops.spmm / ops.sage_fused(hub=...)) -- what matters for SHORT launches (an arxiv-sized graph, a row shard)."""
+        if not self.indptr.is_cuda or self.n_dst == 0:
+            return None
+        if "hub_plan" not in self._cache:
+            from . import ops
+            self._cache["hub_plan"] = ops.hub_plan(self.indptr, self.n_dst)
+        return self._cache["hub_plan"]
+
     def has_zero_in_degree(self):
         """dgl GraphConv's `(graph.in_degrees() == 0).any()` check, evaluated once per graph."""
         if "zero_in" not in self._cache:

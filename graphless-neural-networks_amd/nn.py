@@ -51,6 +51,8 @@ class SAGEConv(nn.Module):
             return linear_fn(agg, w, b)
         fused_tail = ep_scale is not None or ep_shift is not None or relu
         shift = ep_shift if fused_tail else b
+        # (no ops.HubPlan here: a whole-graph launch is long enough to hide its hub rows behind the heaviest-first tile order -- measured on
+        #  the arxiv-shaped graph the extra launch costs 10-60 us per layer and gains nothing; row shards use one: glnn_amd/dist.py)
         if self._in_feats > self._out_feats:
             # project first (linear commutes with the mean): aggregate at the narrower width
             hw = ops.gemm(ops.as_feat(h_src), w)

@@ -157,11 +157,53 @@ def as_feat(t):
 
 
 # ---------------------------------------------------------------------------------------------
+class HubPlan:
+    """glnn_hub_plan for one (indptr, n_dst) launch range: the rows of more than glnn_hub_row_threshold() in-edges, cut into segments of
+    glnn_hub_segment_edges() edges that one workgroup each gathers in front of the aggregation (include/glnn_hip.h, ABI 9).  Built once
+    per range (one pass over the degrees and ONE host read-back: the segment count) and reused by every launch over that range; the slab
+    is scratch of the launching stream (one stream at a time)."""
+
+    def __init__(self, indptr, n_dst):
+        thr, seg = _lib.lib().glnn_hub_row_threshold(), _lib.lib().glnn_hub_segment_edges()
+        deg = indptr[1:n_dst + 1] - indptr[:n_dst]
+        rows = torch.nonzero(deg > thr).flatten()
+        self.n_hub = int(rows.numel())
+        self.rows = rows.contiguous()
+        segs = (deg[rows] + (seg - 1)) // seg
+        self.seg_ptr = torch.zeros(self.n_hub + 1, dtype=torch.int32, device=indptr.device)
+        if self.n_hub:
+            self.seg_ptr[1:] = segs.cumsum(0).to(torch.int32)
+        self.n_seg = int(self.seg_ptr[-1].item()) if self.n_hub else 0
+        self.hub_edges = int(deg[rows].sum().item()) if self.n_hub else 0
+        self.slab = None
+        self.desc = _lib.HubPlanDesc()
+
+    def desc_for(self, d, device):
+        """The C descriptor with a slab wide enough for rows of d floats (None when the range has no hub row)."""
+        if self.n_hub == 0:
+            return None
+        ld = (d + 3) // 4 * 4
+        if self.slab is None or self.slab.shape[1] < ld:
+            self.slab = torch.empty(self.n_seg, ld, dtype=torch.float32, device=device)
+        p = self.desc
+        p.rows, p.seg_ptr, p.n_hub, p.n_seg = _p(self.rows), _p(self.seg_ptr), self.n_hub, self.n_seg
+        p.slab, p.ld_slab, p.slab_rows = _p(self.slab), self.slab.shape[1], self.slab.shape[0]
+        return ctypes.byref(p)
+
+
+def hub_plan(indptr, n_dst):
+    """A HubPlan for launches over rows [0, n_dst) of `indptr`, or None when it has no hub row (cache it per range: it costs a host sync)."""
+    _need_cuda(indptr)
+    plan = HubPlan(indptr, int(n_dst))
+    return plan if plan.n_hub else None
+
+
 def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None,
-         relu=False, out=None, x_self=None, self_rows=None):
+         relu=False, out=None, x_self=None, self_rows=None, hub=None):
     """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d].
     x_self (SAGE_GCN only): the destination rows' own features, default x[:n_dst] (a row shard passes its slice).
-    self_rows (SAGE_GCN only, int64 [n_dst]): destination v's own row is x_self[self_rows[v]] (global-id blocks)."""
+    self_rows (SAGE_GCN only, int64 [n_dst]): destination v's own row is x_self[self_rows[v]] (global-id blocks).
+    hub (optional HubPlan of (indptr, n_dst)): the hub rows' segments are gathered by one workgroup each first (same result bit for bit)."""
     _need_cuda(indptr, indices, x, row_scale, col_scale, ep_scale, ep_shift, out, x_self, self_rows)
     x = as_feat(x)
     if self_rows is not None and (self_rows.dtype != torch.int64 or not self_rows.is_contiguous() or self_rows.numel() < n_dst):
@@ -178,19 +220,22 @@ def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_sca
     _mat(out, "spmm out")
     with _Timed("spmm", d=d, n_dst=n_dst, mode=mode):
         rc = _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out,
-                        as_feat(x_self), self_rows)
+                        as_feat(x_self), self_rows, hub)
     _lib.check(rc, "glnn_spmm_csr_f32")
     return out
 
 
 def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self,
-               self_rows=None):
-    return _lib.lib().glnn_spmm_csr_f32(
-        _p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
-        _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
-        _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self), _p(self_rows),
-        _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
-        _p(out), _ld(out), _stream())
+               self_rows=None, hub=None):
+    args = (_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
+            _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
+            _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self), _p(self_rows),
+            _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
+            _p(out), _ld(out))
+    plan = hub.desc_for(d, x.device) if hub is not None else None
+    if plan is not None:
+        return _lib.lib().glnn_spmm_csr_plan_f32(*args, plan, _stream())
+    return _lib.lib().glnn_spmm_csr_f32(*args, _stream())
 
 
 def pack_weight(w):
@@ -216,7 +261,7 @@ def fused_tile_order(indptr, n_dst):
 
 
 def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
-               w_next=None, out_next=None, want_out=True, tile_order=None):
+               w_next=None, out_next=None, want_out=True, tile_order=None, hub=None):
     """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256).
     w_next [d_out2, d_out]: also returns (.. , out @ w_next.T) -- the projection of the NEXT layer when it projects first;
     with want_out=False the hidden rows themselves are not written at all (returns (None, projected))."""
@@ -241,10 +286,15 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
         if out_next is None:
             out_next = feat_empty(n_dst, d_out2, x.device)
     with _Timed("sage_fused", d=d_in, n_dst=n_dst, d_out=d_out, d_chain=d_out2, d_written=(d_out if out is not None else 0) + d_out2):
-        rc = _lib.lib().glnn_sage_fused_f32(_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d_in, _p(x_self), _ld(x_self),
-                                            _p(w_packed), d_out, _p(_vec(ep_scale, d_out, "ep_scale")),
-                                            _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out) if out is not None else 0,
-                                            _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _p(tile_order), _stream())
+        args = (_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d_in, _p(x_self), _ld(x_self),
+                _p(w_packed), d_out, _p(_vec(ep_scale, d_out, "ep_scale")),
+                _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out) if out is not None else 0,
+                _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _p(tile_order))
+        plan = hub.desc_for(d_in, x.device) if hub is not None else None
+        if plan is not None:
+            rc = _lib.lib().glnn_sage_fused_plan_f32(*args, plan, _stream())
+        else:
+            rc = _lib.lib().glnn_sage_fused_f32(*args, _stream())
     _lib.check(rc, "glnn_sage_fused_f32")
     return out if w_next is None else (out, out_next)
 

@@ -105,6 +105,41 @@ GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, 
  * that sorts the tiles by their heaviest row (descending in-degree) starts the hub rows of a power-law graph first instead of wherever
  * their ids put them -- what matters for SHORT launches (a row shard's chunk: one 8 k-edge hub row is 100 us of a 0.7 ms launch). */
 
+/* ABI 9: HUB ROWS split over workgroups.  A destination row of more than glnn_hub_row_threshold() in-edges is always summed segment by
+ * segment (glnn_hub_segment_edges() edges each, fixed fold order inside a segment, segments added in ascending order) -- by the one
+ * workgroup that owns the row, or, given a plan, by one workgroup PER SEGMENT in a launch of its own in front of the aggregation, whose
+ * partial sums the row's owner then adds up.  Same bits either way; what changes is the tail of SHORT launches: a 17 k-edge row of the
+ * products graph keeps one workgroup busy for ~0.5 ms at d = 256, most of a row shard's 0.7 ms chunk launch (scripts/hub_tail_probe.py).
+ * The plan is per (indptr, n_dst) launch range and caller-built (one pass over the degrees: glnn_amd.ops.hub_plan):
+ *   rows      ascending ids v (relative to `indptr`) of the rows with indptr[v+1] - indptr[v] > threshold; a hub row that is not listed
+ *             is summed by its owner; a listed row must have exactly ceil(degree / segment_edges) segments
+ *   seg_ptr   [n_hub + 1] running segment count (seg_ptr[0] = 0, seg_ptr[n_hub] = n_seg)
+ *   slab      [slab_rows >= n_seg][ld_slab >= d rounded up to 4] floats of scratch, 16-byte aligned; overwritten by every call that is
+ *             given the plan (one stream at a time)
+ * Column-tiled launches (d > 256) ignore the plan.  The reference has no counterpart (dgl's SpMM is one launch, models.py:112,138). */
+typedef struct glnn_hub_plan {
+  const int64_t* rows;
+  const int32_t* seg_ptr;
+  int32_t n_hub, n_seg;
+  float* slab;
+  int64_t ld_slab, slab_rows;
+} glnn_hub_plan;
+GLNN_API int glnn_hub_row_threshold(void);
+GLNN_API int glnn_hub_segment_edges(void);
+GLNN_API int glnn_spmm_csr_plan_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                                    int64_t n_src, const float* x, int64_t ldx, int d, int mode,
+                                    const float* row_scale, const float* col_scale,
+                                    const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                                    const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                    int64_t ldo, const glnn_hub_plan* plan, void* stream);
+GLNN_API int glnn_sage_fused_plan_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                                      int64_t n_src, const float* x, int64_t ldx, int d_in,
+                                      const float* x_self, int64_t ld_self, const float* w_packed,
+                                      int d_out, const float* ep_scale, const float* ep_shift, int relu,
+                                      float* out, int64_t ldo, const float* w2_packed, int d_out2,
+                                      float* out2, int64_t ldo2, const int32_t* tile_order,
+                                      const glnn_hub_plan* plan, void* stream);
+
 /* in_deg[v] = t(indptr[v+1]-indptr[v]); out_deg[u] = t(#edges with source u), as floats, t = `transform`:
  *   GLNN_DEG_RAW          the degree itself            g.in_degrees() / g.out_degrees()
  *   GLNN_DEG_RSQRT_CLAMP1 deg.clamp(min=1) ** -0.5     the norm of dgl GraphConv(norm="both") and utils.py:178-179

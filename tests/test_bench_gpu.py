@@ -77,11 +77,12 @@ def test_bench_two_ranks_driver_launch_line(extra):
     n_pad = -(-out["config"]["nodes"] // 8) * 8        # work-balanced (uneven) row ranges pad every slot to the longest range
     # round 5: the driver passes no flags -- the layer-1 exchange form is chosen by timing both forms on this transport, and the line says so
     l1 = out["config"]["layer1_exchange"]
-    assert l1 in ("narrow", "wide") and ex["layer1_chosen"] == l1 and set(ex["layer1_autotune_ms"]) == {"narrow", "wide"}
-    assert ex["layer1_autotune_ms"][l1] == min(ex["layer1_autotune_ms"].values())
+    assert l1 in ("narrow", "wide") and ex["layer1_chosen"] == l1 and ex["chunks"] in (2, 4, 8)
+    assert set(ex["layer1_autotune_ms"]) == {f"{f}/{c}" for f in ("narrow", "wide") for c in (2, 4, 8)}       # form x chunks of the overlapped exchange
+    assert ex["layer1_autotune_ms"][f"{l1}/{ex['chunks']}"] == min(ex["layer1_autotune_ms"].values())
     per_node = 148 if l1 == "narrow" else 256 + 48
     assert 0 <= ex["GB_received_per_rank_per_forward"] - 4e-9 * n_pad * per_node < 0.15 * 4e-9 * n_pad * per_node, ex
-    assert ex["collectives_per_forward"] == 8
+    assert ex["collectives_per_forward"] == 2 * ex["chunks"]            # layer 1's and layer 3's payload, chunk by chunk
     assert ("global" in out["student"]["batchnorm"]) == bool(extra)
     # ... and the record can diagnose itself: the measured link rate, and per rank kernel time vs wall time = the exposed exchange
     assert ex["link_GBps_measured"] > 0 and ex["link_probe"]["narrow"]["correct"] and ex["link_probe"]["wide"]["correct"]

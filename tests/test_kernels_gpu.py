@@ -286,6 +286,63 @@ def test_aggregation_of_a_row_shard_keeps_the_hub_rows_busy():
         assert torch.equal(part, full[lo:hi])
 
 
+@pytest.mark.parametrize("d", [47, 100, 256])
+def test_hub_rows_split_over_workgroups_give_the_same_bits(d):
+    """ABI 9 (round 5): rows of more than glnn_hub_row_threshold() in-edges are summed segment by segment; with an ops.HubPlan the
+    segments are gathered by one workgroup each in a launch in front of the aggregation (the tail of a shard's short launches), without
+    one by the row's own workgroup -- the same numbers bit for bit: stand-alone aggregation (SAGE-gcn, and SUM with both scales), the
+    fused aggregate + project kernel with its chained projection, whole graph and row range, and all of them against the oracle.  The
+    graph holds several hub rows: one of ~9000 edges, a few of 1100-3000 (one exactly at the threshold: not a hub), ragged last segments."""
+    from glnn_amd import _lib, ops
+    thr, seg = _lib.lib().glnn_hub_row_threshold(), _lib.lib().glnn_hub_segment_edges()
+    n = 30000
+    rs = np.random.RandomState(d)
+    indptr0, indices0 = random_graph(n, 12, seed=d, power=0.7, isolated=3, hub=9000)
+    deg0 = np.diff(indptr0)
+    dst = np.repeat(np.arange(n), deg0)
+    extra_rows = rs.choice(n, 6, replace=False)
+    extra_deg = [thr + 1, thr + seg - 1, 2 * seg + 77, 3000, thr, 1500]          # (thr: stays with its owner)
+    src_x = [rs.randint(0, n, size=max(0, k - int(deg0[r]))) for r, k in zip(extra_rows, extra_deg)]
+    dst_x = [np.full(len(sx), r) for r, sx in zip(extra_rows, src_x)]
+    indptr, indices = csr_from_edges(np.concatenate([indices0] + src_x), np.concatenate([dst] + dst_x), n)
+    deg = np.diff(indptr)
+    assert (deg > thr).sum() >= 5 and deg.max() >= 9000
+    ip, ix = g2d(indptr, indices)
+    x = dev(rs.standard_normal((n, d)).astype(np.float32))
+    plan = ops.hub_plan(ip, n)
+    assert plan.n_hub == int((deg > thr).sum()) and plan.n_seg == int(((deg[deg > thr] + seg - 1) // seg).sum())
+    assert plan.rows.tolist() == np.flatnonzero(deg > thr).tolist()
+    # stand-alone SAGE-gcn aggregation
+    a0 = ops.spmm(ip, ix, x, n, ops.AGG_SAGE_GCN)
+    a1 = ops.spmm(ip, ix, x, n, ops.AGG_SAGE_GCN, hub=plan)
+    assert torch.equal(a0, a1)
+    np.testing.assert_allclose(a1[:, :d].cpu().numpy(), to.sage_gcn_agg(indptr, indices, x.cpu().numpy()), atol=TOL, rtol=0)
+    # a row range holding the big hub: its own plan, same rows
+    hub_row = int(np.argmax(deg))
+    lo, hi = max(0, hub_row - 700), min(n, hub_row + 900)
+    sub = ops.hub_plan(ip[lo:hi + 1], hi - lo)
+    part = ops.spmm(ip[lo:hi + 1], ix, x, hi - lo, ops.AGG_SAGE_GCN, x_self=x[lo:hi], hub=sub)
+    assert sub is not None and torch.equal(part, a0[lo:hi])
+    # SUM with row and column scales (GraphConv norm = both)
+    rsc, csc = dev(rs.uniform(.5, 1.5, n).astype(np.float32)), dev(rs.uniform(.5, 1.5, n).astype(np.float32))
+    s0 = ops.spmm(ip, ix, x, n, ops.AGG_SUM, row_scale=rsc, col_scale=csc)
+    s1 = ops.spmm(ip, ix, x, n, ops.AGG_SUM, row_scale=rsc, col_scale=csc, hub=plan)
+    assert torch.equal(s0, s1)
+    # fused aggregate + project (+ chained projection): plan == no plan, and close to aggregate-then-project in fp64
+    w = dev((rs.standard_normal((64, d)) / np.sqrt(d)).astype(np.float32))
+    w2 = dev((rs.standard_normal((10, 64)) / 8).astype(np.float32))
+    es, eh = dev(rs.uniform(.5, 1.5, 64).astype(np.float32)), dev(rs.standard_normal(64).astype(np.float32))
+    f0, c0 = ops.sage_fused(ip, ix, x, n, w, ep_scale=es, ep_shift=eh, relu=True, w_next=w2)
+    f1, c1 = ops.sage_fused(ip, ix, x, n, w, ep_scale=es, ep_shift=eh, relu=True, w_next=w2, hub=plan, tile_order=ops.fused_tile_order(ip, n))
+    assert torch.equal(f0, f1) and torch.equal(c0, c1)
+    want = torch.relu(a0[:, :d].double() @ w.double().t() * es.double() + eh.double())
+    np.testing.assert_allclose(f1[:, :64].cpu().numpy(), want.cpu().numpy(), atol=TOL, rtol=1e-5)
+    np.testing.assert_allclose(c1[:, :10].cpu().numpy(), (want @ w2.double().t()).cpu().numpy(), atol=TOL, rtol=1e-5)
+    # a graph without hub rows has no plan
+    ip2, _ = g2d(*random_graph(2000, 5, seed=1))
+    assert ops.hub_plan(ip2, 2000) is None
+
+
 def test_gemm_transpose_detecting():
     # A = I (padded) against an ASYMMETRIC B catches swapped C layouts
     from glnn_amd import ops
