@@ -47,10 +47,11 @@ constexpr int kBlock = 512;              // 8 waves
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kRowsPerWave = GLNN_ROWS_PER_WAVE;
 constexpr int kLongRow = GLNN_LONG_ROW;  // degree above which a whole workgroup takes the row
-// HUB rows (round 5): a row of more than kHubRow in-edges is summed SEGMENT BY SEGMENT -- kHubSeg = 512 edges, 64 per wave, the eight wave
-// partials folded as ((p0+p4)+(p1+p5))+((p2+p6)+(p3+p7)), the segments added in ascending order -- so that its segments can be gathered
-// by different workgroups (hub_gather_kernel, one workgroup per segment, into a slab the row's consumer adds up) without changing a bit:
-// with or without a plan, fused or stand-alone launch of a whole graph, a chunk or a shard, a hub row's sum is the same number.
+// HUB rows (round 5): a row of more than kHubRow in-edges is summed in SEGMENTS of kHubSeg = 512 edges, 64 per wave: wave w's share of the row
+// is the sum over the segments s (ascending) of P(s, w), its 64-edge piece of segment s gathered into a fresh accumulator; the eight shares
+// are folded like the eight wave partials of any long row.  So the pieces can be gathered by OTHER workgroups (hub_gather_kernel, one
+// workgroup per segment, into a slab the row's owner reads back) without changing a bit: with or without a plan, whole graph, chunk or
+// shard, a hub row's sum is the same number -- and without a plan the owner pays no barrier for it.
 // Why: a shard's chunk launch takes ~0.7 ms, one workgroup needs ~0.5 ms for a 17 k-edge row at D = 256 (scripts/hub_tail_probe.py).
 #ifndef GLNN_HUB_ROW
 #define GLNN_HUB_ROW 1024
@@ -63,7 +64,7 @@ struct HubPlan {
   const int64_t* rows;          // ascending row ids (relative to the launch's indptr), degree > kHubRow
   const int32_t* seg_ptr;       // [n_hub + 1] first segment of each hub row; seg_ptr[n_hub] = number of segments
   int n_hub;
-  float* slab;                  // [n_seg][ld_slab] partial sums, written by hub_gather_kernel
+  float* slab;                  // [8 n_seg][ld_slab] the wave partials P(s, w) at row 8 s + w, written by hub_gather_kernel
   int64_t ld_slab;
 };
 
@@ -262,18 +263,6 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
 }
 
 // ---- hub rows ---------------------------------------------------------------------------------------------------------
-// the eight wave partials of ONE segment -> its sum in lanes < LPR of wave 0 (other waves: garbage), through four LDS slots:
-// waves 4-7 park, waves 0-3 add theirs, wave 0 adds the four.  Two barriers; every wave of the workgroup must call it.
-template <int LPR>
-__device__ __forceinline__ float4 hub_fold8(float4 acc, float4 (*s_part)[64], int wave, int lane) {
-  if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
-  __syncthreads();
-  if (wave < 4 && lane < LPR) s_part[wave][lane] = add4(acc, s_part[wave][lane]);
-  __syncthreads();
-  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (wave == 0 && lane < LPR) t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
-  return t;
-}
 // index of row v in the plan (uniform), -1 if absent
 __device__ __forceinline__ int hub_find(const HubPlan& h, int64_t v) {
   int lo = 0, hi = h.n_hub - 1;
@@ -285,35 +274,32 @@ __device__ __forceinline__ int hub_find(const HubPlan& h, int64_t v) {
   }
   return -1;
 }
-// sum of a hub row's gathered source rows, valid in lanes < LPR of wave 0.  All 8 waves of the workgroup call it (uniform arguments).
+// THIS WAVE's share T_w of a hub row's sum (valid in lanes < LPR): the partial sums P(s, w) of its 64-edge piece of every segment s, each
+// gathered into a fresh accumulator, added in ascending s -- read from the plan's slab when hub_gather_kernel left them there, gathered
+// here otherwise.  The caller folds the eight shares exactly as it folds the eight wave partials of any long row.  No barrier.
 template <int LPR, int U, bool CS, bool XF>
-__device__ __forceinline__ float4 hub_row_sum(const HubPlan& h, const int32_t* __restrict__ indices, int64_t v, int64_t e0, int64_t e1,
-                                              const float* __restrict__ x, int64_t ldx, int col4, bool col_ok, const float* __restrict__ col_scale,
-                                              float4 (*s_part)[64], int wave, int lane, const XfCols& xf) {
+__device__ __forceinline__ float4 hub_wave_share(const HubPlan& h, const int32_t* __restrict__ indices, int64_t v, int64_t e0, int64_t e1,
+                                                 const float* __restrict__ x, int64_t ldx, int col4, bool col_ok, const float* __restrict__ col_scale,
+                                                 int wave, int lane, const XfCols& xf) {
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
   const int hi = h.n_hub > 0 ? hub_find(h, v) : -1;
   if (hi >= 0) {
-    // the segments were gathered by hub_gather_kernel: add them up in order
-    if (wave == 0 && lane < LPR && col_ok) {
+    if (lane < LPR && col_ok) {
       const int s0 = h.seg_ptr[hi], s1 = h.seg_ptr[hi + 1];
-      for (int sg = s0; sg < s1; ++sg) t = add4(t, ld4(h.slab + (int64_t)sg * h.ld_slab + col4));
+      for (int sg = s0; sg < s1; ++sg) t = add4(t, ld4(h.slab + ((int64_t)sg * 8 + wave) * h.ld_slab + col4));
     }
     return t;
   }
   for (int64_t b = e0; b < e1; b += kHubSeg) {
     const int64_t be = b + kHubSeg < e1 ? b + kHubSeg : e1;
-    const float4 acc = wave_gather_sum<LPR, U, CS, XF>(indices, b, be, wave, 8, x, ldx, col4, col_ok, col_scale, lane, xf);
-    const float4 sgm = hub_fold8<LPR>(acc, s_part, wave, lane);
-    t = add4(t, sgm);
-    __syncthreads();              // the slots are free again
+    t = add4(t, wave_gather_sum<LPR, U, CS, XF>(indices, b, be, wave, 8, x, ldx, col4, col_ok, col_scale, lane, xf));
   }
   return t;
 }
 
-// one workgroup per segment of a hub row: its partial sum -> slab[segment]
+// one workgroup per segment of a hub row: its eight wave partials -> slab[8 segment + wave]
 template <int LPR, int U, bool CS, bool XF>
 __global__ __launch_bounds__(kBlock) void hub_gather_kernel(const SpmmArgs a) {
-  __shared__ float4 s_part[4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col4 = (lane % LPR) * 4;
@@ -331,8 +317,7 @@ __global__ __launch_bounds__(kBlock) void hub_gather_kernel(const SpmmArgs a) {
   const int64_t e1r = a.indptr[v + 1];
   const int64_t e1 = e0 + kHubSeg < e1r ? e0 + kHubSeg : e1r;
   const float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, 8, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
-  const float4 t = hub_fold8<LPR>(acc, s_part, wave, lane);
-  if (wave == 0 && lane < LPR && col_ok) st4(a.hub.slab + (int64_t)sg * a.hub.ld_slab + col4, t);
+  if (lane < LPR && col_ok) st4(a.hub.slab + ((int64_t)sg * 8 + wave) * a.hub.ld_slab + col4, acc);
 }
 
 // ---- long-row role: scan a strided share of the rows, whole workgroup per long row (deterministic LDS fold) ----
@@ -359,14 +344,11 @@ __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int 
     for (int i = 0; i < n_found; ++i) {
       const int64_t v = s_rows[i];
       const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
-      if (e1 - e0 > kHubRow) {      // (uniform: every wave reads the same row)
-        const float4 t = hub_row_sum<LPR, U, CS, XF>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, a.col_scale, s_part, wave, lane, xf);
-        if (wave == 0 && lane < LPR && col_ok) finish_row<MODE, XF>(a, v, e1 - e0, t, col4, ep, xf);
-        __syncthreads();
-        continue;
-      }
-      float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok,
-                                                   a.col_scale, lane, xf);
+      float4 acc;
+      if (e1 - e0 > kHubRow)        // (uniform: every wave reads the same row)
+        acc = hub_wave_share<LPR, U, CS, XF>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, a.col_scale, wave, lane, xf);
+      else
+        acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
       if (lane < LPR) s_part[wave][lane] = acc;
       __syncthreads();
       if (wave == 0 && lane < LPR && col_ok) {
@@ -514,15 +496,16 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
     if (v >= a.n_dst) break;
     const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
     if (e1 - e0 <= kLongRow) continue;
-    float4 t;
-    if (e1 - e0 > kHubRow) {
-      t = hub_row_sum<LPR, U, false, false>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, nullptr, s_part, wave, lane, XfCols{});
-    } else {
-      // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
-      const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
-      t = hub_fold8<LPR>(acc, s_part, wave, lane);
-    }
+    const float4 acc = e1 - e0 > kHubRow
+        ? hub_wave_share<LPR, U, false, false>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, nullptr, wave, lane, XfCols{})
+        : wave_gather_sum<LPR, U, false>(a.indices, e0, e1, wave, kFusedWaves, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
+    // fold 8 wave partials through 4 LDS slots, fixed order: waves 4-7 park, waves 0-3 add theirs, wave 0 sums
+    if (wave >= 4 && lane < LPR) s_part[wave - 4][lane] = acc;
+    __syncthreads();
+    if (wave < 4 && lane < LPR) s_part[wave][lane] = add4(acc, s_part[wave][lane]);
+    __syncthreads();
     if (wave == 0 && lane < LPR && col4 < kpad) {
+      const float4 t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (col_ok) {
         const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
@@ -710,8 +693,8 @@ static int hub_plan_of(const glnn_hub_plan* plan, int d, HubPlan* h, int* n_seg,
   if (!plan || plan->n_hub == 0) return GLNN_OK;
   const int dpad = (d + 3) & ~3;
   GLNN_REQUIRE(plan->n_hub > 0 && plan->n_seg >= plan->n_hub && plan->rows && plan->seg_ptr && plan->slab, "%s: incomplete hub plan", who);
-  GLNN_REQUIRE(plan->ld_slab % 4 == 0 && plan->ld_slab >= dpad && plan->slab_rows >= plan->n_seg && glnn::aligned16(plan->slab),
-               "%s: the hub plan's slab needs >= %d rows of >= %d floats (ld multiple of 4), 16-byte aligned", who, plan->n_seg, dpad);
+  GLNN_REQUIRE(plan->ld_slab % 4 == 0 && plan->ld_slab >= dpad && plan->slab_rows >= 8 * (int64_t)plan->n_seg && glnn::aligned16(plan->slab),
+               "%s: the hub plan's slab needs >= %d rows (8 per segment) of >= %d floats (ld multiple of 4), 16-byte aligned", who, 8 * plan->n_seg, dpad);
   h->rows = plan->rows; h->seg_ptr = plan->seg_ptr; h->n_hub = plan->n_hub; h->slab = plan->slab; h->ld_slab = plan->ld_slab;
   *n_seg = plan->n_seg;
   return GLNN_OK;

@@ -184,7 +184,7 @@ class HubPlan:
             return None
         ld = (d + 3) // 4 * 4
         if self.slab is None or self.slab.shape[1] < ld:
-            self.slab = torch.empty(self.n_seg, ld, dtype=torch.float32, device=device)
+            self.slab = torch.empty(8 * self.n_seg, ld, dtype=torch.float32, device=device)      # (row 8 s + w: wave w's piece of segment s)
         p = self.desc
         p.rows, p.seg_ptr, p.n_hub, p.n_seg = _p(self.rows), _p(self.seg_ptr), self.n_hub, self.n_seg
         p.slab, p.ld_slab, p.slab_rows = _p(self.slab), self.slab.shape[1], self.slab.shape[0]

@@ -105,17 +105,19 @@ GLNN_API int glnn_sage_fused_f32(const int64_t* indptr, const int32_t* indices, 
  * that sorts the tiles by their heaviest row (descending in-degree) starts the hub rows of a power-law graph first instead of wherever
  * their ids put them -- what matters for SHORT launches (a row shard's chunk: one 8 k-edge hub row is 100 us of a 0.7 ms launch). */
 
-/* ABI 9: HUB ROWS split over workgroups.  A destination row of more than glnn_hub_row_threshold() in-edges is always summed segment by
- * segment (glnn_hub_segment_edges() edges each, fixed fold order inside a segment, segments added in ascending order) -- by the one
- * workgroup that owns the row, or, given a plan, by one workgroup PER SEGMENT in a launch of its own in front of the aggregation, whose
- * partial sums the row's owner then adds up.  Same bits either way; what changes is the tail of SHORT launches: a 17 k-edge row of the
- * products graph keeps one workgroup busy for ~0.5 ms at d = 256, most of a row shard's 0.7 ms chunk launch (scripts/hub_tail_probe.py).
- * The plan is per (indptr, n_dst) launch range and caller-built (one pass over the degrees: glnn_amd.ops.hub_plan):
+/* ABI 9: HUB ROWS split over workgroups.  A destination row of more than glnn_hub_row_threshold() in-edges is always summed in segments
+ * of glnn_hub_segment_edges() edges, 1/8 of a segment per wave: a wave's share of the row is the sum over the segments (ascending) of its
+ * piece of each, gathered into a fresh accumulator; the eight shares are folded like the wave partials of any long row.  The pieces are
+ * gathered by the one workgroup that owns the row, or, given a plan, by one workgroup PER SEGMENT in a launch of its own in front of the
+ * aggregation, whose partial sums the row's owner reads back.  Same bits either way; what changes is the tail of SHORT launches: a
+ * 17 k-edge row of the products graph keeps one workgroup busy for ~0.5 ms at d = 256, most of a row shard's 0.7 ms chunk launch
+ * (scripts/hub_tail_probe.py).  The plan is per (indptr, n_dst) launch range and caller-built (one pass over the degrees:
+ * glnn_amd.ops.hub_plan):
  *   rows      ascending ids v (relative to `indptr`) of the rows with indptr[v+1] - indptr[v] > threshold; a hub row that is not listed
  *             is summed by its owner; a listed row must have exactly ceil(degree / segment_edges) segments
  *   seg_ptr   [n_hub + 1] running segment count (seg_ptr[0] = 0, seg_ptr[n_hub] = n_seg)
- *   slab      [slab_rows >= n_seg][ld_slab >= d rounded up to 4] floats of scratch, 16-byte aligned; overwritten by every call that is
- *             given the plan (one stream at a time)
+ *   slab      [slab_rows >= 8 n_seg][ld_slab >= d rounded up to 4] floats of scratch (row 8 s + w = wave w's piece of segment s), 16-byte
+ *             aligned; overwritten by every call that is given the plan (one stream at a time)
  * Column-tiled launches (d > 256) ignore the plan.  The reference has no counterpart (dgl's SpMM is one launch, models.py:112,138). */
 typedef struct glnn_hub_plan {
   const int64_t* rows;
