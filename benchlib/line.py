@@ -98,6 +98,8 @@ def compact(r, detail_path):
         c["arxiv"] = {"error": _short(x["error"], 120)} if "error" in x else {
             "ms": x["ms_per_step"], "Gedges_per_s": x["value"] / 1e9, "verified": x.get("verified"), "student": x["student"]["metric"].split("(", 1)[-1].split(" ", 1)[0],
             "student_ms": x["student"]["ms_per_step"], "nodes": x["config"]["nodes"], "nnz": x["config"]["nnz"], "wall_s": round(x["wall_s"], 1)}
+    if r.get("placement"):      # gathered matrices placed by probe: [what, best ms, worst ms] of the candidates tried (products graph only)
+        c["placement"] = [[_short(q["what"], 40), min(q["ms"]), max(q["ms"])] for q in r["placement"][:4]]
     if "scale_model" in r:
         c["scale_model"] = {f: {"one_gpu_ms": o["one_gpu_forward_ms"],
                                 **{N: {"max_kernel_ms": w["max_kernel_ms"], "GB": w["max_GB_received_per_rank"], "link_ms": w["modelled_link_ms"],

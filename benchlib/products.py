@@ -293,6 +293,8 @@ def run_products(args, rank, world, dev, barrier):
         if not args.no_xl_leg:
             result["xl"] = child_leg("xl", ["--workload", "xl", "--steps", "5", "--warmup", "1"], 900)
 
+    if ops.PLACEMENT_LOG:       # which allocations were tried for the gathered matrices, and the probe ms of each (set-up, outside every timed region)
+        result["placement"] = list(ops.PLACEMENT_LOG)
     emit(result, args)
     if world > 1:
         dist.destroy_process_group()

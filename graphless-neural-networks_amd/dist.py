@@ -323,10 +323,19 @@ class ShardedTeacher:
         self._bufs = {}
         self._col_cache = {}
 
+    # buffers a later layer GATHERS from, and the row order their columns are addressed in (the others feed a GEMM or are outputs)
+    _GATHERED = {"ycm": "cm", "hwcm": "cm", "y": "own", "hw": "own"}
+
     def _full_buffer(self, key, d, device):
         k = (key, d)
         if k not in self._bufs:
-            self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
+            layout = self._GATHERED.get(key[0]) if isinstance(key, tuple) else None
+            if layout is not None and hasattr(self.be, "placed_for_gather") and self.sh.rows > 0:
+                # placed: the allocation in which a gather over this shard's edges runs fastest (ops.placed_for_gather, HIP backend only)
+                self._bufs[k] = self.be.placed_for_gather(self.sh.n_pad, d, device, self.g.indptr, self._cols(layout), self.sh.rows,
+                                                          what=f"ShardedTeacher {key[0]}{key[1]}", zero=True)
+            else:
+                self._bufs[k] = self.be.feat_empty(self.sh.n_pad, d, device, zero=True)
         return self._bufs[k]
 
     def _tile_order(self, off, nr):

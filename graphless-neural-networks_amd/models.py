@@ -210,6 +210,34 @@ class SAGE(nn.Module):
         raise NotImplementedError("SAGE._tail: LayerNorm has per-row statistics and cannot be folded into a kernel epilogue "
                                   "(SAGE.inference applies it as its own pass; the sharded teachers do not support it)")
 
+    # ---- placement of the matrices the whole-graph launches gather from (ops.placed_for_gather: which allocation holds a matrix
+    #      decides whether the gather over it takes 18.1 or 19.4 ms).  Intermediate activations live in buffers that are placed once per
+    #      (graph, layer) and reused by every later call -- they are internal: what inference RETURNS is always a fresh tensor; the input
+    #      features are copied once into a better allocation if one is found (remembered while the same unmodified tensor comes back).
+    def _placed_buffer(self, g, key, rows, d, device):
+        if not ops.placement_applies(rows, d):
+            return None
+        cache = self.__dict__.setdefault("_placed", {})
+        k = (id(g), key, rows, d, str(device))
+        ent = cache.get(k)
+        if ent is None or ent[0]() is not g:
+            import weakref
+            buf = ops.placed_for_gather(rows, d, device, g.indptr, g.indices, g.num_dst_nodes(), what=f"SAGE.inference {key[0]}{key[1]}", zero=True)
+            cache[k] = ent = (weakref.ref(g), buf)
+        return ent[1]
+
+    def _placed_input(self, g, feats, x):
+        if not ops.placement_applies(x.shape[0], x.shape[1]) or x.shape[0] < g.num_dst_nodes():
+            return x
+        import weakref
+        ent = self.__dict__.get("_placed_x")
+        sig = (id(g), feats.data_ptr(), tuple(feats.shape), feats._version)
+        if ent is not None and ent[0]() is feats and ent[1] == sig:
+            return ent[2]
+        px = ops.place_for_gather(x, g.indptr, g.indices, g.num_dst_nodes(), what="SAGE.inference features")
+        self.__dict__["_placed_x"] = (weakref.ref(feats), sig, px)
+        return px
+
     def inference(self, dataloader, feats, whole_graph=True):
         """Layer-wise full-neighbour inference (reference models.py:121-148).
 
@@ -221,6 +249,8 @@ class SAGE(nn.Module):
         whole_graph = whole_graph and getattr(dataloader, "graph", None) is not None     # loaders that do not sweep arange(N)
         with torch.no_grad():
             x = ops.as_feat(feats)
+            if whole_graph:
+                x = self._placed_input(dataloader.graph, feats, x)
             projected = None          # x @ W_l^T handed over by the previous (fused) layer when layer l projects first
             ln = self.norm_type == "layer"
             for l, layer in enumerate(self.layers):
@@ -240,10 +270,13 @@ class SAGE(nn.Module):
                         # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
                         _, projected = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale,
                                                       ep_shift=ep_shift, relu=relu, x_self=x[:n], w_next=nxt.fc_neigh.weight,
-                                                      want_out=False, tile_order=g.fused_tile_order())
+                                                      want_out=False, tile_order=g.fused_tile_order(),
+                                                      out_next=self._placed_buffer(g, ("proj", l), n, nxt._out_feats, x.device))
                         y = x                                                    # (not read: the next layer consumes `projected`)
                     else:
-                        y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
+                        # a hidden layer's rows are what the next layer gathers from: they go to a placed buffer kept across calls
+                        out = self._placed_buffer(g, ("y", l), n, layer._out_feats, x.device) if (nxt is not None and not post_ln) else None
+                        y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
                 else:
                     d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
                     y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132

@@ -35,11 +35,12 @@ class SAGEConv(nn.Module):
         """Aggregate-first layers with d_in, d_out <= 256 run on the single-launch K1F kernel."""
         return self._in_feats <= self._out_feats and self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256
 
-    def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False, w_packed=None):
+    def forward(self, graph, feat, ep_scale=None, ep_shift=None, relu=False, w_packed=None, out=None):
         """out = fc_neigh((sum_{u->v} h[u] + h_dst[v]) / (deg(v)+1)).  ep_* / relu: optional fused tail
         (eval-mode BatchNorm + ReLU of the caller) used by SAGE.inference; bias is folded by the caller then.
         w_packed: ops.pack_weight(fc_neigh.weight) of a caller that sweeps many blocks with the same weights (the chunked
-        inference loop packs once per layer instead of once per chunk)."""
+        inference loop packs once per layer instead of once per chunk).  out (inference only): where the layer's rows go
+        (SAGE.inference hands a placed buffer, ops.placed_for_gather, to the layers whose output the next layer gathers)."""
         h_src, h_dst = feat if isinstance(feat, tuple) else (feat, feat)
         n_dst = graph.num_dst_nodes()
         if h_dst.shape[0] != n_dst:
@@ -57,14 +58,14 @@ class SAGEConv(nn.Module):
             # project first (linear commutes with the mean): aggregate at the narrower width
             hw = ops.gemm(ops.as_feat(h_src), w)
             return ops.spmm(graph.indptr, graph.indices, hw, n_dst, ops.AGG_SAGE_GCN, ep_scale=ep_scale,
-                            ep_shift=shift, relu=relu)
+                            ep_shift=shift, relu=relu, out=out)
         if self._in_feats <= FUSED_SAGE_MAX_IN and self._out_feats <= 256:
             # aggregation + projection + epilogue in one launch: the aggregated rows never reach HBM
             order = graph.fused_tile_order() if n_dst == graph.n_dst else None
             return ops.sage_fused(graph.indptr, graph.indices, h_src, n_dst, w, ep_scale=ep_scale, ep_shift=shift, relu=relu,
-                                  x_self=h_dst, w_packed=w_packed, tile_order=order)
+                                  x_self=h_dst, w_packed=w_packed, tile_order=order, out=out)
         agg = ops.spmm(graph.indptr, graph.indices, h_src, n_dst, ops.AGG_SAGE_GCN)
-        return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu)
+        return ops.gemm(agg, w, ep_scale=ep_scale, ep_shift=shift, relu=relu, out=out)
 
 
 class GraphConv(nn.Module):

@@ -52,3 +52,8 @@ for trial in range(3):                                           # the same matr
         s.record(); f(); e.record(); e.synchronize()
         ts.append(s.elapsed_time(e))
     print(f"indices moved {trial} ptr {ix.data_ptr():#x} x ptr {src.data_ptr():#x}  {statistics.median(ts):7.3f} ms", flush=True)
+# several 2.5 GB source matrices alive at once (distinct physical memory), each timed; then the OUTPUT / index buffers likewise
+held = [src.clone() for _ in range(10)]
+for i, x in enumerate(held):
+    med, lo, hi = timed(x)
+    print(f"simultaneous alloc {i} ptr {x.data_ptr():#x}  {med:7.3f} ms (min {lo:.3f} max {hi:.3f})", flush=True)

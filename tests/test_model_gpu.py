@@ -499,6 +499,40 @@ def test_sage_inference_vs_oracle(dims, norm):
     np.testing.assert_allclose(got_chunked.cpu().numpy(), want, atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("dims", [[100, 256, 256, 47], [64, 48, 48, 12]])
+def test_sage_inference_with_placed_buffers_is_the_same_forward(dims, monkeypatch):
+    """Round 5: the matrices the whole-graph launches gather from -- the input features, a hidden layer's rows, the chained projection --
+    live in PLACED allocations (ops.placed_for_gather: several candidate allocations timed with a gather over the graph, the fastest
+    kept; on the full-size graph the same launch takes 18.1 or 19.4 ms depending on the allocation).  Placement chooses memory, nothing
+    else: the forward equals the unplaced one bit for bit, the buffers are reused by the next call, a modified feature tensor is
+    re-read, what inference returns is a fresh tensor every time, and the oracle agrees."""
+    from glnn_amd import ops
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader
+    n = 6000
+    indptr, indices = random_graph(n, 10, seed=dims[0], power=0.6, isolated=4, hub=1200)
+    x = np.random.RandomState(1).standard_normal((n, dims[0])).astype(np.float32)
+    model, layers, norms = _sage_model(dims, "batch", seed=2)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    loader = FullNeighborLoader(g, 512)
+    feats = torch.from_numpy(x).to(DEV)
+    monkeypatch.setattr(ops, "PLACEMENT_CANDIDATES", 1)                    # off: the plain allocations
+    plain = model.inference(loader, feats).clone()
+    monkeypatch.setattr(ops, "PLACEMENT_CANDIDATES", 4)
+    monkeypatch.setattr(ops, "PLACEMENT_MIN_BYTES", 0)                       # (the real threshold is 256 MB: matrices that miss the caches)
+    del ops.PLACEMENT_LOG[:]
+    a = model.inference(loader, feats)
+    tuned = [r["what"] for r in ops.PLACEMENT_LOG]
+    assert len(tuned) >= 2 and any("features" in w for w in tuned) and all(len(r["ms"]) == 4 and 0 <= r["chosen"] < 4 for r in ops.PLACEMENT_LOG)
+    b = model.inference(loader, feats)
+    assert len(ops.PLACEMENT_LOG) == len(tuned)                              # second call: every buffer reused, nothing tuned again
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a, b) and torch.equal(a, plain)
+    np.testing.assert_allclose(a.cpu().numpy(), to.sage_inference(indptr, indices, x, layers, norms), atol=TOL, rtol=0)
+    feats.mul_(0.5)                                                          # in place: the remembered copy of the features is stale
+    c = model.inference(loader, feats)
+    np.testing.assert_allclose(c.cpu().numpy(), to.sage_inference(indptr, indices, 0.5 * x, layers, norms), atol=TOL, rtol=0)
+    assert torch.equal(a, plain)                                             # earlier results are untouched by later calls
+
+
 def test_evaluate_sage_log_probs_and_score():
     from glnn_amd import train_and_eval as te
     from glnn_amd.graph import CSRGraph, FullNeighborLoader
