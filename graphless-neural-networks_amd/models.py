@@ -203,8 +203,16 @@ class SAGE(nn.Module):
         if self.activation is not F.relu and getattr(self.activation, "__name__", "") != "relu":
             raise NotImplementedError("SAGE.inference: the reference always passes activation=F.relu (models.py:371)")
         if self.norm_type == "batch":
-            s, sh = _bn_eval_fold(self.norms[l], bias)
-            return s, sh, True
+            # the fold is five small launches per layer: remembered while the BatchNorm's tensors and the bias are unmodified (torch's
+            # version counters + ops.PARAM_EPOCH, which this library's raw-pointer writers bump)
+            bn = self.norms[l]
+            ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var) + ((bias,) if bias is not None else ())
+            key = (ops.PARAM_EPOCH, bn.eps) + tuple((t.data_ptr(), t._version) for t in ts)
+            cache = self.__dict__.setdefault("_tail_cache", {})
+            ent = cache.get(l)
+            if ent is None or ent[0] != key:
+                cache[l] = ent = (key,) + _bn_eval_fold(bn, bias)
+            return ent[1], ent[2], True
         if self.norm_type == "none":
             return None, bias, True
         raise NotImplementedError("SAGE._tail: LayerNorm has per-row statistics and cannot be folded into a kernel epilogue "

@@ -288,6 +288,7 @@ class StudentEngine:
         trow = idx if target_rows is None else target_rows
         # nothing sits between the backward and Adam (no gradient exchange): the whole step is ONE C call, and Adam folds the
         # backward's gradient partials itself (glnn_mlp_train_step_f32)
+        ops.note_param_write()      # (the step writes parameters and BatchNorm buffers through raw pointers)
         one_call = self.grad_sync is None and self.exchange is None and getattr(self, "overlap", None) is None and self._one_call
         if one_call:
             ad = self.table.desc

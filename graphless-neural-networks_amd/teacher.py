@@ -305,6 +305,7 @@ class TeacherEngine:
         d.ws_loss, d.ws_loss_floats = ptr(self.ws_loss), self.ws_loss.numel()
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
         keep = [x]                                              # alive until the call below is queued (same-stream reuse is ordered)
+        ops.note_param_write()      # (running statistics are written through raw pointers; Adam follows)
         rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         if rc != 0:
             self.step_count -= 1          # the step never happened: Adam's bias correction and the dropout seeds stay where they were

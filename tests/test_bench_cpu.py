@@ -38,6 +38,8 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
                 "layers": [{"layer": long, "kernel": long, "bound": "hbm", "ms": 24.0, "frac": 0.72}, {"layer": long, "GB_received_per_rank": 44.8},
                            {"layer": long, "bound": "mfma", "ms": 56.0, "frac": 0.74}, {"layer": long, "bound": "hbm", "ms": 46.0, "frac": 0.73},
                            {"layer": long, "GB_received_per_rank": 16.0}, {"layer": long, "bound": "hbm", "ms": 12.0, "frac": 0.55}]},
+         "placement": [{"what": "SAGE.inference " + w, "rows": 2449029, "d": d, "ms": [18.5, 19.4, 18.1, 18.3, 18.6, 20.1, 18.2, 18.4], "chosen": 2}
+                       for w, d in (("features", 100), ("y0", 256), ("proj1", 47), ("y0 reordered", 256), ("features clustered", 100))],
          "arxiv": {"ms_per_step": 0.89, "value": 8.4e9, "verified": True, "wall_s": 15.0, "config": {"nodes": 169343, "nnz": 2484941, "workload": long},
                    "student": {"metric": "student distill steps/s (MLP3w4 128-1024-1024-40, B=512 per rank, " + long, "ms_per_step": 0.135}}}
     c = bench.compact(r, None)
@@ -50,6 +52,7 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 128 and c["student"]["frac_of_fp32_mfma_peak"] == 0.76
     assert set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"} and c["teacher_training"]["steps_per_s"] == 300.0
     assert c["xl"]["ms"] == 160.0 and c["xl"]["verified"] is True and [l["frac"] for l in c["xl"]["layers"]] == [0.72, 0.74, 0.73, 0.55]
+    assert len(c["placement"]) == 4 and c["placement"][1][1:] == [18.1, 20.1]
     assert c["arxiv"]["student"] == "MLP3w4" and c["arxiv"]["student_ms"] == 0.135 and c["arxiv"]["Gedges_per_s"] == 8.4
     r2 = dict(r, xl={"error": long, "wall_s": 1.0}, arxiv={"error": "rc 1: boom", "wall_s": 1.0})        # a failed leg is reported, the line survives
     c2 = bench.compact(r2, None)

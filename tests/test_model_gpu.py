@@ -533,6 +533,57 @@ def test_sage_inference_with_placed_buffers_is_the_same_forward(dims, monkeypatc
     assert torch.equal(a, plain)                                             # earlier results are untouched by later calls
 
 
+def test_remembered_packed_weights_and_folded_tails_follow_every_kind_of_parameter_update():
+    """SAGE.inference remembers the packed weights and the folded eval-mode BatchNorm tails across calls (round 5: eight small launches
+    of a ~0.9 ms arxiv forward).  They must follow the parameters however those change: an in-place torch update, load_state_dict, and the
+    writes THROUGH RAW POINTERS of this library's own training step (running statistics, fused Adam -- invisible to torch's version
+    counters: ops.PARAM_EPOCH).  After each, inference equals the oracle evaluated at the model's current state."""
+    from glnn_amd.graph import CSRGraph, FullNeighborLoader, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.teacher import TeacherEngine
+    dims, n = [24, 32, 32, 5], 3000
+    indptr, indices = random_graph(n, 8, seed=5, power=0.5, isolated=3)
+    x = np.random.RandomState(3).standard_normal((n, dims[0])).astype(np.float32)
+    labels = torch.from_numpy(np.random.RandomState(4).randint(0, dims[-1], n)).to(DEV)
+    model, _, _ = _sage_model(dims, "batch", seed=4)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    loader, feats = FullNeighborLoader(g, 512), torch.from_numpy(x).to(DEV)
+
+    def oracle_now():
+        sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        L = len(dims) - 1
+        layers = [dict(weight=sd[f"encoder.layers.{i}.fc_neigh.weight"], bias=sd[f"encoder.layers.{i}.fc_neigh.bias"]) for i in range(L)]
+        norms = [dict(weight=sd[f"encoder.norms.{i}.weight"], bias=sd[f"encoder.norms.{i}.bias"], running_mean=sd[f"encoder.norms.{i}.running_mean"],
+                      running_var=sd[f"encoder.norms.{i}.running_var"]) for i in range(L - 1)]
+        return to.sage_inference(indptr, indices, x, layers, norms)
+
+    def check(what):
+        model.eval()
+        got = model.inference(loader, feats).cpu().numpy()
+        want = oracle_now()
+        np.testing.assert_allclose(got, want, atol=TOL * max(1.0, float(np.abs(want).max())), rtol=0, err_msg=what)
+        return got
+
+    a = check("fresh model")
+    check("second call (everything remembered)")
+    with torch.no_grad():                                              # in-place torch updates: version counters
+        model.encoder.layers[0].fc_neigh.weight.mul_(1.5)
+        model.encoder.norms[1].running_var.add_(0.7)
+        model.encoder.layers[1].fc_neigh.bias.add_(0.3)
+    b = check("after in-place torch updates")
+    assert np.abs(a - b).max() > 1e-3
+    sd = {k: (v * 0.9 if v.dtype.is_floating_point else v) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    check("after load_state_dict")
+    opt = torch.optim.Adam(model.parameters(), lr=0.05)                # this library's training step: raw-pointer writes
+    model.train()
+    eng = TeacherEngine(model, opt)
+    nl = NodeDataLoader(g, torch.arange(1024), MultiLayerNeighborSampler([4, 4, 4]), batch_size=512, shuffle=False, seed=1)
+    for input_nodes, output_nodes, blocks in nl:
+        eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
+    c = check("after two TeacherEngine steps")
+    assert np.abs(b * 0 + c - a).max() > 1e-3
+
+
 def test_evaluate_sage_log_probs_and_score():
     from glnn_amd import train_and_eval as te
     from glnn_amd.graph import CSRGraph, FullNeighborLoader
