@@ -68,3 +68,16 @@ def kernel_breakdown(timing, steps):
             key = f"spmm d={info['d']}"
         per[key] = per.get(key, 0.0) + s.elapsed_time(e)
     return {k: v / steps for k, v in per.items()}
+
+
+def kernel_breakdown_median(timing, steps):
+    """As kernel_breakdown, but per launch family the MEDIAN over the forwards of the timed region instead of the mean: one stalled launch
+    in one forward (seen twice in the emulation runs of round 5: a single 38 ms spmm among 0.6 ms ones) does not define a rank's time.
+    Falls back to the mean when the records do not divide evenly into forwards."""
+    import statistics
+    if steps < 1 or len(timing) % steps:
+        return kernel_breakdown(timing, steps)
+    per_fwd = len(timing) // steps
+    fams = [kernel_breakdown(timing[i * per_fwd:(i + 1) * per_fwd], 1) for i in range(steps)]
+    return {k: statistics.median(f.get(k, 0.0) for f in fams) for k in fams[0]}
+

@@ -88,7 +88,7 @@ def run_emulated(args, dev):
                     torch.cuda.synchronize()
                     wall = 1e3 * (time.perf_counter() - t0) / steps
                     ops.set_timing(None)
-                kms = C.kernel_breakdown(timing, steps)
+                kms = C.kernel_breakdown_median(timing, steps)
                 fill = sum(s_.elapsed_time(e_) for _, _, s_, e_ in peers.events) / steps
                 c = want.shape[1]
                 diff = float((y[:, :c] - want[sh.lo:sh.hi, :c]).abs().max()) if sh.rows else 0.0
