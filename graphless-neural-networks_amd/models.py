@@ -222,7 +222,7 @@ class SAGE(nn.Module):
     #      decides whether the gather over it takes 18.1 or 19.4 ms).  Intermediate activations live in buffers that are placed once per
     #      (graph, layer) and reused by every later call -- they are internal: what inference RETURNS is always a fresh tensor; the input
     #      features are copied once into a better allocation if one is found (remembered while the same unmodified tensor comes back).
-    def _placed_buffer(self, g, key, rows, d, device):
+    def _placed_buffer(self, g, key, rows, d, device, probe=None):
         if not ops.placement_applies(rows, d):
             return None
         cache = self.__dict__.setdefault("_placed", {})
@@ -230,9 +230,41 @@ class SAGE(nn.Module):
         ent = cache.get(k)
         if ent is None or ent[0]() is not g:
             import weakref
-            buf = ops.placed_for_gather(rows, d, device, g.indptr, g.indices, g.num_dst_nodes(), what=f"SAGE.inference {key[0]}{key[1]}", zero=True)
+            buf = ops.placed_for_gather(rows, d, device, g.indptr, g.indices, g.num_dst_nodes(), what=f"SAGE.inference {key[0]}{key[1]}", zero=True,
+                                        probe=probe)
             cache[k] = ent = (weakref.ref(g), buf)
         return ent[1]
+
+    def _whole_graph_layer(self, l, g, x, projected, place=True):
+        """Layer l of the whole-graph sweep: (y, projected for layer l+1 or None).  place=False: plain allocations (the launch is being
+        used as the PROBE that places the buffer it gathers from -- see _placed_buffer)."""
+        layer = self.layers[l]
+        post_ln = self.norm_type == "layer" and l != self.num_layers - 1
+        ep_scale, ep_shift, relu = (None, layer.fc_neigh.bias, False) if post_ln else self._tail(l)
+        n = g.num_dst_nodes()
+        nxt = self.layers[l + 1] if l + 1 < self.num_layers else None
+        if projected is not None:
+            # the dense half of this layer already came out of the previous layer's kernel: aggregate + epilogue only
+            return ops.spmm(g.indptr, g.indices, projected, n, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu), None
+        if nxt is not None and layer.fused_eligible() and nxt._in_feats > nxt._out_feats and nxt._out_feats <= 256 \
+                and SAGE.CHAIN_NEXT_PROJECTION and not post_ln:
+            # layer l aggregates first in the fused kernel and layer l+1 projects first: chain W_{l+1} behind the
+            # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
+            out_next = self._placed_buffer(g, ("proj", l), n, nxt._out_feats, x.device) if place else None
+            _, proj = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
+                                     x_self=x[:n], w_next=nxt.fc_neigh.weight, want_out=False, tile_order=g.fused_tile_order(),
+                                     out_next=out_next)
+            return x, proj                                               # (y is not read: the next layer consumes `proj`)
+        out = None
+        if place and nxt is not None and not post_ln:
+            # a hidden layer's rows are what the next layer gathers from: they go to a placed buffer kept across calls, chosen by timing
+            # the NEXT layer's own launch on each candidate allocation
+            out = self._placed_buffer(g, ("y", l), n, layer._out_feats, x.device,
+                                      probe=lambda cand: self._whole_graph_layer(l + 1, g, cand, None, place=False))
+        y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+        if post_ln:
+            y = _eval_tail(self, l, y)
+        return y, None
 
     def _placed_input(self, g, feats, x):
         if not ops.placement_applies(x.shape[0], x.shape[1]) or x.shape[0] < g.num_dst_nodes():
@@ -265,26 +297,7 @@ class SAGE(nn.Module):
                 post_ln = ln and l != self.num_layers - 1      # LayerNorm -> ReLU as a pass of its own behind the conv (+ bias)
                 ep_scale, ep_shift, relu = (None, layer.fc_neigh.bias, False) if post_ln else self._tail(l)
                 if whole_graph:
-                    g = dataloader.graph
-                    n = g.num_dst_nodes()
-                    nxt = self.layers[l + 1] if l + 1 < self.num_layers else None
-                    if projected is not None:
-                        # the dense half of this layer already came out of the previous layer's kernel: aggregate + epilogue only
-                        y = ops.spmm(g.indptr, g.indices, projected, n, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu)
-                        projected = None
-                    elif nxt is not None and layer.fused_eligible() and nxt._in_feats > nxt._out_feats and nxt._out_feats <= 256 \
-                            and SAGE.CHAIN_NEXT_PROJECTION and not post_ln:
-                        # layer l aggregates first in the fused kernel and layer l+1 projects first: chain W_{l+1} behind the
-                        # epilogue, so the hidden activations of layer l never reach HBM (products: 2.5 GB written + read)
-                        _, projected = ops.sage_fused(g.indptr, g.indices, x, n, layer.fc_neigh.weight, ep_scale=ep_scale,
-                                                      ep_shift=ep_shift, relu=relu, x_self=x[:n], w_next=nxt.fc_neigh.weight,
-                                                      want_out=False, tile_order=g.fused_tile_order(),
-                                                      out_next=self._placed_buffer(g, ("proj", l), n, nxt._out_feats, x.device))
-                        y = x                                                    # (not read: the next layer consumes `projected`)
-                    else:
-                        # a hidden layer's rows are what the next layer gathers from: they go to a placed buffer kept across calls
-                        out = self._placed_buffer(g, ("y", l), n, layer._out_feats, x.device) if (nxt is not None and not post_ln) else None
-                        y = layer(g, (x, x[:n]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out)
+                    y, projected = self._whole_graph_layer(l, dataloader.graph, x, projected)
                 else:
                     d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
                     y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132
@@ -296,8 +309,6 @@ class SAGE(nn.Module):
                         if post_ln:
                             h = _eval_tail(self, l, h)
                         ops.scatter_rows(h, output_nodes, y)                             # y[output_nodes] = h
-                if post_ln and whole_graph:
-                    y = _eval_tail(self, l, y)
                 x = y
             return x
 

@@ -336,11 +336,17 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
 # offset inside an allocation (profiles/r05_bimodal_launch.txt, scripts/bimodal_probe.py): where the driver put the buffer's pages in
 # HBM.  A matrix that many launches will gather from is therefore PLACED: a few candidate allocations are timed with a gather over the
 # very graph and the fastest one is kept.  One-time set-up work per (graph, matrix), like the tile order or a hub plan; results are
-# untouched (it only chooses which memory holds the rows).  Only for matrices that miss the caches (>= PLACEMENT_MIN_BYTES) and that
-# fit several times (<= PLACEMENT_MAX_BYTES).
+# untouched (it only chooses which memory holds the rows).  Only for matrices far beyond the caches (>= PLACEMENT_MIN_BYTES) that still
+# fit many times (<= PLACEMENT_MAX_BYTES).
 import os as _os
-PLACEMENT_CANDIDATES = int(_os.environ.get("GLNN_PLACEMENT_CANDIDATES", "8"))      # <= 1: off (the first allocation is used)
-PLACEMENT_MIN_BYTES = 256 << 20
+PLACEMENT_CANDIDATES = int(_os.environ.get("GLNN_PLACEMENT_CANDIDATES", "12"))     # <= 1: off (the first allocation is used)
+# Candidates are made in groups of four with a BALLAST allocation between the groups (alive until the choice is made), so that the groups
+# come from different regions of HBM: in some processes every allocation of the first region is slow (scripts/placement_ballast_probe.py:
+# with three or four regions a 17.9-18.0 ms candidate was found in every one of five processes, the first region alone gave 17.96-18.45).
+# Ballast = this fraction of the free device memory, at most PLACEMENT_BALLAST_MAX bytes per gap; 0 = none.
+PLACEMENT_BALLAST_FRAC = float(_os.environ.get("GLNN_PLACEMENT_BALLAST_FRAC", "0.15"))
+PLACEMENT_BALLAST_MAX = 48 << 30
+PLACEMENT_MIN_BYTES = 1 << 30        # (matrices of 0.5-1 GB -- the products features, the 47-wide projection -- showed 1 % spreads: not worth a search)
 PLACEMENT_MAX_BYTES = 8 << 30
 PLACEMENT_LOG = []             # one record per tuned matrix: {"what", "rows", "d", "ms": [...], "chosen"} (bench.py prints it)
 
@@ -350,36 +356,51 @@ def placement_applies(rows, d):
     return PLACEMENT_CANDIDATES > 1 and PLACEMENT_MIN_BYTES <= nbytes <= PLACEMENT_MAX_BYTES
 
 
-def placed_for_gather(rows, d, device, indptr, indices, n_dst, what="", first=None, zero=False):
+def placed_for_gather(rows, d, device, indptr, indices, n_dst, what="", first=None, zero=False, probe=None):
     """An [rows, d] feature buffer for a matrix that launches over (indptr, indices) will gather from, in the allocation where that
     gather runs fastest among PLACEMENT_CANDIDATES tries (all alive at once, so that they are different memory; the losers are freed).
-    `first` (optional, [rows, d]): an existing buffer that competes as candidate 0 (returned itself if it wins).  The probe is the
-    stand-alone SAGE-gcn aggregation of the candidate (its CONTENT is irrelevant to the timing; candidates are zero-filled when
-    `zero`, else whatever the allocator left -- finite garbage is fine for a timing run, NaNs too)."""
+    `first` (optional, [rows, d]): an existing buffer that competes as candidate 0 (returned itself if it wins).  probe(candidate): the
+    launch to time -- the caller's own consumer of the matrix where it has one (SAGE.inference times the next layer's launch); default: the
+    stand-alone SAGE-gcn aggregation of the candidate.  (A candidate's CONTENT is irrelevant to the timing: zeros when `zero`, else
+    whatever the allocator left.)"""
     if not placement_applies(rows, d):
         return first if first is not None else feat_empty(rows, d, device, zero=zero)
-    cands = ([first] if first is not None else []) + [feat_empty(rows, d, device, zero=zero)
-                                                      for _ in range(PLACEMENT_CANDIDATES - (1 if first is not None else 0))]
-    scratch = feat_empty(n_dst, d, device)
+    # (What makes an allocation slow is its physical backing: the same virtual addresses gather in 18.0 ms when the request was served from
+    #  an unfragmented free pool and in 19.0-19.5 ms when small allocations were made in between, or out of a re-used cached block with
+    #  that history: scripts/placement_cause_probe.py, profiles/r05_placement_cause.txt.  Not predictable from here -- hence the probe.)
+    cands, ballast = ([first] if first is not None else []), []
+    while len(cands) < PLACEMENT_CANDIDATES:
+        if len(cands) and len(cands) % 4 == 0 and PLACEMENT_BALLAST_FRAC > 0:
+            free = torch.cuda.mem_get_info(device)[0]
+            nbytes = int(min(PLACEMENT_BALLAST_FRAC * free, PLACEMENT_BALLAST_MAX))
+            if nbytes >= (1 << 30) and free - nbytes > 8 * 4 * rows * round4(d):      # (never squeeze the candidates themselves)
+                ballast.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+        cands.append(feat_empty(rows, d, device, zero=zero))
+    scratch = None
+    if probe is None:
+        scratch = feat_empty(n_dst, d, device)
+
+        def probe(c):
+            _lib.check(_spmm_call(indptr, indices, n_dst, rows, c, d, AGG_SAGE_GCN, None, None, None, None, False, scratch,
+                                  c[:n_dst] if rows >= n_dst else c, None), "glnn_spmm_csr_f32 (placement probe)")
     ms = []
     for c in cands:
-        _spmm_call(indptr, indices, n_dst, rows, c, d, AGG_SAGE_GCN, None, None, None, None, False, scratch, c[:n_dst] if rows >= n_dst else c, None)
+        probe(c)
         best = None
-        for _ in range(2):
+        for _ in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            rc = _spmm_call(indptr, indices, n_dst, rows, c, d, AGG_SAGE_GCN, None, None, None, None, False, scratch,
-                            c[:n_dst] if rows >= n_dst else c, None)
+            probe(c)
             e1.record()
             e1.synchronize()
-            _lib.check(rc, "glnn_spmm_csr_f32 (placement probe)")
             t = e0.elapsed_time(e1)
             best = t if best is None else min(best, t)
         ms.append(best)
     k = min(range(len(cands)), key=lambda i: ms[i])
     PLACEMENT_LOG.append({"what": what, "rows": int(rows), "d": int(d), "ms": [round(v, 3) for v in ms], "chosen": k})
     keep = cands[k]
-    del cands, scratch
+    del cands, scratch, ballast
+    torch.cuda.empty_cache()          # the losers and the ballast go back to the driver, not into the caching allocator's pool
     return keep
 
 

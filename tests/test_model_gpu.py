@@ -522,7 +522,8 @@ def test_sage_inference_with_placed_buffers_is_the_same_forward(dims, monkeypatc
     del ops.PLACEMENT_LOG[:]
     a = model.inference(loader, feats)
     tuned = [r["what"] for r in ops.PLACEMENT_LOG]
-    assert len(tuned) >= 2 and any("features" in w for w in tuned) and all(len(r["ms"]) == 4 and 0 <= r["chosen"] < 4 for r in ops.PLACEMENT_LOG)
+    assert len(tuned) >= 2 and any("features" in w for w in tuned) and any("y0" in w for w in tuned)
+    assert all(len(r["ms"]) == 4 and 0 <= r["chosen"] < 4 for r in ops.PLACEMENT_LOG)
     b = model.inference(loader, feats)
     assert len(ops.PLACEMENT_LOG) == len(tuned)                              # second call: every buffer reused, nothing tuned again
     assert a.data_ptr() != b.data_ptr() and torch.equal(a, b) and torch.equal(a, plain)
