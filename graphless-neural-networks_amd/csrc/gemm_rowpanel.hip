@@ -293,6 +293,10 @@ __device__ __forceinline__ rw_i32x4 rw_rsrc(const float* base, int64_t bytes) { 
   asm volatile("buffer_store_dword %0, %1, %2, %3 offen offset:%4" : : "v"(VAL_), "v"(VOFF_), "s"(RSRC_), "s"(SOFF_), "n"(OFF_) : "memory")
 
 constexpr int kRwRows = 32;       // rows of A per wave tile
+#ifndef GLNN_RW_LOAD_GROUP
+#define GLNN_RW_LOAD_GROUP 4
+#endif
+constexpr int kRwLoadGroup = GLNN_RW_LOAD_GROUP;      // (1 / 2 / 4 / 16 measured 1170 / 1165 / 1152 / 1221 us on 2.45 M x 100 x 256: profiles/r05_k3_power.txt)
 constexpr int kRwWaves = 8;       // waves per workgroup: two per SIMD (4: no neighbour to hide the store phase; 12: measured equal, and KG = 16 spilled)
 
 template <int KG, bool RELU>
@@ -431,12 +435,9 @@ __global__ __launch_bounds__(64 * kRwWaves) void gemm_rowwalk_kernel(const RpArg
         constexpr int kn = (kg + 1) % KG;
         RW_DS_READ(fb[j], bp, (32 * j * KS + 8 * kn) * 4);
       }
-#ifndef GLNN_RW_LOAD_GROUP
-#define GLNN_RW_LOAD_GROUP 4
-#endif
-      // the next tile's fragments of the k-groups that are done: one by one, or GLNN_RW_LOAD_GROUP of them together (a 128-byte line of A
-      // holds four k-groups of a row: requested back to back they meet in the vector cache instead of four separate trips to L2)
-      constexpr int LG = GLNN_RW_LOAD_GROUP;
+      // the next tile's fragments of the k-groups that are done, kRwLoadGroup of them together (a 128-byte line of A holds four k-groups
+      // of a row: requested back to back they meet in the vector cache instead of four separate trips to L2)
+      constexpr int LG = kRwLoadGroup;
       if constexpr (mm == 15 && (kg % LG == LG - 1 || kg == KG - 1)) {
         constexpr int g0 = kg - kg % LG;
         rw_static_for<kg - g0 + 1>([&](auto q_) {
