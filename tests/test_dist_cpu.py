@@ -398,6 +398,39 @@ def test_stat_exchange_hook_world2_gloo():
         np.testing.assert_allclose(m2 / n, z.var(0), atol=1e-6)
 
 
+def _probe_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from glnn_amd.dist import probe_link
+        q.put((rank, probe_link(world, rank, 50_000, "cpu", reps=2)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_link_probe_measures_an_in_place_all_gather_and_returns_the_same_record_on_every_rank(world):
+    """dist.probe_link (round 5: what bench.py --gpus N runs before it picks its exchange form): an in-place all-gather of one slab per
+    rank on the job's own transport, checked for content; seconds = the maximum over ranks, so every rank derives the same rates."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    first = res[0][1]
+    assert first["correct"] and first["backend"] == "gloo" and first["reps"] == 2 and abs(first["slab_MB"] - 0.2) < 1e-9
+    assert first["seconds"] > 0 and abs(first["received_GBps"] - (world - 1) * first["per_link_GBps"]) < 1e-9 * first["received_GBps"] + 1e-12
+    assert abs(first["per_link_GBps"] - 4.0 * 50_000 / first["seconds"] / 1e9) < 1e-12
+    for _, rec in res[1:]:
+        assert rec == first
+
+
 def _emu_setup(n, dims, seed, clustered=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
