@@ -31,7 +31,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n_b = 0
 for b in loader:
     n_b += 1
-    last = b
+    if n_b == 1:
+        last = b            # a FULL batch (the epoch's last one is the remainder)
     if n_b == min(50, len(loader)):
         break
 torch.cuda.synchronize(); t_s = (time.perf_counter() - t0) / n_b
