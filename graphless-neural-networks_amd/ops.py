@@ -369,13 +369,20 @@ def placed_for_gather(rows, d, device, indptr, indices, n_dst, what="", first=No
     #  an unfragmented free pool and in 19.0-19.5 ms when small allocations were made in between, or out of a re-used cached block with
     #  that history: scripts/placement_cause_probe.py, profiles/r05_placement_cause.txt.  Not predictable from here -- hence the probe.)
     cands, ballast = ([first] if first is not None else []), []
-    while len(cands) < PLACEMENT_CANDIDATES:
-        if len(cands) and len(cands) % 4 == 0 and PLACEMENT_BALLAST_FRAC > 0:
-            free = torch.cuda.mem_get_info(device)[0]
-            nbytes = int(min(PLACEMENT_BALLAST_FRAC * free, PLACEMENT_BALLAST_MAX))
-            if nbytes >= (1 << 30) and free - nbytes > 8 * 4 * rows * round4(d):      # (never squeeze the candidates themselves)
-                ballast.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
-        cands.append(feat_empty(rows, d, device, zero=zero))
+    try:
+        while len(cands) < PLACEMENT_CANDIDATES:
+            if len(cands) and len(cands) % 4 == 0 and PLACEMENT_BALLAST_FRAC > 0:
+                free = torch.cuda.mem_get_info(device)[0]
+                nbytes = int(min(PLACEMENT_BALLAST_FRAC * free, PLACEMENT_BALLAST_MAX))
+                if nbytes >= (1 << 30) and free - nbytes > 8 * 4 * rows * round4(d):      # (never squeeze the candidates themselves)
+                    ballast.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+            cands.append(feat_empty(rows, d, device, zero=zero))
+    except torch.cuda.OutOfMemoryError:
+        # a device shared with other tenants (or nearly full): the search is an optimisation -- choose among what did fit
+        del ballast[:]
+        torch.cuda.empty_cache()
+        if not cands:
+            cands.append(feat_empty(rows, d, device, zero=zero))      # (the caller's own allocation: let ITS failure surface)
     scratch = None
     if probe is None:
         scratch = feat_empty(n_dst, d, device)

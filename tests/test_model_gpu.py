@@ -534,6 +534,28 @@ def test_sage_inference_with_placed_buffers_is_the_same_forward(dims, monkeypatc
     assert torch.equal(a, plain)                                             # earlier results are untouched by later calls
 
 
+def test_placement_search_on_a_full_device_uses_the_candidates_that_fit(monkeypatch):
+    """The placement search is an optimisation: when the device runs out of memory while candidates are being allocated (other tenants,
+    two ranks on one GPU) it chooses among the ones that did fit instead of failing the forward."""
+    from glnn_amd import ops
+    n, d = 3000, 64
+    indptr, indices = random_graph(n, 6, seed=3)
+    ip, ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    monkeypatch.setattr(ops, "PLACEMENT_CANDIDATES", 6)
+    monkeypatch.setattr(ops, "PLACEMENT_MIN_BYTES", 0)
+    real, calls = ops.feat_empty, []
+
+    def short_of_memory(rows, dd, device, zero=False):
+        calls.append(rows)
+        if len(calls) > 2:
+            raise torch.cuda.OutOfMemoryError("no memory for candidate %d" % len(calls))
+        return real(rows, dd, device, zero=zero)
+    monkeypatch.setattr(ops, "feat_empty", short_of_memory)
+    del ops.PLACEMENT_LOG[:]
+    buf = ops.placed_for_gather(n, d, torch.device(DEV), ip, ix, n, what="test", probe=lambda c: c.zero_())
+    assert buf.shape == (n, d) and len(ops.PLACEMENT_LOG) == 1 and len(ops.PLACEMENT_LOG[0]["ms"]) == 2
+
+
 def test_remembered_packed_weights_and_folded_tails_follow_every_kind_of_parameter_update():
     """SAGE.inference remembers the packed weights and the folded eval-mode BatchNorm tails across calls (round 5: eight small launches
     of a ~0.9 ms arxiv forward).  They must follow the parameters however those change: an in-place torch update, load_state_dict, and the
