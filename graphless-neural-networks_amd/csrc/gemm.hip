@@ -634,9 +634,15 @@ template <> struct PipeOp<KROW> {
 #define GLNN_PIPE_BLOCK_TILES 8
 #endif
 constexpr int PIPE_BLOCK_TILES = GLNN_PIPE_BLOCK_TILES;      // k-tiles (of 32) per accumulation block: a power of two >= 2
-template <int SA, int SB>
+// AX (KROW A only, round 5): the A operand is alpha[col] * a + beta[col] * z + gamma[col] with a second matrix z of A's shape and per-column
+// constants -- the BatchNorm backward's dz written as an affine map of (dy, z), glnn::BnApplyA -- evaluated on the staged piece between its
+// s_waitcnt and its ds_write_b128 (two v_pk_fma_f32 pairs per piece: the only VALU work of the loop); z pieces ride behind the A pieces
+// in the load order (12 loads per k-tile in flight instead of 8).  Rows behind the descriptors' end are gamma, against B rows that are 0.
+struct PipeAx { const float* z0; int64_t ldz; const float* alpha; const float* beta; const float* gamma; };
+template <int SA, int SB, bool AX = false>
 __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int64_t ext_a, const float* b0, int64_t ldb, int64_t ext_b,
-                                              int64_t kext, int nk, f32x16 (&acc)[2][2]) {
+                                              int64_t kext, int nk, f32x16 (&acc)[2][2], const PipeAx* ax = nullptr) {
+  static_assert(!AX || SA == KROW, "the operand transform is stated for the k-major A of the weight-gradient product");
   using OA = PipeOp<SA>;
   using OB = PipeOp<SB>;
   constexpr int A_OFF = 0, B_OFF = 2 * OA::TILE;
@@ -686,6 +692,24 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   setup(std::integral_constant<int, SB>{}, ldb, ext_b, wn, lds0 + B_OFF, voff + 4, wr_b, rd_b, step_b);
 
   f32x4 st[8];                           // the staged tile: one float4 per piece
+  // AX: the z pieces next to the A pieces, their descriptor / offsets / step, and the lane's per-column constants
+  f32x4 zt[4];
+  i32x4 rsrc_z = rsrc_a;
+  uint32_t voff_z[4] = {0, 0, 0, 0}, step_z = 0;
+  f32x4 ax_al = {0.f, 0.f, 0.f, 0.f}, ax_be = ax_al, ax_ga = ax_al;
+  if constexpr (AX) {
+    const int kr = tid >> 5;
+    int64_t n4 = (tid & 31) * 4;
+    if (n4 > ext_a - 4) n4 = ext_a - 4;
+    rsrc_z = make_rsrc(ax->z0, ((kext - 1) * ax->ldz + ext_a) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) voff_z[q] = (uint32_t)(((kr + 8 * q) * ax->ldz + n4) * 4);
+    step_z = (uint32_t)(32 * ax->ldz * 4);
+    ax_al = *reinterpret_cast<const f32x4*>(ax->alpha + n4);
+    ax_be = *reinterpret_cast<const f32x4*>(ax->beta + n4);
+    ax_ga = *reinterpret_cast<const f32x4*>(ax->gamma + n4);
+  }
+  auto soff_z = [&](int kt) { return kt < nk ? (uint32_t)kt * step_z : (uint32_t)rsrc_z.z; };
   // SGPR offset of k-tile kt (uniform: SALU).  A tile past the end gets the descriptor's own size as offset: every lane is out of
   // range and reads 0 without touching memory -- the prefetches behind the last tile, and the zero tile that pads an odd tile count
   auto soff_a = [&](int kt) { return kt < nk ? (uint32_t)kt * step_a : (uint32_t)rsrc_a.z; };
@@ -697,10 +721,18 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     static_for<8>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
       (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb;   // asm-only operands are not captured implicitly (clang)
-      if constexpr (p < 4) GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
-      else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
+      (void)zt; (void)voff_z; (void)rsrc_z;
+      if constexpr (p < 4) {
+        GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+        if constexpr (AX) GLNN_BLOAD(zt[p], voff_z[p], rsrc_z, sa);
+      } else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
     });
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7]) : : "memory");
+    if constexpr (AX) {
+      asm volatile("" : "+v"(zt[0]), "+v"(zt[1]), "+v"(zt[2]), "+v"(zt[3]) : : "memory");      // (landed with the wait above)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) st[p] = st[p] * ax_al + (zt[p] * ax_be + ax_ga);
+    }
     static_for<8>([&](auto p_) {
       constexpr int p = decltype(p_)::value;
       (void)wr_a; (void)wr_b; (void)st;
@@ -736,12 +768,13 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   // one k-tile out of LDS buffer CUR; tile kt+1 goes registers -> buffer CUR^1, tile kt+2 global -> registers.  The two
   // staging pieces of a k-group sit behind MFMA slots PH and PH+7 (giving every wave of the workgroup its own PH -- four copies
   // of the loop -- so that the waves do not hand their ds_write_b128 to the LDS store path in the same slot measured equal).
-  auto ktile = [&](auto cur_, auto ph_, uint32_t sa, uint32_t sb) {
+  auto ktile = [&](auto cur_, auto ph_, uint32_t sa, uint32_t sb, uint32_t sz) {
     constexpr int CUR = decltype(cur_)::value, PH = decltype(ph_)::value;
     static_for<64>([&](auto m_) {
       constexpr int kg = decltype(m_)::value / 16, mm = decltype(m_)::value % 16;
       constexpr int par = kg & 1;
       (void)wr_a; (void)wr_b; (void)sa; (void)sb; (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)fa; (void)fb; (void)acc;
+      (void)sz; (void)zt; (void)voff_z; (void)rsrc_z; (void)ax_al; (void)ax_be; (void)ax_ga;
       // ^ operands that appear only inside asm / discarded branches are not captured implicitly (clang)
       if constexpr (mm == 0) {
         // fragments of this group: issued >= 4 MFMAs ago; the previous group's second ds_write follows them only if its slot
@@ -756,11 +789,15 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
       if constexpr (SA == KROW && SB == ROWK) GLNN_MFMA(acc[i][j], fa[par].h[i][t / 2][t % 2], fb[par].q[j][t]);
       if constexpr (mm == PH || mm == PH + 7) {
         constexpr int p = 2 * kg + (mm == PH + 7 ? 1 : 0);
-        // piece p: the load issued one k-tile ago has 7 younger ones behind it
-        asm volatile("s_waitcnt vmcnt(7)" : "+v"(st[p]) : : "memory");
+        // piece p: the load issued one k-tile ago has 7 younger ones behind it (AX: an A piece and its z piece have 10 behind them, a B piece 11)
+        if constexpr (!AX) asm volatile("s_waitcnt vmcnt(7)" : "+v"(st[p]) : : "memory");
+        else if constexpr (p < 4) asm volatile("s_waitcnt vmcnt(10)" : "+v"(st[p]), "+v"(zt[p]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" : "+v"(st[p]) : : "memory");
         if constexpr (p < 4) {
+          if constexpr (AX) st[p] = st[p] * ax_al + (zt[p] * ax_be + ax_ga);
           GLNN_DS_WRITE(wr_a, st[p], (CUR ^ 1) * OA::TILE + p * OA::PIECE);
           GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+          if constexpr (AX) GLNN_BLOAD(zt[p], voff_z[p], rsrc_z, sz);
         } else {
           GLNN_DS_WRITE(wr_b, st[p], (CUR ^ 1) * OB::TILE + (p - 4) * OB::PIECE);
           GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
@@ -780,12 +817,14 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
   // cannot see that an asm load has not landed yet, so the loaded values must not cross a branch where it could copy them
   auto kloop = [&](auto ph_) {
     {
-      const uint32_t sa = soff_a(1), sb = soff_b(1);
+      const uint32_t sa = soff_a(1), sb = soff_b(1), sz = soff_z(1);
       static_for<8>([&](auto p_) {
         constexpr int p = decltype(p_)::value;
-        (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb;
-        if constexpr (p < 4) GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
-        else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
+        (void)st; (void)voff; (void)rsrc_a; (void)rsrc_b; (void)sa; (void)sb; (void)sz; (void)zt; (void)voff_z; (void)rsrc_z;
+        if constexpr (p < 4) {
+          GLNN_BLOAD(st[p], voff[p], rsrc_a, sa);
+          if constexpr (AX) GLNN_BLOAD(zt[p], voff_z[p], rsrc_z, sz);
+        } else GLNN_BLOAD(st[p], voff[p], rsrc_b, sb);
       });
     }
     static_for<NR>([&](auto r_) {
@@ -794,8 +833,8 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
     // always an even number of k-tiles (an odd count is padded with one all-zero tile): a separate tail after the loop is a
     // control-flow join, where the compiler may copy the staged registers -- while their asm loads are still in flight
     for (int kt = 0; kt < nk; kt += 2) {
-      ktile(std::integral_constant<int, 0>{}, ph_, soff_a(kt + 2), soff_b(kt + 2));
-      ktile(std::integral_constant<int, 1>{}, ph_, soff_a(kt + 3), soff_b(kt + 3));
+      ktile(std::integral_constant<int, 0>{}, ph_, soff_a(kt + 2), soff_b(kt + 2), soff_z(kt + 2));
+      ktile(std::integral_constant<int, 1>{}, ph_, soff_a(kt + 3), soff_b(kt + 3), soff_z(kt + 3));
       // blocked accumulation: the MFMA chain of an output element is cut every PIPE_BLOCK_TILES k-tiles (256 k) and its partial sum
       // moved into `tot` by VALU adds -- 32 v_pk_add + 32 v_mov_b64 per wave and block.  fp32 rounding noise of a 4096 x K x 2048
       // product against fp64 (scripts/gemm_noise.py, rms relative): one chain 5.7e-7 / 8.1e-7 / 1.15e-6 at K = 1024 / 2048 / 4096
@@ -929,6 +968,8 @@ struct GemmTnArgs {
   int splits; int64_t rows_per_split;
   int a_vec; int b_vec;
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
+  // gemm_tn_kernel_pipe_ax only: A = ax_alpha * a + ax_beta * ax_z + ax_gamma per column (glnn::BnApplyA)
+  const float* ax_z; int64_t ax_ldz; const float* ax_alpha; const float* ax_beta; const float* ax_gamma;
 };
 
 template <int BNT>
@@ -1296,7 +1337,8 @@ __global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const TnMultiArgs mm
 
 // PIPE form of the 128 x 128 weight-gradient tile (see pipe_mainloop): both operands are k(m)-major, so both take the
 // KROW path -- no register transpose, no VALU in the loop.  Plain B, no gather, every split a whole number of k-tiles.
-__global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
+template <bool AX>
+__device__ __forceinline__ void gemm_tn_pipe_body(const GemmTnArgs& g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kk = lane >> 5;
   const int i0 = blockIdx.x * 128, j0 = blockIdx.y * 128;
@@ -1310,8 +1352,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  pipe_mainloop<KROW, KROW>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
-                            ((g.nb + 3) & ~3) - j0, mend - mbeg, (int)((mend - mbeg + BK - 1) / BK), acc);
+  if constexpr (AX) {
+    const PipeAx ax = {g.ax_z + mbeg * g.ax_ldz + i0, g.ax_ldz, g.ax_alpha + i0, g.ax_beta + i0, g.ax_gamma + i0};
+    pipe_mainloop<KROW, KROW, true>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
+                                    ((g.nb + 3) & ~3) - j0, mend - mbeg, (int)((mend - mbeg + BK - 1) / BK), acc, &ax);
+  } else {
+    pipe_mainloop<KROW, KROW>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
+                              ((g.nb + 3) & ~3) - j0, mend - mbeg, (int)((mend - mbeg + BK - 1) / BK), acc);
+  }
   float* cbase = g.c + (g.splits > 1 ? (int64_t)blockIdx.z * g.ka * g.ldc : 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1325,6 +1373,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) {
       }
   }
 }
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel_pipe(const GemmTnArgs g) { gemm_tn_pipe_body<false>(g); }
+// the same product with A = alpha * a + beta * z + gamma evaluated on the staged pieces (glnn::BnApplyA; pipe_mainloop<.., AX>)
+__global__ __launch_bounds__(256) void gemm_tn_kernel_pipe_ax(const GemmTnArgs g) { gemm_tn_pipe_body<true>(g); }
 
 // sum the split partials: c[i] = sum_s ws[s][i]   (fixed order => deterministic)
 // Many splits (the weight gradient over tens of thousands of rows: 64 slabs of a 256 x 256 output): one thread per float4 walking
@@ -1838,10 +1890,19 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
 // split reduction is skipped and *defer describes the slabs (same order as the fold kernel that would have run: four interleaved
 // lanes from 16 splits on, k ascending below); with `defer_colsum` the second stage of col_sum_a likewise.  *used_floats = the
 // workspace prefix that then has to stay untouched until Adam has run.
+// would gemm_tn(..., bn) take this product (the pipelined 128 x 128 kernel with plain float4-addressable operands)?  The caller decides
+// BEFORE it leaves dz unwritten; the one condition not covered is the split of the reduction, which needs rows_per_split x ld < 2^28
+// (any workspace that lets the output split into ~256 workgroups does)
+bool glnn::gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz) {
+  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (ldz % 4 == 0) && glnn::aligned16(a) && glnn::aligned16(b) && glnn::aligned16(z);
+  const bool fast = vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) && ldz >= ((ka + 3) & ~3);
+  return m >= 1 && ka % 4 == 0 && fast && nb > 64 && pipe_enabled() && lda < (1 << 20) && ldb < (1 << 20) && ldz < (1 << 20);
+}
+
 int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                   const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                   uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream,
-                  GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats) {
+                  GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats, const glnn::BnApplyA* bn) {
   if (defer) *defer = {c, nullptr, 0, 0, 0};
   if (defer_colsum) *defer_colsum = {col_sum_a, nullptr, 0, 0, 0};
   if (used_floats) *used_floats = 0;
@@ -1857,6 +1918,15 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   g.b = b; g.ldb = ldb; g.b_rows = b_rows; g.b_scale = b_scale; g.b_shift = b_shift; g.nb = nb;
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
+  g.ax_z = nullptr; g.ax_ldz = 0; g.ax_alpha = g.ax_beta = g.ax_gamma = nullptr;
+  if (bn) {
+    // A = alpha * a + beta * z + gamma on the staged pieces of the pipelined kernel: that kernel's shapes only (checked below)
+    GLNN_REQUIRE(bn->z && bn->alpha && bn->beta && bn->gamma, "glnn::gemm_tn: incomplete BnApplyA");
+    if (!glnn::gemm_tn_takes_bn(a, lda, m, ka, b, ldb, nb, bn->z, bn->ldz) || b_rows || b_scale || col_sum_a || !glnn::aligned16(bn->alpha) ||
+        !glnn::aligned16(bn->beta) || !glnn::aligned16(bn->gamma))
+      return GLNN_ERR_UNSUPPORTED;
+    g.ax_z = bn->z; g.ax_ldz = bn->ldz; g.ax_alpha = bn->alpha; g.ax_beta = bn->beta; g.ax_gamma = bn->gamma;
+  }
   int bnt = nb > 64 ? 128 : 64;
   int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;
   const bool fast = g.a_vec && g.b_vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) &&
@@ -1867,7 +1937,7 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   // unless the reduction is long enough for the pipelined kernel's deeper k-loop to pay (>= 2048 rows)
   // -- nor when a WIDE a is streamed over many rows (penn94's GCN: 4814 x 64 over 41554 rows, 0.8 GB): 64-column tiles read 256-byte
   // pieces of 19 KB rows (1.45 TB/s), 128-column tiles 2.2 TB/s (552 -> 369 us)
-  const bool small = tn_small_regime(fast, gi * gj, pipe_shape, m, ka);
+  const bool small = !bn && tn_small_regime(fast, gi * gj, pipe_shape, m, ka);
   if (small) { bnt = 64; gi = (ka + 63) / 64; gj = (nb + 63) / 64; }
   // split the reduction over m so that the launch has >= ~256 workgroups (one per CU) when the output is small
   int splits = 1;
@@ -1895,7 +1965,8 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   g.rows_per_split = rps;
   splits = (int)((m + rps - 1) / rps);
   g.splits = splits;
-  const bool pipe_ok = pipe_shape && !small && rps * (lda > ldb ? lda : ldb) < (1 << 28);
+  const bool pipe_ok = pipe_shape && !small && rps * (lda > ldb ? lda : ldb) < (1 << 28) && (!bn || rps * bn->ldz < (1 << 28));
+  if (bn && !pipe_ok) return GLNN_ERR_UNSUPPORTED;        // (nothing launched; gemm_tn_takes_bn covers every condition but the workspace-dependent split)
   float* ws_partial = workspace ? workspace + colsum_need : nullptr;
   if (splits > 1) { g.c = ws_partial; g.ldc = nb; } else { g.c = c; g.ldc = ldc; }
   const int xf = !b_scale ? 0 : (g.drop_thr ? 2 : 1);
@@ -1927,7 +1998,11 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
       static int cfg_pipe = 1;
       if (cfg_pipe > 0) cfg_pipe = set_smem(gemm_tn_kernel_pipe, smem_pipe);
       if (cfg_pipe != GLNN_OK) return cfg_pipe;
-      hipLaunchKernelGGL(gemm_tn_kernel_pipe, grid, dim3(256), smem_pipe, st, g);
+      static int cfg_pipe_ax = 1;
+      if (bn && cfg_pipe_ax > 0) cfg_pipe_ax = set_smem(gemm_tn_kernel_pipe_ax, smem_pipe);
+      if (bn && cfg_pipe_ax != GLNN_OK) return cfg_pipe_ax;
+      if (bn) hipLaunchKernelGGL(gemm_tn_kernel_pipe_ax, grid, dim3(256), smem_pipe, st, g);
+      else hipLaunchKernelGGL(gemm_tn_kernel_pipe, grid, dim3(256), smem_pipe, st, g);
     } else if (bnt == 128) {
       if (!fast) GLNN_TN_LAUNCH((gemm_tn_kernel_generic<128>), 0, smem128);
       else if (xf == 0 && !rows) GLNN_TN_LAUNCH((gemm_tn_kernel_t<BM, 128, 0, false>), 1, smem128t);

@@ -12,6 +12,7 @@ namespace glnn {
 
 struct GradFold;
 struct PendingFolds;
+struct BnApplyA;
 
 void set_error(const char* fmt, ...);
 
@@ -37,6 +38,7 @@ struct Options {
   int fuse_apply;           // GLNN_STUDENT_FUSE_APPLY=0: the first hidden layer's BatchNorm-backward apply stays its own launch
   int adam_folds;           // GLNN_STUDENT_ADAM_FOLDS=0: gradient partials are folded before Adam, not by it
   int gemm_stats;           // GLNN_GEMM_STATS=0: BatchNorm statistics always take their own first pass over the GEMM's output
+  int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
 };
 const Options& opts();
 
@@ -128,7 +130,12 @@ int bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int6
                 const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed,
                 float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum, float* workspace, int64_t workspace_floats,
                 void* stream, const BnGroup* g, int* counters = nullptr, int relu = 1, int da_slabs = 0,
-                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr);
+                struct GradFold* defer_colsum = nullptr, const NarrowProduct* prod = nullptr, struct BnApplyA* defer_apply = nullptr);
+// defer_apply (round 5): dz is NOT written.  One pass leaves dy (da behind the dropout and ReLU masks) IN PLACE of da and the per-chunk sums
+// (the partial pass's own numbers: dgamma / dbeta are the plain form's bits), a constants launch turns the totals into alpha / beta / gamma
+// with dz = alpha dy + beta z + gamma, and *defer_apply describes them for the ONE consumer of dz (gemm_tn(..., bn)).  dz_col_sum (the bias
+// gradient in front of the BatchNorm, mathematically 0) is written as 0.  GLNN_ERR_UNSUPPORTED with nothing launched unless: BatchNorm,
+// single rank, da in memory and writable (da == dz: in place), more than 64 row chunks, h % 4 == 0, float4-addressable rows.
 // prod: the input gradient da is NOT in memory (da / ldda ignored): both passes recompute da = dl . w on the matrix cores; BatchNorm
 // two-launch form only (GLNN_ERR_UNSUPPORTED with nothing launched otherwise)
 // defer_colsum: (one-launch form only) dz_col_sum is NOT written; *defer_colsum describes the per-chunk partials left in `workspace`
@@ -160,9 +167,16 @@ struct PendingFolds { int n; GradFold e[kMaxGradFolds]; int has_loss; LossFoldJo
 // defer (n entries, optional): the fold launch is skipped; defer[p] describes problem p's slabs (nslab = 0: c was written directly)
 int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t workspace_floats, void* stream, GradFold* defer = nullptr);
 // gemm.hip: glnn_gemm_tn_f32 with its folds optionally left to the fused Adam launch -- see the definition
+// bn (optional, round 5): the operand is NOT a but dz = alpha[col] * a + beta[col] * z + gamma[col] -- the BatchNorm backward's apply written
+// as an affine map of (dy, z): `a` holds dy (the upstream gradient behind the tail's dropout and ReLU masks, left in place by
+// bn_relu_bwd(..., defer_apply)) and dz is never written.  Evaluated on the staged operand pieces of the pipelined kernel;
+// GLNN_ERR_UNSUPPORTED (nothing launched) for any other shape -- ask gemm_tn_takes_bn first.
+struct BnApplyA { const float* z; int64_t ldz; const float* alpha; const float* beta; const float* gamma; };
+bool gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz);
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,
             const float* b_shift, float drop_p, uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace,
-            int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0);
+            int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0,
+            const BnApplyA* bn = nullptr);
 // student.hip: glnn_adam_step_f32 whose gradient reads fold the pending partial sums (and store the folded gradient); grads_host =
 // host copy of the `grads` pointer table (how a pending fold finds its tensor); pending may be NULL
 int adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* sizes,

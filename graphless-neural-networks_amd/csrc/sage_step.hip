@@ -74,12 +74,26 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
   // ---- backward --------------------------------------------------------------------------------------------------------
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
+  // Layer 0's dz has ONE consumer, dW_0 (the outermost block's input needs no gradient).  Its BatchNorm backward then stops after the pass
+  // that leaves dy and the column sums; dz = alpha dy + beta z + gamma is evaluated on dW_0's operand pieces (glnn::gemm_tn(..., bn)) and
+  // the apply pass -- read da and z, write dz: 1.5 GB on the products configuration -- does not exist (round 5)
+  glnn::BnApplyA ax0 = {};
+  bool apply_in_gemm = false;
   for (int l = L - 1; l >= 0; --l) {
     const glnn_sage_layer& y = d->layer[l];
     const int d_in = d->dims[l], d_out = d->dims[l + 1];
     // dW_l = dz^T agg (+ db for the last layer; hidden layers get it from the activation backward below)
-    GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in,
-                              l == L - 1 ? y.gb : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+    if (l == 0 && apply_in_gemm) {
+      const int rcw = glnn::gemm_tn(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in, nullptr,
+                                    d->ws_tn, d->ws_tn_floats, stream, nullptr, nullptr, nullptr, 0, &ax0);
+      if (rcw == GLNN_ERR_UNSUPPORTED)                     // (dz was not written: there is nothing to fall back to)
+        return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_sage_fwd_bwd_f32: the weight-gradient workspace (%lld floats) is too small for the "
+                          "deferred BatchNorm backward of layer 0; set GLNN_SAGE_FUSE_BN_APPLY=0 or enlarge ws_tn", (long long)d->ws_tn_floats);
+      GLNN_TRY(rcw);
+    } else {
+      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in,
+                                l == L - 1 ? y.gb : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+    }
     if (l == 0) break;                                     // the outermost block's input is feats: no gradient needed
     // dagg = dz W ;  dh = (A^T + I_dst)(dagg / (deg + 1)) over the transposed block
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_out, y.w, d_in, 1, d_in, nullptr, nullptr, nullptr, 0,
@@ -88,9 +102,20 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     GLNN_TRY(glnn_spmm_csr_f32(y.t_indptr, y.t_indices, y.n_src, y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, nullptr, y.inv_deg, nullptr,
                                0, nullptr, nullptr, nullptr, 0, d->dh, d->ld_dh, stream));
     const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh
-    GLNN_TRY(glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, d->batchnorm ? prev.gamma : nullptr, prev.mean, prev.rstd,
-                               d->batchnorm ? prev.a_scale : nullptr, d->batchnorm ? prev.a_shift : nullptr, p, prev.drop_seed, d->dh,
-                               d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+    int rcb = GLNN_ERR_UNSUPPORTED;
+    if (l == 1 && d->batchnorm && glnn::opts().sage_fuse_bn_apply &&
+        glnn::gemm_tn_takes_bn(d->dh, d->ld_dh, prev.n_dst, d_in, prev.agg, prev.ld_agg, d->dims[0], prev.z, prev.ldz) && d->ws_tn &&
+        (int64_t)d->dims[0] * d_in * 8 <= d->ws_tn_floats) {                  // (room for >= 8 split slabs: every split stays inside the descriptor window)
+      rcb = glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, prev.gamma, prev.mean, prev.rstd, prev.a_scale, prev.a_shift, p,
+                              prev.drop_seed, d->dh, d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr, nullptr, 1,
+                              0, nullptr, nullptr, &ax0);
+      if (rcb != GLNN_OK && rcb != GLNN_ERR_UNSUPPORTED) return rcb;
+      apply_in_gemm = rcb == GLNN_OK;
+    }
+    if (rcb == GLNN_ERR_UNSUPPORTED)
+      GLNN_TRY(glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, d->batchnorm ? prev.gamma : nullptr, prev.mean, prev.rstd,
+                                 d->batchnorm ? prev.a_scale : nullptr, d->batchnorm ? prev.a_shift : nullptr, p, prev.drop_seed, d->dh,
+                                 d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr));
     dz = d->dh;
     ld_dz = d->ld_dh;
   }

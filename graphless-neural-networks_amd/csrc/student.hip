@@ -1287,12 +1287,116 @@ int glnn::chunk_sum(const float* ws, int nchunks, int h, float* out, void* strea
   return glnn::check_launch("glnn::chunk_sum");
 }
 
+namespace {
+// ---- deferred apply (bn_relu_bwd(..., defer_apply), round 5) -------------------------------------------------------------------------
+// The partial pass for a consumer that evaluates dz itself: same row -> lane assignment, same accumulation order and same fold as
+// bn_bwd_partial (the per-chunk sums are its bits), but a lane owns FOUR columns (float4 rows: one wave covers 256 columns of a row in
+// one request) and dy -- da behind the tail's dropout and ReLU masks -- is stored in place of da.
+template <bool DROP>
+__global__ __launch_bounds__(256) void bn_bwd_partial_dy4(const BnBwdArgs a, float* dy_out, int64_t lddy) {      // (dy_out aliases a.da: in place)
+  auto ld4g = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col4 = (blockIdx.x * 64 + lane) * 4;
+  const bool col_ok = col4 < a.h;                       // h % 4 == 0: a lane's four columns are all inside or all outside
+  const int cc = col_ok ? col4 : 0;
+  const int64_t r0 = (int64_t)blockIdx.y * kBnRows;
+  int64_t r1 = r0 + kBnRows;
+  if (r1 > a.rows) r1 = a.rows;
+  const float4 mu = ld4g(a.mean + cc), rs = ld4g(a.rstd + cc), sc = ld4g(a.a_scale + cc), sf = ld4g(a.a_shift + cc);
+  const float mu4[4] = {mu.x, mu.y, mu.z, mu.w}, rs4[4] = {rs.x, rs.y, rs.z, rs.w}, sc4[4] = {sc.x, sc.y, sc.z, sc.w}, sf4[4] = {sf.x, sf.y, sf.z, sf.w};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int i0 = 0; i0 < kRowsPerLane; i0 += kUnroll) {       // 8 rows x 2 float4 per lane in flight; not unrolled further (registers -> occupancy)
+    float4 zz[kUnroll], dd[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const int64_t rc = r < r1 ? r : r0;
+      zz[u] = ld4g(a.z + rc * a.ldz + cc);
+      dd[u] = ld4g(a.da + rc * a.ldda + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int64_t r = r0 + rl + 4 * (i0 + u);
+      const float z4[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w}, d4[4] = {dd[u].x, dd[u].y, dd[u].z, dd[u].w};
+      float o[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float dyv = bn_dy_s<true, DROP>(a, z4[t], d4[t], r, cc + t, sc4[t], sf4[t]);
+        const float dy = r < r1 ? dyv : 0.f;
+        s1[t] += dy;
+        s2[t] = fmaf(dy, (z4[t] - mu4[t]) * rs4[t], s2[t]);
+        o[t] = dy;
+      }
+      if (r < r1 && col_ok) *reinterpret_cast<float4*>(dy_out + r * lddy + col4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __shared__ float4 sh1[kRowLanes][64], sh2[kRowLanes][64];
+  sh1[rl][lane] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  sh2[rl][lane] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  __syncthreads();
+  if (rl == 0 && col_ok) {
+    const float4 a0 = sh1[0][lane], a1 = sh1[1][lane], a2 = sh1[2][lane], a3 = sh1[3][lane];
+    const float4 b0 = sh2[0][lane], b1 = sh2[1][lane], b2 = sh2[2][lane], b3 = sh2[3][lane];
+    *reinterpret_cast<float4*>(a.ws1 + (int64_t)blockIdx.y * a.h + col4) =
+        make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+    *reinterpret_cast<float4*>(a.ws2 + (int64_t)blockIdx.y * a.h + col4) =
+        make_float4((b0.x + b1.x) + (b2.x + b3.x), (b0.y + b1.y) + (b2.y + b3.y), (b0.z + b1.z) + (b2.z + b3.z), (b0.w + b1.w) + (b2.w + b3.w));
+  }
+}
+
+// the column totals S1 / S2 -> dz = alpha dy + beta z + gamma  [= g rs (dy - S1/B - (z - mu) rs S2/B)], dgamma = S2, dbeta = S1; the bias
+// gradient in front of the BatchNorm -- the column sum of dz, mathematically 0 -- is written as 0
+__global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const float* __restrict__ totals, int h, float rows, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ gam,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dz_col_sum) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= h) return;
+  const float S1 = totals[col], S2 = totals[h + col];
+  const float inv_b = 1.0f / rows;
+  const float c1 = S1 * inv_b, c2 = S2 * inv_b, rs = rstd[col], grs = gamma[col] * rs;
+  const float k = grs * rs * c2;
+  alpha[col] = grs;
+  beta[col] = -k;
+  gam[col] = fmaf(k, mean[col], -grs * c1);
+  dbeta[col] = S1;
+  dgamma[col] = S2;
+  if (dz_col_sum) dz_col_sum[col] = 0.f;
+}
+}  // namespace
+
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,
                       float* workspace, int64_t workspace_floats, void* stream, const glnn::BnGroup* g, int* counters, int relu,
-                      int da_slabs, glnn::GradFold* defer_colsum, const glnn::NarrowProduct* prod) {
+                      int da_slabs, glnn::GradFold* defer_colsum, const glnn::NarrowProduct* prod, glnn::BnApplyA* defer_apply) {
   if (defer_colsum) *defer_colsum = {dz_col_sum, nullptr, 0, 0, 0};
+  if (defer_apply) {
+    // dy in place of da + per-chunk sums + fold + constants; the apply is left to the ONE consumer of dz (gemm_tn's operand pieces)
+    const int nch = (int)((rows + kBnRows - 1) / kBnRows);
+    if (!gamma || g || prod || da_slabs > 1 || nch <= kManyChunks || (h & 3) || !da || da != dz || ldda != lddz || (ldda & 3) || (ldz & 3) ||
+        !glnn::aligned16(da) || !glnn::aligned16(z) || !glnn::aligned16(mean) || !glnn::aligned16(rstd) || !glnn::aligned16(a_scale) ||
+        !glnn::aligned16(a_shift) || !workspace || !glnn::aligned16(workspace) || workspace_floats < 2ll * nch * h + 5ll * h + 8 || !mean ||
+        !rstd || !a_scale || !a_shift || !dgamma || !dbeta || drop_p < 0.f || drop_p >= 1.f)
+      return GLNN_ERR_UNSUPPORTED;
+    BnBwdArgs a = {};
+    a.da = da; a.ldda = ldda; a.z = z; a.ldz = ldz; a.rows = rows; a.h = h; a.gamma = gamma; a.mean = mean; a.rstd = rstd;
+    a.a_scale = a_scale; a.a_shift = a_shift; a.dthr = glnn::drop_threshold(drop_p); a.dseed = drop_seed; a.dscale = 1.0f / (1.0f - drop_p);
+    a.nchunks = nch; a.relu = relu;
+    a.ws1 = workspace; a.ws2 = workspace + (int64_t)nch * h;
+    float* totals = workspace + 2ll * nch * h;
+    float* cst = totals + 2ll * h + ((4 - ((2ll * nch * h + 2ll * h) & 3)) & 3);          // 16-byte aligned: float4 loads in the consumer
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((h + 255) / 256, nch);
+    if (a.dthr) hipLaunchKernelGGL(bn_bwd_partial_dy4<true>, grid, dim3(256), 0, st, a, dz, lddz);
+    else hipLaunchKernelGGL(bn_bwd_partial_dy4<false>, grid, dim3(256), 0, st, a, dz, lddz);
+    fold_chunks(a.ws1, a.ws2, nch, h, totals, st);
+    hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((h + 255) / 256), dim3(256), 0, st, totals, h, (float)rows, gamma, mean, rstd, cst, cst + h,
+                       cst + 2ll * h, dgamma, dbeta, dz_col_sum);
+    *defer_apply = {z, ldz, cst, cst + h, cst + 2ll * h};
+    return glnn::check_launch("glnn_bn_relu_bwd_f32(deferred apply)");
+  }
   if (prod) {                                            // da = dl . w, recomputed by both passes (bn_bwd_*_sk): two-launch BatchNorm form only
     if (!gamma || g || da_slabs > 1 || prod->k < 1 || prod->k > 64 || !prod->dl || !prod->w || prod->lddl < prod->k || prod->ldw < h ||
         (prod->lddl | prod->ldw | h) % 4 != 0 || !glnn::aligned16(prod->dl) || !glnn::aligned16(prod->w) ||    // float4 staging loads

@@ -724,3 +724,51 @@ def test_sage_step_tail_in_the_gather_is_bit_identical_to_the_materialised_tail(
     diffs = [float((a.double() - b.double()).abs().max()) for a, b in zip(*states)]
     assert all(torch.equal(a, b) for a, b in zip(*states)), diffs
     assert bool(torch.isfinite(states[0][-1]).all())
+
+
+@pytest.mark.parametrize("p", [0.5, 0.0])
+def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypatch):
+    """Round 5: the outermost block's dz has one consumer, dW_0.  Layer 0's BatchNorm backward then stops after ONE pass (dy in place of da,
+    the column sums -- bn_bwd_partial's own bits) and dz = alpha dy + beta z + gamma is evaluated on the staged operand pieces of the
+    pipelined weight-gradient kernel (glnn::gemm_tn(..., bn)): dz_0 is never written.  Against GLNN_SAGE_FUSE_BN_APPLY=0 (the apply as its
+    own launch): same loss and same gradients behind layer 0 bit for bit, the same BatchNorm parameter gradients of layer 0 bit for bit,
+    dW_0 equal to rounding (an affine map instead of bn_dz's expression); the bias in front of the BatchNorm -- true gradient 0,
+    rounding noise in the plain form -- is exactly 0.  The block is big enough (> 64 row chunks of layer-0 destinations) for the
+    deferred form to engage."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    n, dims = 120000, [100, 256, 256, 47]
+    indptr, indices = random_graph(n, 12, seed=21, power=0.6, hub=3000, isolated=50)
+    rs = np.random.RandomState(21)
+    fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
+    ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
+    g = _graph(indptr, indices)
+    (input_nodes, output_nodes, blocks), = list(NodeDataLoader(g, torch.arange(2048), MultiLayerNeighborSampler([5, 10, 15]), batch_size=2048,
+                                                                shuffle=False, seed=5))
+    assert blocks[0].num_dst_nodes() > 64 * 128
+    grads, losses = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_SAGE_FUSE_BN_APPLY", mode)
+        torch.manual_seed(2)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type="batch", device=DEV))
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+        torch.cuda.synchronize()
+        grads.append({k: prm.grad.detach().clone() for k, prm in model.named_parameters()})
+        losses.append(eng.loss_out.clone())
+    assert torch.equal(losses[0], losses[1])
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if k.startswith("encoder.layers.0") and k.endswith("fc_neigh.bias"):
+            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) < 1e-4, k
+            continue
+        if not k.startswith("encoder.layers.0"):
+            assert torch.equal(a, b), k                   # everything behind layer 0 runs the same launches; the norm's sums are the same bits
+            continue
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
