@@ -38,6 +38,7 @@ struct Options {
   int fuse_apply;           // GLNN_STUDENT_FUSE_APPLY=0: the first hidden layer's BatchNorm-backward apply stays its own launch
   int adam_folds;           // GLNN_STUDENT_ADAM_FOLDS=0: gradient partials are folded before Adam, not by it
   int gemm_stats;           // GLNN_GEMM_STATS=0: BatchNorm statistics always take their own first pass over the GEMM's output
+  int spmm_short;           // GLNN_SPMM_SHORT=0: sparse training blocks stay on the one-row-per-wave aggregation kernel
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
 };
 const Options& opts();
@@ -189,8 +190,12 @@ int gemm_split_partials(const float* a, int64_t lda, const int64_t* a_rows, cons
 
 // spmm.hip: the SAGE-"gcn" aggregation over rows stored as pre-activations z, the hidden layer's tail applied in the gather
 struct SourceTail { const float* scale; const float* shift; float drop_p; uint32_t drop_seed; };      // scale / shift NULL: no affine (norm "none")
+// nnz (optional): the block's edge count; a sparse block (<= 6 in-edges per row on average; plain SAGE aggregation) takes the short-row kernel (same bits)
 int spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* z, int64_t ldz, int d,
-                  const SourceTail& tail, float* out, int64_t ldo, void* stream);
+                  const SourceTail& tail, float* out, int64_t ldo, void* stream, int64_t nnz = -1);
+int spmm_csr_nnz(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, int64_t nnz, const float* x, int64_t ldx, int d,
+                 int mode, const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows, float* out, int64_t ldo,
+                 void* stream);
 
 // gemm_rowpanel.hip: C = epi(A . W^T) for short reductions (k <= 128) over many rows -- persistent workgroups that keep a 128-column
 // panel of W in LDS and walk row tiles of A; bit-identical to the tiled kernels.  GLNN_ERR_UNSUPPORTED = nothing launched.

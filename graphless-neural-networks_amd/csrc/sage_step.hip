@@ -46,10 +46,10 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
       // the hidden layer in front left only z: its tail (BatchNorm affine, ReLU, dropout) is evaluated in this layer's gather
       const glnn_sage_layer& pv = d->layer[l - 1];
       const glnn::SourceTail tail = {d->batchnorm ? pv.a_scale : nullptr, d->batchnorm ? pv.a_shift : nullptr, p, pv.drop_seed};
-      GLNN_TRY(glnn::spmm_csr_tail(y.indptr, y.indices, y.n_dst, n_src, pv.z, pv.ldz, d_in, tail, y.agg, y.ld_agg, stream));
+      GLNN_TRY(glnn::spmm_csr_tail(y.indptr, y.indices, y.n_dst, n_src, pv.z, pv.ldz, d_in, tail, y.agg, y.ld_agg, stream, y.nnz));
     } else {
-      GLNN_TRY(glnn_spmm_csr_f32(y.indptr, y.indices, y.n_dst, n_src, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, nullptr, src, ld_src,
-                                 l == 0 ? y.self_rows : nullptr, nullptr, nullptr, 0, y.agg, y.ld_agg, stream));
+      GLNN_TRY(glnn::spmm_csr_nnz(y.indptr, y.indices, y.n_dst, n_src, y.nnz, src, ld_src, d_in, GLNN_AGG_SAGE_GCN, nullptr, src, ld_src,
+                                  l == 0 ? y.self_rows : nullptr, y.agg, y.ld_agg, stream));
     }
     // hidden BatchNorm layers: the projection's epilogue leaves the first pass of the column statistics (glnn::ColStats)
     glnn::ColStats cs = {d->ws_bn, d->ws_bn_floats, 0, 0, 0, nullptr, nullptr, nullptr};
@@ -99,8 +99,8 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_out, y.w, d_in, 1, d_in, nullptr, nullptr, nullptr, 0,
                            d->dagg, d->ld_dagg, nullptr, 0, stream));
     GLNN_TRY(transposes(l, stream));
-    GLNN_TRY(glnn_spmm_csr_f32(y.t_indptr, y.t_indices, y.n_src, y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, nullptr, y.inv_deg, nullptr,
-                               0, nullptr, nullptr, nullptr, 0, d->dh, d->ld_dh, stream));
+    GLNN_TRY(glnn::spmm_csr_nnz(y.t_indptr, y.t_indices, y.n_src, y.n_dst, y.nnz + y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, y.inv_deg,
+                                nullptr, 0, nullptr, d->dh, d->ld_dh, stream));       // (transposed block: 1-2 in-edges per row -> short rows)
     const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh
     int rcb = GLNN_ERR_UNSUPPORTED;
     if (l == 1 && d->batchnorm && glnn::opts().sage_fuse_bn_apply &&

@@ -170,14 +170,24 @@ __device__ __forceinline__ float4 shfl_xor4(float4 v, int m) {
 // Sum of x[indices[e], col4..col4+3] over the edges e in [e0,e1) that belong to this wave:
 // 64-edge chunks  e0 + 64*(wave_id + k*n_waves).  Returns the total in every lane of group 0
 // (lanes < LPR); other lanes hold partial garbage.
+// the two halves of wave_gather_sum: the per-GROUP running sums (continuing `acc`: group g of the lanes takes the edges e with
+// (e - e0) % G == g in ascending order), and the fold of the G group sums
+template <int LPR>
+__device__ __forceinline__ float4 fold_groups(float4 acc) {
+  constexpr int G = 64 / LPR;
+  if (G >= 2) acc = add4(acc, shfl_xor4(acc, 32));
+  if (G >= 4) acc = add4(acc, shfl_xor4(acc, 16));
+  if (G >= 8) acc = add4(acc, shfl_xor4(acc, 8));
+  if (G >= 16) acc = add4(acc, shfl_xor4(acc, 4));
+  return acc;
+}
 template <int LPR, int U, bool CS, bool XF = false>
-__device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ indices, int64_t e0, int64_t e1,
+__device__ __forceinline__ float4 wave_gather_acc(const int32_t* __restrict__ indices, int64_t e0, int64_t e1,
                                                   int wave_id, int n_waves, const float* __restrict__ x,
                                                   int64_t ldx, int col4, bool col_ok,
-                                                  const float* __restrict__ col_scale, int lane, const XfCols& xf) {
+                                                  const float* __restrict__ col_scale, int lane, const XfCols& xf, float4 acc) {
   constexpr int G = 64 / LPR;
   const int g = lane / LPR;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int64_t base = e0 + (int64_t)wave_id * 64; base < e1; base += (int64_t)n_waves * 64) {
     const int64_t rem = e1 - base;
     const int cnt = rem < 64 ? (int)rem : 64;
@@ -212,11 +222,15 @@ __device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ in
       for (int u = 0; u < U; ++u) acc = CS ? fma4(s[u], v[u], acc) : add4(acc, v[u]);
     }
   }
-  if (G >= 2) acc = add4(acc, shfl_xor4(acc, 32));
-  if (G >= 4) acc = add4(acc, shfl_xor4(acc, 16));
-  if (G >= 8) acc = add4(acc, shfl_xor4(acc, 8));
-  if (G >= 16) acc = add4(acc, shfl_xor4(acc, 4));
   return acc;
+}
+template <int LPR, int U, bool CS, bool XF = false>
+__device__ __forceinline__ float4 wave_gather_sum(const int32_t* __restrict__ indices, int64_t e0, int64_t e1,
+                                                  int wave_id, int n_waves, const float* __restrict__ x,
+                                                  int64_t ldx, int col4, bool col_ok,
+                                                  const float* __restrict__ col_scale, int lane, const XfCols& xf) {
+  return fold_groups<LPR>(wave_gather_acc<LPR, U, CS, XF>(indices, e0, e1, wave_id, n_waves, x, ldx, col4, col_ok, col_scale, lane, xf,
+                                                           make_float4(0.f, 0.f, 0.f, 0.f)));
 }
 
 // per-column epilogue constants of a lane's four columns, fetched ONCE per wave: inside finish_row they were eight 4-byte loads
@@ -233,14 +247,11 @@ __device__ __forceinline__ EpCols load_ep_cols(const SpmmArgs& a, int col4) {
   return e;
 }
 
-template <int MODE, bool XF = false>
-__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep,
-                                           const XfCols& xf) {
+// finish_row with the self row (SAGE_GCN; behind the source transform) already in hand: `s`
+template <int MODE>
+__device__ __forceinline__ void finish_row_s(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, float4 s, int col4, const EpCols& ep) {
   float4 y;
   if (MODE == GLNN_AGG_SAGE_GCN) {
-    const int64_t sr = a.self_rows ? a.self_rows[v] : v;
-    float4 s = ld4(a.x_self + sr * a.ld_self + col4);
-    if (XF) s = xf_apply(xf, s, (uint32_t)sr);
     const float dp1 = (float)deg + 1.0f;
     y = mean4(acc, s, dp1);
   } else {
@@ -260,6 +271,17 @@ __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t
     }
   }
   st4_stream(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
+}
+template <int MODE, bool XF = false>
+__device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep,
+                                           const XfCols& xf) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == GLNN_AGG_SAGE_GCN) {
+    const int64_t sr = a.self_rows ? a.self_rows[v] : v;
+    s = ld4(a.x_self + sr * a.ld_self + col4);
+    if (XF) s = xf_apply(xf, s, (uint32_t)sr);
+  }
+  finish_row_s<MODE>(a, v, deg, acc, s, col4, ep);
 }
 
 // ---- hub rows ---------------------------------------------------------------------------------------------------------
@@ -408,6 +430,121 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
     if (deg > kLongRow) continue;
     float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
     if (lane < LPR && col_ok) finish_row<MODE, XF>(a, v, deg, acc, col4, ep, xf);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SHORT ROWS (round 5): the outermost block of a sampled training batch (fan-out 5) has rows whose whole gather is ONE batch of loads.
+// One wave per row then spends its time in the row's dependent chain (ticket -> indptr -> indices -> rows -> store, ~4 memory latencies
+// for 2.4 KB moved): 0.5 M rows x 6 x 400 bytes in 365 us = 3.8 TB/s.  Here a wave takes FOUR consecutive rows per ticket: one load for their five indptr entries (and self-row
+// ids), one for their (contiguous) column indices, then the first three load units of all four rows and the four self rows in flight
+// together; longer rows continue on their own with the running sums carried on.  A group of lanes sees a row's edges in the same order and
+// the same fold as in spmm_csr_kernel, so the two kernels give the same bits; the long-row role is shared.
+// ---------------------------------------------------------------------------------------------
+constexpr int kShortRows = 4;        // rows per ticket
+constexpr int kShortUnits = 3;       // load units (G edges each) of every row gathered with the batch
+__device__ __forceinline__ int64_t readlane64(int64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), l);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <int LPR, int U, int MODE, bool CS, bool XF = false>
+__global__ __launch_bounds__(kBlock) void spmm_csr_short_kernel(const SpmmArgs a) {
+  constexpr int G = 64 / LPR, RB = kShortRows, UB = kShortUnits;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane % LPR, g = lane / LPR;
+  const int col4 = c * 4;
+  const bool col_ok = col4 < a.d;
+  const EpCols ep = load_ep_cols(a, col_ok ? col4 : 0);
+  XfCols xf = {};
+  if (XF) xf = load_xf_cols(a, col_ok ? col4 : 0);
+  if ((int)blockIdx.x < a.n_long_blocks) {
+    long_rows_role<LPR, U, MODE, CS, XF>(a, lane, wave, col4, col_ok, ep, xf);
+    return;
+  }
+  __shared__ int s_ticket;
+  if (threadIdx.x == 0) s_ticket = 0;
+  __syncthreads();
+  const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
+  const int64_t row_base = blk * a.rows_per_block;
+#pragma unroll 1
+  while (true) {
+    int lr = 0;
+    if (lane == 0) lr = atomicAdd(&s_ticket, RB);
+    lr = __builtin_amdgcn_readfirstlane(lr);
+    if (lr >= a.rows_per_block) break;
+    const int64_t v0 = row_base + lr;
+    if (v0 >= a.n_dst) break;
+    int nr = a.rows_per_block - lr;
+    if (nr > RB) nr = RB;
+    if (v0 + nr > a.n_dst) nr = (int)(a.n_dst - v0);
+    // lanes 0 .. nr: the rows' indptr entries (and the self-row ids of global-id blocks) in one request each
+    const int64_t my_ptr = a.indptr[v0 + (lane <= nr ? lane : nr)];
+    int64_t my_self = v0 + (lane < nr ? lane : 0);
+    if (MODE == GLNN_AGG_SAGE_GCN && a.self_rows) my_self = a.self_rows[v0 + (lane < nr ? lane : 0)];
+    int64_t e[RB + 1];
+#pragma unroll
+    for (int r = 0; r <= RB; ++r) e[r] = readlane64(my_ptr, r <= nr ? r : nr);
+    const int64_t ebase = e[0];
+    int64_t span = e[RB] - ebase;
+    const int tot = span < 64 ? (int)span : 64;
+    const int my_idx = lane < tot ? ld_idx_stream(a.indices + ebase + lane) : 0;
+    float my_cs = 0.f;
+    if (CS) my_cs = lane < tot ? a.col_scale[my_idx] : 0.f;
+    int hd[RB];                                            // edges of row r gathered with the batch (a multiple of G, or the whole row)
+    bool live[RB];                                         // a row of this wave (rows above kLongRow belong to the long-row role)
+    float4 v[RB][UB], selfv[RB];
+    float sc[RB][UB];
+    int srcs[RB][UB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int64_t deg = e[r + 1] - e[r];
+      const int off = (int)(e[r] - ebase < 64 ? e[r] - ebase : 64);
+      live[r] = r < nr && deg <= kLongRow;
+      int h = deg < UB * G ? (int)deg : UB * G;
+      if (!live[r] || off + h > tot) h = 0;                // (its first units do not lie inside the loaded indices: the row goes alone)
+      hd[r] = h;
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        const int first = k * G + g;
+        const int ei = off + first;
+        int src;
+        if (G == 1) src = __builtin_amdgcn_readlane(my_idx, ei & 63);
+        else src = __shfl(my_idx, ei & 63);
+        float cs = 0.f;
+        if (CS) cs = (G == 1) ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cs), ei & 63)) : __shfl(my_cs, ei & 63);
+        const bool ok = first < h && col_ok;
+        srcs[r][k] = ok ? src : -1;
+        sc[r][k] = ok ? cs : 0.f;
+        v[r][k] = ok ? ld4(a.x + (int64_t)src * a.ldx + col4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      selfv[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == GLNN_AGG_SAGE_GCN) {
+        const int64_t sr = readlane64(my_self, r < nr ? r : 0);
+        if (live[r] && col_ok) {
+          selfv[r] = ld4(a.x_self + sr * a.ld_self + col4);
+          if (XF) selfv[r] = xf_apply(xf, selfv[r], (uint32_t)sr);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < UB; ++k) {
+        if (XF) {
+          if (srcs[r][k] >= 0) v[r][k] = xf_apply(xf, v[r][k], (uint32_t)srcs[r][k]);
+        }
+        acc = CS ? fma4(sc[r][k], v[r][k], acc) : add4(acc, v[r][k]);
+      }
+      if (!live[r]) continue;                              // (uniform)
+      const int64_t deg = e[r + 1] - e[r];
+      if (deg > hd[r])                                     // the rest of a longer row, its group sums carried on
+        acc = wave_gather_acc<LPR, U, CS, XF>(a.indices, e[r] + hd[r], e[r + 1], 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf, acc);
+      acc = fold_groups<LPR>(acc);
+      if (lane < LPR && col_ok) finish_row_s<MODE>(a, v0 + r, deg, acc, selfv[r], col4, ep);
+    }
   }
 }
 
@@ -642,12 +779,21 @@ int launch_hub_gather(const SpmmArgs& a, int mode, int n_seg, hipStream_t st) {
 }
 
 template <int LPR, int U>
-int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1, int hub_segs = 0) {
+int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_tiles = 1, int hub_segs = 0, bool short_rows = false) {
   const bool cs = a.col_scale != nullptr;
   const dim3 g(grid, col_tiles);
   if (hub_segs > 0) {                    // the hub rows' segments first: one workgroup each, into the plan's slab
     const int rc = launch_hub_gather<LPR, U>(a, mode, hub_segs, st);
     if (rc != GLNN_OK) return rc;
+  }
+  if constexpr (LPR >= 32) {             // (rows of more than 64 floats: the widths of the training blocks)
+    // measured on the products training configuration (profiles/r05_spmm_short.txt): the plain SAGE aggregation of the outermost block (5
+    // in-edges per row, 400-byte rows) 365 -> 294 us; the transposed blocks (1-2 in-edges, 1 KB rows written: bandwidth-bound already) equal;
+    // the tail-in-gather launches (10-15 in-edges, most of a row's edges behind the batch) slower -- those two keep the row kernel
+    if (short_rows && col_tiles == 1 && mode == GLNN_AGG_SAGE_GCN && !a.xf_on) {
+      hipLaunchKernelGGL((spmm_csr_short_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), g, dim3(kBlock), 0, st, a);
+      return glnn::check_launch("glnn_spmm_csr_f32(short rows)");
+    }
   }
   if (mode == GLNN_AGG_SAGE_GCN && a.xf_on) {
     hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false, true>), g, dim3(kBlock), 0, st, a);
@@ -704,7 +850,7 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
                      const float* x, int64_t ldx, int d, int mode, const float* row_scale,
                      const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
                      const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
-                     void* stream, const glnn::SourceTail* tail, const glnn_hub_plan* plan = nullptr) {
+                     void* stream, const glnn::SourceTail* tail, const glnn_hub_plan* plan = nullptr, int64_t nnz_hint = -1) {
   if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
   GLNN_REQUIRE(indptr && x && out, "glnn_spmm_csr_f32: null pointer");   // indices may be NULL iff the graph has no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
@@ -769,12 +915,15 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
     GLNN_REQUIRE(row_blocks + n_long < ((int64_t)1 << 31), "glnn_spmm_csr_f32: n_dst too large for one launch");
     const int grid = (int)(row_blocks + n_long);
     const int dv = (dt + 3) / 4;
+    // a caller that knows the edge count of a sparse block (<= 6 in-edges per row on average: a row's whole gather fits the batch) gets
+    // the short-row kernel -- the same bits, four rows per wave in flight (GLNN_SPMM_SHORT=0: never)
+    const bool short_rows = nnz_hint >= 0 && nnz_hint <= 6 * n_dst && glnn::opts().spmm_short != 0 && a.rows_per_block % kShortRows == 0;
     int rc;
     if (dv <= 4) rc = launch_lpr<4, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
     else if (dv <= 8) rc = launch_lpr<8, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
     else if (dv <= 16) rc = launch_lpr<16, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
-    else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs);
-    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid, wide ? (d + 255) / 256 : 1, hub_segs);
+    else if (dv <= 32) rc = launch_lpr<32, GLNN_SPMM_U>(a, mode, st, grid, 1, hub_segs, short_rows);
+    else rc = launch_lpr<64, GLNN_SPMM_U>(a, mode, st, grid, wide ? (d + 255) / 256 : 1, hub_segs, short_rows);
     if (rc != GLNN_OK) return rc;
   }
   return GLNN_OK;
@@ -804,9 +953,17 @@ extern "C" int glnn_hub_segment_edges(void) { return kHubSeg; }
 // SAGE-"gcn" aggregation of rows that exist only as pre-activations z: every gathered / self row is tail(z) = drop(relu(z * scale +
 // shift)) evaluated in the gather (glnn_sage_fwd_bwd_f32: the hidden layers' h = tail(z) is never written)
 int glnn::spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* z, int64_t ldz, int d,
-                        const glnn::SourceTail& tail, float* out, int64_t ldo, void* stream) {
+                        const glnn::SourceTail& tail, float* out, int64_t ldo, void* stream, int64_t nnz) {
   return spmm_impl(indptr, indices, n_dst, n_src, z, ldz, d, GLNN_AGG_SAGE_GCN, nullptr, nullptr, z, ldz, nullptr, nullptr, nullptr, 0, out, ldo,
-                   stream, &tail);
+                   stream, &tail, nullptr, nnz);
+}
+
+// glnn_spmm_csr_f32 for a caller that knows the block's edge count (glnn_sage_fwd_bwd_f32): sparse blocks take the short-row kernel
+int glnn::spmm_csr_nnz(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, int64_t nnz, const float* x, int64_t ldx, int d,
+                       int mode, const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows, float* out, int64_t ldo,
+                       void* stream) {
+  return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, nullptr, col_scale, x_self, ld_self, self_rows, nullptr, nullptr, 0, out, ldo,
+                   stream, nullptr, nullptr, nnz);
 }
 
 extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,

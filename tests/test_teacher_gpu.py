@@ -772,3 +772,59 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
             continue
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("norm,p,full,gather_tail,hidden", [("batch", 0.3, False, "1", 256), ("none", 0.5, False, "1", 136), ("batch", 0.4, True, "1", 256),
+                                                            ("batch", 0.2, False, "0", 72), ("batch", 0.3, "sparse", "0", 256),
+                                                            ("none", 0.0, "sparse", "1", 100)])
+def test_sage_step_short_row_aggregation_is_bit_identical_to_one_row_per_wave(norm, p, full, gather_tail, hidden, monkeypatch):
+    """Round 5: the outermost block of a sampled batch (<= 6 in-edges per row on average) is aggregated by spmm_csr_short_kernel (four rows
+    per wave in flight: one request for their indptr entries, one for their indices, then the first load units of all four rows together;
+    longer rows continue alone with their sums carried on; rows above the long-row threshold stay with the shared long-row role).  A lane
+    group sees a row's edges in the same order as in spmm_csr_kernel: three optimiser steps end in the same parameters, BatchNorm buffers
+    and loss bit for bit as with GLNN_SPMM_SHORT=0 -- sampled fan-outs (5 for the outermost block: the short kernel; with materialised
+    activations also for an inner block when its average degree allows) and full neighbourhoods (average degree above the bound: both
+    modes run the row kernel, the switch must then change nothing)."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    n, dims = 20000, [100, hidden, hidden, 9]               # 100 / 72 and 136 / 256 floats per row: both lane layouts the short kernel is built for
+    if full == "sparse":
+        # full neighbourhoods of a SPARSE graph (3 in-edges per row on average) with a power-law tail and a 600-edge hub among the seeds: the
+        # short kernel runs on every block, and every path of it is taken -- batch, carried tail (rows of 4 .. 128 edges), lone row, long row
+        indptr, indices = random_graph(n, 3, seed=9, power=0.8, hub=600, isolated=30)
+        hub = int(np.argmax(np.diff(indptr)))
+        seeds = torch.from_numpy(np.concatenate([[hub], np.setdiff1d(np.arange(600), [hub])[:511]]).astype(np.int64))
+    else:
+        indptr, indices = random_graph(n, 10, seed=9, power=0.6, hub=5000, isolated=30)
+    rs = np.random.RandomState(9)
+    fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
+    ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
+    g = _graph(indptr, indices)
+    if full == "sparse":
+        batches = list(NodeDataLoader(g, seeds, MultiLayerFullNeighborSampler(3), batch_size=256, shuffle=False, seed=5))
+        b0 = batches[0][2][0]
+        deg0 = b0.in_degrees()
+        assert int(deg0.max()) > 128 and int(((deg0 > 3) & (deg0 <= 128)).sum()) > 10 and float(deg0.float().mean()) <= 6.0
+    elif full:
+        batches = list(NodeDataLoader(g, torch.arange(768), MultiLayerFullNeighborSampler(3), batch_size=256, shuffle=False, seed=5))
+    else:
+        batches = list(NodeDataLoader(g, torch.arange(1536), MultiLayerNeighborSampler([5, 10, 15]), batch_size=512, shuffle=False, seed=5))
+    monkeypatch.setenv("GLNN_TEACHER_GATHER_TAIL", gather_tail)
+    states = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GLNN_SPMM_SHORT", mode)
+        torch.manual_seed(2)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type=norm, device=DEV))
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=0.0)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        for input_nodes, output_nodes, blocks in batches:
+            eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+        torch.cuda.synchronize()
+        states.append([t.detach().clone() for t in model.state_dict().values()] + [eng.loss_out.clone()])
+    diffs = [float((a.double() - b.double()).abs().max()) for a, b in zip(*states)]
+    assert all(torch.equal(a, b) for a, b in zip(*states)), diffs
+    assert bool(torch.isfinite(states[0][-1]).all())
