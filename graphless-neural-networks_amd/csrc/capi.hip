@@ -39,6 +39,7 @@ static void load_options(Options& o) {
   o.gemm_stats = (int)env_ll("GLNN_GEMM_STATS", 1);
   o.sage_fuse_bn_apply = (int)env_ll("GLNN_SAGE_FUSE_BN_APPLY", 1);
   o.spmm_short = (int)env_ll("GLNN_SPMM_SHORT", 1);
+  o.sage_fuse_bn_dy = (int)env_ll("GLNN_SAGE_FUSE_BN_DY", 1);
 }
 static Options g_opts;
 static std::once_flag g_opts_once;

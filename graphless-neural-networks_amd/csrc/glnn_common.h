@@ -39,6 +39,7 @@ struct Options {
   int adam_folds;           // GLNN_STUDENT_ADAM_FOLDS=0: gradient partials are folded before Adam, not by it
   int gemm_stats;           // GLNN_GEMM_STATS=0: BatchNorm statistics always take their own first pass over the GEMM's output
   int spmm_short;           // GLNN_SPMM_SHORT=0: sparse training blocks stay on the one-row-per-wave aggregation kernel
+  int sage_fuse_bn_dy;      // GLNN_SAGE_FUSE_BN_DY=0: the deferred BatchNorm backward of layer 0 keeps its dy pass (the transposed aggregation writes da)
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
 };
 const Options& opts();
@@ -193,6 +194,18 @@ struct SourceTail { const float* scale; const float* shift; float drop_p; uint32
 // nnz (optional): the block's edge count; a sparse block (<= 6 in-edges per row on average; plain SAGE aggregation) takes the short-row kernel (same bits)
 int spmm_csr_tail(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* z, int64_t ldz, int d,
                   const SourceTail& tail, float* out, int64_t ldo, void* stream, int64_t nnz = -1);
+// spmm.hip: the transposed aggregation A^T dY (col-scaled SUM) whose epilogue is the first pass of the BatchNorm backward of the layer in
+// front: out = dy (da behind the tail's dropout / ReLU masks -- da itself is never written), per-workgroup column sums S1 / S2 in `ws`
+// (*nslots slots; student.hip's bn_bwd_deferred_finish folds them).  GLNN_ERR_UNSUPPORTED = nothing launched.
+struct BnTail { const float* z; int64_t ldz; const float* mean; const float* rstd; const float* a_scale; const float* a_shift; float drop_p;
+                uint32_t drop_seed; int relu; };
+int spmm_csr_bn_dy(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x, int64_t ldx, int d,
+                   const float* col_scale, const BnTail& tail, float* out, int64_t ldo, float* ws, int64_t ws_floats, int* nslots, void* stream);
+// student.hip: the rest of bn_relu_bwd(..., defer_apply) behind partial sums that already exist (ws1 = ws, ws2 = ws + nslots h): fold,
+// constants, *defer_apply.  ws must hold 2 nslots h + 5 h + 8 floats.
+int bn_bwd_deferred_finish(float* ws, int64_t ws_floats, int nslots, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,
+                           const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dz_col_sum, struct BnApplyA* defer_apply,
+                           void* stream);
 int spmm_csr_nnz(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, int64_t nnz, const float* x, int64_t ldx, int d,
                  int mode, const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows, float* out, int64_t ldo,
                  void* stream);

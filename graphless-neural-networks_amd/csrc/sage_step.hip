@@ -99,23 +99,40 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     GLNN_TRY(glnn_gemm_f32(dz, ld_dz, nullptr, nullptr, nullptr, 0.f, 0u, y.n_dst, d_out, y.w, d_in, 1, d_in, nullptr, nullptr, nullptr, 0,
                            d->dagg, d->ld_dagg, nullptr, 0, stream));
     GLNN_TRY(transposes(l, stream));
-    GLNN_TRY(glnn::spmm_csr_nnz(y.t_indptr, y.t_indices, y.n_src, y.n_dst, y.nnz + y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, y.inv_deg,
-                                nullptr, 0, nullptr, d->dh, d->ld_dh, stream));       // (transposed block: 1-2 in-edges per row -> short rows)
     const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh
+    // layer 0's dz has one consumer (see above): its BatchNorm backward is deferred to dW_0's operand loads when that product's shape allows
+    const bool defer = l == 1 && d->batchnorm && glnn::opts().sage_fuse_bn_apply && y.n_src == prev.n_dst &&
+                       glnn::gemm_tn_takes_bn(d->dh, d->ld_dh, prev.n_dst, d_in, prev.agg, prev.ld_agg, d->dims[0], prev.z, prev.ldz) && d->ws_tn &&
+                       (int64_t)d->dims[0] * d_in * 8 <= d->ws_tn_floats;     // (room for >= 8 split slabs: every split stays inside the descriptor window)
     int rcb = GLNN_ERR_UNSUPPORTED;
-    if (l == 1 && d->batchnorm && glnn::opts().sage_fuse_bn_apply &&
-        glnn::gemm_tn_takes_bn(d->dh, d->ld_dh, prev.n_dst, d_in, prev.agg, prev.ld_agg, d->dims[0], prev.z, prev.ldz) && d->ws_tn &&
-        (int64_t)d->dims[0] * d_in * 8 <= d->ws_tn_floats) {                  // (room for >= 8 split slabs: every split stays inside the descriptor window)
-      rcb = glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, prev.gamma, prev.mean, prev.rstd, prev.a_scale, prev.a_shift, p,
-                              prev.drop_seed, d->dh, d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr, nullptr, 1,
-                              0, nullptr, nullptr, &ax0);
+    if (defer && glnn::opts().sage_fuse_bn_dy) {
+      // ... and its first pass (dy, column sums) is the epilogue of the transposed aggregation: da is never written
+      const glnn::BnTail tail = {prev.z, prev.ldz, prev.mean, prev.rstd, prev.a_scale, prev.a_shift, p, prev.drop_seed, 1};
+      int nslots = 0;
+      rcb = glnn::spmm_csr_bn_dy(y.t_indptr, y.t_indices, y.n_src, y.n_dst, d->dagg, d->ld_dagg, d_in, y.inv_deg, tail, d->dh, d->ld_dh, d->ws_bn,
+                                 d->ws_bn_floats - (5ll * d_in + 8), &nslots, stream);
       if (rcb != GLNN_OK && rcb != GLNN_ERR_UNSUPPORTED) return rcb;
-      apply_in_gemm = rcb == GLNN_OK;
+      if (rcb == GLNN_OK) {
+        GLNN_TRY(glnn::bn_bwd_deferred_finish(d->ws_bn, d->ws_bn_floats, nslots, d_in, prev.n_dst, prev.z, prev.ldz, prev.gamma, prev.mean, prev.rstd,
+                                              prev.ggamma, prev.gbeta, prev.gb, &ax0, stream));
+        apply_in_gemm = true;
+      }
     }
-    if (rcb == GLNN_ERR_UNSUPPORTED)
-      GLNN_TRY(glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, d->batchnorm ? prev.gamma : nullptr, prev.mean, prev.rstd,
-                                 d->batchnorm ? prev.a_scale : nullptr, d->batchnorm ? prev.a_shift : nullptr, p, prev.drop_seed, d->dh,
-                                 d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+    if (rcb == GLNN_ERR_UNSUPPORTED) {
+      GLNN_TRY(glnn::spmm_csr_nnz(y.t_indptr, y.t_indices, y.n_src, y.n_dst, y.nnz + y.n_dst, d->dagg, d->ld_dagg, d_in, GLNN_AGG_SUM, y.inv_deg,
+                                  nullptr, 0, nullptr, d->dh, d->ld_dh, stream));
+      if (defer) {
+        rcb = glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, prev.gamma, prev.mean, prev.rstd, prev.a_scale, prev.a_shift, p,
+                                prev.drop_seed, d->dh, d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr, nullptr, 1,
+                                0, nullptr, nullptr, &ax0);
+        if (rcb != GLNN_OK && rcb != GLNN_ERR_UNSUPPORTED) return rcb;
+        apply_in_gemm = rcb == GLNN_OK;
+      }
+      if (rcb == GLNN_ERR_UNSUPPORTED)
+        GLNN_TRY(glnn::bn_relu_bwd(d->dh, d->ld_dh, prev.z, prev.ldz, prev.n_dst, d_in, d->batchnorm ? prev.gamma : nullptr, prev.mean, prev.rstd,
+                                   d->batchnorm ? prev.a_scale : nullptr, d->batchnorm ? prev.a_shift : nullptr, p, prev.drop_seed, d->dh,
+                                   d->ld_dh, prev.ggamma, prev.gbeta, prev.gb, d->ws_bn, d->ws_bn_floats, stream, nullptr));
+    }
     dz = d->dh;
     ld_dz = d->ld_dh;
   }

@@ -549,6 +549,131 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_short_kernel(const SpmmArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
+// A^T dY WITH the first pass of the BatchNorm backward behind it (glnn::spmm_csr_bn_dy, round 5): the transposed aggregation of a training
+// step produces da = dL/dh of a hidden layer whose tail is BatchNorm -> ReLU -> dropout.  Its BatchNorm backward starts with a pass over
+// (da, z) for dy = da behind the masks and the column sums S1 = sum dy, S2 = sum dy xhat.  Here the aggregation's epilogue does that pass
+// on the row it holds: it reads the row of z, stores dy INSTEAD of da and accumulates the row into per-wave column sums -- da is never
+// written or read back (0.5 M x 256 on the products configuration: 1 GB of traffic and a launch).
+// Deterministic by construction: rows are dealt to the waves STATICALLY (row_base + wave + 8 i -- no ticket), a wave adds its rows in
+// ascending order, the eight waves of a workgroup are folded in fixed order into the workgroup's slot [blockIdx.x][h] of ws1 / ws2; the
+// long-row workgroups take their rows in ascending id order.  glnn::bn_bwd_deferred_finish folds the slots.
+// ---------------------------------------------------------------------------------------------
+struct DyTail {
+  const float* z; int64_t ldz; const float* mean; const float* rstd; const float* a_scale; const float* a_shift;
+  uint32_t dthr; uint32_t dseed; float dscale; int relu; float* ws1; float* ws2; int h;
+};
+struct DyCols { float mu[4], rs[4], sc[4], sf[4]; };
+__device__ __forceinline__ DyCols load_dy_cols(const DyTail& t, int col4) {
+  DyCols c;
+  const float4 mu = ld4(t.mean + col4), rs = ld4(t.rstd + col4), sc = ld4(t.a_scale + col4), sf = ld4(t.a_shift + col4);
+  c.mu[0] = mu.x; c.mu[1] = mu.y; c.mu[2] = mu.z; c.mu[3] = mu.w;
+  c.rs[0] = rs.x; c.rs[1] = rs.y; c.rs[2] = rs.z; c.rs[3] = rs.w;
+  c.sc[0] = sc.x; c.sc[1] = sc.y; c.sc[2] = sc.z; c.sc[3] = sc.w;
+  c.sf[0] = sf.x; c.sf[1] = sf.y; c.sf[2] = sf.z; c.sf[3] = sf.w;
+  return c;
+}
+// one finished row: da (the aggregate) -> dy, stored; the row added to the caller's running column sums (bn_bwd_partial's expressions)
+template <bool DROP>
+__device__ __forceinline__ void finish_dy_row(const SpmmArgs& a, const DyTail& t, const DyCols& c, int64_t v, float4 acc, float4 z4, int col4,
+                                              float (&s1)[4], float (&s2)[4]) {
+  const float da[4] = {acc.x, acc.y, acc.z, acc.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w};
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float dav = da[k];
+    if (DROP) dav = glnn::drop_keep(t.dseed, t.dthr, (uint32_t)v, (uint32_t)(col4 + k)) ? dav * t.dscale : 0.f;
+    const float dy = (!t.relu || fmaf(zz[k], c.sc[k], c.sf[k]) > 0.f) ? dav : 0.f;
+    s1[k] += dy;
+    s2[k] = fmaf(dy, (zz[k] - c.mu[k]) * c.rs[k], s2[k]);
+    o[k] = dy;
+  }
+  st4_stream(a.out + v * a.ldo + col4, make_float4(o[0], o[1], o[2], o[3]));
+}
+
+template <int LPR, int U, bool DROP>
+__global__ __launch_bounds__(kBlock) void spmm_bn_dy_kernel(const SpmmArgs a, const DyTail t) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col4 = (lane % LPR) * 4;
+  const bool col_ok = col4 < a.d;                        // d % 4 == 0: a lane's four columns are all inside or all outside
+  const DyCols c = load_dy_cols(t, col_ok ? col4 : 0);
+  const XfCols xf = {};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  __shared__ float4 s_part[kWavesPerBlock][64], s_part2[kWavesPerBlock][64];
+  if ((int)blockIdx.x < a.n_long_blocks) {
+    // ---- long rows: the scan of long_rows_role, the found rows of a chunk taken in ASCENDING order (the sums must not depend on the
+    //      order in which the lanes' atomics landed) ----
+    __shared__ int64_t s_rows[kBlock], s_sorted[kBlock];
+    __shared__ int s_count;
+    const int64_t n_chunks = (a.n_dst + kBlock - 1) / kBlock;
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += a.n_long_blocks) {
+      if (threadIdx.x == 0) s_count = 0;
+      __syncthreads();
+      const int64_t r = (int64_t)threadIdx.x * n_chunks + chunk;
+      if (r < a.n_dst && (a.indptr[r + 1] - a.indptr[r]) > kLongRow) s_rows[atomicAdd(&s_count, 1)] = r;
+      __syncthreads();
+      const int n_found = s_count;
+      if ((int)threadIdx.x < n_found) {
+        const int64_t mine = s_rows[threadIdx.x];
+        int rank = 0;
+        for (int i = 0; i < n_found; ++i) rank += s_rows[i] < mine ? 1 : 0;
+        s_sorted[rank] = mine;
+      }
+      __syncthreads();
+      for (int i = 0; i < n_found; ++i) {
+        const int64_t v = s_sorted[i];
+        const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+        float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave == 0 && lane < LPR && col_ok) z4 = ld4(t.z + v * t.ldz + col4);
+        float4 acc;
+        if (e1 - e0 > kHubRow) acc = hub_wave_share<LPR, U, true, false>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, a.col_scale, wave, lane, xf);
+        else acc = wave_gather_sum<LPR, U, true, false>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
+        if (lane < LPR) s_part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && lane < LPR && col_ok) {
+          float4 sum = s_part[0][lane];
+#pragma unroll
+          for (int w = 1; w < kWavesPerBlock; ++w) sum = add4(sum, s_part[w][lane]);
+          finish_dy_row<DROP>(a, t, c, v, sum, z4, col4, s1, s2);
+        }
+        __syncthreads();
+      }
+    }
+    if (wave == 0 && lane < LPR && col_ok) {             // the long-row workgroup's slot: wave 0's sums
+      st4(t.ws1 + (int64_t)blockIdx.x * t.h + col4, make_float4(s1[0], s1[1], s1[2], s1[3]));
+      st4(t.ws2 + (int64_t)blockIdx.x * t.h + col4, make_float4(s2[0], s2[1], s2[2], s2[3]));
+    }
+    return;
+  }
+  // ---- row role, static: wave w takes the rows row_base + w + 8 i ----
+  const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
+  const int64_t row_base = blk * a.rows_per_block;
+#pragma unroll 1
+  for (int lr = wave; lr < a.rows_per_block; lr += kWavesPerBlock) {
+    const int64_t v = row_base + lr;
+    if (v >= a.n_dst) break;
+    const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+    if (e1 - e0 > kLongRow) continue;
+    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < LPR && col_ok) z4 = ld4(t.z + v * t.ldz + col4);          // (in flight beside the gather)
+    const float4 acc = wave_gather_sum<LPR, U, true, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
+    if (lane < LPR && col_ok) finish_dy_row<DROP>(a, t, c, v, acc, z4, col4, s1, s2);
+  }
+  if (lane < LPR) {
+    s_part[wave][lane] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    s_part2[wave][lane] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  }
+  __syncthreads();
+  if (wave == 0 && lane < LPR && col_ok) {
+    float4 u = s_part[0][lane], w2 = s_part2[0][lane];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) { u = add4(u, s_part[w][lane]); w2 = add4(w2, s_part2[w][lane]); }
+    st4(t.ws1 + (int64_t)blockIdx.x * t.h + col4, u);
+    st4(t.ws2 + (int64_t)blockIdx.x * t.h + col4, w2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1F: fused SAGE-"gcn" layer  out = epi( ((sum_{u->v} x[u] + x_self[v]) / (deg+1)) @ W^T )
 // for aggregate-first layers (d_in <= 256, d_out <= 256): the aggregated rows never go to HBM.
 //   phase A  the 8 waves of a workgroup aggregate a tile of 32 destination rows (4 rows each, the same
@@ -964,6 +1089,48 @@ int glnn::spmm_csr_nnz(const int64_t* indptr, const int32_t* indices, int64_t n_
                        void* stream) {
   return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, nullptr, col_scale, x_self, ld_self, self_rows, nullptr, nullptr, 0, out, ldo,
                    stream, nullptr, nullptr, nnz);
+}
+
+// out = dy of (A x col_scale) behind the BatchNorm tail described by `tail`, plus the per-workgroup column sums for that BatchNorm's
+// backward: see spmm_bn_dy_kernel.  ws: 2 * (*nslots) * d floats (ws1 = ws, ws2 = ws + nslots d).  GLNN_ERR_UNSUPPORTED with nothing
+// launched unless 64 < d <= 256, d % 4 == 0, float4-addressable rows, and ws holds the slots.
+int glnn::spmm_csr_bn_dy(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x, int64_t ldx, int d,
+                         const float* col_scale, const glnn::BnTail& tail, float* out, int64_t ldo, float* ws, int64_t ws_floats, int* nslots,
+                         void* stream) {
+  if (!indptr || !x || !out || !col_scale || !ws || !nslots || n_dst < 1 || n_src < 0 || n_src >= ((int64_t)1 << 31)) return GLNN_ERR_UNSUPPORTED;
+  if (d <= 64 || d > 256 || (d & 3) || (ldx & 3) || (ldo & 3) || (tail.ldz & 3) || ldx < d || ldo < d || tail.ldz < d) return GLNN_ERR_UNSUPPORTED;
+  if (!tail.z || !tail.mean || !tail.rstd || !tail.a_scale || !tail.a_shift || tail.drop_p < 0.f || tail.drop_p >= 1.f) return GLNN_ERR_UNSUPPORTED;
+  if (!glnn::aligned16(x) || !glnn::aligned16(out) || !glnn::aligned16(tail.z) || !glnn::aligned16(tail.mean) || !glnn::aligned16(tail.rstd) ||
+      !glnn::aligned16(tail.a_scale) || !glnn::aligned16(tail.a_shift) || !glnn::aligned16(ws))
+    return GLNN_ERR_UNSUPPORTED;
+  SpmmArgs a = {};
+  a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.d = d; a.col_scale = col_scale; a.out = out; a.ldo = ldo;
+  int64_t n_long = (n_dst + GLNN_LONG_BLOCK_ROWS - 1) / GLNN_LONG_BLOCK_ROWS;
+  if (n_long < 1) n_long = 1;
+  if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
+  a.n_long_blocks = (int)n_long;
+  int64_t rpw = n_dst / (2048 * kWavesPerBlock);
+  if (rpw < 1) rpw = 1;
+  if (rpw > kRowsPerWave) rpw = kRowsPerWave;
+  a.rows_per_block = (int)(kWavesPerBlock * rpw);
+  const int64_t row_blocks = (n_dst + a.rows_per_block - 1) / a.rows_per_block;
+  const int64_t slots = row_blocks + n_long;
+  if (slots >= ((int64_t)1 << 24) || 2 * slots * d > ws_floats) return GLNN_ERR_UNSUPPORTED;
+  DyTail t;
+  t.z = tail.z; t.ldz = tail.ldz; t.mean = tail.mean; t.rstd = tail.rstd; t.a_scale = tail.a_scale; t.a_shift = tail.a_shift;
+  t.dthr = glnn::drop_threshold(tail.drop_p); t.dseed = tail.drop_seed; t.dscale = 1.0f / (1.0f - tail.drop_p); t.relu = tail.relu;
+  t.ws1 = ws; t.ws2 = ws + slots * d; t.h = d;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 g((unsigned)slots);
+  if (d > 128) {
+    if (t.dthr) hipLaunchKernelGGL((spmm_bn_dy_kernel<64, GLNN_SPMM_U, true>), g, dim3(kBlock), 0, st, a, t);
+    else hipLaunchKernelGGL((spmm_bn_dy_kernel<64, GLNN_SPMM_U, false>), g, dim3(kBlock), 0, st, a, t);
+  } else {
+    if (t.dthr) hipLaunchKernelGGL((spmm_bn_dy_kernel<32, GLNN_SPMM_U, true>), g, dim3(kBlock), 0, st, a, t);
+    else hipLaunchKernelGGL((spmm_bn_dy_kernel<32, GLNN_SPMM_U, false>), g, dim3(kBlock), 0, st, a, t);
+  }
+  *nslots = (int)slots;
+  return glnn::check_launch("glnn::spmm_csr_bn_dy");
 }
 
 extern "C" int glnn_degrees_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,

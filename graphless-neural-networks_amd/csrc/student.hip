@@ -1366,6 +1366,21 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const float* __restr
 }
 }  // namespace
 
+int glnn::bn_bwd_deferred_finish(float* ws, int64_t ws_floats, int nslots, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,
+                                 const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dz_col_sum, glnn::BnApplyA* defer_apply,
+                                 void* stream) {
+  GLNN_REQUIRE(ws && glnn::aligned16(ws) && nslots >= 1 && h >= 4 && (h & 3) == 0 && rows >= 1 && gamma && mean && rstd && dgamma && dbeta &&
+               defer_apply && ws_floats >= 2ll * nslots * h + 5ll * h + 8, "glnn::bn_bwd_deferred_finish: bad arguments");
+  float* totals = ws + 2ll * nslots * h;
+  float* cst = totals + 2ll * h;                          // (2 nslots h + 2 h: a multiple of 4 floats behind an aligned base)
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  fold_chunks(ws, ws + (int64_t)nslots * h, nslots, h, totals, st);
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((h + 255) / 256), dim3(256), 0, st, totals, h, (float)rows, gamma, mean, rstd, cst, cst + h,
+                     cst + 2ll * h, dgamma, dbeta, dz_col_sum);
+  *defer_apply = {z, ldz, cst, cst + h, cst + 2ll * h};
+  return glnn::check_launch("glnn::bn_bwd_deferred_finish");
+}
+
 int glnn::bn_relu_bwd(const float* da, int64_t ldda, const float* z, int64_t ldz, int64_t rows, int h, const float* gamma,
                       const float* mean, const float* rstd, const float* a_scale, const float* a_shift, float drop_p,
                       uint32_t drop_seed, float* dz, int64_t lddz, float* dgamma, float* dbeta, float* dz_col_sum,

@@ -728,13 +728,15 @@ def test_sage_step_tail_in_the_gather_is_bit_identical_to_the_materialised_tail(
 
 @pytest.mark.parametrize("p", [0.5, 0.0])
 def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypatch):
-    """Round 5: the outermost block's dz has one consumer, dW_0.  Layer 0's BatchNorm backward then stops after ONE pass (dy in place of da,
-    the column sums -- bn_bwd_partial's own bits) and dz = alpha dy + beta z + gamma is evaluated on the staged operand pieces of the
-    pipelined weight-gradient kernel (glnn::gemm_tn(..., bn)): dz_0 is never written.  Against GLNN_SAGE_FUSE_BN_APPLY=0 (the apply as its
-    own launch): same loss and same gradients behind layer 0 bit for bit, the same BatchNorm parameter gradients of layer 0 bit for bit,
-    dW_0 equal to rounding (an affine map instead of bn_dz's expression); the bias in front of the BatchNorm -- true gradient 0,
-    rounding noise in the plain form -- is exactly 0.  The block is big enough (> 64 row chunks of layer-0 destinations) for the
-    deferred form to engage."""
+    """Round 5: the outermost block's dz has one consumer, dW_0.  Layer 0's BatchNorm backward is then spread over its neighbours:
+    (dy) the transposed aggregation that produces da stores dy -- da behind the dropout / ReLU masks -- instead, and leaves the column sums of
+    the rows it finishes (spmm_bn_dy_kernel: da is never written; GLNN_SAGE_FUSE_BN_DY=0: a pass of its own, bn_bwd_partial's bits);
+    (apply) dz = alpha dy + beta z + gamma is evaluated on the staged operand pieces of the pipelined weight-gradient kernel
+    (glnn::gemm_tn(..., bn)): dz_0 is never written (GLNN_SAGE_FUSE_BN_APPLY=0: the plain three-pass form).
+    Against the plain form: same loss and same gradients behind layer 0 bit for bit; layer 0's BatchNorm parameter gradients bit for bit with
+    the separate dy pass, to summation order with the epilogue; dW_0 to rounding (an affine map instead of bn_dz's expression); the bias in
+    front of the BatchNorm -- true gradient 0, rounding noise in the plain form -- exactly 0.  The block is big enough (> 64 row chunks of
+    layer-0 destinations, hub rows among them) for the deferred forms to engage."""
     from glnn_amd import ops
     from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
     from glnn_amd.models import Model
@@ -748,9 +750,10 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
     (input_nodes, output_nodes, blocks), = list(NodeDataLoader(g, torch.arange(2048), MultiLayerNeighborSampler([5, 10, 15]), batch_size=2048,
                                                                 shuffle=False, seed=5))
     assert blocks[0].num_dst_nodes() > 64 * 128
-    grads, losses = [], []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("GLNN_SAGE_FUSE_BN_APPLY", mode)
+    grads, losses = {}, {}
+    for mode in ("11", "10", "00"):
+        monkeypatch.setenv("GLNN_SAGE_FUSE_BN_APPLY", mode[0])
+        monkeypatch.setenv("GLNN_SAGE_FUSE_BN_DY", mode[1])
         torch.manual_seed(2)
         model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
                            norm_type="batch", device=DEV))
@@ -759,19 +762,22 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
         eng = TeacherEngine(model, opt)
         eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
         torch.cuda.synchronize()
-        grads.append({k: prm.grad.detach().clone() for k, prm in model.named_parameters()})
-        losses.append(eng.loss_out.clone())
-    assert torch.equal(losses[0], losses[1])
-    for k in grads[0]:
-        a, b = grads[0][k], grads[1][k]
-        if k.startswith("encoder.layers.0") and k.endswith("fc_neigh.bias"):
-            assert float(a.abs().max()) == 0.0 and float(b.abs().max()) < 1e-4, k
-            continue
-        if not k.startswith("encoder.layers.0"):
-            assert torch.equal(a, b), k                   # everything behind layer 0 runs the same launches; the norm's sums are the same bits
-            continue
-        scale = max(1.0, float(b.abs().max()))
-        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
+        grads[mode] = {k: prm.grad.detach().clone() for k, prm in model.named_parameters()}
+        losses[mode] = eng.loss_out.clone()
+    assert torch.equal(losses["11"], losses["00"]) and torch.equal(losses["10"], losses["00"])
+    for mode in ("11", "10"):
+        for k in grads["00"]:
+            a, b = grads[mode][k], grads["00"][k]
+            scale = max(1.0, float(b.abs().max()))
+            if k.startswith("encoder.layers.0") and k.endswith("fc_neigh.bias"):
+                assert float(a.abs().max()) == 0.0 and float(b.abs().max()) < 1e-4, (mode, k)
+            elif k.startswith("encoder.layers.0"):
+                assert float((a - b).abs().max()) <= 2e-5 * scale, (mode, k, float((a - b).abs().max()), scale)
+            elif k.startswith("encoder.norms.0") and mode == "11":
+                assert float((a - b).abs().max()) <= 2e-5 * scale, (mode, k, float((a - b).abs().max()), scale)     # (other summation order)
+            else:
+                assert torch.equal(a, b), (mode, k)        # behind layer 0: the same launches; "10": the norm's sums are bn_bwd_partial's bits
+    assert not torch.equal(grads["11"]["encoder.layers.0.fc_neigh.weight"], grads["00"]["encoder.layers.0.fc_neigh.weight"])      # (the switches did switch)
 
 
 @pytest.mark.parametrize("norm,p,full,gather_tail,hidden", [("batch", 0.3, False, "1", 256), ("none", 0.5, False, "1", 136), ("batch", 0.4, True, "1", 256),
