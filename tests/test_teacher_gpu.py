@@ -742,7 +742,9 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
     from glnn_amd.models import Model
     from glnn_amd.teacher import TeacherEngine
     n, dims = 120000, [100, 256, 256, 47]
-    indptr, indices = random_graph(n, 12, seed=21, power=0.6, hub=3000, isolated=50)
+    # symmetric: the 3000-edge hub is also a SOURCE of 3000 rows, so the transposed block of layer 1 has a long row (the long-row role of
+    # the aggregation whose epilogue is the dy pass)
+    indptr, indices = random_graph(n, 6, seed=21, power=0.6, hub=3000, isolated=50, symmetric=True)
     rs = np.random.RandomState(21)
     fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
     ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
@@ -750,8 +752,9 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
     (input_nodes, output_nodes, blocks), = list(NodeDataLoader(g, torch.arange(2048), MultiLayerNeighborSampler([5, 10, 15]), batch_size=2048,
                                                                 shuffle=False, seed=5))
     assert blocks[0].num_dst_nodes() > 64 * 128
+    assert int(torch.bincount(blocks[1].indices.long()).max()) > 128, "no long row in the transposed block of layer 1"
     grads, losses = {}, {}
-    for mode in ("11", "10", "00"):
+    for mode in ("11", "10", "00", "11 again"):
         monkeypatch.setenv("GLNN_SAGE_FUSE_BN_APPLY", mode[0])
         monkeypatch.setenv("GLNN_SAGE_FUSE_BN_DY", mode[1])
         torch.manual_seed(2)
@@ -765,6 +768,7 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
         grads[mode] = {k: prm.grad.detach().clone() for k, prm in model.named_parameters()}
         losses[mode] = eng.loss_out.clone()
     assert torch.equal(losses["11"], losses["00"]) and torch.equal(losses["10"], losses["00"])
+    assert all(torch.equal(grads["11"][k], grads["11 again"][k]) for k in grads["11"])       # the epilogue's column sums are deterministic
     for mode in ("11", "10"):
         for k in grads["00"]:
             a, b = grads[mode][k], grads["00"][k]
