@@ -315,34 +315,57 @@ __global__ __launch_bounds__(256) void tr_fill_kernel(const TrArgs a) {
     }
   }
 }
-// one wave per row of the transposed graph: the atomic fill left its entries in arbitrary order; rank them by value
-// (equal values are interchangeable) so that the fp32 sums of the aggregation kernel are reproducible run to run.
+// The atomic fill left a row's entries in arbitrary order; order them by value (equal values are interchangeable) so that the fp32 sums
+// of the aggregation kernel are reproducible run to run.  A wave takes 64 consecutive rows: rows of <= 4 entries -- nearly all rows of a
+// sampled block's transpose (1-2 in-edges per row) -- are ordered by their own lane in registers; longer rows then one at a time by the
+// whole wave, ranking by value.  (Until round 5 one wave per row whatever its length: 59 us for the 0.5 M-row transpose of the products
+// configuration, most of it the per-row dependent loads.)
 __global__ __launch_bounds__(256) void tr_sort_kernel(const TrArgs a) {
   const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t u = w; u < a.n_src; u += n_waves) {
-    const int64_t s0 = a.t_indptr[u];
-    const int len = (int)(a.t_indptr[u + 1] - s0);
-    const int32_t* src = a.tmp + s0;
-    int32_t* dst = a.t_indices + s0;
-    if (len <= 64) {
-      const int key = lane < len ? src[lane] : 0x7FFFFFFF;
-      int rank = 0;
-      for (int j = 0; j < len; ++j) {
-        const int kj = __shfl(key, j);
-        rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
-      }
-      if (lane < len) dst[rank] = key;
-    } else {
-      for (int i = lane; i < len; i += 64) {
-        const int key = src[i];
+  for (int64_t u0 = w * 64; u0 < a.n_src; u0 += n_waves * 64) {
+    const int64_t u = u0 + lane;
+    const bool valid = u < a.n_src;
+    const int64_t my_s0 = valid ? a.t_indptr[u] : 0;
+    const int my_len = valid ? (int)(a.t_indptr[u + 1] - my_s0) : 0;
+    if (my_len >= 1 && my_len <= 4) {
+      int k[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k[i] = i < my_len ? a.tmp[my_s0 + i] : 0x7FFFFFFF;
+#define GLNN_CSWAP(I, J) { const int lo = k[I] < k[J] ? k[I] : k[J], hi = k[I] < k[J] ? k[J] : k[I]; k[I] = lo; k[J] = hi; }
+      GLNN_CSWAP(0, 1) GLNN_CSWAP(2, 3) GLNN_CSWAP(0, 2) GLNN_CSWAP(1, 3) GLNN_CSWAP(1, 2)
+#undef GLNN_CSWAP
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < my_len) a.t_indices[my_s0 + i] = k[i];
+    }
+    unsigned long long longer = __ballot(my_len > 4);
+    while (longer) {
+      const int l = __ffsll((unsigned long long)longer) - 1;
+      longer &= longer - 1;
+      const int64_t s0 = ((int64_t)__shfl((int)(my_s0 >> 32), l) << 32) | (uint32_t)__shfl((int)(my_s0 & 0xFFFFFFFF), l);
+      const int len = __shfl(my_len, l);
+      const int32_t* src = a.tmp + s0;
+      int32_t* dst = a.t_indices + s0;
+      if (len <= 64) {
+        const int key = lane < len ? src[lane] : 0x7FFFFFFF;
         int rank = 0;
         for (int j = 0; j < len; ++j) {
-          const int kj = src[j];
-          rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+          const int kj = __shfl(key, j);
+          rank += (kj < key || (kj == key && j < lane)) ? 1 : 0;
         }
-        dst[rank] = key;
+        if (lane < len) dst[rank] = key;
+      } else {
+        for (int i = lane; i < len; i += 64) {
+          const int key = src[i];
+          int rank = 0;
+          for (int j = 0; j < len; ++j) {
+            const int kj = src[j];
+            rank += (kj < key || (kj == key && j < i)) ? 1 : 0;
+          }
+          dst[rank] = key;
+        }
       }
     }
   }
@@ -487,7 +510,7 @@ extern "C" int glnn_csr_transpose(const int64_t* indptr, const int32_t* indices,
     hipLaunchKernelGGL(tr_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   }
   if (nnz_out > 0) {
-    int64_t blocks = (n_src * 64 + 255) / 256;
+    int64_t blocks = (n_src + 255) / 256;                 // 64 rows per wave, 4 waves per workgroup
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(tr_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   }
