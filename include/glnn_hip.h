@@ -436,6 +436,12 @@ GLNN_API int glnn_mlp_train_step_f32(const glnn_mlp_step_desc* desc, const float
  *                             layer = logits), hidden output [n_dst, dims[l+1]] (float4 rows: leading dims % 4 == 0)
  *   t_indptr/t_indices/inv_deg/tr_ws  (l >= 1) outputs / workspace of the block's transpose (glnn_csr_transpose sizes)
  *   dagg [max n_dst_l, max dims[l]], dh [max n_src_l, max dims[l]] (l >= 1)   backward scratch
+ * Round 5 (same ABI, same results to rounding): with batchnorm != 0 and float4-addressable buffers big enough (ws_bn >= 2 slots dims[1] +
+ * 5 dims[1] + 8 floats, slots = n_dst_0 / 128 + <= 512; ws_tn >= 8 dims[0] dims[1] floats) the BatchNorm backward of the OUTERMOST layer has
+ * no pass of its own -- the transposed aggregation stores dy = da behind the tail's masks and the column sums, dz = alpha dy + beta z +
+ * gamma is evaluated in the operand loads of dW_0; gb of layer 0 (true gradient 0 in front of a BatchNorm) is then exactly 0.  Otherwise,
+ * or with GLNN_SAGE_FUSE_BN_APPLY=0 / GLNN_SAGE_FUSE_BN_DY=0, the launch sequence above.  Blocks of <= 6 in-edges per row on average
+ * (layer[l].nnz) take the four-rows-per-wave aggregation kernel (GLNN_SPMM_SHORT=0: never; same bits).
  * The optimiser step is NOT included: call glnn_adam_step_f32 next.
  * ------------------------------------------------------------------------------------------ */
 #define GLNN_SAGE_MAX_LAYERS 8
