@@ -47,6 +47,7 @@ SIGNATURES = {
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
     "glnn_mlp_train_step_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_vp],
     "glnn_sage_fwd_bwd_f32": [c_vp, c_vp],
+    "glnn_sage_step_ws_bn_floats": [c_i64, c_int],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_norm_drop_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_bn_bwd_f32": [c_vp, c_i64, c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64,
@@ -71,7 +72,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -161,6 +162,7 @@ def lib():
         h.glnn_block_workspace_bytes.restype = c_i64
         h.glnn_csr_transpose_workspace_bytes.restype = c_i64
         h.glnn_layernorm_bwd_workspace_floats.restype = c_i64
+        h.glnn_sage_step_ws_bn_floats.restype = c_i64
         h.glnn_last_error.argtypes = []
         h.glnn_last_error.restype = ctypes.c_char_p
         h.glnn_reload_options.argtypes = []

@@ -85,7 +85,7 @@ int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, 
 
 }  // namespace
 
-extern "C" int glnn_abi_version(void) { return 9; }
+extern "C" int glnn_abi_version(void) { return 10; }
 
 // test / A-B hook: re-read the GLNN_* switches (glnn::Options).  Not for concurrent use with other calls into the library.
 extern "C" void glnn_reload_options(void) {

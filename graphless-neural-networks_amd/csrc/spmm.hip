@@ -1091,6 +1091,25 @@ int glnn::spmm_csr_nnz(const int64_t* indptr, const int32_t* indices, int64_t n_
                    stream, nullptr, nullptr, nnz);
 }
 
+// the launch shape of spmm_bn_dy_kernel over n_dst rows: long-row workgroups + row workgroups = the number of column-sum slots
+static int64_t bn_dy_grid(int64_t n_dst, int* n_long_blocks, int* rows_per_block) {
+  int64_t n_long = (n_dst + GLNN_LONG_BLOCK_ROWS - 1) / GLNN_LONG_BLOCK_ROWS;
+  if (n_long < 1) n_long = 1;
+  if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
+  int64_t rpw = n_dst / (2048 * kWavesPerBlock);
+  if (rpw < 4) rpw = 4;                                   // (>= 32 rows per workgroup: its 2 x d floats of column sums stay a few % of what it writes)
+  if (rpw > kRowsPerWave) rpw = kRowsPerWave;
+  const int64_t rpb = kWavesPerBlock * rpw;
+  if (n_long_blocks) *n_long_blocks = (int)n_long;
+  if (rows_per_block) *rows_per_block = (int)rpb;
+  return (n_dst + rpb - 1) / rpb + n_long;
+}
+extern "C" int64_t glnn_sage_step_ws_bn_floats(int64_t n_dst_0, int hidden) {
+  if (n_dst_0 < 1 || hidden < 1) return 0;
+  const int64_t h = (hidden + 3) & ~3;
+  return 2 * bn_dy_grid(n_dst_0, nullptr, nullptr) * h + 5 * h + 8;
+}
+
 // out = dy of (A x col_scale) behind the BatchNorm tail described by `tail`, plus the per-workgroup column sums for that BatchNorm's
 // backward: see spmm_bn_dy_kernel.  ws: 2 * (*nslots) * d floats (ws1 = ws, ws2 = ws + nslots d).  GLNN_ERR_UNSUPPORTED with nothing
 // launched unless 64 < d <= 256, d % 4 == 0, float4-addressable rows, and ws holds the slots.
@@ -1105,16 +1124,7 @@ int glnn::spmm_csr_bn_dy(const int64_t* indptr, const int32_t* indices, int64_t 
     return GLNN_ERR_UNSUPPORTED;
   SpmmArgs a = {};
   a.indptr = indptr; a.indices = indices; a.n_dst = n_dst; a.x = x; a.ldx = ldx; a.d = d; a.col_scale = col_scale; a.out = out; a.ldo = ldo;
-  int64_t n_long = (n_dst + GLNN_LONG_BLOCK_ROWS - 1) / GLNN_LONG_BLOCK_ROWS;
-  if (n_long < 1) n_long = 1;
-  if (n_long > GLNN_LONG_BLOCK_CAP) n_long = GLNN_LONG_BLOCK_CAP;
-  a.n_long_blocks = (int)n_long;
-  int64_t rpw = n_dst / (2048 * kWavesPerBlock);
-  if (rpw < 1) rpw = 1;
-  if (rpw > kRowsPerWave) rpw = kRowsPerWave;
-  a.rows_per_block = (int)(kWavesPerBlock * rpw);
-  const int64_t row_blocks = (n_dst + a.rows_per_block - 1) / a.rows_per_block;
-  const int64_t slots = row_blocks + n_long;
+  const int64_t slots = bn_dy_grid(n_dst, &a.n_long_blocks, &a.rows_per_block);
   if (slots >= ((int64_t)1 << 24) || 2 * slots * d > ws_floats) return GLNN_ERR_UNSUPPORTED;
   DyTail t;
   t.z = tail.z; t.ldz = tail.ldz; t.mean = tail.mean; t.rstd = tail.rstd; t.a_scale = tail.a_scale; t.a_shift = tail.a_shift;

@@ -276,6 +276,8 @@ class TeacherEngine:
                 d.dh, d.ld_dh = A.take(4 * max(b.num_src_nodes() for b in blocks[1:]) * wd), wd
             nchunks = (max_rows + 127) // 128
             d.ws_bn_floats = (3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024
+            if L > 1 and self.bn:     # room for the outermost layer's BatchNorm backward without passes of its own (round 5)
+                d.ws_bn_floats = max(d.ws_bn_floats, int(_lib.lib().glnn_sage_step_ws_bn_floats(blocks[0].num_dst_nodes(), dims[1])))
             d.ws_tn_floats = 64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims)
             # split-K slabs, sized as StudentEngine does; the GEMM only splits outputs of < 256 tiles, i.e. <= 512 slabs of 128 x 128
             d.ws_gemm_floats = min(max(16 * max(b.num_dst_nodes() for b in blocks) * min(dims[1:]), 1 << 20), 512 * 128 * 128)

@@ -473,6 +473,10 @@ typedef struct glnn_sage_step_desc {
 } glnn_sage_step_desc;
 
 GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream);
+/* ABI 10: ws_bn floats with which the outermost layer's BatchNorm backward takes the form without passes of its own (see above) for an
+ * outermost block of n_dst_0 destinations and dims[1] = hidden; the step's other uses of ws_bn need (3 chunks + 2 + 3 ceil(chunks / 64)) *
+ * max hidden + 1024 floats, chunks = ceil(max n_dst / 128): allocate the larger of the two. */
+GLNN_API int64_t glnn_sage_step_ws_bn_floats(int64_t n_dst_0, int hidden);
 
 /* y = dropout(relu(z * a_scale + a_shift)) materialised (a_scale/a_shift NULL: plain ReLU): the `norms[l](h)` ->
  * `activation` -> `dropout` tail of a TRAINING-mode SAGE layer (reference models.py:113-117), whose output the next

@@ -781,7 +781,8 @@ def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypa
                 assert float((a - b).abs().max()) <= 2e-5 * scale, (mode, k, float((a - b).abs().max()), scale)     # (other summation order)
             else:
                 assert torch.equal(a, b), (mode, k)        # behind layer 0: the same launches; "10": the norm's sums are bn_bwd_partial's bits
-    assert not torch.equal(grads["11"]["encoder.layers.0.fc_neigh.weight"], grads["00"]["encoder.layers.0.fc_neigh.weight"])      # (the switches did switch)
+    assert not torch.equal(grads["11"]["encoder.layers.0.fc_neigh.weight"], grads["00"]["encoder.layers.0.fc_neigh.weight"])      # (the switches did switch:
+    assert not torch.equal(grads["11"]["encoder.norms.0.weight"], grads["10"]["encoder.norms.0.weight"])    #  the epilogue's column sums have their own order)
 
 
 @pytest.mark.parametrize("norm,p,full,gather_tail,hidden", [("batch", 0.3, False, "1", 256), ("none", 0.5, False, "1", 136), ("batch", 0.4, True, "1", 256),
