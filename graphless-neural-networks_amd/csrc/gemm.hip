@@ -1886,10 +1886,6 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
                        stream, nullptr, nullptr, nullptr, 0);
 }
 
-// glnn_gemm_tn_f32 whose final sums may be left to the fused Adam launch (glnn::PendingFolds): with `defer` the fold launch of a
-// split reduction is skipped and *defer describes the slabs (same order as the fold kernel that would have run: four interleaved
-// lanes from 16 splits on, k ascending below); with `defer_colsum` the second stage of col_sum_a likewise.  *used_floats = the
-// workspace prefix that then has to stay untouched until Adam has run.
 // would gemm_tn(..., bn) take this product (the pipelined 128 x 128 kernel with plain float4-addressable operands)?  The caller decides
 // BEFORE it leaves dz unwritten; the one condition not covered is the split of the reduction, which needs rows_per_split x ld < 2^28
 // (any workspace that lets the output split into ~256 workgroups does)
@@ -1899,6 +1895,10 @@ bool glnn::gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, cons
   return m >= 1 && ka % 4 == 0 && fast && nb > 64 && pipe_enabled() && lda < (1 << 20) && ldb < (1 << 20) && ldz < (1 << 20);
 }
 
+// glnn_gemm_tn_f32 whose final sums may be left to the fused Adam launch (glnn::PendingFolds): with `defer` the fold launch of a
+// split reduction is skipped and *defer describes the slabs (same order as the fold kernel that would have run: four interleaved
+// lanes from 16 splits on, k ascending below); with `defer_colsum` the second stage of col_sum_a likewise.  *used_floats = the
+// workspace prefix that then has to stay untouched until Adam has run.
 int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb,
                   const int64_t* b_rows, const float* b_scale, const float* b_shift, float drop_p,
                   uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace, int64_t workspace_floats, void* stream,
