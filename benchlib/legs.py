@@ -55,10 +55,24 @@ def teacher_training_leg(g, feats, labels, dev, data):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     steps = epochs * len(loader)
+    # the same step WITHOUT the sampler beside it: one full batch stepped through the engine alone (what the kernels of a step cost;
+    # the difference to ms_per_step is the sampler's kernels sharing the GPU from their side stream)
+    from glnn_amd import teacher
+    input_nodes, output_nodes, blocks = next(iter(loader))
+    model.train()
+    eng = teacher.get_engine(model, opt)
+    for _ in range(3):
+        eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(30):
+        eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
+    torch.cuda.synchronize()
+    engine_ms = 1e3 * (time.perf_counter() - t1) / 30
     return {"metric": f"sampled-block GraphSAGE training steps/s ({C.GRAPH}-shaped graph, fan-out 5,10,15, B={bsz}, dropout {p}, BN; "
                       "sampling + block building + forward + NLL + backward + Adam, all on the device)",
             "value": steps / dt, "unit": "steps/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "epoch_s": dt / epochs,
-            "train_nodes": n_train, "loss_first_last": [losses[0], losses[-1]]}
+            "engine_alone_ms_per_step": engine_ms, "train_nodes": n_train, "loss_first_last": [losses[0], losses[-1]]}
 
 
 def roofline_object(timing, nnz, n, with_traffic):

@@ -69,6 +69,8 @@ def compact(r, detail_path):
         c["students_small"] = {s_["student"]: round(s_["ms_per_step"], 4) for s_ in r["students_small"]}
     if "teacher_training" in r:
         c["teacher_training"] = {"steps_per_s": r["teacher_training"]["value"], "ms_per_step": r["teacher_training"]["ms_per_step"]}
+        if "engine_alone_ms_per_step" in r["teacher_training"]:
+            c["teacher_training"]["engine_alone_ms"] = round(r["teacher_training"]["engine_alone_ms_per_step"], 4)
     cb = r.get("cpu_baseline")
     if cb:
         c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": _short(cb["sample"], 200),

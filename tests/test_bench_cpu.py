@@ -27,7 +27,7 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
                       "dense_projection_ms_per_forward": 0.0},
          "student": {"metric": long, "value": 1000.0, "unit": "steps/s", "ms_per_step": 0.93, "steps": 60, "tflops": 119.0, "frac_of_fp32_mfma_peak": 0.76},
          "students_small": [{"student": n, "ms_per_step": 0.06} for n in ("MLP", "MLP3w4", "products-MLP", "cora-MLP")],
-         "teacher_training": {"value": 300.0, "ms_per_step": 3.3, "metric": long},
+         "teacher_training": {"value": 300.0, "ms_per_step": 3.3, "engine_alone_ms_per_step": 2.9, "metric": long},
          "cpu_baseline": {"value": 2.5e7, "unit": "edges/s", "cores": 128, "kind": "port", "sample": long, "student_steps_per_s": 3.5,
                           "student_threads_best": 16, "student_thread_sweep": [{"threads": t} for t in range(50)]},
          "roofline_reordered": {"edges_per_s": 1.0, "ms_per_step": 1.0, "frac": 0.8, "kernel": long},
@@ -50,7 +50,7 @@ def test_compact_line_keeps_the_contract_and_the_headline_numbers_within_4_kb():
     assert c["verified"] is True and c["verify"]["max_abs_diff_vs_unfused_aggregate_first"] == 1e-6
     assert c["roofline"]["frac"] == 0.85 and c["roofline"]["hbm_frac_bracket"] == [0.6, 0.9] and len(c["roofline"]["launches"]) == 3
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 128 and c["student"]["frac_of_fp32_mfma_peak"] == 0.76
-    assert set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"} and c["teacher_training"]["steps_per_s"] == 300.0
+    assert set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"} and c["teacher_training"]["steps_per_s"] == 300.0 and c["teacher_training"]["engine_alone_ms"] == 2.9
     assert c["xl"]["ms"] == 160.0 and c["xl"]["verified"] is True and [l["frac"] for l in c["xl"]["layers"]] == [0.72, 0.74, 0.73, 0.55]
     assert len(c["placement"]) == 4 and c["placement"][1][1:] == [18.1, 20.1]
     assert c["arxiv"]["student"] == "MLP3w4" and c["arxiv"]["student_ms"] == 0.135 and c["arxiv"]["Gedges_per_s"] == 8.4

@@ -48,6 +48,7 @@ def test_bench_single_gpu_line():
     assert out["student"]["value"] > 0
     tt = out["teacher_training"]
     assert tt["value"] > 0 and tt["unit"] == "steps/s" and all(np.isfinite(tt["loss_first_last"]))
+    assert 0 < tt["engine_alone_ms_per_step"] <= 1.5 * tt["ms_per_step"]           # the engine's kernels without the sampler beside them
     rr = out["roofline_reordered"]
     assert rr["order"].startswith("nodes renumbered") and rr["edges_per_s"] > 0 and rr["traffic"] is None
     # the timed output checks itself: fused + chained + project-first forward == stand-alone aggregation + GEMM, aggregate-first
@@ -61,6 +62,7 @@ def test_bench_single_gpu_line():
     assert c["roofline"]["frac"] == rf["frac"] and c["roofline"]["peak"] == 8000.0 and len(c["roofline"]["hbm_frac_bracket"]) == 2
     assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] == cb["value"] and c["cpu_baseline"]["cores"] == cb["cores"]
     assert c["student"]["frac_of_fp32_mfma_peak"] == out["student"]["frac_of_fp32_mfma_peak"] and c["student"]["ms_per_step"] > 0
+    assert c["teacher_training"]["engine_alone_ms"] > 0
     assert c["teacher_training"]["steps_per_s"] == tt["value"] and set(c["students_small"]) == {"MLP", "MLP3w4", "products-MLP", "cora-MLP"}
 
 
