@@ -119,6 +119,33 @@ __global__ __launch_bounds__(kScanThreads) void scan_kernel(V val, int64_t n, un
   }
 }
 
+// The workspaces' 0x7F fill as ONE launch: hipMemsetAsync of a few MB at an arbitrary word count shows up as two fill kernels (aligned body +
+// tail), and a training step issues eight of them (three blocks built, two transposed): ~5 us each.  p: 4-byte aligned, nwords 32-bit words.
+__global__ __launch_bounds__(256) void fill7f_kernel(uint32_t* __restrict__ p, int64_t nwords) {
+  const uint32_t v = 0x7F7F7F7Fu;
+  int64_t head = (16 - (int64_t)(reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+  head >>= 2;
+  if (head > nwords) head = nwords;
+  const int64_t body4 = (nwords - head) >> 2, tail0 = head + 4 * body4;
+  uint4* __restrict__ q = reinterpret_cast<uint4*>(p + head);
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gtid; i < body4; i += stride) q[i] = make_uint4(v, v, v, v);
+  if (gtid < head) p[gtid] = v;
+  if (gtid < nwords - tail0) p[tail0 + gtid] = v;
+}
+static int fill7f(void* p, size_t bytes, hipStream_t st, const char* what) {
+  if (bytes == 0) return GLNN_OK;
+  if ((bytes & 3) || (reinterpret_cast<uintptr_t>(p) & 3)) {                      // (not the layouts of this file; kept correct)
+    return hipMemsetAsync(p, 0x7F, bytes, st) == hipSuccess ? GLNN_OK : glnn::fail(GLNN_ERR_HIP, "%s: memset failed", what);
+  }
+  const int64_t nwords = (int64_t)(bytes >> 2);
+  int64_t blocks = (nwords / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill7f_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint32_t*>(p), nwords);
+  return glnn::check_launch(what);
+}
+
 template <class V, class W>
 int launch_scan(V val, int64_t n, unsigned long long* status, int* ticket, W out, int64_t* total, hipStream_t st, const char* what) {
   const int64_t blocks = (n + kScanTile - 1) / kScanTile;
@@ -429,8 +456,9 @@ static int block_build_impl(const int64_t* g_indptr, const int32_t* g_indices, c
   a.pos = direct ? tables : tables + tab;
   a.mask = (unsigned)(cap - 1); a.slot_of_edge = a.pos + tab;
   const size_t fill_bytes = (size_t)((b1 + b2 + 3) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
-  if (hipMemsetAsync(workspace, 0x7F, fill_bytes, st) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset failed");
-  int rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
+  int rc = fill7f(workspace, fill_bytes, st, "glnn_block_build(fill)");
+  if (rc != GLNN_OK) return rc;
+  rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
   if (rc != GLNN_OK) return rc;
   const int64_t threads = full ? ns * 64 : ns + ns * (int64_t)fanout;
   const dim3 grid((unsigned)((threads + 255) / 256));
@@ -494,8 +522,11 @@ extern "C" int glnn_csr_transpose(const int64_t* indptr, const int32_t* indices,
   // per training step.  Degrees that could carry 0x7F7F7F7F + count past INT_MAX keep the separate zero fill.
   const bool one_fill = nnz_out < (1 << 23);
   a.cursor_base = one_fill ? 0x7F7F7F7F : 0;
-  if (hipMemsetAsync(workspace, 0x7F, (size_t)(b * 8 + 16) + (one_fill ? sizeof(int) * (size_t)n_src : 0), st) != hipSuccess ||
-      (!one_fill && hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)n_src, st) != hipSuccess))
+  {
+    const int rcf = fill7f(workspace, (size_t)(b * 8 + 16) + (one_fill ? sizeof(int) * (size_t)n_src : 0), st, "glnn_csr_transpose(fill)");
+    if (rcf != GLNN_OK) return rcf;
+  }
+  if (!one_fill && hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)n_src, st) != hipSuccess)
     return glnn::fail(GLNN_ERR_HIP, "glnn_csr_transpose: memset failed");
   if (nnz > 0) {
     int64_t blocks = (nnz + 255) / 256;
