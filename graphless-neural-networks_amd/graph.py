@@ -217,6 +217,9 @@ class MultiLayerFullNeighborSampler:
         self.n_layers = int(n_layers)
 
 
+_SIDE_STREAMS = {}          # device index -> the stream batches are built on, shared by all loaders of that device
+
+
 class NodeDataLoader:
     """dgl.dataloading.NodeDataLoader(g, nids, sampler, batch_size, shuffle, drop_last) (reference
     train_and_eval.py:182-202) over the resident CSR.  Yields (input_nodes, output_nodes, blocks) with
@@ -286,7 +289,13 @@ class NodeDataLoader:
             return
         main = torch.cuda.current_stream(self.g.device)
         if self._side is None:
-            self._side = torch.cuda.Stream(self.g.device)
+            # ONE side stream per device for every loader: the caching allocator keeps a pool per stream and never returns it, so a
+            # stream per loader grew the reserved memory by ~2 GB per loader on the products configuration (scripts/loader_repeat_probe.py)
+            key = torch.device(self.g.device).index
+            key = torch.cuda.current_device() if key is None else key
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(self.g.device)
+            self._side = _SIDE_STREAMS[key]
         side = self._side
 
         side.wait_stream(main)          # ONCE: the graph / nids may have been produced on the consumer's stream; later builds
