@@ -111,7 +111,9 @@ def roofline_object(timing, nnz, n, with_traffic):
         "dense_projection_ms_per_forward": gemm_ms,
         "note": "achieved = SURVEY 8(d) algorithmic bytes nnz*(4D+4)+n*(8D+8) / mean HIP-event launch time over the timed region"
                 + ("" if C.GRAPH == "ogbn-products" else "; the feature matrix fits the 256 MB Infinity Cache at this shape, so the "
-                   "rate is a cache rate and the HBM fraction is not meaningful (SURVEY 8d)"),
+                   "rate is a cache rate and the HBM fraction is not meaningful (SURVEY 8d); the events are taken over a second pass of "
+                   "the same forwards (inside the timed region they cost a sub-millisecond forward a third of its time), and a launch's "
+                   "bracket includes what the event records themselves put in front of it"),
     }
 
 
