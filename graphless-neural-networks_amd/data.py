@@ -21,9 +21,13 @@ SHAPES = {
 
 def _powerlaw_endpoints(n, m, alpha, offset, gen, device):
     """m node ids drawn with P(i) ~ (rank_i + offset)^-alpha, ranks randomly permuted over node ids."""
-    w = (torch.arange(n, device=device, dtype=torch.float64) + offset).pow(-alpha)
+    # The cumulative weights are summed on the HOST: a device cumsum in float64 is a decoupled look-back scan whose grouping of the partial
+    # sums follows the timing of its workgroups, so its last bits -- and with them a few of the 124 M endpoints -- changed from process to
+    # process (scripts/train_determinism_probe.py: two variants of the "seeded" products graph, sampled batches differing by one node).
+    w = (torch.arange(n, dtype=torch.float64) + offset).pow(-alpha)
     cdf = torch.cumsum(w, 0)
     cdf /= cdf[-1].clone()
+    cdf = cdf.to(device)
     perm = torch.randperm(n, generator=gen, device=device)
     out = torch.empty(m, dtype=torch.int64, device=device)
     step = 1 << 24
