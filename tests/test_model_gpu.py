@@ -1,6 +1,8 @@
 """GPU parity of the preserved Python surface (Model / train_mini_batch / evaluate_mini_batch /
 SAGE.inference / GCN.forward / feature_prop) against the golden vectors produced by the reference
 and against the CPU oracle.  Bar: 1e-4 abs fp32 (tests/parity_rules.py explains the Adam gauge cases)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1154,3 +1156,18 @@ def test_driver_loops_vs_reference_golden(name):
     for k, v in model.state_dict().items():
         if v.ndim:
             np.testing.assert_allclose(v.cpu().numpy(), z[f"{name}.final.{k}"], atol=2e-4, rtol=0, err_msg=k)
+
+
+def test_teacher_forward_and_student_steps_are_bit_reproducible_across_processes():
+    """scripts/forward_repro_probe.py in two processes: the same synthetic graphs, the same SAGE.inference output (arxiv shape and a
+    0.25-scale products shape: fused launches, hub rows, chained projection) and the same student parameters after five steps (MLP3w4 at
+    B = 512: latency kernels, Adam folds; MLP3w8 at B = 4096: pipelined GEMMs, split-K slabs), sha256 for sha256.  Every reduction in the
+    library has a fixed order; nothing depends on addresses or timing."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "forward_repro_probe.py")], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("teacher forward", "student"))])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
