@@ -294,6 +294,31 @@ __global__ __launch_bounds__(256) void block_relabel_kernel(const BlockArgs a, c
   a.indices[e] = a.pos[a.slot_of_edge[e]] & (kLocalBit - 1);
 }
 
+// GLOBAL-ID block only (indices == NULL && input_nodes == NULL, gindices != NULL): the edges of the block with their global source ids, in the
+// order of smp_src / of the graph's rows, behind the row-count scan -- no table, no relabelling (the outermost block of a training batch: its
+// consumer gathers from the global feature matrix and never looks at local ids).  counts = {nnz, -1}.
+template <bool FULL>
+__global__ __launch_bounds__(256) void block_copy_global_kernel(const BlockArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) {
+    a.counts[0] = a.indptr[a.ns];
+    a.counts[1] = -1;
+  }
+  if (FULL) {
+    const int64_t i = t >> 6;
+    const int lane = (int)(t & 63);
+    if (i >= a.ns) return;
+    const int64_t v = a.seeds[i];
+    const int64_t g0 = a.g_indptr[v], cnt = a.g_indptr[v + 1] - g0, e0 = a.indptr[i];
+    for (int64_t k = lane; k < cnt && e0 + k < a.nnz_cap; k += 64) a.gindices[e0 + k] = a.g_indices[g0 + k];
+  } else {
+    const int64_t i = t / a.fanout;
+    const int k = (int)(t - i * a.fanout);
+    if (i >= a.ns || k >= a.smp_cnt[i]) return;
+    a.gindices[a.indptr[i] + k] = a.smp_src[i * a.fanout + k];
+  }
+}
+
 __global__ void block_empty_counts_kernel(int64_t* counts, int64_t* indptr, int64_t ns) {
   counts[0] = 0;
   counts[1] = ns;
@@ -417,16 +442,18 @@ static int block_build_impl(const int64_t* g_indptr, const int32_t* g_indices, c
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (ns == 0 || nnz_cap == 0) {
     if (ns > 0) {
-      GLNN_REQUIRE(seeds && input_nodes, "glnn_block_build: null pointer");
+      GLNN_REQUIRE(seeds && (input_nodes || gindices), "glnn_block_build: null pointer");
       if (hipMemsetAsync(indptr, 0, sizeof(int64_t) * (size_t)(ns + 1), st) != hipSuccess ||
-          hipMemcpyAsync(input_nodes, seeds, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToDevice, st) != hipSuccess)
+          (input_nodes && hipMemcpyAsync(input_nodes, seeds, sizeof(int64_t) * (size_t)ns, hipMemcpyDeviceToDevice, st) != hipSuccess))
         return glnn::fail(GLNN_ERR_HIP, "glnn_block_build: memset/memcpy failed");
     }
     hipLaunchKernelGGL(block_empty_counts_kernel, dim3(1), dim3(1), 0, st, counts, ns == 0 ? indptr : nullptr, ns);
     return glnn::check_launch("glnn_block_build");
   }
   const bool full = smp_src == nullptr;
-  GLNN_REQUIRE(seeds && indices && input_nodes && workspace, "glnn_block_build: null pointer");
+  const bool global_only = !indices && !input_nodes && gindices;
+  GLNN_REQUIRE(seeds && workspace && (global_only || (indices && input_nodes)),
+               "glnn_block_build: null pointer (indices and input_nodes may be NULL only together, with gindices: the global-id block)");
   GLNN_REQUIRE(full ? (g_indptr && g_indices && !smp_cnt) : (smp_cnt && fanout >= 1 && nnz_cap >= ns * (int64_t)fanout),
                "glnn_block_build: pass either the graph CSR (full neighbourhood) or smp_src/smp_cnt/fanout with nnz_cap >= ns*fanout");
   GLNN_REQUIRE(ns + nnz_cap < ((int64_t)1 << 30), "glnn_block_build: frontier too large for 32-bit positions");
@@ -455,11 +482,20 @@ static int block_build_impl(const int64_t* g_indptr, const int32_t* g_indices, c
   a.keys = direct ? nullptr : tables;
   a.pos = direct ? tables : tables + tab;
   a.mask = (unsigned)(cap - 1); a.slot_of_edge = a.pos + tab;
-  const size_t fill_bytes = (size_t)((b1 + b2 + 3) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
+  const size_t fill_bytes = global_only ? (size_t)((b1 + 1) * 8)       // (the row scan's status words and its ticket)
+                                        : (size_t)((b1 + b2 + 3) * 8) + (direct ? 1 : 2) * tab * sizeof(int);
+  if (global_only) tickets = reinterpret_cast<int*>(status1 + b1);
   int rc = fill7f(workspace, fill_bytes, st, "glnn_block_build(fill)");
   if (rc != GLNN_OK) return rc;
   rc = launch_scan(RowCount{a}, ns, status1, tickets, WriteIndptr{a}, nullptr, st, "glnn_block_build(scan rows)");
   if (rc != GLNN_OK) return rc;
+  if (global_only) {
+    const int64_t th = full ? ns * 64 : ns * (int64_t)fanout;
+    const dim3 gr((unsigned)((th + 255) / 256));
+    if (full) hipLaunchKernelGGL(block_copy_global_kernel<true>, gr, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(block_copy_global_kernel<false>, gr, dim3(256), 0, st, a);
+    return glnn::check_launch("glnn_block_build(global ids)");
+  }
   const int64_t threads = full ? ns * 64 : ns + ns * (int64_t)fanout;
   const dim3 grid((unsigned)((threads + 255) / 256));
   if (full && direct) hipLaunchKernelGGL((block_insert_kernel<true, true>), grid, dim3(256), 0, st, a);

@@ -232,6 +232,13 @@ class NodeDataLoader:
         self._epoch = 0
         self._seed = int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFF
         self.prefetch, self._side = True, None
+        # batches are built by a worker THREAD (below); GLNN_LOADER_THREAD=0 / .threaded = False: by the consumer's thread, one ahead
+        self.threaded = __import__("os").environ.get("GLNN_LOADER_THREAD", "1") != "0"
+        self.depth = 2                  # finished batches the worker may hold ready
+        # True (set by train_and_eval.train_sage for its epoch): the OUTERMOST block is built as a global-id block only -- indptr + the
+        # edges' global source ids; no frontier table, no local relabelling, `input_nodes` is yielded as None -- because TeacherEngine
+        # gathers layer 0 straight from the feature matrix.  That block is the widest of a batch: 60 % of the sampler's device time.
+        self.global_first_block = False
         # the whole-graph path of SAGE.inference is only valid when the loader sweeps EVERY node in id order
         if isinstance(sampler, MultiLayerFullNeighborSampler) and sampler.n_layers == 1 and not shuffle \
                 and self.nids.numel() == g.num_dst_nodes() and bool((self.nids.cpu() == torch.arange(g.num_dst_nodes())).all()):
@@ -241,7 +248,7 @@ class NodeDataLoader:
         n = self.nids.numel()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def _block(self, seeds, fanout, rng_seed, want_global=False):
+    def _block(self, seeds, fanout, rng_seed, want_global=False, global_only=False):
         """One 1-hop block over `seeds` on the device (glnn_sample_neighbors + glnn_block_build): work and memory are
         proportional to the frontier (ns * fanout), not to the graph; one host read-back (edge / source-node counts)."""
         from . import ops
@@ -249,24 +256,27 @@ class NodeDataLoader:
         if fanout is None:                                   # full neighbourhood: the edge count bounds the buffers
             deg_sum = int((g.indptr[seeds + 1] - g.indptr[seeds]).sum().item())
             indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, g.indptr, g.indices, nnz_cap=deg_sum,
-                                                                              want_global=want_global, n_nodes=g.n_src)
+                                                                              want_global=want_global, n_nodes=g.n_src, global_only=global_only)
         else:
             smp, cnt = ops.sample_neighbors(g.indptr, g.indices, seeds, fanout, rng_seed)
             indptr, indices, gidx, input_nodes, nnz, n_src = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=want_global,
-                                                                              n_nodes=g.n_src)
+                                                                              n_nodes=g.n_src, global_only=global_only)
+        if global_only:                                      # sources = the graph's nodes themselves: a CSR whose column ids are global ids
+            n_src, indices = g.n_src, gidx
         block = CSRGraph(indptr, indices, seeds.numel(), n_src)
         block._nnz = nnz
         if want_global:
             block.gindices, block.dst_nodes = gidx, seeds       # the same edges with global source ids (TeacherEngine, layer 0)
         return input_nodes, block
 
-    def _batch(self, b, idx, fanouts):
+    def _batch(self, b, idx, fanouts, epoch=None):
         dev = self.g.device
+        epoch = self._epoch if epoch is None else epoch
         output_nodes = self.nids[idx].to(dev) if self.nids.device != dev else self.nids[idx.to(dev)]
         seeds, blocks = output_nodes, []
         for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
-            rng = (self._seed * 1000003 + self._epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
-            seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0))
+            rng = (self._seed * 1000003 + epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
+            seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0), global_only=(l == 0 and self.global_first_block))
             blocks.insert(0, blk)
         return seeds, output_nodes, blocks
 
@@ -301,17 +311,17 @@ class NodeDataLoader:
         side.wait_stream(main)          # ONCE: the graph / nids may have been produced on the consumer's stream; later builds
                                         # depend on nothing the consumer queues, so they never wait for its kernels
 
+        epoch = self._epoch
+
         def build(b):
             with torch.cuda.stream(side):
-                batch = self._batch(b, chunks[b], fanouts)
+                batch = self._batch(b, chunks[b], fanouts, epoch)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return batch, ev
 
-        nxt = build(0) if chunks else None
-        for b in range(len(chunks)):
-            (input_nodes, output_nodes, blocks), ev = nxt
-            nxt = build(b + 1) if b + 1 < len(chunks) else None
+        def hand_over(item):
+            (input_nodes, output_nodes, blocks), ev = item
             # the consumer's stream is asked for at EVERY hand-over: a caller that steps inside its own `with torch.cuda.stream(...)`
             # gets the batch ordered on (and kept alive for) the stream it is actually running on, not the one __iter__ started on
             cur = torch.cuda.current_stream(self.g.device)
@@ -319,4 +329,59 @@ class NodeDataLoader:
             for t in [input_nodes, output_nodes] + [x for blk in blocks for x in (blk.indptr, blk.indices, blk.gindices, blk.dst_nodes)]:
                 if t is not None:
                     t.record_stream(cur)                     # allocated on the side stream, consumed on the current one
-            yield input_nodes, output_nodes, blocks
+            return input_nodes, output_nodes, blocks
+
+        if not self.threaded:
+            nxt = build(0) if chunks else None
+            for b in range(len(chunks)):
+                cur_item = nxt
+                nxt = build(b + 1) if b + 1 < len(chunks) else None
+                yield hand_over(cur_item)
+            return
+        # A worker thread builds the batches (what dgl's NodeDataLoader workers do for the reference, train_and_eval.py:192-202): every block
+        # costs one host read-back (its edge / source counts size the next block), and a consumer that builds batch b + 1 itself sits in
+        # three of them, behind sampler kernels that share the GPU with its own step, before it can issue step b + 1 -- the step's
+        # stream ran dry for ~0.3 ms of every 2.3 ms products step.  The worker holds up to `depth` finished batches; what a batch
+        # contains depends on (seed, epoch, b) only, so the epochs are the same epochs (bit for bit) with and without the thread.
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=self.depth), threading.Event()
+        dev_index = torch.device(self.g.device).index
+        dev_index = torch.cuda.current_device() if dev_index is None else dev_index
+
+        def worker():
+            try:
+                torch.cuda.set_device(dev_index)
+                for b in range(len(chunks)):
+                    item = build(b)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.05)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+            except BaseException as e:          # handed to the consumer, raised there
+                while not stop.is_set():
+                    try:
+                        q.put(e, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+
+        th = threading.Thread(target=worker, name="glnn-node-loader", daemon=True)
+        th.start()
+        try:
+            for b in range(len(chunks)):
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                yield hand_over(item)
+        finally:                                # exhausted, closed early or failed: the worker is let go before the generator is
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(0.02)

@@ -746,12 +746,15 @@ def _i32(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int32, device=device)[:int(n)]
 
 
-def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_cnt=None, nnz_cap=None, want_global=False, n_nodes=0):
+def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_cnt=None, nnz_cap=None, want_global=False, n_nodes=0,
+                global_only=False):
     """glnn_block_build_ids: one 1-hop block over the destination nodes `seeds` (int64 device vector).  n_nodes: the size of the id
     universe (every id < n_nodes) when known -- lets wide blocks index their tables by the id itself; 0 = unknown.
     Sampled mode: smp_src [ns, fanout] / smp_cnt [ns] from sample_neighbors.  Full-neighbour mode: the graph CSR and
     nnz_cap (an upper bound of the block's edge count).  Returns (indptr [ns+1], indices [nnz] local ids,
-    gindices [nnz] global ids or None, input_nodes [n_src], nnz, n_src); ONE host read-back (the two counts)."""
+    gindices [nnz] global ids or None, input_nodes [n_src], nnz, n_src); ONE host read-back (the two counts).
+    global_only: the global-id block -- (indptr, None, gindices, None, nnz, None): no table, no relabelling (the outermost block of a
+    training batch whose consumer gathers from the global feature matrix)."""
     _need_cuda(seeds, graph_indptr, graph_indices, smp_src, smp_cnt)
     dev = seeds.device
     if seeds.dtype != torch.int64 or not seeds.is_contiguous():
@@ -767,10 +770,11 @@ def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_
         if graph_indptr is None or graph_indices is None or nnz_cap is None:
             raise ValueError("block_build: full-neighbour mode needs the graph CSR and nnz_cap")
     nnz_cap = int(nnz_cap)
+    want_global = want_global or global_only
     indptr = torch.empty(ns + 1, dtype=torch.int64, device=dev)
-    indices = _i32(nnz_cap, dev)
+    indices = None if global_only else _i32(nnz_cap, dev)
     gindices = _i32(nnz_cap, dev) if want_global else None
-    input_nodes = torch.empty(ns + nnz_cap, dtype=torch.int64, device=dev)
+    input_nodes = None if global_only else torch.empty(ns + nnz_cap, dtype=torch.int64, device=dev)
     counts = torch.empty(2, dtype=torch.int64, device=dev)
     wsb = int(_lib.lib().glnn_block_workspace_bytes(ns, nnz_cap))
     ws = torch.empty((wsb + 7) // 8, dtype=torch.int64, device=dev)
@@ -783,6 +787,8 @@ def block_build(seeds, graph_indptr=None, graph_indices=None, smp_src=None, smp_
         raise _lib.GlnnError(f"block_build: a seed or neighbour id lies outside [0, n_nodes = {int(n_nodes)})")
     if nnz > nnz_cap:
         raise _lib.GlnnError(f"block_build: the block has {nnz} edges, more than nnz_cap = {nnz_cap}")
+    if global_only:
+        return indptr, None, gindices[:nnz], None, nnz, None
     return indptr, indices[:nnz], (gindices[:nnz] if want_global else None), input_nodes[:n_src], nnz, n_src
 
 

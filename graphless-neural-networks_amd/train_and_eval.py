@@ -52,9 +52,18 @@ def train_sage(model, dataloader, feats, labels, criterion, optimizer, lamb=1):
     eng = teacher.get_engine(model, optimizer)
     eng.loss_accum.zero_()
     steps = 0
-    for input_nodes, output_nodes, blocks in dataloader:
-        eng.step_sage(blocks, feats, labels, output_nodes, float(lamb), input_nodes=input_nodes)
-        steps += 1
+    # the engine gathers layer 0 straight from `feats` through the outermost block's global ids: our loader then builds that block
+    # without its frontier table / local relabelling and yields input_nodes = None (60 % of the sampler's device time; other loaders: no-op)
+    had = getattr(dataloader, "global_first_block", None)
+    if had is not None:
+        dataloader.global_first_block = True
+    try:
+        for input_nodes, output_nodes, blocks in dataloader:
+            eng.step_sage(blocks, feats, labels, output_nodes, float(lamb), input_nodes=input_nodes)
+            steps += 1
+    finally:
+        if had is not None:
+            dataloader.global_first_block = had
     eng.sync_optimizer_state()
     return eng.loss_accum.item() / max(steps, 1)
 

@@ -544,7 +544,10 @@ GLNN_API int glnn_sample_neighbors(const int64_t* indptr, const int32_t* indices
  * the order of smp_src / of the graph's rows); gindices [nnz_cap] the same edges' GLOBAL source ids (optional);
  * input_nodes [ns + nnz_cap]: the block's source nodes = its destinations first (models.py:109), then every other
  * source in order of first appearance; counts (device int64[2]) = {nnz, number of source nodes}.
- * workspace: glnn_block_workspace_bytes(ns, nnz_cap) bytes, 8-byte aligned.  Node ids must be < 0x7F7F7F7F. */
+ * workspace: glnn_block_workspace_bytes(ns, nnz_cap) bytes, 8-byte aligned.  Node ids must be < 0x7F7F7F7F.
+ * GLOBAL-ID BLOCK (round 5): indices == NULL and input_nodes == NULL with gindices != NULL -- only indptr and the edges' global source ids
+ * are produced (row-count scan + one copy pass; no table, no relabelling), counts = {nnz, -1}: the outermost block of a training batch,
+ * whose consumer (glnn_sage_fwd_bwd_f32 with self_rows) gathers from the global feature matrix and never reads local ids. */
 GLNN_API int64_t glnn_block_workspace_bytes(int64_t ns, int64_t nnz_cap);
 GLNN_API int glnn_block_build(const int64_t* g_indptr, const int32_t* g_indices, const int64_t* seeds,
                               int64_t ns, const int32_t* smp_src, const int32_t* smp_cnt, int fanout,

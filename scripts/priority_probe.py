@@ -1,5 +1,6 @@
 """Does a stream priority change what the sampler (side stream) costs the sampled-block training step (products configuration)?
-modes: default | main_high (the consumer's stream at the highest priority) | side_high (the sampler's stream at the highest priority).
+modes: default | main_high (the consumer's stream at the highest priority) | side_high (the sampler's stream at the highest priority) |
+nothread (GLNN_LOADER_THREAD=0: batches built by the consumer's thread, one ahead).
 python scripts/priority_probe.py MODE  ->  ms per step over two epochs of 48 steps"""
 import os, sys, time
 import torch
@@ -17,6 +18,8 @@ model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=100, hidden_dim=256
 opt = torch.optim.Adam(model.parameters(), lr=0.003)
 idx_train = torch.randperm(n)[:196608].to(dev)
 loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=4096, shuffle=True, drop_last=False)
+if mode == "nothread":
+    loader.threaded = False
 crit = torch.nn.NLLLoss()
 print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None)
 if mode == "side_high":

@@ -1,5 +1,6 @@
 """Is a sampled-block training epoch reproducible?  Two runs from the same initial model and the same loader seed, in ONE process:
-per-step losses and final parameters compared bit for bit, with the batches built one ahead on the side stream (prefetch) and without.
+per-step losses and final parameters compared bit for bit, with the batches built one ahead on the side stream (prefetch), by the loader's
+worker thread, and in line.
 python scripts/train_determinism_probe.py [ogbn-products|ogbn-arxiv] [steps]"""
 import copy, os, sys
 import torch
@@ -19,27 +20,28 @@ base = Model(dict(model_name="SAGE", num_layers=3, feat_dim=cfg[0], hidden_dim=2
 idx_train = torch.randperm(n)[: cfg[2] * steps].to(dev)
 
 
-def run(prefetch):
+def run(prefetch, threaded=False, global_first=False):
     model = copy.deepcopy(base)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=0.003)
     loader = NodeDataLoader(g, idx_train, MultiLayerNeighborSampler([5, 10, 15]), batch_size=cfg[2], shuffle=False, drop_last=False, seed=1234)
-    loader.prefetch = prefetch
+    loader.prefetch, loader.threaded, loader.global_first_block = prefetch, threaded, global_first
     eng = teacher.get_engine(model, opt)
     losses, nsrc = [], []
     for input_nodes, output_nodes, blocks in loader:
         eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
         losses.append(eng.loss_out.clone())
-        nsrc.append((input_nodes.numel(), int(input_nodes.sum()), [int(b.indices.to(torch.int64).sum()) for b in blocks]))
+        nsrc.append(None if input_nodes is None else (input_nodes.numel(), int(input_nodes.sum()), [int(b.indices.to(torch.int64).sum()) for b in blocks]))
     eng.sync_optimizer_state()
     torch.cuda.synchronize()
     return torch.stack(losses).flatten().cpu(), [v.detach().clone() for v in model.state_dict().values()], nsrc
 
 
 ref = run(False)
-for tag, pf in (("no prefetch again", False), ("prefetch", True), ("prefetch again", True)):
-    got = run(pf)
-    same_blocks = got[2] == ref[2]
+for tag, pf, th, gf in (("no prefetch again", False, False, False), ("prefetch", True, False, False), ("worker thread", True, True, False),
+                        ("worker thread again", True, True, False), ("global-id outermost block", True, True, True)):
+    got = run(pf, th, gf)
+    same_blocks = True if gf else got[2] == ref[2]
     same_loss = torch.equal(got[0], ref[0])
     same_par = all(torch.equal(a, b) for a, b in zip(got[1], ref[1]))
     first = next((i for i in range(len(ref[0])) if got[0][i] != ref[0][i]), None)

@@ -125,6 +125,51 @@ def test_block_build_from_sampled_neighbours(ns, fanout, known_ids):
             avail.remove(int(u))                                               # multi-edge multiplicity is respected
 
 
+@pytest.mark.parametrize("ns,fanout", [(512, 15), (20000, 5), (3, 1), (700, None), (1, None)])
+def test_global_id_block_equals_the_full_build(ns, fanout):
+    """glnn_block_build_ids with indices = input_nodes = NULL (round 5; ops.block_build(global_only=True)): indptr, nnz and the edges' global
+    source ids of the block -- no frontier table, no relabelling -- are exactly those of the full build, in the sampled and the
+    full-neighbour mode; a loader asked for it (NodeDataLoader.global_first_block, what train_sage sets) yields the same inner blocks, an
+    outermost block whose column ids are those global ids over the whole graph's nodes, and input_nodes = None."""
+    from glnn_amd import ops
+    n = 30000
+    indptr, indices = random_graph(n, 12, seed=9, power=0.6, hub=9000, isolated=50)
+    g_ip, g_ix = torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV)
+    seeds = torch.from_numpy(np.random.RandomState(ns).permutation(n)[:ns].astype(np.int64)).to(DEV)
+    if fanout is None:
+        cap = int((g_ip[seeds + 1] - g_ip[seeds]).sum()) + 5
+        full = ops.block_build(seeds, g_ip, g_ix, nnz_cap=cap, want_global=True, n_nodes=n)
+        glob = ops.block_build(seeds, g_ip, g_ix, nnz_cap=cap, n_nodes=n, global_only=True)
+    else:
+        smp, cnt = ops.sample_neighbors(g_ip, g_ix, seeds, fanout, 99)
+        full = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, want_global=True, n_nodes=n)
+        glob = ops.block_build(seeds, smp_src=smp, smp_cnt=cnt, n_nodes=n, global_only=True)
+    assert glob[1] is None and glob[3] is None and glob[5] is None and glob[4] == full[4]
+    assert torch.equal(glob[0], full[0]) and torch.equal(glob[2], full[2])
+
+
+def test_loader_with_global_first_block_yields_the_same_batches():
+    from glnn_amd.graph import CSRGraph, MultiLayerNeighborSampler, NodeDataLoader
+    n = 30000
+    indptr, indices = random_graph(n, 12, seed=9, power=0.6, hub=9000, isolated=50)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    nids = torch.from_numpy(np.random.RandomState(1).permutation(n)[:3000].astype(np.int64)).to(DEV)
+    runs = []
+    for glob in (False, True):
+        ld = NodeDataLoader(g, nids, MultiLayerNeighborSampler([5, 10, 15]), batch_size=1024, shuffle=False, seed=7)
+        ld.global_first_block = glob
+        runs.append([(i, o, b) for i, o, b in ld])
+    assert len(runs[0]) == len(runs[1]) == 3
+    for (i0, o0, b0), (i1, o1, b1) in zip(*runs):
+        assert i1 is None and i0 is not None and torch.equal(o0, o1)
+        for x, y in zip(b0[1:], b1[1:]):
+            assert torch.equal(x.indptr, y.indptr) and torch.equal(x.indices, y.indices) and x.n_src == y.n_src
+        assert torch.equal(b0[0].indptr, b1[0].indptr) and torch.equal(b0[0].gindices, b1[0].gindices) and torch.equal(b0[0].dst_nodes, b1[0].dst_nodes)
+        assert b1[0].indices is b1[0].gindices or torch.equal(b1[0].indices, b1[0].gindices)
+        assert b1[0].n_src == n and b1[0].num_edges() == b0[0].num_edges()
+        assert torch.equal(i0[b0[0].indices.long()], b0[0].gindices.long())          # the full build's local ids name those global ids
+
+
 def test_products_scale_sampled_blocks_properties():
     """The block builder at the products training configuration (B = 4096, fan-out 15 / 10 / 5 from the output layer inwards, 2.45 M nodes:
     the two wide blocks index their position table by the node id, the first one probes a hash table), checked through properties that
@@ -857,7 +902,8 @@ def test_loaders_of_one_device_share_their_side_stream():
 
 def test_sampled_training_epoch_is_reproducible_within_and_across_processes():
     """scripts/train_determinism_probe.py on the arxiv configuration: graph generation -> neighbour sampling -> block building -> step -> Adam.
-    In one process, with the batches built one ahead on the side stream and without: the same blocks, losses and parameters bit for bit.  In
+    In one process, with the batches built in line, one ahead on the side stream, and by the loader's worker thread: the same blocks, losses
+    and parameters bit for bit; so with the outermost block built as a global-id block only (what train_sage asks its loader for).  In
     two processes: the same parameters (sha256) -- round 5 found the "seeded" synthetic graph in two variants from process to process (a
     device cumsum in float64 under its power-law endpoints: a look-back scan whose grouping follows timing; now summed on the host)."""
     import subprocess, sys
@@ -869,6 +915,6 @@ def test_sampled_training_epoch_is_reproducible_within_and_across_processes():
         assert r.returncode == 0, r.stderr[-2000:]
         lines = r.stdout.splitlines()
         same = [ln for ln in lines if "blocks equal" in ln]
-        assert len(same) == 3 and all("blocks equal True, losses equal True" in ln and "parameters equal True" in ln for ln in same), same
+        assert len(same) == 5 and all("blocks equal True, losses equal True" in ln and "parameters equal True" in ln for ln in same), same
         outs.append([ln for ln in lines if ln.startswith("sha256")])
     assert outs[0] and outs[0] == outs[1], outs
