@@ -170,6 +170,42 @@ def test_loader_with_global_first_block_yields_the_same_batches():
         assert torch.equal(i0[b0[0].indices.long()], b0[0].gindices.long())          # the full build's local ids name those global ids
 
 
+def test_loader_worker_thread_stops_on_early_exit_and_hands_over_exceptions():
+    """The batches of a device-resident graph are built by a worker thread (NodeDataLoader.threaded): a consumer that leaves the loop early
+    does not leave the thread behind, and an exception raised while a batch is built surfaces in the consumer's loop."""
+    import gc, threading
+    from glnn_amd.graph import CSRGraph, MultiLayerNeighborSampler, NodeDataLoader
+    n = 20000
+    indptr, indices = random_graph(n, 10, seed=3, power=0.5)
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    ld = NodeDataLoader(g, torch.arange(8192, device=DEV), MultiLayerNeighborSampler([5, 10]), batch_size=512, seed=1)
+    assert ld.threaded
+    alive = lambda: [t for t in threading.enumerate() if t.name == "glnn-node-loader"]
+    for k, batch in enumerate(ld):
+        if k == 1:
+            break
+    gc.collect()
+    assert not alive()
+    it = iter(ld)
+    next(it)
+    it.close()
+    assert not alive()
+    real, calls = ld._batch, []
+
+    def failing(b, idx, fanouts, epoch=None):
+        calls.append(b)
+        if b == 2:
+            raise RuntimeError("boom in batch 2")
+        return real(b, idx, fanouts, epoch)
+
+    ld._batch = failing
+    seen = 0
+    with pytest.raises(RuntimeError, match="boom in batch 2"):
+        for batch in ld:
+            seen += 1
+    assert seen == 2 and not alive()
+
+
 def test_products_scale_sampled_blocks_properties():
     """The block builder at the products training configuration (B = 4096, fan-out 15 / 10 / 5 from the output layer inwards, 2.45 M nodes:
     the two wide blocks index their position table by the node id, the first one probes a hash table), checked through properties that
