@@ -590,6 +590,9 @@ __device__ __forceinline__ void finish_dy_row(const SpmmArgs& a, const DyTail& t
   st4_stream(a.out + v * a.ldo + col4, make_float4(o[0], o[1], o[2], o[3]));
 }
 
+#ifndef GLNN_BN_DY_BATCH
+#define GLNN_BN_DY_BATCH 1
+#endif
 template <int LPR, int U, bool DROP>
 __global__ __launch_bounds__(kBlock) void spmm_bn_dy_kernel(const SpmmArgs a, const DyTail t) {
   const int lane = threadIdx.x & 63;
@@ -648,6 +651,76 @@ __global__ __launch_bounds__(kBlock) void spmm_bn_dy_kernel(const SpmmArgs a, co
   // ---- row role, static: wave w takes the rows row_base + w + 8 i ----
   const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
   const int64_t row_base = blk * a.rows_per_block;
+#if GLNN_BN_DY_BATCH
+  // ... kShortRows of ITS rows at a time (the transposed blocks of a sampled batch have 1-2 entries per row: a wave that took one row after
+  // the other spent its time in the row's chain indptr -> index -> column scale / source row -> store, at 2.9 TB/s of a launch that streams
+  // z in and dy out): the indptr pairs of the four rows in one request, their first two load units, column scales and z rows in
+  // flight together; a longer row continues on its own with its sums carried on.  The rows are finished in ascending order and a row's
+  // units are added in ascending order, so dy AND the column sums are the bits of the one-row-at-a-time form (GLNN_BN_DY_BATCH=0).
+  {
+    constexpr int G = 64 / LPR, RB = kShortRows, UB = 2;      // (two units: 1-2 entries per row, and the batch stays inside 128 VGPRs -- two workgroups per CU)
+    const int g = lane / LPR;
+#pragma unroll 1
+    for (int lr0 = wave; lr0 < a.rows_per_block; lr0 += kWavesPerBlock * RB) {
+      int nr = 0;                                            // this wave's rows of the batch: a prefix (rows ascend)
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        if (lr0 + kWavesPerBlock * r < a.rows_per_block && row_base + lr0 + kWavesPerBlock * r < a.n_dst) nr = r + 1;
+      if (nr == 0) break;
+      const int rl = (lane >> 1) < nr ? (lane >> 1) : 0;     // lanes 2r, 2r + 1: indptr[v_r], indptr[v_r + 1]
+      const int64_t my_ptr = a.indptr[row_base + lr0 + kWavesPerBlock * rl + (lane & 1)];
+      int64_t e0[RB], e1[RB];
+      bool live[RB];
+      int hd[RB], my_idx[RB];
+      float my_cs[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        e0[r] = readlane64(my_ptr, 2 * r);
+        e1[r] = readlane64(my_ptr, 2 * r + 1);
+        const int64_t deg = e1[r] - e0[r];
+        live[r] = r < nr && deg <= kLongRow;                 // (rows above kLongRow belong to the long-row role)
+        hd[r] = live[r] ? (deg < UB * G ? (int)deg : UB * G) : 0;
+        my_idx[r] = lane < hd[r] ? ld_idx_stream(a.indices + e0[r] + lane) : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) my_cs[r] = lane < hd[r] ? a.col_scale[my_idx[r]] : 0.f;
+      float4 v[RB][UB], z4[RB];
+      float sc[RB][UB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        z4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live[r] && lane < LPR && col_ok) z4[r] = ld4(t.z + (row_base + lr0 + kWavesPerBlock * r) * t.ldz + col4);
+#pragma unroll
+        for (int k = 0; k < UB; ++k) {
+          const int first = k * G + g;
+          int src;
+          float cs;
+          if (G == 1) {
+            src = __builtin_amdgcn_readlane(my_idx[r], first & 63);
+            cs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_cs[r]), first & 63));
+          } else {
+            src = __shfl(my_idx[r], first & 63);
+            cs = __shfl(my_cs[r], first & 63);
+          }
+          const bool ok = first < hd[r] && col_ok;
+          sc[r][k] = ok ? cs : 0.f;
+          v[r][k] = ok ? ld4(a.x + (int64_t)src * a.ldx + col4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (!live[r]) continue;                              // (uniform)
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < UB; ++k) acc = fma4(sc[r][k], v[r][k], acc);
+        if (e1[r] - e0[r] > hd[r])
+          acc = wave_gather_acc<LPR, U, true, false>(a.indices, e0[r] + hd[r], e1[r], 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf, acc);
+        acc = fold_groups<LPR>(acc);
+        if (lane < LPR && col_ok) finish_dy_row<DROP>(a, t, c, row_base + lr0 + kWavesPerBlock * r, acc, z4[r], col4, s1, s2);
+      }
+    }
+  }
+#else
 #pragma unroll 1
   for (int lr = wave; lr < a.rows_per_block; lr += kWavesPerBlock) {
     const int64_t v = row_base + lr;
@@ -659,6 +732,7 @@ __global__ __launch_bounds__(kBlock) void spmm_bn_dy_kernel(const SpmmArgs a, co
     const float4 acc = wave_gather_sum<LPR, U, true, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
     if (lane < LPR && col_ok) finish_dy_row<DROP>(a, t, c, v, acc, z4, col4, s1, s2);
   }
+#endif
   if (lane < LPR) {
     s_part[wave][lane] = make_float4(s1[0], s1[1], s1[2], s1[3]);
     s_part2[wave][lane] = make_float4(s2[0], s2[1], s2[2], s2[3]);
