@@ -23,7 +23,8 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
                  "glnn_sage_fwd_bwd_f32: layer %d: null pointer or bad block sizes", l);
     GLNN_REQUIRE(l == 0 || y.n_src == d->layer[l - 1].n_dst, "glnn_sage_fwd_bwd_f32: block %d has %lld sources, block %d %lld destinations",
                  l, (long long)y.n_src, l - 1, (long long)d->layer[l - 1].n_dst);
-    GLNN_REQUIRE(l == 0 || (y.t_indptr && y.t_indices && y.inv_deg && y.tr_ws), "glnn_sage_fwd_bwd_f32: layer %d needs the transpose buffers", l);
+    // (tr_ws == NULL: the caller built the transposed block and 1/(deg+1) itself -- e.g. its batch loader, off the step's stream)
+    GLNN_REQUIRE(l == 0 || (y.t_indptr && y.t_indices && y.inv_deg), "glnn_sage_fwd_bwd_f32: layer %d needs the transpose buffers", l);
   }
   GLNN_REQUIRE(L == 1 || (d->dagg && d->dh), "glnn_sage_fwd_bwd_f32: backward scratch missing");
 
@@ -31,6 +32,7 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
   // forward was measured equal and removed in round 4)
   auto transposes = [&](int l, void* st) -> int {
     const glnn_sage_layer& y = d->layer[l];
+    if (!y.tr_ws) return GLNN_OK;                            // prebuilt by the caller
     GLNN_TRY(glnn_csr_transpose(y.indptr, y.indices, y.n_dst, y.n_src, y.nnz, 1, y.t_indptr, y.t_indices, y.tr_ws, y.tr_ws_bytes, st));
     return glnn_degrees_f32(y.indptr, nullptr, y.n_dst, y.n_src, 0, GLNN_DEG_INV_PLUS1, y.inv_deg, nullptr, st);
   };

@@ -21,6 +21,7 @@ class CSRGraph:
         self._cache = {}
         self.gindices = None       # outermost training block only: the edges' GLOBAL source ids (see NodeDataLoader)
         self.dst_nodes = None
+        self.t_indptr = self.t_indices = self.inv_deg = None      # inner training blocks of an engine-mode loader: the transposed block (+ self) and 1/(deg+1)
 
     # ---- construction -------------------------------------------------------------------------
     @classmethod
@@ -277,6 +278,13 @@ class NodeDataLoader:
         for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
             rng = (self._seed * 1000003 + epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
             seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0), global_only=(l == 0 and self.global_first_block))
+            if l > 0 and self.global_first_block and blk.indptr.is_cuda:
+                # the consumer is TeacherEngine (train_sage): what its backward needs of an inner block -- the block transposed with a self
+                # entry per destination, 1 / (in-degree + 1) -- depends on the block alone, so it is built HERE, beside the previous step,
+                # instead of by ten launches on the step's own stream (the same two library calls: the same bits)
+                from . import ops
+                blk.t_indptr, blk.t_indices = ops.csr_transpose(blk.indptr, blk.indices, blk.n_dst, blk.n_src, blk.num_edges(), add_self=True)
+                blk.inv_deg, _ = ops.degrees(blk.indptr, None, blk.n_dst, blk.n_src, 0, want_out=False, transform=ops.DEG_INV_PLUS1)
             blocks.insert(0, blk)
         return seeds, output_nodes, blocks
 
@@ -326,7 +334,8 @@ class NodeDataLoader:
             # gets the batch ordered on (and kept alive for) the stream it is actually running on, not the one __iter__ started on
             cur = torch.cuda.current_stream(self.g.device)
             cur.wait_event(ev)
-            for t in [input_nodes, output_nodes] + [x for blk in blocks for x in (blk.indptr, blk.indices, blk.gindices, blk.dst_nodes)]:
+            for t in [input_nodes, output_nodes] + [x for blk in blocks for x in (blk.indptr, blk.indices, blk.gindices, blk.dst_nodes,
+                                                                                    blk.t_indptr, blk.t_indices, blk.inv_deg)]:
                 if t is not None:
                     t.record_stream(cur)                     # allocated on the side stream, consumed on the current one
             return input_nodes, output_nodes, blocks

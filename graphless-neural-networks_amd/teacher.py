@@ -263,7 +263,10 @@ class TeacherEngine:
                     max_rows, max_hidden = max(max_rows, n_dst), max(max_hidden, dims[l + 1])
                     if self.bn:
                         y.mean, y.rstd, y.a_scale, y.a_shift = (A.take(4 * dims[l + 1]) for _ in range(4))
-                if l >= 1:
+                if l >= 1 and getattr(blk, "t_indptr", None) is not None:      # transposed by the loader (NodeDataLoader.global_first_block)
+                    y.t_indptr, y.t_indices, y.inv_deg = ptr(blk.t_indptr), ptr(blk.t_indices), ptr(blk.inv_deg)
+                    y.tr_ws, y.tr_ws_bytes = None, 0
+                elif l >= 1:
                     nnz_t = nnz + n_dst
                     wsb = int(_lib.lib().glnn_csr_transpose_workspace_bytes(n_src, nnz_t))
                     y.t_indptr, y.t_indices, y.inv_deg = A.take(8 * (n_src + 1)), A.take(4 * max(nnz_t, 1)), A.take(4 * n_dst)

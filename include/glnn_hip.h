@@ -454,6 +454,9 @@ typedef struct glnn_sage_layer {
   float* agg; int64_t ld_agg; float* z; int64_t ldz; float* h; int64_t ldh;      /* h may be NULL (hidden layers): the tail of z is then
                                                                                    * applied inside the next layer's aggregation, never written */
   int64_t* t_indptr; int32_t* t_indices; float* inv_deg; void* tr_ws; int64_t tr_ws_bytes;
+  /* (layers >= 1) scratch the step fills: the block transposed with one self entry per destination (glnn_csr_transpose(..., add_self = 1)) and
+   * 1 / (in-degree + 1) (glnn_degrees_f32, GLNN_DEG_INV_PLUS1).  tr_ws == NULL: t_indptr / t_indices / inv_deg already HOLD them -- built by
+   * the caller, e.g. by its batch loader beside the previous step (round 5: the ten launches leave the step's stream). */
   uint32_t drop_seed;
 } glnn_sage_layer;
 

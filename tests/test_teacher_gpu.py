@@ -164,6 +164,13 @@ def test_loader_with_global_first_block_yields_the_same_batches():
         assert i1 is None and i0 is not None and torch.equal(o0, o1)
         for x, y in zip(b0[1:], b1[1:]):
             assert torch.equal(x.indptr, y.indptr) and torch.equal(x.indices, y.indices) and x.n_src == y.n_src
+            # engine mode: the inner blocks arrive with what the step's backward needs of them (built beside the previous step)
+            from glnn_amd import ops
+            assert x.t_indptr is None and y.t_indptr is not None
+            ti, tx = ops.csr_transpose(x.indptr, x.indices, x.n_dst, x.n_src, x.num_edges(), add_self=True)
+            assert torch.equal(y.t_indptr, ti) and torch.equal(y.t_indices, tx)
+            deg = (x.indptr[1:] - x.indptr[:-1]).float()
+            torch.testing.assert_close(y.inv_deg, 1.0 / (deg + 1.0), rtol=1e-6, atol=0)
         assert torch.equal(b0[0].indptr, b1[0].indptr) and torch.equal(b0[0].gindices, b1[0].gindices) and torch.equal(b0[0].dst_nodes, b1[0].dst_nodes)
         assert b1[0].indices is b1[0].gindices or torch.equal(b1[0].indices, b1[0].gindices)
         assert b1[0].n_src == n and b1[0].num_edges() == b0[0].num_edges()
