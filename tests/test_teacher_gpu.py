@@ -961,3 +961,53 @@ def test_sampled_training_epoch_is_reproducible_within_and_across_processes():
         assert len(same) == 5 and all("blocks equal True, losses equal True" in ln and "parameters equal True" in ln for ln in same), same
         outs.append([ln for ln in lines if ln.startswith("sha256")])
     assert outs[0] and outs[0] == outs[1], outs
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_train_sage_with_the_engine_mode_loader_equals_the_default_blocks_on_random_graphs(seed):
+    """train_sage asks its loader for global-id outermost blocks and prebuilt transposes (round 5); stepping TeacherEngine by hand over the
+    loader's default (fully relabelled) blocks is the same training bit for bit -- on random graphs with isolated nodes, hubs, fan-outs above
+    and below the degrees, 1-3 layers, hidden widths on both sides of the dy-in-aggregation form's limits, a ragged last batch, dropout."""
+    import copy
+    from glnn_amd import teacher, train_and_eval as te
+    from glnn_amd.graph import CSRGraph, MultiLayerFullNeighborSampler, MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    rs = np.random.RandomState(100 + seed)
+    n = int(rs.choice([300, 2000, 9000]))
+    indptr, indices = random_graph(n, float(rs.choice([2, 6, 20])), seed=seed, power=float(rs.choice([0.0, 0.6])), hub=int(rs.choice([0, n // 3])),
+                                   isolated=int(rs.choice([0, 11])))
+    g = CSRGraph(torch.from_numpy(indptr).to(DEV), torch.from_numpy(indices).to(DEV), n)
+    L = int(rs.choice([1, 2, 3]))
+    f, h, c = int(rs.choice([16, 100])), int(rs.choice([64, 128, 256])), int(rs.choice([5, 47]))
+    p = float(rs.choice([0.0, 0.5]))
+    sampler = MultiLayerNeighborSampler([int(v) for v in rs.choice([2, 5, 15], L)]) if rs.rand() < 0.8 else MultiLayerFullNeighborSampler(L)
+    torch.manual_seed(seed)
+    base = Model(dict(model_name="SAGE", num_layers=L, feat_dim=f, hidden_dim=h, label_dim=c, dropout_ratio=p, norm_type=str(rs.choice(["batch", "none"])),
+                      device=DEV))
+    feats = torch.randn(n, f, device=DEV)
+    labels = torch.randint(0, c, (n,), device=DEV)
+    nids = torch.from_numpy(rs.permutation(n)[: int(0.7 * n)].astype(np.int64)).to(DEV)
+    bs = int(rs.choice([64, 257]))
+    outs = []
+    for engine_mode in (False, True):
+        model = copy.deepcopy(base)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+        loader = NodeDataLoader(g, nids, sampler, batch_size=bs, shuffle=False, drop_last=False, seed=77)
+        if engine_mode:
+            mean = te.train_sage(model, loader, feats, labels, torch.nn.NLLLoss(), opt)
+            assert loader.global_first_block is False                      # restored
+        else:
+            eng = teacher.get_engine(model, opt)
+            eng.loss_accum.zero_()
+            k = 0
+            for input_nodes, output_nodes, blocks in loader:
+                assert input_nodes is not None and blocks[-1].t_indptr is None
+                eng.step_sage(blocks, feats, labels, output_nodes, 1.0, input_nodes=input_nodes)
+                k += 1
+            eng.sync_optimizer_state()
+            mean = eng.loss_accum.item() / k
+        outs.append((mean, [v.detach().clone() for v in model.state_dict().values()]))
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
