@@ -289,7 +289,8 @@ class NodeDataLoader:
         return seeds, output_nodes, blocks
 
     def __iter__(self):
-        """Batches are built ONE AHEAD on a side HIP stream: the sampler's kernels and its small host read-backs (edge / node
+        """Batches are built AHEAD on a side HIP stream (by a worker thread, up to `depth` of them; `threaded = False`: by the consumer's
+        thread, one ahead): the sampler's kernels and its small host read-backs (edge / node
         counts of every block) overlap the consumer's work on the current stream -- e.g. TeacherEngine's forward / backward of
         the previous batch -- instead of draining it at every read-back (what the CPU workers of dgl's NodeDataLoader do
         for the reference, here as stream-level concurrency on the GPU)."""
