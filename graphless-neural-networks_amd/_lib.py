@@ -36,6 +36,8 @@ SIGNATURES = {
     "glnn_softmax_loss_f32": [c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64,
                               c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_log_softmax_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_vp],
+    "glnn_classifier_loss_f32": [c_vp, c_i64, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_int,
+                                 c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp],
     "glnn_linear_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "glnn_bn_stats_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -72,7 +74,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)

@@ -40,6 +40,7 @@ static void load_options(Options& o) {
   o.sage_fuse_bn_apply = (int)env_ll("GLNN_SAGE_FUSE_BN_APPLY", 1);
   o.spmm_short = (int)env_ll("GLNN_SPMM_SHORT", 1);
   o.sage_fuse_bn_dy = (int)env_ll("GLNN_SAGE_FUSE_BN_DY", 1);
+  o.cls_fused = (int)env_ll("GLNN_STUDENT_CLS_FUSED", 1);
 }
 static Options g_opts;
 static std::once_flag g_opts_once;
@@ -85,7 +86,7 @@ int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, 
 
 }  // namespace
 
-extern "C" int glnn_abi_version(void) { return 10; }
+extern "C" int glnn_abi_version(void) { return 11; }
 
 // test / A-B hook: re-read the GLNN_* switches (glnn::Options).  Not for concurrent use with other calls into the library.
 extern "C" void glnn_reload_options(void) {

@@ -41,6 +41,7 @@ struct Options {
   int spmm_short;           // GLNN_SPMM_SHORT=0: sparse training blocks stay on the one-row-per-wave aggregation kernel
   int sage_fuse_bn_dy;      // GLNN_SAGE_FUSE_BN_DY=0: the deferred BatchNorm backward of layer 0 keeps its dy pass (the transposed aggregation writes da)
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
+  int cls_fused;            // GLNN_STUDENT_CLS_FUSED=0: the large-batch classifier stays a split-K GEMM launch + a loss launch (cls_block.hip off)
 };
 const Options& opts();
 
@@ -119,6 +120,18 @@ int softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, int kind
                  void* stream, int* counter, float* col_sum, const float* slabs = nullptr, int nslab = 0, const float* bias = nullptr,
                  struct PendingFolds* pf = nullptr);
 // pf: the loss / bias-gradient partials are registered there for the fused Adam launch instead of being folded by the last workgroup
+// student.hip: loss = sum of n per-workgroup partials * inv_rows (the second launch of the counter-less loss form)
+int loss_finalize(const float* partial, int n, float inv_rows, float* loss_out, float* loss_accum, void* stream);
+// cls_block.hip (round 6): logits = tail(a) . w^T + bias of a LARGE batch in front of a narrow classifier (n <= 48, k % 256 == 0, k <= 4096) by
+// row-local workgroups, with log_softmax + loss + dlogits behind it in the same launch (ls != NULL; softmax_loss's counter-less form:
+// per-four-rows loss partials in ls->ws, folded by the fused Adam launch (ls->pf) or by loss_finalize).  a_scale / a_shift NULL: a is the
+// stored tail.  GLNN_ERR_UNSUPPORTED = nothing launched.
+struct ClsLoss {
+  int kind; const int64_t* labels; const int64_t* label_rows; const float* target_logp; int64_t ldt; const int64_t* target_rows; float lamb;
+  float* dlogits; int64_t ldg; float* loss_out; float* loss_accum; float* ws; int64_t ws_floats; struct PendingFolds* pf;
+};
+int cls_fwd(const float* a, int64_t lda, const float* a_scale, const float* a_shift, float drop_p, uint32_t drop_seed, int64_t m, int k,
+            const float* w, int64_t ldw, int n, const float* bias, float* logits, int64_t ldz, const ClsLoss* ls, void* stream);
 // slabs / nslab / bias: the logits are still the split-K partials of gemm_split_partials (slabs[s][rows][c]); they are summed, the
 // bias added and the result stored to `logits` by the loss kernel itself
 // da = dl[rows, k] . w[k, h] (w rows ldw apart: a Linear's [out = k, in = h] weight), k <= 64: see bn_bwd_*_sk in student.hip

@@ -145,6 +145,23 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       GLNN_TRY(glnn::bn_finalize_tiles(pend, m, d->dims[l], stream));
     have_pend = have_next;
     pend = next;
+    // (round 6) a large batch in front of a narrow classifier: the product and -- when neither the bias gradient nor a last-workgroup fold is
+    // asked of the loss kernel -- log_softmax + loss + dlogits behind it as ONE row-local launch (cls_block.hip); the choice depends on the
+    // forward's shapes only, never on the backward's form
+    if (lat != GLNN_OK && last && L >= 2 && !rows && !layernorm) {
+      const glnn::ClsLoss cl = {kind, labels, kind == GLNN_LOSS_NLL ? target_rows : nullptr, target_logp, ldt,
+                                kind == GLNN_LOSS_KL ? target_rows : nullptr, lamb, d->dlogits, d->ld_dlogits, d->loss_out, d->loss_accum,
+                                d->ws_loss, d->ws_loss_floats, pf};
+      int rc = GLNN_ERR_UNSUPPORTED;
+      if (!loss_cnt && !fused_bias) {
+        rc = glnn::cls_fwd(src, ld_src, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, d->dims[l + 1], d->b[l], out, ldo, &cl, stream);
+        loss_done = rc == GLNN_OK;
+      }
+      if (rc == GLNN_ERR_UNSUPPORTED)
+        rc = glnn::cls_fwd(src, ld_src, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, d->dims[l + 1], d->b[l], out, ldo, nullptr, stream);
+      if (rc == GLNN_OK) lat = GLNN_OK;
+      else if (rc != GLNN_ERR_UNSUPPORTED) return rc;
+    }
     // a deep, narrow last layer (MLP3w4: 1024 -> 40) is split over K; its partial slabs are folded by the loss kernel, not by a launch
     if (lat != GLNN_OK && last && d->dims[L] <= 64 && slab_consumers) {
       const int rc = glnn::gemm_split_partials(src, ld_src, rows, a_scale, a_shift, gp, gseed, m, d->dims[l], w_l, ldw_l, 0,

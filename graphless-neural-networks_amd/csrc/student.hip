@@ -1117,6 +1117,11 @@ int glnn::softmax_loss(const float* logits, int64_t ldz, int64_t rows, int c, in
   return glnn::check_launch("glnn_softmax_loss_f32");
 }
 
+int glnn::loss_finalize(const float* partial, int n, float inv_rows, float* loss_out, float* loss_accum, void* stream) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partial, n, inv_rows, loss_out, loss_accum);
+  return glnn::check_launch("glnn::loss_finalize");
+}
+
 extern "C" int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t rows, int c, int kind,
                                      const int64_t* labels, const int64_t* label_rows, const float* target_logp,
                                      int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,

@@ -540,6 +540,34 @@ def softmax_loss(logits, kind, lamb, labels=None, label_rows=None, target_logp=N
     return loss_out, dlogits
 
 
+def classifier_loss(a, w, bias, kind, lamb=1.0, a_scale=None, a_shift=None, drop_p=0.0, drop_seed=0, labels=None, label_rows=None,
+                    target_logp=None, target_rows=None, logits=None, dlogits=None, loss_out=None, loss_accum=None, workspace=None):
+    """glnn_classifier_loss_f32: logits = tail(a) . w^T + bias and, with kind >= 0, log_softmax + NLL / KL + dlogits behind it in the same
+    launch (large batches in front of a narrow classifier; raises GlnnError(UNSUPPORTED) for other shapes).  kind = -1: logits only.
+    Returns (logits, loss_out, dlogits)."""
+    _need_cuda(a, w, bias, a_scale, a_shift, labels, label_rows, target_logp, target_rows, logits, dlogits, loss_out, loss_accum)
+    _mat(a, "classifier_loss a")
+    rows, k = a.shape
+    c = w.shape[0]
+    dev = a.device
+    if logits is None:
+        logits = torch.empty((rows, c), dtype=torch.float32, device=dev)
+    if kind >= 0:
+        if dlogits is None:
+            dlogits = torch.empty((rows, c), dtype=torch.float32, device=dev)
+        if loss_out is None:
+            loss_out = torch.empty(1, dtype=torch.float32, device=dev)
+        if workspace is None:
+            workspace = torch.empty(1024, dtype=torch.float32, device=dev)
+    rc = _lib.lib().glnn_classifier_loss_f32(
+        _p(a), _ld(a), _p(a_scale), _p(a_shift), float(drop_p), int(drop_seed) & 0xFFFFFFFF, rows, k, _p(w), _ld(w), c, _p(bias),
+        _p(logits), _ld(logits), kind, _p(labels), _p(label_rows), _p(target_logp), _ld(target_logp) if target_logp is not None else 0,
+        _p(target_rows), float(lamb), _p(dlogits), _ld(dlogits) if dlogits is not None else 0, _p(loss_out), _p(loss_accum),
+        _p(workspace), workspace.numel() if workspace is not None else 0, _stream())
+    _lib.check(rc, "glnn_classifier_loss_f32")
+    return logits, loss_out, dlogits
+
+
 def log_softmax(logits, out=None):
     _need_cuda(logits, out)
     _mat(logits, "log_softmax logits")

@@ -215,6 +215,21 @@ GLNN_API int glnn_softmax_loss_f32(const float* logits, int64_t ldz, int64_t row
                                    int64_t ldl, float* loss_out, float* loss_accum,
                                    float* workspace, int64_t workspace_floats, void* stream);
 
+/* The last layer of a student and its criterion in ONE launch (ABI 11; reference models.py:45-52 last Linear + train_and_eval.py:77-84):
+ *   logits = tail(a) . w^T + bias,  tail(a) = dropout(relu(a * a_scale + a_shift)) (a_scale / a_shift NULL: a is used as stored),
+ *   followed by glnn_softmax_loss_f32's arithmetic on those logits (same loss / dlogits bits), by workgroups that own 16 rows.
+ *   For LARGE batches in front of a NARROW classifier: rows > 1024, c <= 48, k % 256 == 0, 256 <= k <= 4096, float4-addressable rows of
+ *   a and w; kind < 0: logits only (dlogits / loss_out / workspace unused).  With a criterion: rows <= 4096 and
+ *   workspace >= ceil(rows/4) floats.  Any other shape: GLNN_ERR_UNSUPPORTED with nothing launched (use glnn_gemm_f32 +
+ *   glnn_softmax_loss_f32). */
+GLNN_API int glnn_classifier_loss_f32(const float* a, int64_t lda, const float* a_scale, const float* a_shift,
+                                      float drop_p, uint32_t drop_seed, int64_t rows, int k, const float* w, int64_t ldw,
+                                      int c, const float* bias, float* logits, int64_t ldz, int kind,
+                                      const int64_t* labels, const int64_t* label_rows, const float* target_logp,
+                                      int64_t ldt, const int64_t* target_rows, float lamb, float* dlogits, int64_t ldg,
+                                      float* loss_out, float* loss_accum, float* workspace, int64_t workspace_floats,
+                                      void* stream);
+
 /* row-wise log_softmax only (evaluate paths, train_and_eval.py:98,124). in place allowed. */
 GLNN_API int glnn_log_softmax_f32(const float* logits, int64_t ldz, int64_t rows, int c, float* out,
                                   int64_t ldo, void* stream);

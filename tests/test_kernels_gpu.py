@@ -497,6 +497,62 @@ def test_softmax_loss_indexed_targets_and_accum(n, rows, c):
     np.testing.assert_allclose(d2.cpu().numpy(), g2, atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize("rows,k,c,p", [(4096, 2048, 47, 0.2), (4001, 256, 40, 0.5), (1030, 512, 7, 0.0), (2500, 1024, 48, 0.3), (4096, 768, 1, 0.1)])
+@pytest.mark.parametrize("kind", ["nll", "kl"])
+def test_classifier_loss_one_launch_vs_oracle_and_the_two_launch_form(rows, k, c, p, kind):
+    """glnn_classifier_loss_f32 (cls_block.hip): logits = dropout(relu(z * a_scale + a_shift)) . W^T + b by 16-row workgroups with the
+    criterion behind it in the same launch.  (a) logits against float64 on the engine's own dropout mask (1e-4), loss and dlogits against the
+    oracle; (b) the stored-tail form (plain operand) gives the same logits bit for bit as the operand transform; (c) loss and dlogits
+    are the BITS glnn_softmax_loss_f32 produces from the same logits (one wave per row, the same expressions and shuffle trees, the
+    same per-four-rows partials); ragged row counts, 1 ... 48 classes, indexed targets."""
+    from glnn_amd import ops
+    r = np.random.RandomState(rows + k + c)
+    z = dev(r.standard_normal((rows, k)).astype(np.float32))
+    sc = dev((0.5 + r.rand(k)).astype(np.float32))
+    sh = dev((0.3 * r.standard_normal(k)).astype(np.float32))
+    w = dev((r.standard_normal((c, k)) / np.sqrt(k)).astype(np.float32))
+    b = dev((0.1 * r.standard_normal(c)).astype(np.float32))
+    n_all = rows + 37
+    idx = dev(r.permutation(n_all)[:rows].astype(np.int64))
+    seed, lamb = 12345 + rows, 0.7
+    if kind == "nll":
+        y_all = r.randint(0, c, n_all).astype(np.int64)
+        kw = dict(labels=dev(y_all), label_rows=idx)
+        knd = ops.LOSS_NLL
+    else:
+        t_all = so.log_softmax(r.standard_normal((n_all, c)).astype(np.float32))
+        kw = dict(target_logp=ops.as_feat(dev(t_all)), target_rows=idx)
+        knd = ops.LOSS_KL
+    logits, loss, dl = ops.classifier_loss(z, w, b, knd, lamb, a_scale=sc, a_shift=sh, drop_p=p, drop_seed=seed, **kw)
+    # (a)
+    act = ops.act_fwd(z, sc, sh, p, seed)
+    ref = act.double() @ w.double().t() + b.double()
+    assert float((logits.double() - ref).abs().max()) < TOL
+    tgt = y_all[idx.cpu().numpy()] if kind == "nll" else t_all[idx.cpu().numpy()]
+    loss_w, dz_w = so.loss_and_dlogits(logits.cpu().numpy(), tgt, kind, lamb)
+    assert abs(float(loss.item()) - float(loss_w)) < TOL
+    np.testing.assert_allclose(dl.cpu().numpy(), dz_w, atol=1e-6, rtol=1e-4)
+    # (b)
+    logits_b, loss_b, dl_b = ops.classifier_loss(act, w, b, knd, lamb, **kw)
+    assert torch.equal(logits_b, logits) and torch.equal(dl_b, dl) and float(loss_b) == float(loss)
+    only, _, _ = ops.classifier_loss(z, w, b, -1, a_scale=sc, a_shift=sh, drop_p=p, drop_seed=seed)
+    assert torch.equal(only, logits)
+    # (c)
+    loss_2, dl_2 = ops.softmax_loss(logits, knd, lamb, **kw)
+    assert torch.equal(dl_2, dl)
+    assert float(loss_2) == float(loss)
+
+
+def test_classifier_loss_refuses_other_shapes():
+    from glnn_amd import ops
+    from glnn_amd._lib import GlnnError
+    for rows, k, c in [(512, 2048, 47), (4096, 200, 47), (4096, 2048, 64)]:
+        z = torch.randn(rows, k, device=DEV)
+        w = torch.randn(c, k, device=DEV)
+        with pytest.raises(GlnnError):
+            ops.classifier_loss(z, w, None, -1)
+
+
 @pytest.mark.parametrize("rows,c", [(1000, 47), (50001, 2), (4096, 7)])          # the last two: eight rows per wavefront
 def test_log_softmax(rows, c):
     from glnn_amd import ops
