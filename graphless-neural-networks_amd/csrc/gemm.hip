@@ -55,6 +55,12 @@ struct GemmArgs {
   // pass of the BatchNorm statistics over C taken from the accumulators (glnn::gemm_stats)
   float* st_mean; float* st_m2;
   int* st_done;       // host side only: set to 1 by the launcher when the kernel that writes them was chosen
+  // gemm_kernel_pipe<true> only (else bd_z == NULL; glnn::gemm_bn_dy): C is the input gradient da of a hidden layer whose tail is
+  // BatchNorm -> ReLU -> dropout over the pre-activations bd_z.  The epilogue stores dy = da behind the tail's masks instead of da and
+  // leaves, per 128-row tile and column, S1 = sum dy and S2 = sum dy * xhat at bd_s1 / bd_s2[tile_row * n + col]: the first pass of the
+  // BatchNorm backward taken from the accumulators (it used to read da and z back: 64 MB for MLP3w8's first hidden layer)
+  const float* bd_z; int64_t bd_ldz; const float* bd_scale; const float* bd_shift; const float* bd_mean; const float* bd_rstd;
+  uint32_t bd_thr; uint32_t bd_seed; float bd_dscale; int bd_relu; float* bd_s1; float* bd_s2;
 };
 
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -934,6 +940,75 @@ __device__ __forceinline__ void pipe_tile_stats(const GemmArgs& g, const f32x16 
   }
 }
 
+// g.bd_z != NULL: acc (= da of the tile) -> dy in place, column partial sums of the tile's valid rows to bd_s1 / bd_s2.  The element
+// arithmetic is bn_dy's (student.hip): dropout decision by glnn::drop_keep's hash, ReLU gate on fma(z, a_scale, a_shift) > 0.  A column's 128
+// values sit in 2 lanes (lane halves) x 2 waves (row halves) x 32 registers: registers ascending, shuffle, then LDS -- a fixed order.
+__device__ __forceinline__ void pipe_tile_bn_dy(const GemmArgs& g, f32x16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn, int li, int kk) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // free: every LDS write of the main loop is behind its last barrier
+  float* red1 = smem;                                               // [2 row halves][128 columns]
+  float* red2 = smem + 256;
+  const int rows = (int)(g.m - m0 < 128 ? g.m - m0 : 128);
+  float zz[2][2][16];
+  int colc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + li;
+    colc[j] = col < g.n ? col : g.n - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {                                // all 64 loads of the lane are in flight together
+        const int row = wm * 64 + i * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+        const int64_t gr = m0 + (row < rows ? row : rows - 1);
+        zz[j][i][r] = g.bd_z[gr * g.bd_ldz + colc[j]];
+      }
+  }
+  float s1[2], s2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float mu = g.bd_mean[colc[j]], rs = g.bd_rstd[colc[j]], sc = g.bd_scale[colc[j]], sf = g.bd_shift[colc[j]];
+    const uint32_t hcol = g.bd_seed ^ (((uint32_t)colc[j] >> 1) * 0x85EBCA77u + 0x632BE5ABu);
+    const bool hi = colc[j] & 1;
+    s1[j] = 0.f; s2[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + 4 * kk + (r & 3) + 8 * (r >> 2);
+        float dav = acc[i][j][r];
+        if (g.bd_thr) {
+          uint32_t h = hcol ^ ((uint32_t)(m0 + row) * 0x9E3779B1u);
+          h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+          dav = (hi ? (h >> 16) : (h & 0xFFFFu)) >= g.bd_thr ? dav * g.bd_dscale : 0.f;
+        }
+        const bool on = !g.bd_relu || fmaf(zz[j][i][r], sc, sf) > 0.f;
+        const float dy = (on && row < rows) ? dav : 0.f;
+        acc[i][j][r] = dy;
+        s1[j] += dy;
+        s2[j] = fmaf(dy, (zz[j][i][r] - mu) * rs, s2[j]);
+      }
+    s1[j] += __shfl_xor(s1[j], 32);
+    s2[j] += __shfl_xor(s2[j], 32);
+  }
+  __syncthreads();
+  if (kk == 0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { red1[wm * 128 + wn * 64 + j * 32 + li] = s1[j]; red2[wm * 128 + wn * 64 + j * 32 + li] = s2[j]; }
+  }
+  __syncthreads();
+  if (wm == 0 && kk == 0) {
+    const int64_t base = (m0 / 128) * (int64_t)g.n;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = wn * 64 + j * 32 + li, col = n0 + c;
+      if (col < g.n) {
+        g.bd_s1[base + col] = red1[c] + red1[128 + c];
+        g.bd_s2[base + col] = red2[c] + red2[128 + c];
+      }
+    }
+  }
+}
+
 // C = epi(A . W^T) (B_KN = false, W [n,k]) or epi(A . W) (B_KN = true, W [k,n]): plain A, K % 32 == 0, no split-K
 template <bool B_KN>
 __global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
@@ -951,6 +1026,9 @@ __global__ __launch_bounds__(256) void gemm_kernel_pipe(const GemmArgs g) {
     pipe_mainloop<ROWK, KROW>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + n0, g.ldb, ((g.n + 3) & ~3) - n0, g.k, g.k / BK, acc);
   else
     pipe_mainloop<ROWK, ROWK>(g.a + m0 * g.lda, g.lda, g.m - m0, g.b + (int64_t)n0 * g.ldb, g.ldb, g.n - n0, g.k, g.k / BK, acc);
+  if constexpr (B_KN) {
+    if (g.bd_z) pipe_tile_bn_dy(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
+  }
   store_tile<128, 128, 2, 2>(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
   if (g.st_mean) pipe_tile_stats(g, acc, m0, n0, wave >> 1, wave & 1, lane & 31, lane >> 5);
 }
@@ -1576,6 +1654,8 @@ static int gemm_impl(const float* a, int64_t lda, const int64_t* a_rows, const f
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
   g.ksplits = 1; g.ktiles_per_split = (k + BK - 1) / BK; g.ws = nullptr; g.defer_fold = 0;
   g.st_mean = g.st_m2 = nullptr; g.st_done = nullptr;
+  g.bd_z = nullptr; g.bd_ldz = 0; g.bd_scale = g.bd_shift = g.bd_mean = g.bd_rstd = nullptr; g.bd_thr = g.bd_seed = 0u; g.bd_dscale = 1.f;
+  g.bd_relu = 0; g.bd_s1 = g.bd_s2 = nullptr;
   int tile_stats_done = 0;
   if (cs && !relu && !row_scale && !defer_splits && cs->ws && cs->ws_floats >= 2 * ((m + BM - 1) / BM) * (int64_t)n) {
     g.st_mean = cs->ws; g.st_m2 = cs->ws + ((m + BM - 1) / BM) * (int64_t)n; g.st_done = &tile_stats_done;
@@ -1687,6 +1767,27 @@ int glnn::gemm_stats(const float* a, int64_t lda, int64_t m, int k, const float*
   if (cs) { cs->done = 0; cs->nparts = 0; cs->chunk_rows = 0; cs->ws_cnt = cs->ws_mean = cs->ws_m2 = nullptr; }
   return gemm_impl(a, lda, nullptr, nullptr, nullptr, 0.f, 0u, m, k, w, ldw, 0, n, nullptr, nullptr, bias, 0, c, ldc, workspace, workspace_floats,
                    stream, nullptr, cs);
+}
+
+// dy = masks(a . w) with w [k, n] -- the input gradient of a hidden layer behind its tail's dropout / ReLU masks -- and the per-128-row-tile
+// column sums S1 / S2 of the BatchNorm backward (s1 / s2 [ceil(m / 128)][n]) out of the pipelined kernel's epilogue; da itself is never
+// written.  GLNN_ERR_UNSUPPORTED (nothing launched) unless the pipelined kernel takes the shape: float4-addressable plain operands,
+// k % 32 == 0, n > 64, byte offsets inside the descriptor windows.
+int glnn::gemm_bn_dy(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const glnn::BnTail& t, float* c, int64_t ldc,
+                     float* s1, float* s2, void* stream) {
+  if (!a || !w || !c || !s1 || !s2 || !t.z || !t.mean || !t.rstd || !t.a_scale || !t.a_shift || m < 1 || k < 1 || n <= 64) return GLNN_ERR_UNSUPPORTED;
+  if (lda < k || ldw < n || ldc < n || t.ldz < n || t.drop_p < 0.f || t.drop_p >= 1.f) return GLNN_ERR_UNSUPPORTED;
+  const bool vec = lda % 4 == 0 && ldw % 4 == 0 && glnn::aligned16(a) && glnn::aligned16(w) && lda >= ((k + 3) & ~3) && ldw >= ((n + 3) & ~3);
+  const bool window = lda < (1 << 21) && (int64_t)k * ldw < (1 << 28);
+  if (!vec || !window || !pipe_enabled() || k % BK != 0 || (m + 127) / 128 > 0x7fffffffLL) return GLNN_ERR_UNSUPPORTED;
+  GemmArgs g = {};
+  g.a = a; g.lda = lda; g.m = m; g.k = k; g.b = w; g.ldb = ldw; g.n = n; g.c = c; g.ldc = ldc; g.a_vec = g.b_vec = 1;
+  g.ksplits = 1; g.ktiles_per_split = k / BK; g.drop_scale = 1.f;
+  g.bd_z = t.z; g.bd_ldz = t.ldz; g.bd_scale = t.a_scale; g.bd_shift = t.a_shift; g.bd_mean = t.mean; g.bd_rstd = t.rstd;
+  g.bd_thr = glnn::drop_threshold(t.drop_p); g.bd_seed = t.drop_seed; g.bd_dscale = 1.0f / (1.0f - t.drop_p); g.bd_relu = t.relu ? 1 : 0;
+  g.bd_s1 = s1; g.bd_s2 = s2;
+  static int cfg_pipe = 1;
+  return launch_gemm_kernel(gemm_kernel_pipe<true>, cfg_pipe, pipe_lds_bytes(ROWK, KROW), g, 128, reinterpret_cast<hipStream_t>(stream), 128);
 }
 
 extern "C" int glnn_gemm_f32(const float* a, int64_t lda, const int64_t* a_rows, const float* a_scale,

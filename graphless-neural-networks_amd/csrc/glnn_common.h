@@ -41,6 +41,7 @@ struct Options {
   int spmm_short;           // GLNN_SPMM_SHORT=0: sparse training blocks stay on the one-row-per-wave aggregation kernel
   int sage_fuse_bn_dy;      // GLNN_SAGE_FUSE_BN_DY=0: the deferred BatchNorm backward of layer 0 keeps its dy pass (the transposed aggregation writes da)
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
+  int bn0_in_gemm;          // GLNN_STUDENT_BN0_IN_GEMM=0: the first hidden layer's BatchNorm backward stays partial + apply launches behind a plain input-gradient GEMM
   int cls_fused;            // GLNN_STUDENT_CLS_FUSED=0: the large-batch classifier stays a split-K GEMM launch + a loss launch (cls_block.hip off)
 };
 const Options& opts();
@@ -214,6 +215,15 @@ struct BnTail { const float* z; int64_t ldz; const float* mean; const float* rst
                 uint32_t drop_seed; int relu; };
 int spmm_csr_bn_dy(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x, int64_t ldx, int d,
                    const float* col_scale, const BnTail& tail, float* out, int64_t ldo, float* ws, int64_t ws_floats, int* nslots, void* stream);
+// gemm.hip (round 6): the input-gradient product of a hidden layer whose epilogue is the first pass of that layer's BatchNorm backward --
+// see the definition; student.hip's bn_bwd_parts_finish turns the tile partials into the constants of the deferred apply
+int gemm_bn_dy(const float* a, int64_t lda, int64_t m, int k, const float* w, int64_t ldw, int n, const BnTail& t, float* c, int64_t ldc, float* s1,
+               float* s2, void* stream);
+// student.hip: S1 / S2 = sums over nparts partials (ascending), then dz = alpha dy + beta z + gamma as *defer_apply (cst: 3 h floats,
+// 16-byte aligned), dgamma = S2, dbeta = S1, dz_col_sum = 0 -- ONE launch
+int bn_bwd_parts_finish(const float* s1, const float* s2, int nparts, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,
+                        const float* mean, const float* rstd, float* cst, float* dgamma, float* dbeta, float* dz_col_sum,
+                        struct BnApplyA* defer_apply, void* stream);
 // student.hip: the rest of bn_relu_bwd(..., defer_apply) behind partial sums that already exist (ws1 = ws, ws2 = ws + nslots h): fold,
 // constants, *defer_apply.  ws must hold 2 nslots h + 5 h + 8 floats.
 int bn_bwd_deferred_finish(float* ws, int64_t ws_floats, int nslots, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,

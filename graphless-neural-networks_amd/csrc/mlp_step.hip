@@ -261,6 +261,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
   const bool fuse_apply = opt.fuse_apply && pf && defer;
   // (large batches: the same idea -- the first layer's weight gradient applying the BatchNorm backward in its operand loads -- was
   //  measured break-even on MLP3w8 and slower on 512-wide students; experiments/gemm_tn_bn.md)
+  // (round 6) the FIRST hidden layer's BatchNorm backward without its two passes over (da, z): the input-gradient product's epilogue stores dy
+  // (da behind the tail's masks) and the tile column sums (glnn::gemm_bn_dy), one small launch turns them into the constants of
+  // dz = alpha dy + beta z + gamma, and dz's ONE consumer -- the first layer's weight gradient -- evaluates that in its operand loads
+  // (glnn::gemm_tn(..., bn): the pipelined kernel, plain operands); dz_0 is never written, its column sum (the bias gradient in front of the
+  // BatchNorm, mathematically 0) is 0.  MLP3w8: partial 11.6 + apply 19.4 us and 160 MB of traffic leave the step.
+  glnn::BnApplyA bn0 = {};
+  bool have_bn0 = false;
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
   for (int l = L - 1; l >= 0; --l) {
@@ -301,7 +308,7 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
       const int rc0 = glnn::gemm_tn(dz, ld_dz, m, d->dims[1], pregather ? d->xb : feats, pregather ? d->ld_xb : ldx, pregather ? nullptr : idx,
                             nullptr, nullptr, 0.f, 0u, d->dims[0], d->gw[0],
                             d->dims[0], (L == 1 && !fused_bias) ? d->gb[0] : nullptr, ws0, ws0_floats, stream,
-                            fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats);
+                            fold_later ? &fw : nullptr, fold_later ? &fc : nullptr, &used, d->ws_tn_floats, have_bn0 ? &bn0 : nullptr);
       GLNN_TRY(rc0);
       if (fold_later) {
         GLNN_REQUIRE(pf->n + 2 <= glnn::kMaxGradFolds, "glnn_mlp_train_step_f32: too many pending gradient folds");   // (gemm_tn skipped its own fold launch)
@@ -405,6 +412,35 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
     float* wg_dw = narrow_wg ? d->ws_tn + tn_off : nullptr;
     float* wg_db = (narrow_wg && wg_colsum) ? wg_dw + ((wg_chunks * d->dims[l + 1] * d->dims[l] + 3) & ~(int64_t)3) : nullptr;
     const glnn::NarrowProduct np = {dz, ld_dz, d->dims[l + 1], d->w[l], d->dims[l], wg_dw, wg_db};
+    if (l == 1 && !narrow && !defer && opt.bn0_in_gemm && d->batchnorm == 1 && grp == nullptr && m > 1024 && d->dims[1] % 4 == 0 &&
+        (pregather || !idx) && d->da && dz != d->da) {      // (dy goes where da would have gone)
+      const float* b0 = pregather ? d->xb : feats;
+      const int64_t ldb0 = pregather ? d->ld_xb : ldx;
+      const int64_t nparts = (m + 127) / 128;
+      const int64_t wsb_floats = (pf && L >= 2) ? d->ws_bn_floats / (L - 1) / 4 * 4 : d->ws_bn_floats;      // (this layer's slice is the first)
+      const int64_t ld_dy = d->ld_da;
+      const int64_t ldmax = ld_dy > ldb0 ? (ld_dy > d->ldz[0] ? ld_dy : d->ldz[0]) : (ldb0 > d->ldz[0] ? ldb0 : d->ldz[0]);
+      // every condition of gemm_tn(..., bn), the workspace-dependent split included (rows_per_split <= m): decided BEFORE dz is left unwritten
+      const bool tn_ok = glnn::gemm_tn_takes_bn(d->da, ld_dy, m, d->dims[1], b0, ldb0, d->dims[0], d->z[0], d->ldz[0]) && m * ldmax < (1 << 28) &&
+                         !(L == 1 && !fused_bias);
+      const int64_t h4 = (2 * nparts * d->dims[1] + 3) & ~(int64_t)3;
+      if (tn_ok && glnn::aligned16(d->ws_bn) && wsb_floats >= h4 + 3ll * d->dims[1]) {
+        float* s1 = d->ws_bn;
+        float* s2 = d->ws_bn + nparts * d->dims[1];
+        const glnn::BnTail tail = {d->z[0], d->ldz[0], d->mean[0], d->rstd[0], d->a_scale[0], d->a_shift[0], p, seed, 1};
+        const int rc = glnn::gemm_bn_dy(dz, ld_dz, m, d->dims[2], d->w[1], d->dims[1], d->dims[1], tail, d->da, ld_dy, s1, s2, stream);
+        if (rc == GLNN_OK) {
+          GLNN_TRY(glnn::bn_bwd_parts_finish(s1, s2, (int)nparts, d->dims[1], m, d->z[0], d->ldz[0], d->gamma[0], d->mean[0], d->rstd[0],
+                                             d->ws_bn + h4, d->ggamma[0], d->gbeta[0], d->gb[0], &bn0, stream));
+          have_bn0 = true;
+          dz = d->da;
+          ld_dz = ld_dy;
+          continue;
+        } else if (rc != GLNN_ERR_UNSUPPORTED) {
+          return rc;
+        }
+      }
+    }
     if (!narrow) GLNN_TRY(input_gradient());
     if (layernorm) {
       GLNN_TRY(glnn_layernorm_bwd_f32(d->da, d->ld_da, d->z[l - 1], d->ldz[l - 1], m, d->dims[l], d->gamma[l - 1], d->beta[l - 1],

@@ -1369,7 +1369,50 @@ __global__ __launch_bounds__(256) void bn_bwd_consts_kernel(const float* __restr
   dgamma[col] = S2;
   if (dz_col_sum) dz_col_sum[col] = 0.f;
 }
+// the same behind per-tile partials that are still unfolded (glnn::gemm_bn_dy): a thread sums its column's nparts partials (all loads of a
+// batch of 16 in flight, added ascending) and goes on to the constants -- fold + constants in ONE launch
+__global__ __launch_bounds__(256) void bn_bwd_parts_consts_kernel(const float* __restrict__ p1, const float* __restrict__ p2, int nparts, int h,
+                                                                  float rows, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, float* __restrict__ alpha, float* __restrict__ beta,
+                                                                  float* __restrict__ gam, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dz_col_sum) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= h) return;
+  float S1 = 0.f, S2 = 0.f;
+  for (int k0 = 0; k0 < nparts; k0 += 16) {
+    float t1[16], t2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = k0 + u < nparts ? k0 + u : nparts - 1;
+      t1[u] = p1[(int64_t)k * h + col];
+      t2[u] = p2[(int64_t)k * h + col];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (k0 + u < nparts) { S1 += t1[u]; S2 += t2[u]; }
+  }
+  const float inv_b = 1.0f / rows;
+  const float c1 = S1 * inv_b, c2 = S2 * inv_b, rs = rstd[col], grs = gamma[col] * rs;
+  const float k = grs * rs * c2;
+  alpha[col] = grs;
+  beta[col] = -k;
+  gam[col] = fmaf(k, mean[col], -grs * c1);
+  dbeta[col] = S1;
+  dgamma[col] = S2;
+  if (dz_col_sum) dz_col_sum[col] = 0.f;
+}
 }  // namespace
+
+int glnn::bn_bwd_parts_finish(const float* s1, const float* s2, int nparts, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,
+                              const float* mean, const float* rstd, float* cst, float* dgamma, float* dbeta, float* dz_col_sum,
+                              glnn::BnApplyA* defer_apply, void* stream) {
+  GLNN_REQUIRE(s1 && s2 && nparts >= 1 && h >= 4 && (h & 3) == 0 && rows >= 1 && gamma && mean && rstd && cst && glnn::aligned16(cst) && dgamma &&
+               dbeta && defer_apply, "glnn::bn_bwd_parts_finish: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_parts_consts_kernel, dim3((h + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), s1, s2, nparts, h, (float)rows,
+                     gamma, mean, rstd, cst, cst + h, cst + 2ll * h, dgamma, dbeta, dz_col_sum);
+  *defer_apply = {z, ldz, cst, cst + h, cst + 2ll * h};
+  return glnn::check_launch("glnn::bn_bwd_parts_finish");
+}
 
 int glnn::bn_bwd_deferred_finish(float* ws, int64_t ws_floats, int nslots, int h, int64_t rows, const float* z, int64_t ldz, const float* gamma,
                                  const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dz_col_sum, glnn::BnApplyA* defer_apply,

@@ -376,6 +376,29 @@ def test_classifier_input_gradient_recomputed_in_the_batchnorm_backward(dims, bs
         assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
 
 
+@pytest.mark.parametrize("dims,bsz,p,kind", [([100, 2048, 2048, 47], 4096, 0.2, "kl"), ([100, 256, 256, 47], 4096, 0.5, "kl"),
+                                             ([72, 544, 544, 40], 2500, 0.3, "kl"), ([100, 608, 608, 7], 2049, 0.0, "nll"),
+                                             ([100, 512, 512, 512, 47], 4096, 0.2, "kl")])      # (feature width > 64: the weight gradient's pipelined kernel)
+def test_first_hidden_layer_batchnorm_backward_out_of_the_input_gradient_product(dims, bsz, p, kind, monkeypatch):
+    """Large batches (round 6): the first hidden layer's BatchNorm backward has no passes of its own -- the input-gradient product's epilogue
+    stores dy and the tile column sums (gemm.hip pipe_tile_bn_dy), one launch makes the constants, the first layer's weight gradient
+    applies dz = alpha dy + beta z + gamma in its operand loads -- against partial + apply behind a plain product
+    (GLNN_STUDENT_BN0_IN_GEMM=0).  Different summation orders only: forward identical, every gradient to fp32 rounding (the bias
+    gradient in front of the BatchNorm, mathematically 0, is exactly 0 in the new form and rounding noise in the old one); ragged rows,
+    hidden widths off the 128-column tile grid, with / without dropout, a four-layer student."""
+    base, x, tgt, k = _variant_inputs(dims, bsz, "batch", p, kind, 37)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_STUDENT_BN0_IN_GEMM", mode)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 1))
+    (_, _, g0, l0, z0), (_, _, g1, l1, z1) = runs
+    assert float(l0) == float(l1) and torch.equal(z0, z1)
+    gs = max(float(a.abs().max()) for a in g0)
+    assert any(not torch.equal(a, b) for a, b in zip(g0, g1)), "both runs took the same path"
+    for a, b in zip(g0, g1):
+        assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
+
+
 @pytest.mark.parametrize("dims,bsz,norm,p", [([1433, 128, 7], 140, "none", 0.6), ([3703, 128, 6], 512, "none", 0.6), ([4814, 64, 64, 2], 300, "batch", 0.2),
                                              ([1433, 256, 256, 40], 4096, "batch", 0.5)])
 def test_wide_unaligned_first_layer_through_a_padded_shadow_of_its_weight(dims, bsz, norm, p, monkeypatch):
