@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-xl-leg", action="store_true", help="N = 1, products at scale 1.0: skip the 'xl' object (BASELINE configs[4]: one rank-forward "
                     "of the synthetic 100M-node / 2B-edge graph, run as a child process of this one after the products legs)")
     ap.add_argument("--no-arxiv-leg", action="store_true", help="N = 1, products at scale 1.0: skip the 'arxiv' object (BASELINE configs[1] + [2])")
+    ap.add_argument("--deadline-s", type=float, default=1500.0, help="N > 1: rank 0 prints a line with value null and exits when the run has not finished after this many "
+                    "seconds (a collective that hangs cannot be caught as an exception; the RCCL timeout is set behind it)")
     ap.add_argument("--detail-file", default=None, help="also write the long detail object to this file (default: gpurun_out/bench_detail.json when that directory exists)")
     args = ap.parse_args()
     if args.steps is None:
@@ -118,12 +120,31 @@ def main():
     backend = os.environ.get("GLNN_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    args.side_group, args.ladder = None, None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tmo = datetime.timedelta(seconds=args.deadline_s + 120)      # behind the deadline: rank 0's own null line comes first
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        # the side channel of the fail-safe ladder (benchlib.products.Ladder): success / failure of every transport stage is agreed on over
+        # gloo, not over the communicator that may just have failed
+        try:
+            args.side_group = dist.new_group(backend="gloo", timeout=tmo)
+        except Exception as e:      # noqa: BLE001
+            print(f"bench.py: no gloo side group ({type(e).__name__}: {e}); failures will not be agreed on across ranks", file=sys.stderr, flush=True)
+        if rank == 0 and args.workload == "products" and not args.emulate:
+            import threading
+            from benchlib.products import emit_failure
+
+            def watchdog():
+                emit_failure(args, 0, world, args.ladder, f"deadline of {args.deadline_s:.0f} s exceeded (a collective that never returns?)")
+                os._exit(3)
+            wd = threading.Timer(args.deadline_s, watchdog)
+            wd.daemon = True
+            wd.start()
 
     def barrier():
         if world > 1:
@@ -138,7 +159,16 @@ def main():
         if world != 1:
             raise SystemExit("--emulate runs on ONE GPU (it plays the ranks of an N-rank job one after the other)")
         return run_emulated(args, dev)
-    return run_products(args, rank, world, dev, barrier)
+    if world == 1:
+        return run_products(args, rank, world, dev, barrier)
+    try:
+        return run_products(args, rank, world, dev, barrier)
+    except Exception as e:      # noqa: BLE001  (N > 1: whatever still escapes the ladder ends in a line, not in a traceback only)
+        import traceback
+        from benchlib.products import emit_failure
+        traceback.print_exc()
+        emit_failure(args, rank, world, args.ladder, f"{type(e).__name__}: {e}"[:300])
+        sys.exit(0 if rank == 0 else 1)
 
 
 def self_launch(args):

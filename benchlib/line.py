@@ -80,6 +80,14 @@ def compact(r, detail_path):
         c["exchange"] = {k: ex.get(k) for k in ("GB_received_per_rank_per_forward", "collectives_per_forward", "link_GBps_measured", "layer1_autotune_ms",
                                                 "layer1_chosen", "chunks", "kernel_ms_max", "kernel_ms_mean", "wall_ms_max", "exchange_exposed_ms_max",
                                                 "exchange_exposed_ms_mean")}
+        if ex.get("ladder"):        # which rung of the fail-safe ladder ran, and what failed on the way down (strings cut to 100 chars)
+            ld = ex["ladder"]
+            c["exchange"]["ladder"] = {"teacher_rung": ld.get("teacher_rung"), "student_rung": ld.get("student_rung"),
+                                       "errors": {k: _short(v, 100) for k, v in list((ld.get("errors") or {}).items())[:6]} or None}
+            if ld.get("stage"):
+                c["exchange"]["ladder"]["stage"] = ld["stage"]
+        if isinstance(ex.get("layer1_autotune_ms"), dict):
+            c["exchange"]["layer1_autotune_ms"] = {k: (_short(v, 60) if isinstance(v, str) else v) for k, v in ex["layer1_autotune_ms"].items()}
         if ex.get("link_probe"):
             c["exchange"]["link_probe_GBps"] = {k: [round(v["per_link_GBps"], 2), round(v["received_GBps"], 2)] for k, v in ex["link_probe"].items()}
         if ex.get("ranks"):       # per rank: [kernel ms, wall ms, exposed exchange ms]; per launch family: the slowest rank's ms
@@ -89,6 +97,8 @@ def compact(r, detail_path):
                 for k, v in q["kernels"].items():
                     fam[k] = max(fam.get(k, 0.0), v)
             c["exchange"]["family_ms_max"] = {k: round(v, 3) for k, v in fam.items()}
+    if r.get("error"):
+        c["error"] = _short(r["error"], 200)
     x = r.get("xl")
     if x:                      # BASELINE configs[4] on the same clock: one rank-forward of the synthetic 100M-node / 2B-edge graph (child process)
         c["xl"] = {"error": _short(x["error"], 120)} if "error" in x else {

@@ -13,6 +13,54 @@ from .legs import child_leg, clustered_leg, hbm_estimate, reordered_leg, rooflin
 from .line import emit
 
 
+class Ladder:
+    """The fail-safe ladder of an N > 1 run.  No multi-rank RCCL collective of this repository has ever executed
+    on hardware, so every stage that touches the transport -- link probe, every autotune candidate, the timed regions -- runs under
+    attempt(): an exception on ANY rank is recorded and agreed on over a gloo side group (not over the communicator that may just
+    have failed), and the run steps down to the next, plainer form instead of ending without a line:
+        teacher  autotuned chunked / overlapped all-gathers -> synchronous un-chunked in-place all-gather -> synchronous out-of-place
+                 (list form) all-gather -> a line with value null and the errors
+        student  all-reduce from inside the backward -> one all-reduce after the backward -> student object with value null
+    A collective that HANGS cannot be caught; the deadline watchdog of bench.py prints the null line for that case."""
+
+    def __init__(self, world, side):
+        self.world, self.side, self.errors, self.stage = world, side, {}, "start"
+
+    def agree(self, ok):
+        if self.world == 1 or self.side is None:
+            return ok
+        import torch.distributed as dist
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32)          # a CPU tensor: the gloo side group
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.side)
+        return int(t.item()) == 0
+
+    def attempt(self, key, fn):
+        """fn() on every rank -> (ok on ALL ranks, its result here).  Exactly one agree() per call on every rank."""
+        self.stage = key
+        err, res = None, None
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+        except Exception as e:      # noqa: BLE001  (whatever the transport raises)
+            err = f"{type(e).__name__}: {e}".replace("\n", " ")[:300]
+        ok = self.agree(err is None)
+        if not ok:
+            self.errors[key] = err or "failed on another rank"
+        return ok, (res if ok else None)
+
+
+def emit_failure(args, rank, world, lad, why):
+    """The line of a run that could not produce its number: the contract keys with value null, and what failed where."""
+    if rank == 0:
+        emit({"metric": "aggregated edges/sec (teacher fwd) + student distill steps/sec, ogbn-products 1/2/4/8 GPU", "value": None, "unit": "edges/s",
+              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+              "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": None, "rccl_ranks": world, "backend": None,
+              "config": {"workload": f"{C.GRAPH}-shaped SAGE teacher forward + {C.STUDENT['name']} student step", "scale": args.scale},
+              "error": why, "exchange": {"ladder": {"teacher_rung": None, "student_rung": None, "errors": (lad.errors if lad else None) or None,
+                                                    "stage": lad.stage if lad else None}}}, args)
+    return None
+
+
 def run_products(args, rank, world, dev, barrier):
     import torch.distributed as dist
     from glnn_amd import data, ops
@@ -48,108 +96,158 @@ def run_products(args, rank, world, dev, barrier):
     # N > 1: destination-row ranges cut by WORK (in-edges + 2 per row), not by row count
     shards = RowShards(n, world, rank, chunks=(args.chunks or 4) if world > 1 else 1, bounds=RowShards.balanced_bounds(g.indptr, world) if world > 1 else None)
     ref_own, link_probe, autotune = None, None, None
+    lad = Ladder(world, getattr(args, "side_group", None))
+    args.ladder = lad
+    rung = None
     if world == 1 and args.layer1_exchange == "auto":
         args.layer1_exchange = "narrow"
     if world > 1:
+        from glnn_amd import dist as gdist
         from glnn_amd.dist import probe_link as gdist_probe
+        for spec in filter(None, os.environ.get("GLNN_BENCH_INJECT", "").split(",")):      # tests: "async:1000000,probe:1"
+            kind, cnt = spec.split(":")
+            gdist.INJECT_FAIL[kind] = int(cnt)
         if not args.no_verify:      # the unsharded forward of this rank's rows, before the full graph is dropped: the sharded result
             with torch.no_grad():   # (whatever the transport did) must reproduce it
                 ref_own = teacher.inference(FullNeighborLoader(g, 4096), feats)[shards.lo:shards.hi].clone()
         shard_graph = g.row_range(shards.lo, shards.hi)
         # what the transport delivers for the layer-1 payloads (narrow / wide slab of one rank): recorded, and the model's link rate
-        link_probe = {w_: gdist_probe(world, rank, shards.rpr * ((d_ + 3) // 4 * 4), dev) for w_, d_ in (("narrow", C.SAGE_DIMS[0]), ("wide", C.SAGE_DIMS[1]))}
-        if args.exchange == "halo":
-            sharded = HaloShardedTeacher(teacher.encoder, shard_graph, shards, ops, overlap=not args.no_halo_overlap)
-        else:
+        _, link_probe = lad.attempt("link probe", lambda: {w_: gdist_probe(world, rank, shards.rpr * ((d_ + 3) // 4 * 4), dev)
+                                                           for w_, d_ in (("narrow", C.SAGE_DIMS[0]), ("wide", C.SAGE_DIMS[1]))})
+        base_bounds = shards.bounds
+
+        def time_candidate(form, ch):
+            sh_c = RowShards(n, world, rank, chunks=ch, bounds=base_bounds)
+            cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form)
+            with torch.no_grad():
+                cand.forward(feats)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    cand.forward(feats)
+                barrier()
+            tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * float(tt.item())
+
+        def build_first():
+            """rung 0: what the flags ask for -- the halo exchange, a given all-gather form, or (default) the autotuned one"""
+            nonlocal autotune, shards
+            if args.exchange == "halo":
+                return HaloShardedTeacher(teacher.encoder, shard_graph, shards, ops, overlap=not args.no_halo_overlap)
             if args.layer1_exchange == "auto":
                 # self-tuning: the driver passes no flags and the right form depends on a link rate nobody has measured -- so measure the
                 # forms themselves (what layer 1 puts on the wire x how many chunks the overlapped exchange is cut into), on this
-                # transport, outside the timed region (max over ranks; identical decision on every rank)
+                # transport, outside the timed region (max over ranks; identical decision on every rank).  A candidate that fails on any
+                # rank is recorded as an error string and skipped on every rank.
                 autotune, best = {}, None
                 for form in ("narrow", "wide"):
                     for ch in ([args.chunks] if args.chunks else [2, 4, 8]):
-                        sh_c = RowShards(n, world, rank, chunks=ch, bounds=shards.bounds)
-                        cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form)
-                        with torch.no_grad():
-                            cand.forward(feats)
-                            barrier()
-                            t0 = time.perf_counter()
-                            for _ in range(3):
-                                cand.forward(feats)
-                            barrier()
-                        tt = torch.tensor([(time.perf_counter() - t0) / 3], device=dev, dtype=torch.float64)
-                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                        autotune[f"{form}/{ch}"] = 1e3 * float(tt.item())
-                        if best is None or autotune[f"{form}/{ch}"] < autotune[best]:
-                            best = f"{form}/{ch}"
-                        del cand, sh_c
+                        key = f"{form}/{ch}"
+                        ok, ms = lad.attempt(f"autotune {key}", lambda: time_candidate(form, ch))
+                        autotune[key] = ms if ok else "error: " + lad.errors[f"autotune {key}"]
+                        if ok and (best is None or ms < autotune[best]):
+                            best = key
                         torch.cuda.empty_cache()
+                if best is None:
+                    raise RuntimeError("every overlapped all-gather form failed")
                 args.layer1_exchange, ch = best.split("/")
-                shards = RowShards(n, world, rank, chunks=int(ch), bounds=shards.bounds)
-            sharded = ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
+                shards = RowShards(n, world, rank, chunks=int(ch), bounds=base_bounds)
+            return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
+
+        def build_sync(list_form):
+            nonlocal shards
+            gdist.SAFE_LIST_FORM = list_form
+            args.exchange, args.layer1_exchange = "allgather", "narrow"
+            shards = RowShards(n, world, rank, chunks=1, bounds=base_bounds)
+            return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange="narrow")
+
+        rungs = [("as configured", build_first),
+                 ("synchronous un-chunked in-place all-gather", lambda: build_sync(False)),
+                 ("synchronous out-of-place (list form) all-gather", lambda: build_sync(True))]
         shard_rows, shard_nnz = shards.rows, int(shard_graph.num_edges())
         del g
         torch.cuda.empty_cache()
+        sharded = None
 
         def teacher_forward():
             with torch.no_grad():
                 return sharded.forward(feats)
     else:
         loader = FullNeighborLoader(g, 4096)
+        rungs = [("1 GPU", None)]
 
         def teacher_forward():
             return teacher.inference(loader, feats)
 
     edges_per_forward = 3 * nnz
 
-    # ---- teacher: W warm-up forwards, then exactly K timed forwards ---------------------------------------
-    out_timed = None
-    for _ in range(args.warmup):
-        out_timed = teacher_forward()                   # (held like the timed loop holds it: the allocator then has its second output buffer)
-    if world == 1 and C.GRAPH != "ogbn-products":      # sub-millisecond forwards: --warmup of them is a few ms of load, and the part's clocks
-        t_w = time.perf_counter()                      # take a few hundred ms to come up (the first 0.17 s region of a fresh process measured
-        while time.perf_counter() - t_w < 0.6:         # 0.96-1.21 ms per forward, every later one 0.83): warm up for 0.6 s
-            for _ in range(20):
-                out_timed = teacher_forward()
-            torch.cuda.synchronize()
-    timing = []
-    # A sub-millisecond forward (the arxiv-shaped graph: three launches, 0.85 ms) is timed WITHOUT the per-launch events and the events
-    # are taken over a second pass of the same K forwards: two timing events per launch inside the timed region cost it 0.25-0.4 ms per
-    # forward (profiles/r05_arxiv_event_overhead.txt: 1.10-1.26 ms with them, 0.84 without).  The products forward (33 ms) keeps them
-    # inside the timed region, as the contract asks.
-    events_apart = world == 1 and C.GRAPH != "ogbn-products"
-    barrier()
-    if not events_apart:
-        ops.set_timing(timing)      # per-launch HIP events on every rank (N > 1: kernel time vs wall time = the exposed exchange)
-    from glnn_amd import dist as gdist
-    gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out_timed = teacher_forward()
-    ev1.record()                    # this rank's own end on its compute stream, before it waits for the others
-    barrier()
-    t_teacher = time.perf_counter() - t0
-    regions_ms = None
-    if events_apart:
-        # ... and the K forwards are timed three times, the median region is the figure (a 0.17 s region right after process start
-        # measured 0.84 / 0.97 / 1.21 ms per forward from process to process around a kernel sum of 0.84; all three regions are recorded)
-        regs = [t_teacher]
-        for _ in range(2):
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out_timed = teacher_forward()
-            barrier()
-            regs.append(time.perf_counter() - t0)
-        regions_ms = [1e3 * r_ / args.steps for r_ in regs]
-        t_teacher = sorted(regs)[1]
-        ops.set_timing(timing)
-        for _ in range(args.steps):
-            teacher_forward()
+    def timed_teacher():
+        nonlocal out_timed
+        # ---- teacher: W warm-up forwards, then exactly K timed forwards ---------------------------------------
+        for _ in range(args.warmup):
+            out_timed = teacher_forward()                   # (held like the timed loop holds it: the allocator then has its second output buffer)
+        if world == 1 and C.GRAPH != "ogbn-products":      # sub-millisecond forwards: --warmup of them is a few ms of load, and the part's clocks
+            t_w = time.perf_counter()                      # take a few hundred ms to come up (the first 0.17 s region of a fresh process measured
+            while time.perf_counter() - t_w < 0.6:         # 0.96-1.21 ms per forward, every later one 0.83): warm up for 0.6 s
+                for _ in range(20):
+                    out_timed = teacher_forward()
+                torch.cuda.synchronize()
+        timing = []
+        # A sub-millisecond forward (the arxiv-shaped graph: three launches, 0.85 ms) is timed WITHOUT the per-launch events and the events
+        # are taken over a second pass of the same K forwards: two timing events per launch inside the timed region cost it 0.25-0.4 ms per
+        # forward (profiles/r05_arxiv_event_overhead.txt: 1.10-1.26 ms with them, 0.84 without).  The products forward (33 ms) keeps them
+        # inside the timed region, as the contract asks.
+        events_apart = world == 1 and C.GRAPH != "ogbn-products"
         barrier()
-    ops.set_timing(None)
+        if not events_apart:
+            ops.set_timing(timing)      # per-launch HIP events on every rank (N > 1: kernel time vs wall time = the exposed exchange)
+        gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(args.steps):
+            out_timed = teacher_forward()
+        ev1.record()                    # this rank's own end on its compute stream, before it waits for the others
+        barrier()
+        t_teacher = time.perf_counter() - t0
+        regions_ms = None
+        if events_apart:
+            # ... and the K forwards are timed three times, the median region is the figure (a 0.17 s region right after process start
+            # measured 0.84 / 0.97 / 1.21 ms per forward from process to process around a kernel sum of 0.84; all three regions are recorded)
+            regs = [t_teacher]
+            for _ in range(2):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    out_timed = teacher_forward()
+                barrier()
+                regs.append(time.perf_counter() - t0)
+            regions_ms = [1e3 * r_ / args.steps for r_ in regs]
+            t_teacher = sorted(regs)[1]
+            ops.set_timing(timing)
+            for _ in range(args.steps):
+                teacher_forward()
+            barrier()
+        ops.set_timing(None)
+        return dict(timing=timing, ev0=ev0, ev1=ev1, t_teacher=t_teacher, regions_ms=regions_ms)
+
+    out_timed, tr = None, None
+    from glnn_amd import dist as gdist
+    for rung, build in rungs:
+        if build is not None:
+            ok, sharded = lad.attempt(f"set-up [{rung}]", build)
+            if not ok:
+                continue
+        ok, tr = lad.attempt(f"timed region [{rung}]", timed_teacher)
+        ops.set_timing(None)
+        if ok:
+            break
+        sharded, out_timed = None, None
+        torch.cuda.empty_cache()
+    if tr is None:
+        return emit_failure(args, rank, world, lad, "teacher forward: every rung of the ladder failed")
+    timing, ev0, ev1, t_teacher, regions_ms = tr["timing"], tr["ev0"], tr["ev1"], tr["t_teacher"], tr["regions_ms"]
     rank_diag = None
     if world > 1:
         kms = C.kernel_breakdown(timing, args.steps)
@@ -180,13 +278,6 @@ def run_products(args, rank, world, dev, barrier):
     student.train()
     opt = torch.optim.Adam(student.parameters(), lr=sd["lr"], weight_decay=sd["wd"])
     eng = StudentEngine(student, opt, sd["batch"])
-    if world > 1 and args.student_global_bn:     # one N*B-row batch split over ranks, global BN statistics, summed gradients
-        eng.enable_batch_split(world, rank)
-    elif world > 1:   # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
-        if args.no_grad_overlap:
-            eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
-        else:                                   # big weight gradients are all-reduced from inside the backward (grad_ready hook)
-            eng.overlap = OverlappedGradSync(eng, world, average=True)
     out_t = ops.as_feat(out_t)
     k_student = args.steps * args.student_steps_per_step
     w_student = max(args.warmup, 3)
@@ -194,21 +285,52 @@ def run_products(args, rank, world, dev, barrier):
     gen.manual_seed(1234 + rank)
     nb = max(1, n // sd["batch"])
     perm = torch.randperm(n, generator=gen)[: nb * sd["batch"]].view(nb, -1).to(dev)     # train_and_eval.py:65-71
-    for i in range(w_student):
-        eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(k_student):
-        eng.step(feats, perm[(w_student + i) % nb], ops.LOSS_KL, out_t, 1.0)
-    barrier()
-    t_student = time.perf_counter() - t0
-    if world > 1:
+
+    def student_overlapped():
+        eng.overlap = OverlappedGradSync(eng, world, average=True)      # big weight gradients are all-reduced from inside the backward (grad_ready hook)
+
+    def student_after_backward():
+        if getattr(eng, "overlap", None) is not None:
+            eng.overlap.detach()
+            eng.overlap = None
+        eng.grad_sync = make_grad_sync(eng.flat_grads, world, average=True)
+
+    def timed_student():
+        for i in range(w_student):
+            eng.step(feats, perm[i % nb], ops.LOSS_KL, out_t, 1.0)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k_student):
+            eng.step(feats, perm[(w_student + i) % nb], ops.LOSS_KL, out_t, 1.0)
+        barrier()
+        return time.perf_counter() - t0
+
+    if world == 1:
+        s_rungs = [("1 GPU", None)]
+    elif args.student_global_bn:     # one N*B-row batch split over ranks, global BN statistics, summed gradients
+        s_rungs = [("batch split, global BatchNorm statistics", lambda: eng.enable_batch_split(world, rank))]
+    elif args.no_grad_overlap:       # data parallel: every rank runs its own B-row batches, gradients averaged over ranks
+        s_rungs = [("one all-reduce after the backward", student_after_backward)]
+    else:
+        s_rungs = [("all-reduce from inside the backward", student_overlapped), ("one all-reduce after the backward", student_after_backward)]
+    t_student, s_rung = None, None
+    for s_rung, setup in s_rungs:
+        if setup is not None:
+            ok, _ = lad.attempt(f"student set-up [{s_rung}]", setup)
+            if not ok:
+                continue
+        ok, t_student = lad.attempt(f"student timed region [{s_rung}]", timed_student)
+        if ok:
+            break
+    if t_student is None:            # no gradient exchange works: the student figure is null, the line still stands
+        t_student = float("nan")
+    if world > 1 and t_student == t_student:
         tt = torch.tensor([t_student], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_student = float(tt.item())
     student_steps_per_s = world * k_student / t_student      # B-row batches processed per second, whole job
     student_local_ms = None
-    if world > 1 and not args.student_global_bn:
+    if world > 1 and not args.student_global_bn and t_student == t_student:
         # diagnostic, outside the timed region: the same step WITHOUT the gradient exchange (a second engine on a copy of the model: one
         # C call per step, Adam fused) -- the difference to the timed step is what data parallelism costs per step (exposed all-reduce
         # + the two-call form of the step), max over ranks
@@ -260,6 +382,8 @@ def run_products(args, rank, world, dev, barrier):
             "collectives_per_forward": gdist.EXCHANGE_STATS["collectives"] / args.steps,
             "link_probe": link_probe, "link_GBps_measured": link_probe["narrow"]["per_link_GBps"] if link_probe else None,
             "layer1_autotune_ms": autotune, "layer1_chosen": args.layer1_exchange if args.exchange == "allgather" else None,
+            "ladder": {"teacher_rung": rung, "student_rung": s_rung, "errors": lad.errors or None,
+                       "side_channel": "gloo group" if lad.side is not None else None},
             "chunks": shards.chunks,
             "ranks": rank_diag,
             "kernel_ms_max": max(r_["kernel_ms"] for r_ in rank_diag), "kernel_ms_mean": float(np.mean([r_["kernel_ms"] for r_ in rank_diag])),
@@ -279,7 +403,7 @@ def run_products(args, rank, world, dev, barrier):
                     "batchnorm": "global batch statistics (exchange hook)" if (world > 1 and args.student_global_bn)
                                  else "per-rank batch statistics",
                     "scaling": "weak",
-                    "gradient_exchange": None if world == 1 else ("one all-reduce after the backward" if args.no_grad_overlap and not args.student_global_bn
+                    "gradient_exchange": None if world == 1 else ("one all-reduce after the backward" if "after" in (s_rung or "") and not args.student_global_bn
                                                                   else "weight gradients >= 1 MB all-reduced from inside the backward (grad_ready hook), the rest after it"),
                     "local_step_ms": student_local_ms,
                     "dp_overhead_ms": None if student_local_ms is None else 1e3 * t_student / k_student - student_local_ms,
@@ -287,6 +411,9 @@ def run_products(args, rank, world, dev, barrier):
     }
     result["student"]["tflops"] = result["student"]["gflop_per_step"] * k_student / t_student / 1e3      # per GPU
     result["student"]["frac_of_fp32_mfma_peak"] = result["student"]["tflops"] / 157.3      # v_mfma_f32_32x32x2_f32 dense peak
+    if t_student != t_student:      # every gradient-exchange rung failed: null figures, the errors are under exchange.ladder
+        for k_ in ("value", "ms_per_step", "tflops", "frac_of_fp32_mfma_peak"):
+            result["student"][k_] = None
 
     # ---- roofline of the dominant kernel (N = 1): per-launch HIP events from the timed region -------------
     if world == 1 and timing:

@@ -204,6 +204,21 @@ def record_truth(encoder, graph, x, be):
     return truth, h
 
 
+# The bench's fail-safe ladder (benchlib/products.py): SAFE_LIST_FORM = True makes every RCCL all-gather take the out-of-place list
+# form (what the gloo tests run) instead of the in-place all_gather_into_tensor on a slab of the receive buffer; INJECT_FAIL[kind] = n
+# makes the next n collectives of that kind raise (tests only: "async" = the chunked overlapped all-gathers, "sync" = all_gather_rows,
+# "grad_overlap" / "grad" = the student's gradient all-reduces, "probe" = the link probe).
+SAFE_LIST_FORM = False
+INJECT_FAIL = {}
+
+
+def _inject(kind):
+    n = INJECT_FAIL.get(kind, 0)
+    if n > 0:
+        INJECT_FAIL[kind] = n - 1
+        raise RuntimeError(f"injected failure of a '{kind}' collective (dist.INJECT_FAIL)")
+
+
 def _storage_rows(buf):
     """The contiguous [rows, ld] tensor behind a feature view [rows, d] (ld = row stride >= d)."""
     if buf.is_contiguous():
@@ -224,7 +239,8 @@ def all_gather_rows(buf, shards, group=None, tag=None):
     if _emu(group):
         group.fill_slots(base, mine, shards, tag, shards.rpr, 0)
         return buf
-    if dist.get_backend(group) == "nccl":
+    _inject("sync")
+    if dist.get_backend(group) == "nccl" and not SAFE_LIST_FORM:
         dist.all_gather_into_tensor(base, mine, group=group)
     else:   # gloo (CPU tests): list form
         tmp = [torch.empty_like(mine) for _ in range(shards.world)]
@@ -241,7 +257,8 @@ def _all_gather_block(out_block, mine, shards, group, tag=None, chunk=0):
     if _emu(group):
         group.fill_slots(out_block, mine, shards, tag, shards.cr, chunk * shards.cr)
         return lambda: None
-    if dist.get_backend(group) == "nccl":
+    _inject("async")
+    if dist.get_backend(group) == "nccl" and not SAFE_LIST_FORM:
         work = dist.all_gather_into_tensor(out_block, mine, group=group, async_op=True)
         return work.wait
     tmp = [torch.empty_like(mine) for _ in range(shards.world)]
@@ -266,6 +283,9 @@ def probe_link(world, rank, floats_per_rank, device, group=None, reps=3):
     mine = out[rank * m:(rank + 1) * m]
     mine.fill_(float(rank))
     nccl = dist.get_backend(group) == "nccl"
+
+    nccl = nccl and not SAFE_LIST_FORM
+    _inject("probe")
 
     def once():
         if nccl:
@@ -919,6 +939,7 @@ def make_grad_sync(flat_grads, world, group=None, average=False):
         return None
 
     def sync():
+        _inject("grad")
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
         if average:
             flat_grads.mul_(1.0 / world)
@@ -961,7 +982,15 @@ class OverlappedGradSync:
         engine.desc.grad_ready = self.callback
         engine.grad_sync = self.finish
 
+    def detach(self):
+        """Take the hook out of the engine again (the bench's ladder falls back to one all-reduce after the backward)."""
+        from . import _lib
+        self.eng.desc.grad_ready = _lib.GRAD_READY_FN()
+        self.eng.grad_sync = None
+        self.works, self.error = [], None
+
     def _reduce(self, t, async_op):
+        _inject("grad_overlap")
         if FORCE_COLLECTIVES or self.world > 1:
             self.collectives += 1                       # (not EXCHANGE_STATS: that is the teacher's feature exchange)
             if self.average and dist.get_backend(self.group) == "nccl":

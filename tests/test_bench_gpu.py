@@ -107,6 +107,37 @@ def test_bench_two_ranks_driver_launch_line(extra):
     assert len(json.dumps(out["_compact"])) <= 4096
 
 
+def test_bench_two_ranks_survive_failing_collectives():
+    """the first hardware `--gpus N` run must not be able to end without a line.  With every chunked / overlapped
+    all-gather, the link probe and the in-backward gradient all-reduce made to raise (glnn_amd.dist.INJECT_FAIL through GLNN_BENCH_INJECT),
+    the driver's own launch line still ends in ONE valid line: every autotune candidate is an error string, the teacher ran on the
+    synchronous un-chunked all-gather (and verifies against the unsharded forward), the student on one all-reduce after the backward,
+    and the line says which rungs ran and what failed above them."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo", "GLNN_BENCH_INJECT": "async:1000000,grad_overlap:1000000,probe:1"})
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["verified"] is True and out["verify"]["max_abs_diff_vs_unsharded"] <= 1e-4
+    ex = out["exchange"]
+    assert all(isinstance(v, str) and v.startswith("error: ") and "injected" in v for v in ex["layer1_autotune_ms"].values()) and len(ex["layer1_autotune_ms"]) == 6
+    lad = ex["ladder"]
+    assert lad["teacher_rung"] == "synchronous un-chunked in-place all-gather" and lad["student_rung"] == "one all-reduce after the backward"
+    assert "link probe" in lad["errors"] and "set-up [as configured]" in lad["errors"] and any(k.startswith("student") for k in lad["errors"])
+    assert ex["link_probe"] is None and ex["link_GBps_measured"] is None and ex["chunks"] == 1 and out["config"]["layer1_exchange"] == "narrow"
+    assert out["student"]["value"] > 0 and "one all-reduce after" in out["student"]["gradient_exchange"]
+    c = out["_compact"]["exchange"]["ladder"]
+    assert c["teacher_rung"] == lad["teacher_rung"] and c["student_rung"] == lad["student_rung"] and c["errors"]
+
+
+def test_bench_two_ranks_print_a_null_line_when_no_all_gather_works():
+    """... and when every rung fails (every all-gather of the forward raises), the line carries value null and the errors instead of a number."""
+    out = _run([sys.executable, "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo", "GLNN_BENCH_INJECT": "async:1000000,sync:1000000"})
+    assert out["value"] is None and out["n_gpus"] == 2 and "every rung" in out["error"] and out["_compact"]["error"] == out["error"]
+    errs = out["exchange"]["ladder"]["errors"]
+    assert "timed region [synchronous un-chunked in-place all-gather]" in errs and "timed region [synchronous out-of-place (list form) all-gather]" in errs
+
+
 @pytest.mark.parametrize("l1", ["narrow", "wide"])
 def test_bench_self_launches_its_ranks(l1):
     """`python bench.py --gpus 2` with NO launcher: bench.py spawns the two ranks itself (it used to run one rank and
