@@ -73,15 +73,18 @@ def main():
     ap.add_argument("--shuffle-ids", action="store_true", help="--locality p: randomly permute the node ids of the clustered graph")
     ap.add_argument("--partition", default="none", choices=["none", "lp"],
                     help="N > 1: renumber the nodes with glnn_amd.data.locality_order (label propagation) before the row ranges are cut")
-    ap.add_argument("--layer1-exchange", default="auto", choices=["auto", "narrow", "wide"],
+    ap.add_argument("--mixed-fraction", type=float, default=0.5, help="--layer1-exchange mixed: the fraction of every chunk's rows that travels wide")
+    ap.add_argument("--emulate-forms", default=None, help="--emulate: comma-separated subset of narrow,wide,mixed,halo-lp (default: all)")
+    ap.add_argument("--layer1-exchange", default="auto", choices=["auto", "narrow", "wide", "mixed"],
                     help="N > 1, all-gather exchange: what the widening first layer (100 -> 256) puts on the wire -- its 100-wide aggregate "
                          "(every rank projects all rows itself) or its 256-wide fused output (no replicated work, 2.56x the bytes).  auto (default): "
-                         "both forms are timed on this job's transport before the timed region (3 forwards each) and the faster one runs; "
+                         "the forms (narrow, wide, mixed at --mixed-fraction) are timed on this job's transport before the timed region (3 forwards each) and the fastest one runs; "
                          "--workload xl and N = 1 treat auto as narrow")
     ap.add_argument("--chunks", type=int, default=0, help="N > 1 / --emulate: chunks of the overlapped all-gather exchange (0 = 4, or chosen by the "
                     "layer-1 autotune among 2, 4, 8)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed output ('verified' on the JSON line)")
     ap.add_argument("--no-clustered-leg", action="store_true", help="N = 1: skip roofline_clustered (the forward on a graph with communities)")
+    ap.add_argument("--no-chunked-leg", action="store_true", help="N = 1: skip `chunked` (the reference's chunk-by-chunk sweep, SAGE.inference(whole_graph=False), timed beside the whole-graph form)")
     ap.add_argument("--no-small-students", action="store_true", help="N = 1: skip students_small (the B = 512 arxiv students' step times)")
     ap.add_argument("--workload", default="products", choices=["products", "arxiv", "xl"],
                     help="products = the metric's config (default); xl = BASELINE.json configs[4]: 12.5M-node / 250M-edge shard per GPU "

@@ -29,7 +29,9 @@ def run_emulated(args, dev):
     enc = teacher.encoder
     steps, out = max(1, args.steps), {}
     forms = [("allgather-narrow", "products", dict(exchange="allgather", l1="narrow")), ("allgather-wide", "products", dict(exchange="allgather", l1="wide")),
-             ("halo-lp", "clustered", dict(exchange="halo"))]
+             (f"allgather-mixed{args.mixed_fraction:g}", "products", dict(exchange="allgather", l1="mixed")), ("halo-lp", "clustered", dict(exchange="halo"))]
+    if args.emulate_forms:
+        forms = [f for f in forms if any(f[0].startswith(w) or f[0].endswith(w) for w in args.emulate_forms.split(","))]
     graphs = {}
     for form, gkind, cfg in forms:
         if gkind not in graphs:
@@ -74,7 +76,7 @@ def run_emulated(args, dev):
                 if cfg["exchange"] == "halo":
                     t = gdist.HaloShardedTeacher(enc, shard, sh, ops, group=peers, overlap=True)
                 else:
-                    t = gdist.ShardedTeacher(enc, shard, sh, ops, group=peers, widening_exchange=cfg["l1"])
+                    t = gdist.ShardedTeacher(enc, shard, sh, ops, group=peers, widening_exchange=cfg["l1"], mixed_fraction=args.mixed_fraction)
                 with torch.no_grad():
                     for _ in range(2):
                         t.forward(feats)                   # warm-up (buffers, relabelled columns, packed weights, hub plans, first launches)

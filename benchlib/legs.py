@@ -28,6 +28,34 @@ def child_leg(name, argv, timeout_s):
         return {"error": f"{type(e).__name__}: {e}"[:300], "wall_s": time.perf_counter() - t0}
 
 
+def chunked_leg(g, feats, teacher, FullNeighborLoader, ops, whole_out, forwards=3):
+    """The DROP-IN form of the metric's forward: SAGE.inference(loader, feats, whole_graph=False) is the literal
+    loop of reference models.py:133-145 -- per layer, per 4096-row chunk of the loader: block of the chunk's in-edges, gather the input
+    rows, SAGEConv on the block, BN / ReLU epilogue, scatter the output rows -- and what every loader that is not an arange sweep gets.
+    Same edges, same result (max |diff| against the whole-graph output of the timed region is reported); `launches` = library calls per
+    forward (one batch of chunk blocks is built per sweep, the rest is per chunk)."""
+    loader = FullNeighborLoader(g, 4096)
+    enc = teacher.encoder
+    out = enc.inference(loader, feats, whole_graph=False)       # warm-up: allocator, packed weights
+    torch.cuda.synchronize()
+    calls = []
+    ops.set_timing(calls)
+    enc.inference(loader, feats, whole_graph=False)
+    torch.cuda.synchronize()
+    ops.set_timing(None)
+    t0 = time.perf_counter()
+    for _ in range(forwards):
+        out = enc.inference(loader, feats, whole_graph=False)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / forwards
+    nnz = g.num_edges()
+    diff = float((out[:whole_out.shape[0]] - whole_out).abs().max()) if whole_out is not None else None
+    return {"what": "SAGE.inference(loader, feats, whole_graph=False): the reference's chunked sweep (models.py:133-145), "
+                    f"{-(-g.n_dst // 4096)} chunks x {teacher.encoder.num_layers} layers",
+            "ms": ms, "Gedges_per_s": 3 * nnz / ms / 1e6, "launches": len(calls), "forwards": forwards,
+            "max_abs_diff_vs_whole_graph": diff}
+
+
 def teacher_training_leg(g, feats, labels, dev, data):
     """Epochs of the reference's train_sage on the bench graph with the reference's config for it (train.conf.yaml:170-177 /
     196-204: fan-out 5,10,15; B=512 dropout 0.2 lr 0.01 on arxiv, B=4096 dropout 0.5 lr 0.003 on products): neighbour sampling

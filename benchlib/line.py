@@ -23,7 +23,12 @@ def emit(result, args):
 
 
 def _short(v, n=160):
-    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + "..."
+    """Strings longer than n are cut at the last word boundary in front of the limit (never mid-word)."""
+    if not isinstance(v, str) or len(v) <= n:
+        return v
+    cut = v[:n - 3]
+    sp = cut.rfind(" ")
+    return (cut[:sp] if sp > n // 2 else cut) + "..."
 
 
 def compact(r, detail_path):
@@ -50,7 +55,8 @@ def compact(r, detail_path):
             h = rf["hbm_bytes_estimated"]
             c["roofline"]["hbm_frac_bracket"] = [h["frac_of_peak_lower"], h["frac_of_peak_upper"]]
         if "all_aggregation_launches" in rf:
-            c["roofline"]["launches"] = [{"d": l["d"], "ms": l["avg_ms"], "GBps": l["GBps"]} for l in rf["all_aggregation_launches"]]
+            c["roofline"]["launches"] = [{"d": l["d"], "ms": l["avg_ms"], "GBps": l["GBps"], "frac": round(l["GBps"] / C.HBM_PEAK_GBS, 4)}
+                                         for l in rf["all_aggregation_launches"]]
             c["roofline"]["dense_ms"] = rf.get("dense_projection_ms_per_forward")
     for key in ("roofline_reordered", "roofline_clustered"):
         if key in r:
@@ -59,6 +65,8 @@ def compact(r, detail_path):
         c["layers"] = [{k: _short(l.get(k), 60) for k in ("layer", "bound", "ms", "achieved", "unit", "frac", "GB_received_per_rank", "emulated_fill_ms",
                                                            "modelled_link_ms") if l.get(k) is not None} for l in r["layers"]]
         c["per_forward"] = {k: r["per_forward"][k] for k in ("wall_ms", "kernel_ms", "emulated_fill_ms", "GB_received_per_rank")}
+    if r.get("chunked"):      # the drop-in chunked sweep beside the whole-graph `value`
+        c["chunked"] = {k: r["chunked"][k] for k in ("ms", "Gedges_per_s", "launches", "max_abs_diff_vs_whole_graph")}
     st = r.get("student")
     if st:
         c["student"] = {"metric": _short(st["metric"], 90), "value": st["value"], "unit": st["unit"], "ms_per_step": st["ms_per_step"], "steps": st["steps"],

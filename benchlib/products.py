@@ -9,7 +9,7 @@ import torch
 from . import common as C
 from .checker import verify_sharded, verify_single
 from .cpu_baseline import cpu_baseline
-from .legs import child_leg, clustered_leg, hbm_estimate, reordered_leg, roofline_object, small_student_leg, teacher_training_leg
+from .legs import child_leg, chunked_leg, clustered_leg, hbm_estimate, reordered_leg, roofline_object, small_student_leg, teacher_training_leg
 from .line import emit
 
 
@@ -118,7 +118,7 @@ def run_products(args, rank, world, dev, barrier):
 
         def time_candidate(form, ch):
             sh_c = RowShards(n, world, rank, chunks=ch, bounds=base_bounds)
-            cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form)
+            cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form, mixed_fraction=args.mixed_fraction)
             with torch.no_grad():
                 cand.forward(feats)
                 barrier()
@@ -141,7 +141,7 @@ def run_products(args, rank, world, dev, barrier):
                 # transport, outside the timed region (max over ranks; identical decision on every rank).  A candidate that fails on any
                 # rank is recorded as an error string and skipped on every rank.
                 autotune, best = {}, None
-                for form in ("narrow", "wide"):
+                for form in ("narrow", "wide", "mixed"):
                     for ch in ([args.chunks] if args.chunks else [2, 4, 8]):
                         key = f"{form}/{ch}"
                         ok, ms = lad.attempt(f"autotune {key}", lambda: time_candidate(form, ch))
@@ -153,7 +153,7 @@ def run_products(args, rank, world, dev, barrier):
                     raise RuntimeError("every overlapped all-gather form failed")
                 args.layer1_exchange, ch = best.split("/")
                 shards = RowShards(n, world, rank, chunks=int(ch), bounds=base_bounds)
-            return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange)
+            return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange, mixed_fraction=args.mixed_fraction)
 
         def build_sync(list_form):
             nonlocal shards
@@ -259,6 +259,9 @@ def run_products(args, rank, world, dev, barrier):
     verify = None
     if not args.no_verify:
         verify = verify_single(g, feats, teacher, out_timed, ops) if world == 1 else verify_sharded(out_timed, ref_own, dev, dist)
+    chunked = None
+    if world == 1 and not args.no_chunked_leg:
+        chunked = chunked_leg(g, feats, teacher, FullNeighborLoader, ops, out_timed)
     del out_timed, ref_own
     placement = None
     if world > 1:
@@ -392,7 +395,10 @@ def run_products(args, rank, world, dev, barrier):
             "exchange_exposed_ms_mean": float(np.mean([r_["exchange_exposed_ms"] for r_ in rank_diag])),
             "what": (("all-gathers of the narrow side of each layer boundary: 100-wide aggregate of layer 1 (chunked, overlapped "
                       "with the aggregation; the projection is replicated and consumes chunks in arrival order)" if args.layer1_exchange == "narrow" else
-                      "all-gathers: 256-wide fused output of layer 1 (chunked, overlapped with the aggregation; no replicated projection)")
+                      "all-gathers: 256-wide fused output of layer 1 (chunked, overlapped with the aggregation; no replicated projection)"
+                      if args.layer1_exchange == "wide" else
+                      f"all-gathers: layer 1 mixed -- {args.mixed_fraction:g} of every chunk's rows as 256-wide fused output, the rest as 100-wide "
+                      "aggregate with a replicated projection (chunked, overlapped)")
                      + ", 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none")
                     if args.exchange == "allgather" else
                     "halo all-to-all of the narrow side of each layer boundary, only the remote rows this rank's edges reference"},
@@ -415,6 +421,8 @@ def run_products(args, rank, world, dev, barrier):
         for k_ in ("value", "ms_per_step", "tflops", "frac_of_fp32_mfma_peak"):
             result["student"][k_] = None
 
+    if chunked is not None:
+        result["chunked"] = chunked
     # ---- roofline of the dominant kernel (N = 1): per-launch HIP events from the timed region -------------
     if world == 1 and timing:
         full = C.GRAPH == "ogbn-products" and args.scale == 1.0

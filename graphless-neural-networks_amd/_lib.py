@@ -49,6 +49,7 @@ SIGNATURES = {
     "glnn_mlp_fwd_bwd_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp],
     "glnn_mlp_train_step_f32": [c_vp, c_vp, c_i64, c_vp, c_i64, c_int, c_vp, c_vp, c_i64, c_vp, c_f32, c_vp, c_vp, c_vp],
     "glnn_sage_fwd_bwd_f32": [c_vp, c_vp],
+    "glnn_sage_train_step_f32": [c_vp, c_vp, c_vp],
     "glnn_sage_step_ws_bn_floats": [c_i64, c_int],
     "glnn_act_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_f32, c_u32, c_vp, c_i64, c_vp],
     "glnn_norm_drop_fwd_f32": [c_vp, c_i64, c_i64, c_int, c_vp, c_vp, c_int, c_f32, c_u32, c_vp, c_i64, c_vp],

@@ -1990,10 +1990,27 @@ extern "C" int glnn_gemm_tn_f32(const float* a, int64_t lda, int64_t m, int ka, 
 // would gemm_tn(..., bn) take this product (the pipelined 128 x 128 kernel with plain float4-addressable operands)?  The caller decides
 // BEFORE it leaves dz unwritten; the one condition not covered is the split of the reduction, which needs rows_per_split x ld < 2^28
 // (any workspace that lets the output split into ~256 workgroups does)
-bool glnn::gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz) {
+bool glnn::gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz,
+                            int64_t workspace_floats) {
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (ldz % 4 == 0) && glnn::aligned16(a) && glnn::aligned16(b) && glnn::aligned16(z);
   const bool fast = vec && lda >= ((ka + 3) & ~3) && ldb >= ((nb + 3) & ~3) && ldz >= ((ka + 3) & ~3);
-  return m >= 1 && ka % 4 == 0 && fast && nb > 64 && pipe_enabled() && lda < (1 << 20) && ldb < (1 << 20) && ldz < (1 << 20);
+  if (!(m >= 1 && ka % 4 == 0 && fast && nb > 64 && pipe_enabled() && lda < (1 << 20) && ldb < (1 << 20) && ldz < (1 << 20))) return false;
+  if (workspace_floats < 0) return true;
+  // the split plan of gemm_tn for this product against a workspace of that size (the window condition depends on it):
+  // rows_per_split x the largest pitch must stay below 2^28 floats' worth of descriptor window
+  const int64_t tiles = (int64_t)((ka + BM - 1) / BM) * ((nb + 127) / 128), slab = (int64_t)ka * nb;
+  int64_t splits = 1;
+  if (workspace_floats > 0 && tiles < 256) {
+    splits = (256 + tiles - 1) / tiles;
+    const int64_t by_rows = (m + 4 * BK - 1) / (4 * BK);
+    if (splits > by_rows) splits = by_rows;
+    if (splits * slab > workspace_floats) splits = workspace_floats / slab;
+    if (splits < 1) splits = 1;
+  }
+  int64_t rps = (m + splits - 1) / splits;
+  rps = (rps + BK - 1) / BK * BK;
+  const int64_t ldm = lda > ldb ? (lda > ldz ? lda : ldz) : (ldb > ldz ? ldb : ldz);
+  return rps * ldm < (1 << 28);
 }
 
 // glnn_gemm_tn_f32 whose final sums may be left to the fused Adam launch (glnn::PendingFolds): with `defer` the fold launch of a

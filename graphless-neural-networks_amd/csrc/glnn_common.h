@@ -188,7 +188,8 @@ int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t wo
 // bn_relu_bwd(..., defer_apply)) and dz is never written.  Evaluated on the staged operand pieces of the pipelined kernel;
 // GLNN_ERR_UNSUPPORTED (nothing launched) for any other shape -- ask gemm_tn_takes_bn first.
 struct BnApplyA { const float* z; int64_t ldz; const float* alpha; const float* beta; const float* gamma; };
-bool gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz);
+bool gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz,
+                      int64_t workspace_floats = -1);      // workspace_floats >= 0: also the split-dependent window condition, planned against that workspace
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,
             const float* b_shift, float drop_p, uint32_t drop_seed, int nb, float* c, int64_t ldc, float* col_sum_a, float* workspace,
             int64_t workspace_floats, void* stream, GradFold* defer, GradFold* defer_colsum, int64_t* used_floats, int64_t plan_floats = 0,

@@ -12,7 +12,11 @@
     if (rc_ != GLNN_OK) return rc_; \
   } while (0)
 
-extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream) {
+// pf != NULL (glnn_sage_train_step_f32, round 6): the fused Adam launch follows immediately and is the only consumer of the gradients, so the
+// last sums of gradient partials -- the split slabs of every weight gradient, the column-sum partials behind the last layer's bias gradient,
+// the loss kernel's per-workgroup losses -- are registered in *pf for it instead of being folded by launches of their own (six launches of
+// ~4.6 us each on the products configuration); every weight gradient then gets its own part of ws_tn (the slabs wait there for Adam).
+static int sage_fwd_bwd_impl(const glnn_sage_step_desc* d, void* stream, glnn::PendingFolds* pf) {
   GLNN_REQUIRE(d && d->x && d->labels && d->dlogits && d->loss_out, "glnn_sage_fwd_bwd_f32: null pointer");
   const int L = d->num_layers;
   GLNN_REQUIRE(L >= 1 && L <= GLNN_SAGE_MAX_LAYERS, "glnn_sage_fwd_bwd_f32: num_layers=%d outside [1,%d]", L, GLNN_SAGE_MAX_LAYERS);
@@ -71,8 +75,9 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
   }
   // ---- loss + dlogits (labels indexed by the batch's output nodes) ----------------------------------------------------
   const glnn_sage_layer& top = d->layer[L - 1];
-  GLNN_TRY(glnn_softmax_loss_f32(top.z, top.ldz, top.n_dst, d->dims[L], GLNN_LOSS_NLL, d->labels, d->label_rows, nullptr, 0, nullptr, d->lamb,
-                                 d->dlogits, d->ld_dlogits, nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream));
+  GLNN_TRY(glnn::softmax_loss(top.z, top.ldz, top.n_dst, d->dims[L], GLNN_LOSS_NLL, d->labels, d->label_rows, nullptr, 0, nullptr, d->lamb,
+                              d->dlogits, d->ld_dlogits, nullptr, 0, d->loss_out, d->loss_accum, d->ws_loss, d->ws_loss_floats, stream, nullptr, nullptr,
+                              nullptr, 0, nullptr, pf));
   // ---- backward --------------------------------------------------------------------------------------------------------
   const float* dz = d->dlogits;
   int64_t ld_dz = d->ld_dlogits;
@@ -81,20 +86,35 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
   // the apply pass -- read da and z, write dz: 1.5 GB on the products configuration -- does not exist (round 5)
   glnn::BnApplyA ax0 = {};
   bool apply_in_gemm = false;
+  int64_t tn_off = 0;                                        // pf: the part of ws_tn whose slabs already wait for Adam
   for (int l = L - 1; l >= 0; --l) {
     const glnn_sage_layer& y = d->layer[l];
     const int d_in = d->dims[l], d_out = d->dims[l + 1];
     // dW_l = dz^T agg (+ db for the last layer; hidden layers get it from the activation backward below)
+    // (pf: a product whose remaining part of ws_tn cannot hold eight slabs folds at once in the whole workspace instead -- never unsplit)
+    const bool later = pf && d->ws_tn && d->ws_tn_floats - tn_off >= 8ll * d_in * d_out + 64ll * d_out && pf->n + 2 <= glnn::kMaxGradFolds;
+    glnn::GradFold fw = {}, fc = {};
+    int64_t used = 0;
+    float* wsp = d->ws_tn ? d->ws_tn + (later ? tn_off : 0) : nullptr;
+    const int64_t wsf = d->ws_tn_floats - (later ? tn_off : 0);
+    auto keep_folds = [&]() {
+      if (!later) return;
+      if (fw.nslab > 0) pf->e[pf->n++] = fw;
+      if (fc.nslab > 0) pf->e[pf->n++] = fc;
+      if (fw.nslab > 0 || fc.nslab > 0) tn_off += (used + 3) & ~(int64_t)3;
+    };
     if (l == 0 && apply_in_gemm) {
       const int rcw = glnn::gemm_tn(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in, nullptr,
-                                    d->ws_tn, d->ws_tn_floats, stream, nullptr, nullptr, nullptr, 0, &ax0);
+                                    wsp, wsf, stream, later ? &fw : nullptr, nullptr, &used, d->ws_tn_floats, &ax0);
       if (rcw == GLNN_ERR_UNSUPPORTED)                     // (dz was not written: there is nothing to fall back to)
         return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_sage_fwd_bwd_f32: the weight-gradient workspace (%lld floats) is too small for the "
                           "deferred BatchNorm backward of layer 0; set GLNN_SAGE_FUSE_BN_APPLY=0 or enlarge ws_tn", (long long)d->ws_tn_floats);
       GLNN_TRY(rcw);
+      keep_folds();
     } else {
-      GLNN_TRY(glnn_gemm_tn_f32(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in,
-                                l == L - 1 ? y.gb : nullptr, d->ws_tn, d->ws_tn_floats, stream));
+      GLNN_TRY(glnn::gemm_tn(dz, ld_dz, y.n_dst, d_out, y.agg, y.ld_agg, nullptr, nullptr, nullptr, 0.f, 0u, d_in, y.gw, d_in,
+                             l == L - 1 ? y.gb : nullptr, wsp, wsf, stream, later ? &fw : nullptr, later ? &fc : nullptr, &used, d->ws_tn_floats));
+      keep_folds();
     }
     if (l == 0) break;                                     // the outermost block's input is feats: no gradient needed
     // dagg = dz W ;  dh = (A^T + I_dst)(dagg / (deg + 1)) over the transposed block
@@ -104,7 +124,7 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     const glnn_sage_layer& prev = d->layer[l - 1];         // its tail produced h_l: dz_{l-1} in place on dh
     // layer 0's dz has one consumer (see above): its BatchNorm backward is deferred to dW_0's operand loads when that product's shape allows
     const bool defer = l == 1 && d->batchnorm && glnn::opts().sage_fuse_bn_apply && y.n_src == prev.n_dst &&
-                       glnn::gemm_tn_takes_bn(d->dh, d->ld_dh, prev.n_dst, d_in, prev.agg, prev.ld_agg, d->dims[0], prev.z, prev.ldz) && d->ws_tn &&
+                       glnn::gemm_tn_takes_bn(d->dh, d->ld_dh, prev.n_dst, d_in, prev.agg, prev.ld_agg, d->dims[0], prev.z, prev.ldz, 8ll * d->dims[0] * d_in) && d->ws_tn &&      // (planned against the eight slabs that are guaranteed below)
                        (int64_t)d->dims[0] * d_in * 8 <= d->ws_tn_floats;     // (room for >= 8 split slabs: every split stays inside the descriptor window)
     int rcb = GLNN_ERR_UNSUPPORTED;
     if (defer && glnn::opts().sage_fuse_bn_dy) {
@@ -139,4 +159,20 @@ extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream)
     ld_dz = d->ld_dh;
   }
   return GLNN_OK;
+}
+
+extern "C" int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* d, void* stream) { return sage_fwd_bwd_impl(d, stream, nullptr); }
+
+// The whole optimisation step of the sampled-block teacher -- forward + NLL + backward + Adam (reference train_and_eval.py:39-53 incl.
+// optimizer.step()) -- in ONE call (ABI 11): glnn_sage_fwd_bwd_f32 followed by glnn_adam_step_f32 on the same stream, for hosts that have
+// nothing to put between them (no gradient exchange), with the backward's last partial sums left to the Adam launch.  Same partials, same
+// fold order: the same parameters, moments and loss as the two calls, bit for bit.
+extern "C" int glnn_sage_train_step_f32(const glnn_sage_step_desc* d, const glnn_adam_desc* adam, void* stream) {
+  GLNN_REQUIRE(adam && adam->params && adam->grads && adam->exp_avg && adam->exp_avg_sq && adam->sizes && adam->grads_host,
+               "glnn_sage_train_step_f32: the Adam descriptor is incomplete");
+  glnn::PendingFolds pf = {};
+  const bool folds = glnn::opts().adam_folds && adam->num_tensors <= 32;
+  GLNN_TRY(sage_fwd_bwd_impl(d, stream, folds ? &pf : nullptr));
+  return glnn::adam_step(adam->params, adam->grads, adam->exp_avg, adam->exp_avg_sq, adam->sizes, adam->num_tensors, adam->max_size, adam->lr,
+                         adam->beta1, adam->beta2, adam->eps, adam->weight_decay, adam->step, adam->grads_host, folds ? &pf : nullptr, stream);
 }

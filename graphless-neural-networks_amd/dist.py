@@ -32,7 +32,10 @@ class RowShards:
         layout "cm"   chunk-major slots     [chunk][rank][cr]: what the chunked, overlapped exchange produces
     Column indices are relabelled ONCE per layout (ShardedTeacher._cols); activations are never re-packed."""
 
-    def __init__(self, n, world, rank, chunks=1, bounds=None):
+    def __init__(self, n, world, rank, chunks=1, bounds=None, chunk_sizes=None, kinds=None):
+        """chunk_sizes (round 6): rows per chunk of a slot, UNEQUAL chunks allowed (sum >= the longest range) -- the chunk-major layout is
+        then [chunk k][rank][chunk_sizes[k]]; `kinds` labels the chunks (the mixed layer-1 exchange: "W" = exchanged as the layer's wide
+        output, "N" = as its narrow aggregate).  Default: `chunks` equal chunks."""
         self.n, self.world, self.rank, self.chunks = int(n), int(world), int(rank), max(1, int(chunks))
         if bounds is None:
             per = (self.n + self.world - 1) // self.world
@@ -42,8 +45,20 @@ class RowShards:
                 or any(a > b for a, b in zip(self.bounds[:-1], self.bounds[1:])):
             raise ValueError(f"RowShards: bounds must be {self.world + 1} non-decreasing offsets from 0 to n")
         longest = max(1, max(b - a for a, b in zip(self.bounds[:-1], self.bounds[1:])))
-        self.cr = (longest + self.chunks - 1) // self.chunks          # rows per chunk
-        self.rpr = self.cr * self.chunks                              # rows per slot
+        if chunk_sizes is None:
+            self.cr = (longest + self.chunks - 1) // self.chunks      # rows per chunk
+            self.csize = [self.cr] * self.chunks
+        else:
+            self.csize = [int(c) for c in chunk_sizes]
+            self.chunks = len(self.csize)
+            if self.chunks < 1 or min(self.csize) < 1 or sum(self.csize) < longest:
+                raise ValueError("RowShards: chunk_sizes must be positive and cover the longest range")
+            self.cr = max(self.csize)
+        self.kinds = list(kinds) if kinds is not None else [None] * self.chunks
+        self.coff = [0]
+        for c in self.csize:
+            self.coff.append(self.coff[-1] + c)                       # chunk k holds own-range offsets [coff[k], coff[k + 1])
+        self.rpr = self.coff[-1]                                      # rows per slot
         self.lo, self.hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.rows = self.hi - self.lo
         self.slot = self.rank * self.rpr
@@ -62,8 +77,28 @@ class RowShards:
 
     def chunk_rows(self, c):
         """(offset inside the own range, row count) of chunk c of this rank."""
-        off = c * self.cr
-        return off, max(0, min(self.rows - off, self.cr))
+        off = self.coff[c]
+        return off, max(0, min(self.rows - off, self.csize[c]))
+
+    def chunk_block(self, c):
+        """(first row, rows) of chunk c's block [world][csize[c]] in a chunk-major buffer."""
+        return self.world * self.coff[c], self.world * self.csize[c]
+
+    def chunk_slot(self, c, rank=None):
+        """First row of `rank`'s (default: this rank's) slot inside chunk c's block of a chunk-major buffer."""
+        return self.world * self.coff[c] + (self.rank if rank is None else rank) * self.csize[c]
+
+    def mixed(self, fraction, quantum=64):
+        """The shards of the MIXED layer-1 exchange: every chunk is cut into a leading "W" part of ~fraction of its rows (a multiple of
+        `quantum` rows: whole tiles of the fused kernel) and an "N" part with the rest.  fraction 0 / 1 leave one kind only."""
+        sizes, kinds = [], []
+        for c in self.csize:
+            fw = min(c, max(0, int(round(fraction * c / quantum)) * quantum))
+            for sz, kd in ((fw, "W"), (c - fw, "N")):
+                if sz > 0:
+                    sizes.append(sz)
+                    kinds.append(kd)
+        return RowShards(self.n, self.world, self.rank, bounds=self.bounds, chunk_sizes=sizes, kinds=kinds)
 
     def position(self, v, layout):
         """Row of node id(s) v (int64 tensor) in a buffer of the given layout."""
@@ -74,7 +109,10 @@ class RowShards:
         i = v - b[r]
         if layout == "own":
             return r * self.rpr + i
-        return ((i // self.cr) * self.world + r) * self.cr + i % self.cr
+        off = torch.tensor(self.coff, dtype=torch.int64, device=v.device)
+        size = torch.tensor(self.csize, dtype=torch.int64, device=v.device)
+        k = torch.searchsorted(off[1:], i, right=True)
+        return self.world * off[k] + r * size[k] + (i - off[k])
 
     def cm_position(self, v):
         return self.position(v, "cm")
@@ -254,8 +292,9 @@ def _all_gather_block(out_block, mine, shards, group, tag=None, chunk=0):
     """Asynchronous all-gather of one contiguous [world*cr, ld] block from this rank's [cr, ld] slot inside it (in place).
     Returns a callable that makes the current stream wait for it."""
     _count(out_block)
+    cs = shards.csize[chunk]
     if _emu(group):
-        group.fill_slots(out_block, mine, shards, tag, shards.cr, chunk * shards.cr)
+        group.fill_slots(out_block, mine, shards, tag, cs, shards.coff[chunk])
         return lambda: None
     _inject("async")
     if dist.get_backend(group) == "nccl" and not SAFE_LIST_FORM:
@@ -267,7 +306,7 @@ def _all_gather_block(out_block, mine, shards, group, tag=None, chunk=0):
     def finish():
         work.wait()
         for r, t in enumerate(tmp):
-            out_block[r * shards.cr:(r + 1) * shards.cr].copy_(t)
+            out_block[r * cs:(r + 1) * cs].copy_(t)
     return finish
 
 
@@ -329,17 +368,22 @@ class ShardedTeacher:
     arrival order.  The gathered activations then live in a chunk-major row order ([chunk][rank][rows]); the next
     layer reads them through a column-index array relabelled once at construction -- no data is ever re-packed."""
 
-    def __init__(self, encoder, graph_shard, shards, be, group=None, widening_exchange="narrow"):
+    def __init__(self, encoder, graph_shard, shards, be, group=None, widening_exchange="narrow", mixed_fraction=0.5, mixed_quantum=64):
         """widening_exchange: what a widening layer (2*d_in <= d_out: products layer 1, 100 -> 256) puts on the wire --
         "narrow": its d_in-wide aggregate, every rank then projects ALL rows itself (least bytes, replicated GEMM);
         "wide":   its d_out-wide output of the fused aggregate+project kernel on the own rows only (no replicated work,
-                  d_out/d_in times the bytes).  Both are chunked and overlapped when shards.chunks > 1; results are identical."""
+                  d_out/d_in times the bytes);
+        "mixed":  (round 6) a fraction `mixed_fraction` of every chunk's rows travels wide, the rest narrow -- the continuous form between
+                  the two: `shards` is replaced by shards.mixed(mixed_fraction) (twice the chunks, alternating kinds).
+        All are chunked and overlapped when shards.chunks > 1; results are identical."""
+        if widening_exchange not in ("narrow", "wide", "mixed"):
+            raise ValueError("ShardedTeacher: widening_exchange must be 'narrow', 'wide' or 'mixed'")
+        if widening_exchange == "mixed":
+            shards = shards.mixed(mixed_fraction, mixed_quantum)
         self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
         if graph_shard.n_dst != shards.rows:
             raise ValueError(f"ShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
-        if widening_exchange not in ("narrow", "wide"):
-            raise ValueError("ShardedTeacher: widening_exchange must be 'narrow' or 'wide'")
-        self.widening_exchange = widening_exchange
+        self.widening_exchange, self.mixed_fraction = widening_exchange, mixed_fraction
         self._bufs = {}
         self._col_cache = {}
 
@@ -411,7 +455,7 @@ class ShardedTeacher:
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
             if nr > 0:
-                p0 = (c * sh.world + sh.rank) * sh.cr
+                p0 = sh.chunk_slot(c)
                 out.append((off, nr, slice(p0, p0 + nr)))
         return out
 
@@ -420,7 +464,7 @@ class ShardedTeacher:
         sh = self.sh
         off, nr = sh.chunk_rows(c)
         if layout == "cm":
-            p0 = (c * sh.world + sh.rank) * sh.cr
+            p0 = sh.chunk_slot(c)
             return x[p0:p0 + nr]
         base = sh.lo if layout == "nat" else sh.slot
         return x[base + off:base + off + nr]
@@ -445,55 +489,50 @@ class ShardedTeacher:
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
 
     def _widening_layer_overlapped(self, l, x, layout, w, tail):
-        """2*d_in <= d_out, world > 1: chunked aggregate -> async all-gather -> replicated GEMM.  Returns a chunk-major buffer."""
+        """2*d_in <= d_out, world > 1: per chunk, by its kind (RowShards.kinds):
+             "N" / None   aggregate the own rows -> async all-gather of the d_in-wide aggregate -> REPLICATED GEMM of every rank's rows
+                          (the "narrow" exchange: least bytes, every rank multiplies all rows)
+             "W"          fused aggregate + project of the own rows -> async all-gather of the d_out-wide output (the "wide" exchange:
+                          no replicated work, d_out / d_in times the bytes)
+           Every chunk's all-gather is issued as soon as its producer is queued; the replicated GEMMs consume the narrow chunks in
+           arrival order.  A MIXED exchange (round 6) is chunks of both kinds: the fraction of the rows that travels wide is the dial
+           between link time and replicated MFMA work.  Returns the chunk-major gathered output (every rank's rows)."""
         be, g, sh = self.be, self.g, self.sh
         ep_scale, ep_shift, relu = tail
         d_in, d_out = w.shape[1], w.shape[0]
-        agg = self._full_buffer(("agg", l), d_in, x.device)      # chunk-major [C][P][cr]
-        base = _storage_rows(agg)
-        span = sh.world * sh.cr
+        kinds = [k or ("W" if self.widening_exchange == "wide" else "N") for k in sh.kinds]
+        y = self._full_buffer(("ycm", l), d_out, x.device)       # chunk-major [chunk][rank][rows]
+        ybase = _storage_rows(y)
+        agg = abase = None
+        if "N" in kinds:
+            agg = self._full_buffer(("agg", l), d_in, x.device)
+            abase = _storage_rows(agg)
         idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
-            p0 = (c * sh.world + sh.rank) * sh.cr
-            if nr > 0:
-                be.spmm(g.indptr[off:off + nr + 1], idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=self._chunk_self(x, layout, c),
-                        **self._kw(off, nr))
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("agg", l), c))
-        y = self._full_buffer(("ycm", l), d_out, x.device)
+            b0, bn = sh.chunk_block(c)
+            p0, cs = sh.chunk_slot(c), sh.csize[c]
+            xs = self._chunk_self(x, layout, c)
+            ip = g.indptr[off:off + nr + 1]
+            if kinds[c] == "N":
+                if nr > 0:
+                    be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=xs, **self._kw(off, nr))
+                works.append(_all_gather_block(abase[b0:b0 + bn], abase[p0:p0 + cs], sh, self.group, ("agg", l), c))
+            else:
+                if nr > 0:
+                    if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                        be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
+                                      **self._kw(off, nr, fused=True, d_in=d_in))
+                    else:
+                        a_ = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
+                        be.gemm(a_, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
+                works.append(_all_gather_block(ybase[b0:b0 + bn], ybase[p0:p0 + cs], sh, self.group, ("y", l), c))
         for c in range(sh.chunks):
             works[c]()
-            be.gemm(agg[c * span:(c + 1) * span], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[c * span:(c + 1) * span])
-        return y
-
-    def _plain_layer_overlapped(self, l, x, layout, w, tail):
-        """Aggregate-first layer whose d_out-wide OUTPUT is exchanged, chunks > 1 ("wide" exchange of a widening layer): the own
-        rows go through the fused aggregate + project kernel chunk by chunk, each chunk's all-gather is issued asynchronously
-        as soon as the chunk is queued.  Returns the chunk-major gathered buffer (every rank's rows)."""
-        be, g, sh = self.be, self.g, self.sh
-        ep_scale, ep_shift, relu = tail
-        d_in, d_out = w.shape[1], w.shape[0]
-        y = self._full_buffer(("ycm", l), d_out, x.device)       # chunk-major [C][P][cr]
-        base = _storage_rows(y)
-        span = sh.world * sh.cr
-        idx = self._cols(layout)
-        works = []
-        for c in range(sh.chunks):
-            off, nr = sh.chunk_rows(c)
-            p0 = (c * sh.world + sh.rank) * sh.cr
-            if nr > 0:
-                ip = g.indptr[off:off + nr + 1]
-                xs = self._chunk_self(x, layout, c)
-                if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
-                    be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
-                                  **self._kw(off, nr, fused=True, d_in=d_in))
-                else:
-                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
-                    be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("y", l), c))
-        for wk in works:
-            wk()
+            if kinds[c] == "N":
+                b0, bn = sh.chunk_block(c)
+                be.gemm(agg[b0:b0 + bn], w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[b0:b0 + bn])
         return y
 
     def _plain_then_narrow_overlapped(self, l, x, layout):
@@ -507,14 +546,14 @@ class ShardedTeacher:
         d_mid, d_out = w1.shape[0], w2.shape[0]
         last = l + 1 == enc.num_layers - 1
         y_own = None      # (fallback branch only: the fused launch never writes layer l's rows; own rows, not an n_pad-row buffer)
-        hw = self._full_buffer(("hwcm", l + 1), d_out, x.device)          # chunk-major [C][P][cr]
+        hw = self._full_buffer(("hwcm", l + 1), d_out, x.device)          # chunk-major [chunk][rank][rows]
         base = _storage_rows(hw)
-        span = sh.world * sh.cr
         idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
             off, nr = sh.chunk_rows(c)
-            p0 = (c * sh.world + sh.rank) * sh.cr
+            b0, bn = sh.chunk_block(c)
+            p0 = sh.chunk_slot(c)
             if nr > 0:
                 xs = self._chunk_self(x, layout, c)
                 ip = g.indptr[off:off + nr + 1]
@@ -531,7 +570,7 @@ class ShardedTeacher:
                     agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
                     be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
                     be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
-            works.append(_all_gather_block(base[c * span:(c + 1) * span], base[p0:p0 + sh.cr], sh, self.group, ("hw", l + 1), c))
+            works.append(_all_gather_block(base[b0:b0 + bn], base[p0:p0 + sh.csize[c]], sh, self.group, ("hw", l + 1), c))
         out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l + 1), d_out, x.device)
         for wk in works:
             wk()
@@ -572,8 +611,8 @@ class ShardedTeacher:
                         out=out, x_self=hw[sh.slot:sh.slot + sh.rows], **self._kw(0, sh.rows))
             elif not complete:
                 raise RuntimeError("ShardedTeacher: internal error, an aggregating layer needs every node's input row")
-            elif multi and not last and 2 * d_in <= d_out and self.widening_exchange == "wide" and sh.chunks > 1 and not next_narrow:
-                x = self._plain_layer_overlapped(l, x, layout, w, tail)       # exchange the wide output, chunked + overlapped
+            elif multi and not last and 2 * d_in <= d_out and self.widening_exchange in ("wide", "mixed") and sh.chunks > 1 and not next_narrow:
+                x = self._widening_layer_overlapped(l, x, layout, w, tail)    # exchange the wide output (of all / of the "W" chunks), chunked + overlapped
                 layout, y_own = "cm", None
                 l += 1
                 continue
@@ -582,7 +621,7 @@ class ShardedTeacher:
                 # project all rows itself -- the all-gather moves d_in instead of d_out floats per node (0.98 GB
                 # instead of 2.5 GB on products) for the price of a replicated [N, d_in] x [d_in, d_out] GEMM.
                 if sh.chunks > 1:
-                    x = self._widening_layer_overlapped(l, x, layout, w, tail)
+                    x = self._widening_layer_overlapped(l, x, layout, w, tail)      # (every chunk "N")
                     layout = "cm"
                 else:
                     agg = self._full_buffer(("agg", l), d_in, x.device)

@@ -235,6 +235,13 @@ class SAGE(nn.Module):
             cache[k] = ent = (weakref.ref(g), buf)
         return ent[1]
 
+    def release_placed(self):
+        """Drop the placed buffers this encoder keeps across inference calls (the hidden layers' rows per (graph, layer) and the placed copy
+        of the input features): a long-lived process that is done with a graph gets its memory back."""
+        self.__dict__.pop("_placed", None)
+        self.__dict__.pop("_placed_x", None)
+        torch.cuda.empty_cache()
+
     def _whole_graph_layer(self, l, g, x, projected, place=True):
         """Layer l of the whole-graph sweep: (y, projected for layer l+1 or None).  place=False: plain allocations (the launch is being
         used as the PROBE that places the buffer it gathers from -- see _placed_buffer)."""

@@ -368,41 +368,58 @@ def placed_for_gather(rows, d, device, indptr, indices, n_dst, what="", first=No
     # (What makes an allocation slow is its physical backing: the same virtual addresses gather in 18.0 ms when the request was served from
     #  an unfragmented free pool and in 19.0-19.5 ms when small allocations were made in between, or out of a re-used cached block with
     #  that history: scripts/placement_cause_probe.py, profiles/r05_placement_cause.txt.  Not predictable from here -- hence the probe.)
+    # The search is an optimisation and must never be what runs a device out of memory: the candidates + the ballast together
+    # stay below the free memory minus a headroom of two more matrices (the probe's own scratch / the next layer's output are allocated
+    # while the candidates are alive), the probe loop is under the same handler as the allocations, and every failure falls back to the
+    # plain allocation the caller would have made without the search.
+    nbytes_m = 4 * rows * round4(d)
     cands, ballast = ([first] if first is not None else []), []
+    scratch = None
+
+    def fallback():
+        del cands[:], ballast[:]
+        torch.cuda.empty_cache()
+        return first if first is not None else feat_empty(rows, d, device, zero=zero)
+
     try:
-        while len(cands) < PLACEMENT_CANDIDATES:
+        budget = torch.cuda.mem_get_info(device)[0] - 2 * nbytes_m
+        want = PLACEMENT_CANDIDATES
+        while len(cands) < want:
+            if budget < nbytes_m:
+                break                                     # (a nearly full or shared device: choose among what fits)
             if len(cands) and len(cands) % 4 == 0 and PLACEMENT_BALLAST_FRAC > 0:
                 free = torch.cuda.mem_get_info(device)[0]
-                nbytes = int(min(PLACEMENT_BALLAST_FRAC * free, PLACEMENT_BALLAST_MAX))
-                if nbytes >= (1 << 30) and free - nbytes > 8 * 4 * rows * round4(d):      # (never squeeze the candidates themselves)
-                    ballast.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
+                nb = int(min(PLACEMENT_BALLAST_FRAC * free, PLACEMENT_BALLAST_MAX))
+                # (never squeeze the candidates themselves, nor the headroom)
+                if nb >= (1 << 30) and free - nb > 8 * nbytes_m and budget - nb >= (want - len(cands)) * nbytes_m:
+                    ballast.append(torch.empty(nb, dtype=torch.uint8, device=device))
+                    budget -= nb
             cands.append(feat_empty(rows, d, device, zero=zero))
-    except torch.cuda.OutOfMemoryError:
-        # a device shared with other tenants (or nearly full): the search is an optimisation -- choose among what did fit
-        del ballast[:]
-        torch.cuda.empty_cache()
-        if not cands:
-            cands.append(feat_empty(rows, d, device, zero=zero))      # (the caller's own allocation: let ITS failure surface)
-    scratch = None
-    if probe is None:
-        scratch = feat_empty(n_dst, d, device)
+            budget -= nbytes_m
+        if len(cands) <= 1:
+            return fallback() if not cands else cands[0]
+        if probe is None:
+            scratch = feat_empty(n_dst, d, device)
 
-        def probe(c):
-            _lib.check(_spmm_call(indptr, indices, n_dst, rows, c, d, AGG_SAGE_GCN, None, None, None, None, False, scratch,
-                                  c[:n_dst] if rows >= n_dst else c, None), "glnn_spmm_csr_f32 (placement probe)")
-    ms = []
-    for c in cands:
-        probe(c)
-        best = None
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            def probe(c):
+                _lib.check(_spmm_call(indptr, indices, n_dst, rows, c, d, AGG_SAGE_GCN, None, None, None, None, False, scratch,
+                                      c[:n_dst] if rows >= n_dst else c, None), "glnn_spmm_csr_f32 (placement probe)")
+        ms = []
+        for c in cands:
             probe(c)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            best = t if best is None else min(best, t)
-        ms.append(best)
+            best = None
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                probe(c)
+                e1.record()
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                best = t if best is None else min(best, t)
+            ms.append(best)
+    except torch.cuda.OutOfMemoryError:
+        scratch = None
+        return fallback()
     k = min(range(len(cands)), key=lambda i: ms[i])
     PLACEMENT_LOG.append({"what": what, "rows": int(rows), "d": int(d), "ms": [round(v, 3) for v in ms], "chosen": k})
     keep = cands[k]

@@ -127,6 +127,7 @@ class TeacherEngine:
         # rows it gathers (glnn::spmm_csr_tail; same arithmetic per element, so the step is bit-identical to the materialised form, one pass
         # over the layer's activations and its buffer less).  GLNN_TEACHER_GATHER_TAIL=0 (read here, once) keeps the act_fwd launches.
         self.gather_tail = os.environ.get("GLNN_TEACHER_GATHER_TAIL", "1") != "0"
+        self._one_call = os.environ.get("GLNN_TEACHER_ONE_CALL", "1") != "0"
         self.base_seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self.grad_sync = None
 
@@ -311,11 +312,21 @@ class TeacherEngine:
         d.loss_out, d.loss_accum = ptr(self.loss_out), ptr(self.loss_accum)
         keep = [x]                                              # alive until the call below is queued (same-stream reuse is ordered)
         ops.note_param_write()      # (running statistics are written through raw pointers; Adam follows)
-        rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
+        # nothing sits between the backward and Adam (no gradient exchange): the whole step is ONE C call and Adam folds the backward's
+        # last partial sums itself (glnn_sage_train_step_f32, round 6; GLNN_TEACHER_ONE_CALL=0 keeps the two calls)
+        one_call = self.grad_sync is None and self._one_call
+        if one_call:
+            g_ = self.opt.param_groups[0]
+            ad = self.table.desc
+            ad.lr, ad.beta1, ad.beta2, ad.eps, ad.weight_decay, ad.step = g_["lr"], g_["betas"][0], g_["betas"][1], g_["eps"], g_["weight_decay"], self.step_count
+            rc = _lib.lib().glnn_sage_train_step_f32(ctypes.byref(d), ctypes.byref(ad), ops._stream())
+        else:
+            rc = _lib.lib().glnn_sage_fwd_bwd_f32(ctypes.byref(d), ops._stream())
         if rc != 0:
             self.step_count -= 1          # the step never happened: Adam's bias correction and the dropout seeds stay where they were
-        _lib.check(rc, "glnn_sage_fwd_bwd_f32")
-        self._adam()
+        _lib.check(rc, "glnn_sage_train_step_f32" if one_call else "glnn_sage_fwd_bwd_f32")
+        if not one_call:
+            self._adam()
 
     # ------------------------------------------------------------------------------------------ full-graph GCN
     @torch.no_grad()

@@ -491,6 +491,11 @@ typedef struct glnn_sage_step_desc {
 } glnn_sage_step_desc;
 
 GLNN_API int glnn_sage_fwd_bwd_f32(const glnn_sage_step_desc* desc, void* stream);
+/* ... and the same followed by the fused Adam launch in ONE call (ABI 11; reference train_and_eval.py:39-53 incl. optimizer.step()):
+ * the backward leaves its last partial sums (split slabs of the weight gradients, the last layer's bias-gradient column partials, the
+ * per-workgroup losses) to Adam -- the same parameters, moments and loss as glnn_sage_fwd_bwd_f32 + glnn_adam_step_f32, bit for bit.
+ * `adam` as in glnn_mlp_train_step_f32. */
+GLNN_API int glnn_sage_train_step_f32(const glnn_sage_step_desc* desc, const glnn_adam_desc* adam, void* stream);
 /* ABI 10: ws_bn floats with which the outermost layer's BatchNorm backward takes the form without passes of its own (see above) for an
  * outermost block of n_dst_0 destinations and dims[1] = hidden; the step's other uses of ws_bn need (3 chunks + 2 + 3 ceil(chunks / 64)) *
  * max hidden + 1024 floats, chunks = ceil(max n_dst / 128): allocate the larger of the two. */

@@ -814,6 +814,46 @@ def test_sage_step_tail_in_the_gather_is_bit_identical_to_the_materialised_tail(
     assert bool(torch.isfinite(states[0][-1]).all())
 
 
+@pytest.mark.parametrize("norm,p,wd", [("batch", 0.3, 0.0), ("none", 0.5, 5e-4), ("batch", 0.0, 5e-4)])
+def test_one_call_sage_train_step_equals_fwd_bwd_plus_adam_bit_for_bit(norm, p, wd, monkeypatch):
+    """glnn_sage_train_step_f32 (round 6): forward + NLL + backward + Adam of the sampled-block teacher in ONE call, the backward's last
+    partial sums -- the split slabs of every weight gradient, the column partials behind the last layer's bias gradient, the per-workgroup
+    losses -- folded by the Adam launch instead of by six launches of their own.  Same partials, same order: three steps end in the same
+    parameters, moments, BatchNorm buffers, gradients and loss as glnn_sage_fwd_bwd_f32 + glnn_adam_step_f32 (GLNN_TEACHER_ONE_CALL=0), bit for
+    bit (and with GLNN_STUDENT_ADAM_FOLDS=0: the one-call form without the folds)."""
+    from glnn_amd import ops
+    from glnn_amd.graph import MultiLayerNeighborSampler, NodeDataLoader
+    from glnn_amd.models import Model
+    from glnn_amd.teacher import TeacherEngine
+    n, dims = 60000, [100, 128, 128, 9]
+    indptr, indices = random_graph(n, 10, seed=11, power=0.6, hub=3000, isolated=30)
+    rs = np.random.RandomState(11)
+    fd = ops.as_feat(torch.from_numpy(rs.standard_normal((n, dims[0])).astype(np.float32)).to(DEV))
+    ld = torch.from_numpy(rs.randint(0, dims[-1], n).astype(np.int64)).to(DEV)
+    g = _graph(indptr, indices)
+    batches = list(NodeDataLoader(g, torch.arange(3072), MultiLayerNeighborSampler([5, 10, 15]), batch_size=1024, shuffle=False, seed=5))
+    states = []
+    for one_call, folds in (("0", "1"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("GLNN_TEACHER_ONE_CALL", one_call)
+        monkeypatch.setenv("GLNN_STUDENT_ADAM_FOLDS", folds)
+        torch.manual_seed(2)
+        model = Model(dict(model_name="SAGE", num_layers=3, feat_dim=dims[0], hidden_dim=dims[1], label_dim=dims[-1], dropout_ratio=p,
+                           norm_type=norm, device=DEV))
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=wd)
+        model.train()
+        eng = TeacherEngine(model, opt)
+        assert eng._one_call == (one_call == "1")
+        for input_nodes, output_nodes, blocks in batches:
+            eng.step_sage(blocks, fd, ld, output_nodes, 1.0, input_nodes=input_nodes)
+        torch.cuda.synchronize()
+        states.append([t.detach().clone() for t in model.state_dict().values()] + [opt.state[q]["exp_avg"].clone() for q in model.parameters()]
+                      + [eng.grad(q).clone() for q in model.parameters()] + [eng.loss_out.clone()])
+    for other in states[1:]:
+        diffs = [float((a.double() - b.double()).abs().max()) for a, b in zip(states[0], other)]
+        assert all(torch.equal(a, b) for a, b in zip(states[0], other)), diffs
+    assert bool(torch.isfinite(states[0][-1]).all())
+
+
 @pytest.mark.parametrize("p", [0.5, 0.0])
 def test_sage_step_bn_backward_apply_inside_the_weight_gradient_gemm(p, monkeypatch):
     """Round 5: the outermost block's dz has one consumer, dW_0.  Layer 0's BatchNorm backward is then spread over its neighbours:
