@@ -31,7 +31,7 @@ def run_emulated(args, dev):
     forms = [("allgather-narrow", "products", dict(exchange="allgather", l1="narrow")), ("allgather-wide", "products", dict(exchange="allgather", l1="wide")),
              (f"allgather-mixed{args.mixed_fraction:g}", "products", dict(exchange="allgather", l1="mixed")), ("halo-lp", "clustered", dict(exchange="halo"))]
     if args.emulate_forms:
-        forms = [f for f in forms if any(f[0].startswith(w) or f[0].endswith(w) for w in args.emulate_forms.split(","))]
+        forms = [f for f in forms if any(w in f[0] for w in args.emulate_forms.split(","))]
     graphs = {}
     for form, gkind, cfg in forms:
         if gkind not in graphs:

@@ -95,8 +95,11 @@ static int sage_fwd_bwd_impl(const glnn_sage_step_desc* d, void* stream, glnn::P
     const bool later = pf && d->ws_tn && d->ws_tn_floats - tn_off >= 8ll * d_in * d_out + 64ll * d_out && pf->n + 2 <= glnn::kMaxGradFolds;
     glnn::GradFold fw = {}, fc = {};
     int64_t used = 0;
-    float* wsp = d->ws_tn ? d->ws_tn + (later ? tn_off : 0) : nullptr;
-    const int64_t wsf = d->ws_tn_floats - (later ? tn_off : 0);
+    // (slabs of earlier products wait in [0, tn_off) for Adam: a product that cannot keep its own there still works BEHIND them, in whatever is
+    //  left -- fewer splits, folded at once; glnn_amd/teacher.py sizes ws_tn for every layer's slabs so that this does not happen)
+    const bool behind = later || (pf && tn_off > 0);
+    float* wsp = d->ws_tn ? d->ws_tn + (behind ? tn_off : 0) : nullptr;
+    const int64_t wsf = d->ws_tn_floats - (behind ? tn_off : 0);
     auto keep_folds = [&]() {
       if (!later) return;
       if (fw.nslab > 0) pf->e[pf->n++] = fw;

@@ -282,7 +282,8 @@ class TeacherEngine:
             d.ws_bn_floats = (3 * nchunks + 2 + 3 * ((nchunks + 63) // 64)) * max_hidden + 1024
             if L > 1 and self.bn:     # room for the outermost layer's BatchNorm backward without passes of its own (round 5)
                 d.ws_bn_floats = max(d.ws_bn_floats, int(_lib.lib().glnn_sage_step_ws_bn_floats(blocks[0].num_dst_nodes(), dims[1])))
-            d.ws_tn_floats = 64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims)
+            # (x L: in the one-call step every layer's split slabs wait in ws_tn for the Adam launch to fold them -- csrc/sage_step.hip)
+            d.ws_tn_floats = L * (64 * max(dims) + 256 * 128 * 128 + 2 * max(dims) * max(dims))
             # split-K slabs, sized as StudentEngine does; the GEMM only splits outputs of < 256 tiles, i.e. <= 512 slabs of 128 x 128
             d.ws_gemm_floats = min(max(16 * max(b.num_dst_nodes() for b in blocks) * min(dims[1:]), 1 << 20), 512 * 128 * 128)
             d.ws_bn, d.ws_tn, d.ws_gemm = A.take(4 * d.ws_bn_floats), A.take(4 * d.ws_tn_floats), A.take(4 * d.ws_gemm_floats)
