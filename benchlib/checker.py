@@ -104,6 +104,13 @@ class CheckedBackend:
             return (acc + x_self[r0:r0 + k, :d].double()) / (deg.double() + 1).unsqueeze(1)
         return acc * row_scale[r0:r0 + k].double().unsqueeze(1) if row_scale is not None else acc
 
+    def _agg_ref_rows(self, indptr, indices, x, r0, k, mode, self_sel, row_scale=None, col_scale=None):
+        """The SAGE-gcn reference with the k self rows given directly (self_sel[i] = the self row of destination r0 + i)."""
+        d = x.shape[1]
+        acc = self._agg_ref(indptr, indices, x, r0, k, self.be.AGG_SUM, None, None, col_scale)
+        deg = indptr[r0 + 1:r0 + k + 1] - indptr[r0:r0 + k]
+        return (acc + self_sel[:, :d].double()) / (deg.double() + 1).unsqueeze(1)
+
     @staticmethod
     def _epi(y, ep_scale, ep_shift, relu):
         if ep_scale is not None:
@@ -122,15 +129,21 @@ class CheckedBackend:
         # (kw: the hub plan of the HIP backend.  The row-range relaunch below runs WITHOUT one: plan and no plan must agree bit for bit)
         out = self.be.spmm(indptr, indices, x, n_dst, mode, row_scale=row_scale, col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift,
                            relu=relu, out=out, x_self=x_self, self_rows=self_rows, **kw)
-        if n_dst and self_rows is None:
+        if n_dst:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)
-            ref = self._epi(self._agg_ref(indptr, indices, x, r0, k, mode, xs, row_scale, col_scale), ep_scale, ep_shift, relu)
+            if self_rows is not None:      # the self row of destination v is xs[self_rows[v]]: a view the reference below can index by v - r0
+                sel = xs[self_rows[r0:r0 + k]]
+                xs_again, sr = xs, self_rows[r0:r0 + k].contiguous()
+                ref = self._epi(self._agg_ref_rows(indptr, indices, x, r0, k, mode, sel, row_scale, col_scale), ep_scale, ep_shift, relu)
+            else:
+                xs_again, sr = xs[r0:r0 + k], None
+                ref = self._epi(self._agg_ref(indptr, indices, x, r0, k, mode, xs, row_scale, col_scale), ep_scale, ep_shift, relu)
             diff = float((out[r0:r0 + k].double() - ref).abs().max())
             again = self.be.spmm(indptr[r0:r0 + k + 1], indices, x, k, mode, row_scale=None if row_scale is None else row_scale[r0:r0 + k],
-                                 col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, x_self=xs[r0:r0 + k])
+                                 col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, x_self=xs_again, **({} if sr is None else {"self_rows": sr}))
             self._note(f"spmm d={x.shape[1]} rows={n_dst}", diff, bool(torch.equal(again, out[r0:r0 + k])))
-            if self.conservation and mode == self.be.AGG_SAGE_GCN and not relu:
+            if self.conservation and mode == self.be.AGG_SAGE_GCN and not relu and self_rows is None:
                 err = self._conservation(indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift)
                 self.report[-1]["conservation_rel_err_fp64_all_rows"] = err
                 self.ok = self.ok and err < 1e-5

@@ -88,9 +88,16 @@ class RowShards:
         """First row of `rank`'s (default: this rank's) slot inside chunk c's block of a chunk-major buffer."""
         return self.world * self.coff[c] + (self.rank if rank is None else rank) * self.csize[c]
 
-    def mixed(self, fraction, quantum=64):
-        """The shards of the MIXED layer-1 exchange: every chunk is cut into a leading "W" part of ~fraction of its rows (a multiple of
-        `quantum` rows: whole tiles of the fused kernel) and an "N" part with the rest.  fraction 0 / 1 leave one kind only."""
+    def mixed(self, fraction, quantum=64, by_chunk=True):
+        """The shards of the MIXED layer-1 exchange.  by_chunk (default): the first round(fraction * chunks) chunks are "W" (exchanged as the
+        layer's wide output), the rest "N" (narrow aggregate + replicated projection) -- the layout and the chunk count stay what they are,
+        so the layers behind keep their launches (cutting every chunk in two doubled the launches of layers 2 and 3 and cost more than the
+        mixed layer 1 saved: profiles/scale_model_r06_c2_mixed_twice_the_chunks.json).  by_chunk=False: every chunk is cut into a leading "W"
+        part of ~fraction of its rows (a multiple of `quantum` rows) and an "N" part (unequal chunks, twice as many)."""
+        if by_chunk:
+            nw = min(self.chunks, max(0, int(round(fraction * self.chunks))))
+            return RowShards(self.n, self.world, self.rank, bounds=self.bounds, chunk_sizes=list(self.csize),
+                             kinds=["W"] * nw + ["N"] * (self.chunks - nw))
         sizes, kinds = [], []
         for c in self.csize:
             fw = min(c, max(0, int(round(fraction * c / quantum)) * quantum))
@@ -368,18 +375,18 @@ class ShardedTeacher:
     arrival order.  The gathered activations then live in a chunk-major row order ([chunk][rank][rows]); the next
     layer reads them through a column-index array relabelled once at construction -- no data is ever re-packed."""
 
-    def __init__(self, encoder, graph_shard, shards, be, group=None, widening_exchange="narrow", mixed_fraction=0.5, mixed_quantum=64):
+    def __init__(self, encoder, graph_shard, shards, be, group=None, widening_exchange="narrow", mixed_fraction=0.5, mixed_quantum=0):
         """widening_exchange: what a widening layer (2*d_in <= d_out: products layer 1, 100 -> 256) puts on the wire --
         "narrow": its d_in-wide aggregate, every rank then projects ALL rows itself (least bytes, replicated GEMM);
         "wide":   its d_out-wide output of the fused aggregate+project kernel on the own rows only (no replicated work,
                   d_out/d_in times the bytes);
         "mixed":  (round 6) a fraction `mixed_fraction` of every chunk's rows travels wide, the rest narrow -- the continuous form between
-                  the two: `shards` is replaced by shards.mixed(mixed_fraction) (twice the chunks, alternating kinds).
+                  the two: `shards` is replaced by shards.mixed(mixed_fraction) (whole chunks of either kind).
         All are chunked and overlapped when shards.chunks > 1; results are identical."""
         if widening_exchange not in ("narrow", "wide", "mixed"):
             raise ValueError("ShardedTeacher: widening_exchange must be 'narrow', 'wide' or 'mixed'")
         if widening_exchange == "mixed":
-            shards = shards.mixed(mixed_fraction, mixed_quantum)
+            shards = shards.mixed(mixed_fraction, mixed_quantum or 64, by_chunk=not mixed_quantum)      # (mixed_quantum > 0: the cut-every-chunk form)
         self.enc, self.g, self.sh, self.be, self.group = encoder, graph_shard, shards, be, group
         if graph_shard.n_dst != shards.rows:
             raise ValueError(f"ShardedTeacher: the graph shard has {graph_shard.n_dst} rows, the shard range {shards.rows}")
@@ -576,6 +583,15 @@ class ShardedTeacher:
             wk()
         es, eh, rl = tail2
         idx_cm = self._cols("cm")
+        if sh.rows > 0 and getattr(be, "SELF_ROWS", False):
+            # ONE launch over all own rows (round 6): the output rows are contiguous, only the SELF rows sit in per-chunk slots of the
+            # chunk-major buffer -- addressed through self_rows (the global-id form of the aggregation) instead of one launch per chunk
+            # (N = 8, 4 chunks: 0.75 -> 0.60 ms per rank; a short launch pays its ramp and its tail once per launch)
+            if "own_cm" not in self._col_cache:
+                self._col_cache["own_cm"] = sh.position(torch.arange(sh.lo, sh.hi, device=g.indptr.device, dtype=torch.int64), "cm").contiguous()
+            be.spmm(g.indptr, idx_cm, hw, sh.rows, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=rl, out=out, x_self=hw,
+                    self_rows=self._col_cache["own_cm"], **self._kw(0, sh.rows))
+            return out
         for off, nr, sl in self._pieces("cm"):
             be.spmm(g.indptr[off:off + nr + 1], idx_cm, hw, nr, be.AGG_SAGE_GCN, ep_scale=es, ep_shift=eh, relu=rl,
                     out=out[off:off + nr], x_self=hw[sl], **self._kw(off, nr))

@@ -181,6 +181,7 @@ class FullNeighborLoader:
     def __init__(self, graph, batch_size):
         self.graph = graph
         self.batch_size = int(batch_size)
+        self.global_blocks = False      # True (set by SAGE.inference for its chunked sweep): row-range blocks with global source ids, see __iter__
 
     def __len__(self):
         return (self.graph.n_dst + self.batch_size - 1) // self.batch_size
@@ -196,6 +197,16 @@ class FullNeighborLoader:
         for b in range(len(bounds) - 1):
             s, e = bounds[b], bounds[b + 1]
             output_nodes = torch.arange(s, e, device=g.device)
+            if getattr(self, "global_blocks", False):
+                # engine mode (round 6, set by SAGE.inference for its sweep): the chunk's block IS rows [s, e) of the resident CSR -- absolute
+                # row offsets into the one indices array, GLOBAL source ids -- so nothing is built, relabelled or gathered: the consumer's
+                # aggregation reads its source rows straight from the layer's input matrix (input_nodes = None)
+                block = CSRGraph(g.indptr[s:e + 1], g.indices, e - s, g.n_src)
+                block._nnz = offs[b + 1] - offs[b]
+                block.dst_range = (s, e)
+                block._cache["tile_order"] = None      # (a 4096-row launch: the order would cost six small launches per chunk)
+                yield None, output_nodes, [block]
+                continue
             indptr, indices, _, input_nodes, nnz, n_src = ops.block_build(output_nodes, g.indptr, g.indices, nnz_cap=offs[b + 1] - offs[b],
                                                                           n_nodes=g.n_src)
             block = CSRGraph(indptr, indices, e - s, n_src)

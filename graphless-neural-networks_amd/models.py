@@ -309,6 +309,32 @@ class SAGE(nn.Module):
                     d_out = self.hidden_dim if l != self.num_layers - 1 else self.output_dim
                     y = ops.feat_empty(x.shape[0], d_out, x.device, zero=True)           # models.py:129-132
                     wp = ops.pack_weight(layer.fc_neigh.weight) if layer.fused_eligible() else None     # once per layer, not per chunk
+                    # Loaders that can hand out GLOBAL-id blocks (FullNeighborLoader.global_blocks, round 6) are asked to for this sweep: the
+                    # chunk loop of models.py:133-145 stays -- one block, one conv, one slice of y per chunk -- but feats[input_nodes] and
+                    # y[output_nodes] = h are not copies any more: the conv gathers its source rows from x itself and writes its rows of y
+                    # (products: 711 -> ~60 ms per forward; a layer that projects first projects x once, not once per chunk)
+                    engine = hasattr(dataloader, "global_blocks") and not post_ln
+                    xp = ops.gemm(x, layer.fc_neigh.weight) if engine and layer._in_feats > layer._out_feats else None
+                    if engine:
+                        dataloader.global_blocks = True
+                    try:
+                        it = iter(dataloader)
+                        for input_nodes, output_nodes, blocks in it:
+                            if input_nodes is not None:
+                                break
+                            block = blocks[0]
+                            s_, e_ = block.dst_range
+                            if xp is not None:
+                                ops.spmm(block.indptr, block.indices, xp, e_ - s_, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
+                                         out=y[s_:e_], x_self=xp[s_:e_])
+                            else:
+                                layer(block, (x, x[s_:e_]), ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, w_packed=wp, out=y[s_:e_])
+                        else:
+                            x = y
+                            continue
+                    finally:
+                        if engine:
+                            dataloader.global_blocks = False
                     for input_nodes, output_nodes, blocks in dataloader:
                         block = blocks[0].int().to(x.device)
                         h = ops.gather_rows(x, input_nodes)                              # feats[input_nodes]

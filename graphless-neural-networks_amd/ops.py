@@ -448,6 +448,7 @@ def _storage_copy(dst, src):
 
 
 DEG_RAW, DEG_RSQRT_CLAMP1, DEG_INV_PLUS1 = 0, 1, 2
+SELF_ROWS = True      # spmm(..., self_rows=) is available (dist.ShardedTeacher asks: the numpy test backend has no such argument)
 
 
 def degrees(indptr, indices, n_dst, n_src, nnz, want_out=True, transform=DEG_RAW, want_in=True):

@@ -100,7 +100,8 @@ def _worker(rank, world, port, n, dims, seed, chunks, balanced, widening, q):
         from glnn_amd import dist as gdist
         gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
         with torch.no_grad():
-            y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, widening_exchange=widening, mixed_quantum=8).forward(x)
+            y_own = ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, widening_exchange=widening.split("-")[0],
+                                   mixed_quantum=8 if widening.endswith("cut") else 0).forward(x)
         stats = dict(gdist.EXCHANGE_STATS, n_pad=sh.n_pad)
         # DP gradient exchange
         flat = torch.full((10,), float(rank + 1))
@@ -117,7 +118,8 @@ def _worker(rank, world, port, n, dims, seed, chunks, balanced, widening, q):
     (8, 203, [6, 16, 5], 1, False, "narrow"),
     (2, 1003, [8, 24, 24, 6], 3, False, "wide"), (2, 1003, [8, 24, 24, 6], 1, True, "wide"), (4, 1003, [8, 24, 24, 6], 4, True, "wide"),
     (2, 90, [6, 16, 5], 4, False, "wide"),
-    (2, 1003, [8, 24, 24, 6], 3, False, "mixed"), (4, 1003, [8, 24, 24, 6], 2, True, "mixed"), (2, 90, [6, 16, 5], 4, False, "mixed")])
+    (2, 1003, [8, 24, 24, 6], 3, False, "mixed"), (4, 1003, [8, 24, 24, 6], 2, True, "mixed"), (2, 90, [6, 16, 5], 4, False, "mixed"),
+    (2, 1003, [8, 24, 24, 6], 3, False, "mixed-cut"), (4, 1003, [8, 24, 24, 6], 2, True, "mixed-cut")])
 def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced, widening):
     """world 2 / 4 / 8, equal and work-balanced (uneven) row ranges, plain and chunked-overlapped exchange; a widening layer
     exchanging its narrow aggregate (replicated projection), its wide output, or (round 6, "mixed") half of every chunk's rows each way --
@@ -162,14 +164,14 @@ def test_sharded_teacher_gloo_equals_unsharded(world, n, dims, chunks, balanced,
         d_in, d_out = dims[l], dims[l + 1]
         if d_in > d_out:
             per_node += r4(d_out)
-        elif l < L - 1 and 2 * d_in <= d_out and widening in ("narrow", "mixed"):
+        elif l < L - 1 and 2 * d_in <= d_out and widening in ("narrow", "mixed", "mixed-cut"):
             per_node += r4(d_in)
         elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
             per_node += r4(d_out)
     for rank, lo, hi, y, flat, stats in res:
         np.testing.assert_allclose(y, want[lo:hi], atol=1e-4, rtol=0)
         covered[lo:hi] = True
-        if widening != "mixed":      # (mixed: W chunks move d_out floats per row, N chunks d_in: counted in test_emulated_rank_equals_unsharded_rows)
+        if not widening.startswith("mixed"):      # (mixed: W chunks move d_out floats per row, N chunks d_in: counted in test_emulated_rank_equals_unsharded_rows)
             assert stats["floats_received"] == stats["n_pad"] * per_node, (stats, per_node)
         np.testing.assert_allclose(flat, np.full(10, (world + 1) / 2))      # mean of 1..world
     assert covered.all()
@@ -460,7 +462,7 @@ def _emu_setup(n, dims, seed, clustered=False):
 @pytest.mark.parametrize("world,n,dims,chunks,balanced,widening", [
     (2, 1001, [12, 16, 16, 5], 1, False, "narrow"), (4, 1003, [8, 24, 24, 6], 3, True, "narrow"), (8, 1001, [8, 24, 24, 6], 2, True, "narrow"),
     (4, 1003, [8, 24, 24, 6], 4, True, "wide"), (2, 90, [6, 16, 5], 4, False, "wide"), (4, 640, [12, 16, 16, 5], 2, False, "narrow"),
-    (4, 1003, [8, 24, 24, 6], 2, True, "mixed"), (8, 1001, [8, 24, 24, 6], 2, False, "mixed")])
+    (4, 1003, [8, 24, 24, 6], 2, True, "mixed"), (8, 1001, [8, 24, 24, 6], 4, False, "mixed"), (4, 1003, [8, 24, 24, 6], 2, True, "mixed-cut")])
 def test_emulated_rank_equals_unsharded_rows(world, n, dims, chunks, balanced, widening):
     """dist.EmulatedPeers (bench.py --emulate N / --workload xl): ONE process plays rank r of an N-rank job, every collective is a
     local fill of the same bytes.  With the truth of an unsharded forward as the peers' data, every emulated rank's output equals
@@ -479,7 +481,7 @@ def test_emulated_rank_equals_unsharded_rows(world, n, dims, chunks, balanced, w
         d_in, d_out = dims[l], dims[l + 1]
         if d_in > d_out:
             per_node += r4(d_out)
-        elif l < L - 1 and 2 * d_in <= d_out and widening in ("narrow", "mixed"):
+        elif l < L - 1 and 2 * d_in <= d_out and widening in ("narrow", "mixed", "mixed-cut"):
             per_node += r4(d_in)
         elif l < L - 1 and not dims[l + 1] > dims[l + 2]:
             per_node += r4(d_out)
@@ -490,9 +492,10 @@ def test_emulated_rank_equals_unsharded_rows(world, n, dims, chunks, balanced, w
             peers = gdist.EmulatedPeers(world, rank, truth=truth if use_truth else None)
             gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
             with torch.no_grad():
-                st = gdist.ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, group=peers, widening_exchange=widening, mixed_quantum=8)
+                st = gdist.ShardedTeacher(enc, g.row_range(sh.lo, sh.hi), sh, be, group=peers, widening_exchange=widening.split("-")[0],
+                                          mixed_quantum=8 if widening.endswith("cut") else 0)
                 y = st.forward(x)
-            if widening == "mixed":      # layer 1: "W" chunks move the wide output, "N" chunks the narrow aggregate; the other layers as in the narrow form
+            if widening.startswith("mixed"):      # layer 1: "W" chunks move the wide output, "N" chunks the narrow aggregate; the other layers as in the narrow form
                 m = st.sh
                 assert set(m.kinds) == {"W", "N"} and m.rpr == sh.rpr
                 l1 = sum(world * c * (r4(dims[1]) if k == "W" else r4(dims[0])) for c, k in zip(m.csize, m.kinds))

@@ -522,6 +522,17 @@ def test_sage_inference_vs_oracle(dims, norm):
     np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL, rtol=0)
     got_chunked = model.encoder.inference(loader, torch.from_numpy(x).to(DEV), whole_graph=False)
     np.testing.assert_allclose(got_chunked.cpu().numpy(), want, atol=TOL, rtol=0)
+    assert loader.global_blocks is False       # (the engine mode of the sweep -- global-id row-range blocks, no gather / scatter -- is switched back off)
+
+    class Plain:      # a loader WITHOUT the engine mode: the literal loop of models.py:133-145 (block build, feats[input_nodes], conv, y[output_nodes] = h)
+        def __init__(self, inner):
+            self.inner = inner
+
+        def __iter__(self):
+            return iter(self.inner)
+    got_literal = model.encoder.inference(Plain(loader), torch.from_numpy(x).to(DEV), whole_graph=False)
+    np.testing.assert_allclose(got_literal.cpu().numpy(), want, atol=TOL, rtol=0)
+    assert float((got_literal - got_chunked).abs().max()) <= 2e-5
 
 
 @pytest.mark.parametrize("dims", [[100, 256, 256, 47], [64, 48, 48, 12]])
