@@ -125,6 +125,7 @@ class RowShards:
         return self.position(v, "cm")
 
 
+CHUNK_STREAMS = int(__import__("os").environ.get("GLNN_CHUNK_STREAMS", "1"))      # producer chunk launches alternate between this many streams (ShardedTeacher)
 EXCHANGE_STATS = {"collectives": 0, "floats_received": 0}      # per process; tests and bench read / reset it
 FORCE_COLLECTIVES = False      # tests: issue the collectives even for world == 1 (a 1-rank RCCL group exercises the transport calls)
 
@@ -495,6 +496,27 @@ class ShardedTeacher:
                 agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=x[sl], **self._kw(off, nr))
                 be.gemm(agg, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=out_own[off:off + nr])
 
+    # Producer chunks on ALTERNATING streams (round 6, GLNN_CHUNK_STREAMS=2): a chunk launch is short (a rank's rows / chunks), and launched
+    # back to back on one stream every one pays its ramp and its tail (N = 8: two launches of the fused layer 2 take 2.56 ms where one
+    # over the same rows would take ~2.3; four take 2.74).  On two streams the next chunk's workgroups fill the CUs the previous chunk's
+    # tail leaves idle; each chunk's all-gather is issued on ITS stream (the collective orders itself behind that stream only).
+    def _chunk_stream(self, c, device):
+        import contextlib
+        n = CHUNK_STREAMS
+        if n <= 1 or device.type != "cuda":
+            return contextlib.nullcontext()
+        pool = self.__dict__.setdefault("_streams", [torch.cuda.Stream(device=device) for _ in range(n)])
+        st = pool[c % n]
+        if c < n:
+            st.wait_stream(torch.cuda.current_stream(device))          # the chunk's inputs were produced on the caller's stream
+        return torch.cuda.stream(st)
+
+    def _chunk_join(self, device):
+        if CHUNK_STREAMS > 1 and device.type == "cuda" and "_streams" in self.__dict__:
+            cur = torch.cuda.current_stream(device)
+            for st in self._streams:
+                cur.wait_stream(st)
+
     def _widening_layer_overlapped(self, l, x, layout, w, tail):
         """2*d_in <= d_out, world > 1: per chunk, by its kind (RowShards.kinds):
              "N" / None   aggregate the own rows -> async all-gather of the d_in-wide aggregate -> REPLICATED GEMM of every rank's rows
@@ -517,24 +539,26 @@ class ShardedTeacher:
         idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
-            off, nr = sh.chunk_rows(c)
-            b0, bn = sh.chunk_block(c)
-            p0, cs = sh.chunk_slot(c), sh.csize[c]
-            xs = self._chunk_self(x, layout, c)
-            ip = g.indptr[off:off + nr + 1]
-            if kinds[c] == "N":
-                if nr > 0:
-                    be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=xs, **self._kw(off, nr))
-                works.append(_all_gather_block(abase[b0:b0 + bn], abase[p0:p0 + cs], sh, self.group, ("agg", l), c))
-            else:
-                if nr > 0:
-                    if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
-                        be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
-                                      **self._kw(off, nr, fused=True, d_in=d_in))
-                    else:
-                        a_ = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
-                        be.gemm(a_, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
-                works.append(_all_gather_block(ybase[b0:b0 + bn], ybase[p0:p0 + cs], sh, self.group, ("y", l), c))
+          with self._chunk_stream(c, x.device):
+              off, nr = sh.chunk_rows(c)
+              b0, bn = sh.chunk_block(c)
+              p0, cs = sh.chunk_slot(c), sh.csize[c]
+              xs = self._chunk_self(x, layout, c)
+              ip = g.indptr[off:off + nr + 1]
+              if kinds[c] == "N":
+                  if nr > 0:
+                      be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, out=agg[p0:p0 + nr], x_self=xs, **self._kw(off, nr))
+                  works.append(_all_gather_block(abase[b0:b0 + bn], abase[p0:p0 + cs], sh, self.group, ("agg", l), c))
+              else:
+                  if nr > 0:
+                      if hasattr(be, "sage_fused") and d_in <= 256 and d_out <= 256:
+                          be.sage_fused(ip, idx, x, nr, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr], x_self=xs,
+                                        **self._kw(off, nr, fused=True, d_in=d_in))
+                      else:
+                          a_ = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
+                          be.gemm(a_, w, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, out=y[p0:p0 + nr])
+                  works.append(_all_gather_block(ybase[b0:b0 + bn], ybase[p0:p0 + cs], sh, self.group, ("y", l), c))
+        self._chunk_join(x.device)
         for c in range(sh.chunks):
             works[c]()
             if kinds[c] == "N":
@@ -558,26 +582,28 @@ class ShardedTeacher:
         idx = self._cols(layout)
         works = []
         for c in range(sh.chunks):
-            off, nr = sh.chunk_rows(c)
-            b0, bn = sh.chunk_block(c)
-            p0 = sh.chunk_slot(c)
-            if nr > 0:
-                xs = self._chunk_self(x, layout, c)
-                ip = g.indptr[off:off + nr + 1]
-                es, eh, rl = tail1
-                if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256 and d_out <= 256:
-                    # aggregate + project + tail + the NEXT layer's projection in one launch: layer l's rows never reach HBM
-                    be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
-                                  want_out=False, **self._kw(off, nr, fused=True, d_in=w1.shape[1]))
-                else:
-                    if y_own is None:
-                        if ("y_own", l) not in self._bufs:
-                            self._bufs[("y_own", l)] = be.feat_empty(sh.rows, d_mid, x.device)
-                        y_own = self._bufs[("y_own", l)]
-                    agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
-                    be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
-                    be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
-            works.append(_all_gather_block(base[b0:b0 + bn], base[p0:p0 + sh.csize[c]], sh, self.group, ("hw", l + 1), c))
+          with self._chunk_stream(c, x.device):
+              off, nr = sh.chunk_rows(c)
+              b0, bn = sh.chunk_block(c)
+              p0 = sh.chunk_slot(c)
+              if nr > 0:
+                  xs = self._chunk_self(x, layout, c)
+                  ip = g.indptr[off:off + nr + 1]
+                  es, eh, rl = tail1
+                  if hasattr(be, "sage_fused") and w1.shape[1] <= 256 and d_mid <= 256 and d_out <= 256:
+                      # aggregate + project + tail + the NEXT layer's projection in one launch: layer l's rows never reach HBM
+                      be.sage_fused(ip, idx, x, nr, w1, ep_scale=es, ep_shift=eh, relu=rl, x_self=xs, w_next=w2, out_next=hw[p0:p0 + nr],
+                                    want_out=False, **self._kw(off, nr, fused=True, d_in=w1.shape[1]))
+                  else:
+                      if y_own is None:
+                          if ("y_own", l) not in self._bufs:
+                              self._bufs[("y_own", l)] = be.feat_empty(sh.rows, d_mid, x.device)
+                          y_own = self._bufs[("y_own", l)]
+                      agg = be.spmm(ip, idx, x, nr, be.AGG_SAGE_GCN, x_self=xs, **self._kw(off, nr))
+                      be.gemm(agg, w1, ep_scale=es, ep_shift=eh, relu=rl, out=y_own[off:off + nr])
+                      be.gemm(y_own[off:off + nr], w2, out=hw[p0:p0 + nr])
+              works.append(_all_gather_block(base[b0:b0 + bn], base[p0:p0 + sh.csize[c]], sh, self.group, ("hw", l + 1), c))
+        self._chunk_join(x.device)
         out = be.feat_empty(sh.rows, d_out, x.device) if last else self._own(("y", l + 1), d_out, x.device)
         for wk in works:
             wk()
