@@ -644,7 +644,11 @@ constexpr int PIPE_BLOCK_TILES = GLNN_PIPE_BLOCK_TILES;      // k-tiles (of 32) 
 // constants -- the BatchNorm backward's dz written as an affine map of (dy, z), glnn::BnApplyA -- evaluated on the staged piece between its
 // s_waitcnt and its ds_write_b128 (two v_pk_fma_f32 pairs per piece: the only VALU work of the loop); z pieces ride behind the A pieces
 // in the load order (12 loads per k-tile in flight instead of 8).  Rows behind the descriptors' end are gamma, against B rows that are 0.
-struct PipeAx { const float* z0; int64_t ldz; const float* alpha; const float* beta; const float* gamma; };
+struct PipeAx { const float* z0; int64_t ldz; const float* alpha; const float* beta; const float* gamma;
+                // (round 6) alpha == NULL: the constants are made HERE from the still unfolded tile partials S1 / S2 (p1 / p2 [nparts][h], already
+                // offset to the tile's first column) -- bn_bwd_parts_consts_kernel's arithmetic and order, one launch less in front of the product
+                const float* p1; const float* p2; int nparts; int64_t h; float inv_rows; const float* bn_gamma; const float* bn_mean; const float* bn_rstd;
+                float* dgamma; float* dbeta; float* colsum; };
 template <int SA, int SB, bool AX = false>
 __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int64_t ext_a, const float* b0, int64_t ldb, int64_t ext_b,
                                               int64_t kext, int nk, f32x16 (&acc)[2][2], const PipeAx* ax = nullptr) {
@@ -711,9 +715,40 @@ __device__ __forceinline__ void pipe_mainloop(const float* a0, int64_t lda, int6
 #pragma unroll
     for (int q = 0; q < 4; ++q) voff_z[q] = (uint32_t)(((kr + 8 * q) * ax->ldz + n4) * 4);
     step_z = (uint32_t)(32 * ax->ldz * 4);
-    ax_al = *reinterpret_cast<const f32x4*>(ax->alpha + n4);
-    ax_be = *reinterpret_cast<const f32x4*>(ax->beta + n4);
-    ax_ga = *reinterpret_cast<const f32x4*>(ax->gamma + n4);
+    if (ax->alpha) {
+      ax_al = *reinterpret_cast<const f32x4*>(ax->alpha + n4);
+      ax_be = *reinterpret_cast<const f32x4*>(ax->beta + n4);
+      ax_ga = *reinterpret_cast<const f32x4*>(ax->gamma + n4);
+    } else {
+      f32x4 S1 = {0.f, 0.f, 0.f, 0.f}, S2 = S1;
+      for (int k0 = 0; k0 < ax->nparts; k0 += 16) {
+        f32x4 t1[16], t2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int k = k0 + u < ax->nparts ? k0 + u : ax->nparts - 1;
+          t1[u] = *reinterpret_cast<const f32x4*>(ax->p1 + (int64_t)k * ax->h + n4);
+          t2[u] = *reinterpret_cast<const f32x4*>(ax->p2 + (int64_t)k * ax->h + n4);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (k0 + u < ax->nparts) { S1 += t1[u]; S2 += t2[u]; }
+      }
+      const f32x4 rs = *reinterpret_cast<const f32x4*>(ax->bn_rstd + n4), gm = *reinterpret_cast<const f32x4*>(ax->bn_gamma + n4);
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(ax->bn_mean + n4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float c1 = S1[i] * ax->inv_rows, c2 = S2[i] * ax->inv_rows, grs = gm[i] * rs[i];
+        const float kq = grs * rs[i] * c2;
+        ax_al[i] = grs;
+        ax_be[i] = -kq;
+        ax_ga[i] = fmaf(kq, mu[i], -grs * c1);
+      }
+      if (ax->dgamma && tid < 32) {          // one workgroup per column block writes the parameter gradients (the caller passes dgamma to those only)
+        *reinterpret_cast<f32x4*>(ax->dbeta + n4) = S1;
+        *reinterpret_cast<f32x4*>(ax->dgamma + n4) = S2;
+        if (ax->colsum) *reinterpret_cast<f32x4*>(ax->colsum + n4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
   auto soff_z = [&](int kt) { return kt < nk ? (uint32_t)kt * step_z : (uint32_t)rsrc_z.z; };
   // SGPR offset of k-tile kt (uniform: SALU).  A tile past the end gets the descriptor's own size as offset: every lane is out of
@@ -1048,6 +1083,9 @@ struct GemmTnArgs {
   uint32_t drop_thr; uint32_t drop_seed; float drop_scale;
   // gemm_tn_kernel_pipe_ax only: A = ax_alpha * a + ax_beta * ax_z + ax_gamma per column (glnn::BnApplyA)
   const float* ax_z; int64_t ax_ldz; const float* ax_alpha; const float* ax_beta; const float* ax_gamma;
+  // ... or (ax_alpha == NULL) the constants made in the kernel's prologue from the tile partials (PipeAx)
+  const float* ax_p1; const float* ax_p2; int ax_nparts; float ax_inv_rows; const float* ax_bn_gamma; const float* ax_bn_mean; const float* ax_bn_rstd;
+  float* ax_dgamma; float* ax_dbeta; float* ax_colsum;
 };
 
 template <int BNT>
@@ -1431,7 +1469,13 @@ __device__ __forceinline__ void gemm_tn_pipe_body(const GemmTnArgs& g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if constexpr (AX) {
-    const PipeAx ax = {g.ax_z + mbeg * g.ax_ldz + i0, g.ax_ldz, g.ax_alpha + i0, g.ax_beta + i0, g.ax_gamma + i0};
+    const bool own = blockIdx.y == 0 && blockIdx.z == 0;      // the workgroups that also store dgamma / dbeta (/ the zero bias gradient) of their columns
+    const PipeAx ax = g.ax_alpha ? PipeAx{g.ax_z + mbeg * g.ax_ldz + i0, g.ax_ldz, g.ax_alpha + i0, g.ax_beta + i0, g.ax_gamma + i0,
+                                          nullptr, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}
+                                 : PipeAx{g.ax_z + mbeg * g.ax_ldz + i0, g.ax_ldz, nullptr, nullptr, nullptr, g.ax_p1 + i0, g.ax_p2 + i0, g.ax_nparts,
+                                          (int64_t)g.ka, g.ax_inv_rows, g.ax_bn_gamma + i0, g.ax_bn_mean + i0, g.ax_bn_rstd + i0,
+                                          own ? g.ax_dgamma + i0 : nullptr, own ? g.ax_dbeta + i0 : nullptr,
+                                          (own && g.ax_colsum) ? g.ax_colsum + i0 : nullptr};
     pipe_mainloop<KROW, KROW, true>(g.a + mbeg * g.lda + i0, g.lda, ((g.ka + 3) & ~3) - i0, g.b + mbeg * g.ldb + j0, g.ldb,
                                     ((g.nb + 3) & ~3) - j0, mend - mbeg, (int)((mend - mbeg + BK - 1) / BK), acc, &ax);
   } else {
@@ -2037,13 +2081,26 @@ int glnn::gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b
   g.a_vec = (lda % 4 == 0) && glnn::aligned16(a);
   g.b_vec = (ldb % 4 == 0) && glnn::aligned16(b);
   g.ax_z = nullptr; g.ax_ldz = 0; g.ax_alpha = g.ax_beta = g.ax_gamma = nullptr;
+  g.ax_p1 = g.ax_p2 = nullptr; g.ax_nparts = 0; g.ax_inv_rows = 0.f; g.ax_bn_gamma = g.ax_bn_mean = g.ax_bn_rstd = nullptr;
+  g.ax_dgamma = g.ax_dbeta = g.ax_colsum = nullptr;
   if (bn) {
     // A = alpha * a + beta * z + gamma on the staged pieces of the pipelined kernel: that kernel's shapes only (checked below)
-    GLNN_REQUIRE(bn->z && bn->alpha && bn->beta && bn->gamma, "glnn::gemm_tn: incomplete BnApplyA");
-    if (!glnn::gemm_tn_takes_bn(a, lda, m, ka, b, ldb, nb, bn->z, bn->ldz) || b_rows || b_scale || col_sum_a || !glnn::aligned16(bn->alpha) ||
-        !glnn::aligned16(bn->beta) || !glnn::aligned16(bn->gamma))
+    const bool parts = bn->p1 != nullptr;
+    GLNN_REQUIRE(bn->z && (parts ? (bn->p2 && bn->nparts >= 1 && bn->bn_gamma && bn->bn_mean && bn->bn_rstd && bn->dgamma && bn->dbeta)
+                                 : (bn->alpha && bn->beta && bn->gamma)), "glnn::gemm_tn: incomplete BnApplyA");
+    if (!glnn::gemm_tn_takes_bn(a, lda, m, ka, b, ldb, nb, bn->z, bn->ldz) || b_rows || b_scale || col_sum_a)
+      return GLNN_ERR_UNSUPPORTED;
+    if (parts ? !(glnn::aligned16(bn->p1) && glnn::aligned16(bn->p2) && glnn::aligned16(bn->bn_gamma) && glnn::aligned16(bn->bn_mean) &&
+                  glnn::aligned16(bn->bn_rstd) && glnn::aligned16(bn->dgamma) && glnn::aligned16(bn->dbeta) &&
+                  (!bn->colsum || glnn::aligned16(bn->colsum)))
+              : !(glnn::aligned16(bn->alpha) && glnn::aligned16(bn->beta) && glnn::aligned16(bn->gamma)))
       return GLNN_ERR_UNSUPPORTED;
     g.ax_z = bn->z; g.ax_ldz = bn->ldz; g.ax_alpha = bn->alpha; g.ax_beta = bn->beta; g.ax_gamma = bn->gamma;
+    if (parts) {
+      g.ax_alpha = g.ax_beta = g.ax_gamma = nullptr;
+      g.ax_p1 = bn->p1; g.ax_p2 = bn->p2; g.ax_nparts = bn->nparts; g.ax_inv_rows = 1.0f / (float)bn->rows; g.ax_bn_gamma = bn->bn_gamma;
+      g.ax_bn_mean = bn->bn_mean; g.ax_bn_rstd = bn->bn_rstd; g.ax_dgamma = bn->dgamma; g.ax_dbeta = bn->dbeta; g.ax_colsum = bn->colsum;
+    }
   }
   int bnt = nb > 64 ? 128 : 64;
   int gi = (ka + BM - 1) / BM, gj = (nb + bnt - 1) / bnt;

@@ -41,6 +41,7 @@ struct Options {
   int spmm_short;           // GLNN_SPMM_SHORT=0: sparse training blocks stay on the one-row-per-wave aggregation kernel
   int sage_fuse_bn_dy;      // GLNN_SAGE_FUSE_BN_DY=0: the deferred BatchNorm backward of layer 0 keeps its dy pass (the transposed aggregation writes da)
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
+  int bn0_consts_in_gemm;   // GLNN_STUDENT_BN0_CONSTS_IN_GEMM=0: the constants of the deferred apply come from a launch of their own (bn_bwd_parts_finish)
   int bn0_in_gemm;          // GLNN_STUDENT_BN0_IN_GEMM=0: the first hidden layer's BatchNorm backward stays partial + apply launches behind a plain input-gradient GEMM
   int cls_fused;            // GLNN_STUDENT_CLS_FUSED=0: the large-batch classifier stays a split-K GEMM launch + a loss launch (cls_block.hip off)
 };
@@ -187,7 +188,12 @@ int gemm_tn_batch(const TnProblem* problems, int n, float* workspace, int64_t wo
 // as an affine map of (dy, z): `a` holds dy (the upstream gradient behind the tail's dropout and ReLU masks, left in place by
 // bn_relu_bwd(..., defer_apply)) and dz is never written.  Evaluated on the staged operand pieces of the pipelined kernel;
 // GLNN_ERR_UNSUPPORTED (nothing launched) for any other shape -- ask gemm_tn_takes_bn first.
-struct BnApplyA { const float* z; int64_t ldz; const float* alpha; const float* beta; const float* gamma; };
+struct BnApplyA { const float* z; int64_t ldz; const float* alpha; const float* beta; const float* gamma;
+                  // (round 6) p1 != NULL instead of alpha / beta / gamma: the per-tile column sums S1 / S2 [nparts][ka] are still unfolded; the product
+                  // folds them (ascending) and makes the constants in its prologue, and the workgroups of the first column stripe store
+                  // dgamma = S2, dbeta = S1 (and colsum = 0) -- bn_bwd_parts_finish's results without its launch
+                  const float* p1 = nullptr; const float* p2 = nullptr; int nparts = 0; int64_t rows = 0; const float* bn_gamma = nullptr;
+                  const float* bn_mean = nullptr; const float* bn_rstd = nullptr; float* dgamma = nullptr; float* dbeta = nullptr; float* colsum = nullptr; };
 bool gemm_tn_takes_bn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, int nb, const float* z, int64_t ldz,
                       int64_t workspace_floats = -1);      // workspace_floats >= 0: also the split-dependent window condition, planned against that workspace
 int gemm_tn(const float* a, int64_t lda, int64_t m, int ka, const float* b, int64_t ldb, const int64_t* b_rows, const float* b_scale,

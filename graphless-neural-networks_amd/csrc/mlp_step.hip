@@ -430,6 +430,13 @@ static int mlp_fwd_bwd_impl(const glnn_mlp_step_desc* d, const float* feats, int
         const glnn::BnTail tail = {d->z[0], d->ldz[0], d->mean[0], d->rstd[0], d->a_scale[0], d->a_shift[0], p, seed, 1};
         const int rc = glnn::gemm_bn_dy(dz, ld_dz, m, d->dims[2], d->w[1], d->dims[1], d->dims[1], tail, d->da, ld_dy, s1, s2, stream);
         if (rc == GLNN_OK) {
+          if (opt.bn0_consts_in_gemm && glnn::aligned16(d->gamma[0]) && glnn::aligned16(d->mean[0]) && glnn::aligned16(d->rstd[0]) &&
+              glnn::aligned16(d->ggamma[0]) && glnn::aligned16(d->gbeta[0]) && glnn::aligned16(d->gb[0])) {
+            // ... and the constants are made in the weight gradient's own prologue (every workgroup folds the 32 tile partials of its 128 columns)
+            bn0 = {};
+            bn0.z = d->z[0]; bn0.ldz = d->ldz[0]; bn0.p1 = s1; bn0.p2 = s2; bn0.nparts = (int)nparts; bn0.rows = m; bn0.bn_gamma = d->gamma[0];
+            bn0.bn_mean = d->mean[0]; bn0.bn_rstd = d->rstd[0]; bn0.dgamma = d->ggamma[0]; bn0.dbeta = d->gbeta[0]; bn0.colsum = d->gb[0];
+          } else
           GLNN_TRY(glnn::bn_bwd_parts_finish(s1, s2, (int)nparts, d->dims[1], m, d->z[0], d->ldz[0], d->gamma[0], d->mean[0], d->rstd[0],
                                              d->ws_bn + h4, d->ggamma[0], d->gbeta[0], d->gb[0], &bn0, stream));
           have_bn0 = true;

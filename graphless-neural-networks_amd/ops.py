@@ -396,6 +396,11 @@ def placed_for_gather(rows, d, device, indptr, indices, n_dst, what="", first=No
                     budget -= nb
             cands.append(feat_empty(rows, d, device, zero=zero))
             budget -= nbytes_m
+    except torch.cuda.OutOfMemoryError:
+        # a device shared with other tenants (or nearly full): choose among the candidates that did fit
+        del ballast[:]
+        torch.cuda.empty_cache()
+    try:
         if len(cands) <= 1:
             return fallback() if not cands else cands[0]
         if probe is None:

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify --no-small-students --no-xl-leg --no-arxiv-leg"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify --no-small-students --no-xl-leg --no-arxiv-leg --no-chunked-leg"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $CMD > "$OUT/write.log" 2>&1
 python scripts/pmc_to_json.py "$OUT/fetch" "$OUT/write" "$OUT/pmc_traffic.json" "$OUT/${TAG}_pmc_hbm_traffic.csv"

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify --no-small-students --no-xl-leg --no-arxiv-leg > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-train-leg --reorder none --no-clustered-leg --no-verify --no-small-students --no-xl-leg --no-arxiv-leg --no-chunked-leg > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train" -- python scripts/bench_train_sage.py ${2:-ogbn-arxiv} > "$OUT/train.log" 2>&1
 for d in bench train; do
   f=$(ls "$OUT"/$d/*/*kernel_stats.csv 2>/dev/null | head -1)

@@ -399,6 +399,22 @@ def test_first_hidden_layer_batchnorm_backward_out_of_the_input_gradient_product
         assert float((a - b).abs().max()) <= 2e-6 * gs, (tuple(a.shape), float((a - b).abs().max()), gs)
 
 
+@pytest.mark.parametrize("dims,bsz,p", [([100, 2048, 2048, 47], 4096, 0.2), ([72, 544, 544, 40], 2500, 0.3)])
+def test_deferred_batchnorm_constants_made_in_the_weight_gradient_prologue_are_the_same_bits(dims, bsz, p, monkeypatch):
+    """... and the constants of that deferred apply (alpha, beta, gamma per column from the folded tile sums) are made in the prologue of the
+    weight-gradient product itself (pipe_mainloop<.., AX>, PipeAx::p1) instead of by a launch in front of it
+    (GLNN_STUDENT_BN0_CONSTS_IN_GEMM=0: bn_bwd_parts_consts_kernel): the same sums in the same order, the same expressions -- every
+    gradient, the loss and the logits bit for bit."""
+    base, x, tgt, k = _variant_inputs(dims, bsz, "batch", p, "kl", 39)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GLNN_STUDENT_BN0_CONSTS_IN_GEMM", mode)
+        runs.append(_variant_run(base, dims, bsz, x, tgt, k, 2))
+    (s0, m0, g0, l0, z0), (s1, m1, g1, l1, z1) = runs
+    for a, b in zip(s0 + m0 + g0 + [l0, z0], s1 + m1 + g1 + [l1, z1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dims,bsz,norm,p", [([1433, 128, 7], 140, "none", 0.6), ([3703, 128, 6], 512, "none", 0.6), ([4814, 64, 64, 2], 300, "batch", 0.2),
                                              ([1433, 256, 256, 40], 4096, "batch", 0.5)])
 def test_wide_unaligned_first_layer_through_a_padded_shadow_of_its_weight(dims, bsz, norm, p, monkeypatch):
