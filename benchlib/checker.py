@@ -60,7 +60,7 @@ class CheckedBackend:
         sum_v (deg_v + 1) * mean_v == sum_u (edges of the launch out of u) * x_u + sum_v x_self_v  (a full pass over x per launch)."""
         self.be, self.sample, self.tol, self.report, self.ok, self.conservation = be, int(sample), tol, [], True, conservation
 
-    def _conservation(self, indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift):
+    def _conservation(self, indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift, self_rows=None):
         d, dev = x.shape[1], x.device
         e0, e1 = int(indptr[0]), int(indptr[n_dst])
         cnt = torch.bincount(indices[e0:e1].long(), minlength=x.shape[0]).double()
@@ -76,7 +76,7 @@ class CheckedBackend:
             if ep_scale is not None:
                 y = y / ep_scale.double()
             lhs += (deg1[sl].unsqueeze(1) * y).sum(0)
-            rhs += xs[sl, :d].double().sum(0)
+            rhs += (xs[sl, :d] if self_rows is None else xs[self_rows[sl].long()][:, :d]).double().sum(0)
         for s0 in range(0, x.shape[0], step):
             sl = slice(s0, min(x.shape[0], s0 + step))
             rhs += (cnt[sl].unsqueeze(1) * x[sl, :d].double()).sum(0)
@@ -143,8 +143,8 @@ class CheckedBackend:
             again = self.be.spmm(indptr[r0:r0 + k + 1], indices, x, k, mode, row_scale=None if row_scale is None else row_scale[r0:r0 + k],
                                  col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu, x_self=xs_again, **({} if sr is None else {"self_rows": sr}))
             self._note(f"spmm d={x.shape[1]} rows={n_dst}", diff, bool(torch.equal(again, out[r0:r0 + k])))
-            if self.conservation and mode == self.be.AGG_SAGE_GCN and not relu and self_rows is None:
-                err = self._conservation(indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift)
+            if self.conservation and mode == self.be.AGG_SAGE_GCN and not relu:
+                err = self._conservation(indptr, indices, x, n_dst, xs, out, ep_scale, ep_shift, self_rows)
                 self.report[-1]["conservation_rel_err_fp64_all_rows"] = err
                 self.ok = self.ok and err < 1e-5
         return out
