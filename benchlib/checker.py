@@ -164,12 +164,24 @@ class CheckedBackend:
         if n_dst:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)
-            h = self._epi(self._agg_ref(indptr, indices, x, r0, k, self.be.AGG_SAGE_GCN, xs) @ w.detach().double().t(), ep_scale, ep_shift, relu)
             o, o2 = (res, None) if w_next is None else res
+            chunks = kw.get("chunks")
+            if chunks is not None:      # ONE launch over chunks: self rows and output rows of row v sit at the chunk's rows of the whole buffers
+                v = torch.arange(r0, r0 + k, device=x.device)
+                starts = torch.tensor([chunks.row_start[c] for c in range(chunks.n_chunks)], device=x.device)
+                c = torch.searchsorted(starts, v, right=True) - 1
+                self_idx = torch.tensor([chunks.self_row[i] for i in range(chunks.n_chunks)], device=x.device)[c] + v - starts[c]
+                out_idx = torch.tensor([chunks.out_row[i] for i in range(chunks.n_chunks)], device=x.device)[c] + v - starts[c]
+                agg = self._agg_ref_rows(indptr, indices, x, r0, k, self.be.AGG_SAGE_GCN, xs[self_idx])
+                o, o2 = (None if o is None else o[out_idx]), (None if o2 is None else o2[out_idx])
+            else:
+                agg = self._agg_ref(indptr, indices, x, r0, k, self.be.AGG_SAGE_GCN, xs)
+                o, o2 = (None if o is None else o[r0:r0 + k]), (None if o2 is None else o2[r0:r0 + k])
+            h = self._epi(agg @ w.detach().double().t(), ep_scale, ep_shift, relu)
             diff = 0.0
             if o is not None:
-                diff = float((o[r0:r0 + k].double() - h).abs().max())
+                diff = float((o.double() - h).abs().max())
             if w_next is not None:
-                diff = max(diff, float((o2[r0:r0 + k].double() - h @ w_next.detach().double().t()).abs().max()))
+                diff = max(diff, float((o2.double() - h @ w_next.detach().double().t()).abs().max()))
             self._note(f"sage_fused d={x.shape[1]}->{w.shape[0]}" + (f"->{w_next.shape[0]}" if w_next is not None else "") + f" rows={n_dst}", diff)
         return res

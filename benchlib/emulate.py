@@ -81,6 +81,8 @@ def run_emulated(args, dev):
                     for _ in range(2):
                         t.forward(feats)                   # warm-up (buffers, relabelled columns, packed weights, hub plans, first launches)
                     timing, peers.events = [], []
+                    if hasattr(t, "chunk_ready"):
+                        t.chunk_ready = []                 # (one-launch layers: when every chunk's completion signal fired, relative to the launch)
                     gdist.EXCHANGE_STATS.update(collectives=0, floats_received=0)
                     torch.cuda.synchronize()
                     ops.set_timing(timing)
@@ -94,7 +96,17 @@ def run_emulated(args, dev):
                 fill = sum(s_.elapsed_time(e_) for _, _, s_, e_ in peers.events) / steps
                 c = want.shape[1]
                 diff = float((y[:, :c] - want[sh.lo:sh.hi, :c]).abs().max()) if sh.rows else 0.0
-                ranks.append({"rank": r, "rows": sh.rows, "nnz": int(shard.num_edges()), "wall_ms": wall, "kernel_ms": sum(kms.values()), "fill_ms": fill,
+                # per one-launch layer in forward order: the ms after the launch began at which chunk 0, 1, .. became sendable, then the launch's end
+                launches, cur_ = [], []
+                for k_, s_, e_ in (getattr(t, "chunk_ready", None) or []):
+                    cur_.append(s_.elapsed_time(e_))
+                    if k_ == -1:
+                        launches.append(cur_)
+                        cur_ = []
+                n_ol = len(launches) // max(1, steps)
+                signals = [[round(float(np.median([launches[s_ * n_ol + i][j] for s_ in range(steps)])), 3) for j in range(len(launches[i]))]
+                           for i in range(n_ol)] if n_ol else None
+                ranks.append({"rank": r, "rows": sh.rows, "chunk_signal_ms": signals, "nnz": int(shard.num_edges()), "wall_ms": wall, "kernel_ms": sum(kms.values()), "fill_ms": fill,
                               "GB_received": 4e-9 * gdist.EXCHANGE_STATS["floats_received"] / steps, "kernels": kms,
                               "halo_rows": getattr(getattr(t, "plan", None), "n_halo", None), "max_abs_diff_vs_unsharded": diff})
                 del t, peers, shard, y

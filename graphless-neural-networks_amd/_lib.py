@@ -28,6 +28,12 @@ SIGNATURES = {
                                c_int, c_vp, c_i64, c_vp, c_vp],
     "glnn_sage_fused_plan_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
                                  c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "glnn_sage_fused_chunks_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
+                                   c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "glnn_signal_alloc": [c_vp],
+    "glnn_signal_free": [c_vp],
+    "glnn_signal_read": [c_vp, c_vp],
+    "glnn_stream_wait_value32": [c_vp, c_vp, c_u32],
     "glnn_degrees_f32": [c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp, c_vp, c_vp],
     "glnn_gemm_f32": [c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_u32, c_i64, c_int, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_int,
                       c_vp, c_i64, c_vp, c_i64, c_vp],
@@ -75,7 +81,7 @@ MLP_COUNTERS = 1024
 _F = ctypes.c_void_p * MLP_MAX_LAYERS
 
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 # glnn_exchange_fn: int (*)(void* ctx, const float* send, float* recv, int64_t floats, void* stream)
 GRAD_READY_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
@@ -93,6 +99,15 @@ class HubPlanDesc(ctypes.Structure):
     """glnn_hub_plan of include/glnn_hip.h (field for field)."""
     _fields_ = [("rows", c_vp), ("seg_ptr", c_vp), ("n_hub", ctypes.c_int32), ("n_seg", ctypes.c_int32), ("slab", c_vp),
                 ("ld_slab", c_i64), ("slab_rows", c_i64)]
+
+
+MAX_CHUNKS = 8
+
+
+class ChunkSignalsDesc(ctypes.Structure):
+    """glnn_chunk_signals of include/glnn_hip.h (field for field)."""
+    _fields_ = [("n_chunks", ctypes.c_int32), ("row_start", c_i64 * (MAX_CHUNKS + 1)), ("self_row", c_i64 * MAX_CHUNKS),
+                ("out_row", c_i64 * MAX_CHUNKS), ("arrivals", c_vp), ("signal", c_vp * MAX_CHUNKS), ("epoch", ctypes.c_uint32)]
 
 
 class MlpStepDesc(ctypes.Structure):
@@ -172,7 +187,7 @@ def lib():
         h.glnn_reload_options.restype = None
         if h.glnn_abi_version() != ABI_VERSION:
             raise GlnnError(f"{LIB_PATH}: ABI version {h.glnn_abi_version()} != {ABI_VERSION} expected by this package; rebuild")
-        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc), (4, HubPlanDesc)):
+        for which, mirror in ((0, MlpStepDesc), (1, SageStepDesc), (2, SageLayer), (3, AdamDesc), (4, HubPlanDesc), (5, ChunkSignalsDesc)):
             if h.glnn_struct_bytes(which) != ctypes.sizeof(mirror):
                 raise GlnnError(f"{LIB_PATH}: sizeof({mirror.__name__}) is {h.glnn_struct_bytes(which)} in the library, "
                                 f"{ctypes.sizeof(mirror)} in this binding")

@@ -88,7 +88,7 @@ int move_rows(const float* x, int64_t ldx, const int64_t* rows, int64_t n_rows, 
 
 }  // namespace
 
-extern "C" int glnn_abi_version(void) { return 11; }
+extern "C" int glnn_abi_version(void) { return 12; }
 
 // test / A-B hook: re-read the GLNN_* switches (glnn::Options).  Not for concurrent use with other calls into the library.
 extern "C" void glnn_reload_options(void) {
@@ -104,6 +104,7 @@ extern "C" int64_t glnn_struct_bytes(int which) {
   if (which == 2) return (int64_t)sizeof(glnn_sage_layer);
   if (which == 3) return (int64_t)sizeof(glnn_adam_desc);
   if (which == 4) return (int64_t)sizeof(glnn_hub_plan);
+  if (which == 5) return (int64_t)sizeof(glnn_chunk_signals);
   return -1;
 }
 

@@ -765,6 +765,57 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kFusedWaves = 8;                      // one wave per 32-column panel of W (d_out <= 256)
 constexpr int kFusedBlock = 64 * kFusedWaves;       // 16-wave workgroups measured 1.5x slower (they drain badly)
 
+// Round 6: ONE launch over the CHUNKS of a rank's rows (glnn_sage_fused_chunks_f32).  The rows of chunk c -- tiles [tile_start[c],
+// tile_start[c + 1]) -- read their self rows and write their outputs at a per-chunk row shift (the chunk-major buffers of the sharded
+// forward keep a rank's chunks in separate slots), and every workgroup ARRIVES on its chunk's counter when its waves' stores are done: stores ->
+// (acknowledged by the L2) -> atomic add; the wave that completes the count stores the launch's epoch to the chunk's
+// signal word, on which the host's exchange stream waits (hipStreamWaitValue32) before it sends the chunk -- while the same launch is
+// still working on the next chunk.
+struct ChunkMap {
+  int n;
+  int tile_start[GLNN_MAX_CHUNKS + 1];
+  int64_t self_shift[GLNN_MAX_CHUNKS];                  // self row of own row v = x_self + (v + self_shift[c]) * ld_self
+  int64_t out_shift[GLNN_MAX_CHUNKS];                   // output row of own row v = v + out_shift[c] (out and out2)
+  int* arrivals;                                        // [n] counters, zero between launches (the completing wave resets its counter)
+  uint32_t* signal[GLNN_MAX_CHUNKS];
+  uint32_t epoch;
+};
+
+// How a chunk's rows become visible to the stream that waits for its signal (three forms were measured, N = 8 emulated, the 256 -> 256 -> 47
+// layer of a rank, profiles/r06_one_launch_ab.txt): a release per storing wave (buffer_wbl2 sc0 sc1 = a write-back of the XCD's whole L2,
+// 19 k of them per launch) took 3.45 ms instead of 2.55; write-through stores (sc0 sc1) + s_waitcnt cost nothing on the 47-wide rows (2.42 ms)
+// but +17 % on a 256-wide output (dword stores are not combined on their way to memory).  Shipped: PLAIN stores, acknowledged by the L2
+// (s_waitcnt vmcnt(0)) before the wave arrives; the write-back to memory is ONE per chunk and comes from the waiting side --
+// glnn_stream_wait_value32 puts an empty kernel behind the wait, whose end-of-kernel release writes every XCD's L2 back, as between any two
+// kernels.
+template <bool CM>
+__device__ __forceinline__ void store_out(float* p, float v) {
+  *p = v;
+}
+
+template <bool CM>
+__device__ __forceinline__ void chunk_arrive(const ChunkMap& cm, int chunk, bool stored, int lane, int* s_arrived) {
+  if constexpr (CM) {
+    if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's stores have been acknowledged (they sit in this XCD's L2)
+    if (lane != 0) return;
+    // the workgroup's eight waves count themselves in LDS; the last one arrives for the tile (ONE global atomic per tile: with one per
+    // wave the 100 -> 256 layer issued a same-address atomic every 16 ns and ran 17 % slower)
+    if (atomicAdd(s_arrived, 1) != kFusedWaves - 1) return;
+    int* cnt = cm.arrivals + chunk;
+    const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int expected = 0;
+    uint32_t* sig = nullptr;
+#pragma unroll
+    for (int c = 0; c < GLNN_MAX_CHUNKS; ++c)
+      if (c == chunk) { expected = cm.tile_start[c + 1] - cm.tile_start[c]; sig = cm.signal[c]; }
+    if (prev == expected - 1) {
+      // every other tile's rows were acknowledged before its add was performed; nothing of theirs is read here
+      __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sig, cm.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 struct FusedArgs {
   const int64_t* indptr; const int32_t* indices; int64_t n_dst;
   const float* x; int64_t ldx; int d_in;
@@ -777,9 +828,10 @@ struct FusedArgs {
   const float* w2_packed; int d_out2; int kgroups2; float* out2; int64_t ldo2;
   const int32_t* tile_order;                            // optional permutation of the tile ids (heaviest tiles first)
   HubPlan hub;                                          // n_hub == 0: hub rows are summed by the tile's own workgroup
+  ChunkMap cm;                                          // n == 0: off (the kernel's CM = false instantiation never reads it)
 };
 
-template <int LPR, int U, int RT>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains
+template <int LPR, int U, int RT, bool CM = false>      // RT = 32-row sub-tiles per workgroup: each W fragment load feeds RT MFMA chains; CM: chunk map
 __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs a) {
   constexpr int kFusedRows = 32 * RT;
   extern __shared__ __attribute__((aligned(16))) float lds_a[];      // [kFusedRows][kpad + 4]
@@ -790,12 +842,23 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
   const bool col_ok = col4 < a.d_in;
   const int kpad = a.kgroups * 8;
   const int lda = kpad + 4;
-  const int64_t row0 = (int64_t)(a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x) * kFusedRows;
+  const int tile_id = a.tile_order ? a.tile_order[blockIdx.x] : (int)blockIdx.x;
+  const int64_t row0 = (int64_t)tile_id * kFusedRows;
+  int chunk = 0;
+  int64_t self_shift = 0, out_shift = 0;
+  if constexpr (CM) {
+    self_shift = a.cm.self_shift[0];
+    out_shift = a.cm.out_shift[0];
+#pragma unroll
+    for (int c = 1; c < GLNN_MAX_CHUNKS; ++c)
+      if (c < a.cm.n && tile_id >= a.cm.tile_start[c]) { chunk = c; self_shift = a.cm.self_shift[c]; out_shift = a.cm.out_shift[c]; }
+  }
 
   // ---- phase A: the 8 waves pull rows of the tile from an LDS ticket (degrees vary by 100x: a static
   //      4-rows-per-wave split leaves most waves idle at the barrier behind the heaviest one) ---------
   __shared__ int s_next;
-  if (threadIdx.x == 0) s_next = 0;
+  __shared__ int s_arrived;                            // (CM: waves of this workgroup that are done)
+  if (threadIdx.x == 0) { s_next = 0; if (CM) s_arrived = 0; }
   __syncthreads();
 #pragma unroll 1
   while (true) {
@@ -813,7 +876,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
       if (!deferred) {
         const float4 acc = wave_gather_sum<LPR, U, false>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, nullptr, lane, XfCols{});
         if (lane < LPR && col_ok) {
-          const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
+          const float4 sf = ld4(a.x_self + (v + self_shift) * a.ld_self + col4);
           const float dp1 = (float)deg + 1.0f;
           y = mean4(acc, sf, dp1);
           if (col4 + 1 >= a.d_in) y.y = 0.f;
@@ -844,7 +907,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
       const float4 t = add4(add4(s_part[0][lane], s_part[1][lane]), add4(s_part[2][lane], s_part[3][lane]));
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (col_ok) {
-        const float4 sf = ld4(a.x_self + v * a.ld_self + col4);
+        const float4 sf = ld4(a.x_self + (v + self_shift) * a.ld_self + col4);
         const float dp1 = (float)(e1 - e0) + 1.0f;
         y = mean4(t, sf, dp1);
         if (col4 + 1 >= a.d_in) y.y = 0.f;
@@ -860,7 +923,7 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
   const int n_tiles = (a.d_out + 31) / 32;
   const int nt = wave;                                 // column panel of W
   const bool chain = a.w2_packed != nullptr;
-  if (nt >= n_tiles && !chain) return;
+  if (nt >= n_tiles && !chain) { chunk_arrive<CM>(a.cm, chunk, false, lane, &s_arrived); return; }
   const int li = lane & 31, kk = lane >> 5;
   f32x16 acc[RT];
 #pragma unroll
@@ -914,15 +977,15 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
         float v = fmaf(acc[t][r], es, eh);
         if (a.relu) v = fmaxf(v, 0.f);
         if (!col_ok2) v = 0.f;
-        if (a.out && col_ok2 && row < a.n_dst) a.out[row * a.ldo + col] = v;
+        if (a.out && col_ok2 && row < a.n_dst) store_out<CM>(a.out + (row + out_shift) * a.ldo + col, v);
         if (chain && col < a.kgroups2 * 8) lds_a[lr * ldh + col] = v;
       }
   }
-  if (!chain) return;
+  if (!chain) { chunk_arrive<CM>(a.cm, chunk, true, lane, &s_arrived); return; }
   __syncthreads();
   // ---- phase C: [32*RT x d_out] hidden tile (LDS) x W2 panel `wave` on the MFMA -> out2 ----------------
   const int n_tiles2 = (a.d_out2 + 31) / 32;
-  if (nt >= n_tiles2) return;
+  if (nt >= n_tiles2) { chunk_arrive<CM>(a.cm, chunk, a.out != nullptr && nt < n_tiles, lane, &s_arrived); return; }
   {
     const float4* wp = reinterpret_cast<const float4*>(a.w2_packed) + ((int64_t)nt * a.kgroups2) * 64 + lane;
     const float* ap = lds_a + li * ldh + kk * 4;
@@ -948,10 +1011,11 @@ __global__ __launch_bounds__(kFusedBlock) void sage_fused_kernel(const FusedArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-          if (row < a.n_dst) a.out2[row * a.ldo2 + col2] = acc[t][r];
+          if (row < a.n_dst) store_out<CM>(a.out2 + (row + out_shift) * a.ldo2 + col2, acc[t][r]);
         }
     }
   }
+  chunk_arrive<CM>(a.cm, chunk, true, lane, &s_arrived);
 }
 
 // W [d_out, d_in] (ldw) -> MFMA B-fragment order: wp[nt][kg][lane][t] = W[nt*32 + (lane&31)][kg*8 + (lane>>5)*4 + t]
@@ -1258,7 +1322,7 @@ static int sage_fused_impl(const int64_t* indptr, const int32_t* indices, int64_
                            int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
                            int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
                            int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
-                           const glnn_hub_plan* plan, void* stream) {
+                           const glnn_hub_plan* plan, void* stream, const glnn_chunk_signals* chunks = nullptr) {
   if (n_dst == 0) return GLNN_OK;
   GLNN_REQUIRE(indptr && x && x_self && w_packed && (out || w2_packed), "glnn_sage_fused_f32: null pointer");   // indices NULL iff no edges
   GLNN_REQUIRE(!w2_packed || (out2 && d_out2 >= 1 && d_out2 <= 256 && ldo2 >= d_out2 && glnn::aligned16(w2_packed)),
@@ -1276,6 +1340,24 @@ static int sage_fused_impl(const int64_t* indptr, const int32_t* indices, int64_
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
   a.w2_packed = w2_packed; a.d_out2 = w2_packed ? d_out2 : 0; a.kgroups2 = w2_packed ? (d_out + 7) / 8 : 0; a.out2 = out2; a.ldo2 = ldo2;
   a.tile_order = tile_order;
+  a.cm = ChunkMap{};
+  if (chunks) {
+    const int nc = chunks->n_chunks;
+    GLNN_REQUIRE(nc >= 1 && nc <= GLNN_MAX_CHUNKS && chunks->arrivals && chunks->row_start[0] == 0 && chunks->row_start[nc] >= n_dst,
+                 "glnn_sage_fused_chunks_f32: 1..%d chunks covering rows [0, n_dst), arrival counters", GLNN_MAX_CHUNKS);
+    const int64_t tiles = (n_dst + 31) / 32;
+    a.cm.n = nc; a.cm.arrivals = chunks->arrivals; a.cm.epoch = chunks->epoch;
+    for (int c = 0; c < nc; ++c) {
+      const int64_t r0 = chunks->row_start[c], r1 = chunks->row_start[c + 1];
+      GLNN_REQUIRE(r0 % 32 == 0 && r1 >= r0 && chunks->signal[c] && chunks->self_row[c] >= 0 && chunks->out_row[c] >= 0,
+                   "glnn_sage_fused_chunks_f32: chunk %d: row_start must be an ascending multiple of 32, signal / rows set", c);
+      a.cm.tile_start[c] = (int)(r0 / 32 < tiles ? r0 / 32 : tiles);
+      a.cm.self_shift[c] = chunks->self_row[c] - r0;
+      a.cm.out_shift[c] = chunks->out_row[c] - r0;
+      a.cm.signal[c] = chunks->signal[c];
+    }
+    for (int c = nc; c <= GLNN_MAX_CHUNKS; ++c) a.cm.tile_start[c] = (int)tiles;
+  }
   // one 32-row sub-tile per workgroup (RT = 1).  RT = 2 (64-row tiles, every W fragment load feeding two MFMA chains) was measured
   // 1.5x slower in round 1 -- big workgroups drain badly -- and its instantiations were removed in round 3
   constexpr int rt = 1;
@@ -1303,7 +1385,11 @@ static int sage_fused_impl(const int64_t* indptr, const int32_t* indices, int64_
     else rc = launch_hub_gather<64, GLNN_FUSED_U>(h, GLNN_AGG_SUM, hub_segs, st);
     if (rc != GLNN_OK) return rc;
   }
-#define GLNN_FUSED_LAUNCH(LPR_, RT_) hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a)
+#define GLNN_FUSED_LAUNCH(LPR_, RT_)                                                                                                          \
+  do {                                                                                                                                        \
+    if (a.cm.n) hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_, true>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a); \
+    else hipLaunchKernelGGL((sage_fused_kernel<LPR_, GLNN_FUSED_U, RT_>), dim3((unsigned)blocks), dim3(kFusedBlock), smem, st, a);             \
+  } while (0)
   if (kv <= 16 && dv <= 16) GLNN_FUSED_LAUNCH(16, 1); else if (kv <= 32) GLNN_FUSED_LAUNCH(32, 1); else GLNN_FUSED_LAUNCH(64, 1);
 #undef GLNN_FUSED_LAUNCH
   return glnn::check_launch("glnn_sage_fused_f32");
@@ -1325,4 +1411,55 @@ extern "C" int glnn_sage_fused_plan_f32(const int64_t* indptr, const int32_t* in
                                         const glnn_hub_plan* plan, void* stream) {
   return sage_fused_impl(indptr, indices, n_dst, n_src, x, ldx, d_in, x_self, ld_self, w_packed, d_out, ep_scale, ep_shift, relu, out, ldo,
                          w2_packed, d_out2, out2, ldo2, tile_order, plan, stream);
+}
+
+extern "C" int glnn_sage_fused_chunks_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src, const float* x,
+                                          int64_t ldx, int d_in, const float* x_self, int64_t ld_self, const float* w_packed,
+                                          int d_out, const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                          int64_t ldo, const float* w2_packed, int d_out2, float* out2, int64_t ldo2, const int32_t* tile_order,
+                                          const glnn_hub_plan* plan, const glnn_chunk_signals* chunks, void* stream) {
+  GLNN_REQUIRE(chunks, "glnn_sage_fused_chunks_f32: chunks is NULL (use glnn_sage_fused_plan_f32)");
+  return sage_fused_impl(indptr, indices, n_dst, n_src, x, ldx, d_in, x_self, ld_self, w_packed, d_out, ep_scale, ep_shift, relu, out, ldo,
+                         w2_packed, d_out2, out2, ldo2, tile_order, plan, stream, chunks);
+}
+
+extern "C" int glnn_signal_alloc(uint32_t** signal) {
+  GLNN_REQUIRE(signal, "glnn_signal_alloc: null pointer");
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return glnn::fail(GLNN_ERR_HIP, "glnn_signal_alloc: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+  }
+  if (hipMemset(p, 0, 8) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_signal_alloc: memset failed");
+  *signal = reinterpret_cast<uint32_t*>(p);
+  return GLNN_OK;
+}
+
+extern "C" int glnn_signal_free(uint32_t* signal) {
+  if (signal && hipFree(signal) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_signal_free: hipFree failed");
+  return GLNN_OK;
+}
+
+extern "C" int glnn_signal_read(const uint32_t* signal, uint32_t* value) {
+  GLNN_REQUIRE(signal && value, "glnn_signal_read: null pointer");
+  if (hipMemcpy(value, signal, 4, hipMemcpyDeviceToHost) != hipSuccess) return glnn::fail(GLNN_ERR_HIP, "glnn_signal_read: copy failed");
+  return GLNN_OK;
+}
+
+__global__ void signal_fence_kernel() {}
+
+extern "C" int glnn_stream_wait_value32(void* stream, uint32_t* signal, uint32_t value) {
+  GLNN_REQUIRE(signal, "glnn_stream_wait_value32: null pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (hipStreamWaitValue32(st, signal, value, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+    (void)hipGetLastError();
+    return glnn::fail(GLNN_ERR_HIP, "glnn_stream_wait_value32: hipStreamWaitValue32 failed (not supported on this device?)");
+  }
+  // the signalled rows sit in the producing XCDs' L2s (see store_out): an empty kernel, whose end-of-kernel release writes the L2s back
+  static const bool no_fence = getenv("GLNN_SIGNAL_NO_FENCE") != nullptr;      // (tests: the negative control)
+  if (!no_fence) {
+    hipLaunchKernelGGL(signal_fence_kernel, dim3(1), dim3(64), 0, st);
+    return glnn::check_launch("glnn_stream_wait_value32(fence)");
+  }
+  return GLNN_OK;
 }

@@ -374,6 +374,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const BnBwdArgs a) {
 // MLP3w8 resident at once).  The reduction index is split between the two lane halves of v_mfma_f32_32x32x2_f32 as [0, KH) / [KH, 2 KH)
 // (any pairing of k is a valid order), so a lane's A operands are KH consecutive floats of one row: ds_read_b128.
 typedef float sk_f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GLNN_SK_WG_WAVES
+#define GLNN_SK_WG_WAVES 3
+#endif
+#ifndef GLNN_SK_APPLY_WAVES
+#define GLNN_SK_APPLY_WAVES 3
+#endif
 
 template <int KH>
 struct SkLds {
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? 
 // order) and stored as row-chunk slab dw_ws[chunk][k][h] (folded by Adam or chunk_sum_kernel: k ascending); workgroups of the first
 // column block also store the chunk's column sums of dl (the bias gradient) to db_ws[chunk][k].  Replaces a gemm_tn launch that re-read z.
 template <int KH, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? 3 : 2))) void bn_bwd_partial_wg_sk(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? GLNN_SK_WG_WAVES : 2))) void bn_bwd_partial_wg_sk(const BnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
   const int c0 = blockIdx.x * 64;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? 
 }
 
 template <int KH, bool DROP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void bn_bwd_apply_sk(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KH <= 24 ? GLNN_SK_APPLY_WAVES : 3))) void bn_bwd_apply_sk(const BnBwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, kk = lane >> 5;
   const int c0 = blockIdx.x * 64;
   const int64_t r0 = (int64_t)blockIdx.y * kBnRows, wr0 = r0 + 32 * wave;

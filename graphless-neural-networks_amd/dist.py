@@ -32,6 +32,8 @@ class RowShards:
         layout "cm"   chunk-major slots     [chunk][rank][cr]: what the chunked, overlapped exchange produces
     Column indices are relabelled ONCE per layout (ShardedTeacher._cols); activations are never re-packed."""
 
+    CHUNK_QUANTUM = 32
+
     def __init__(self, n, world, rank, chunks=1, bounds=None, chunk_sizes=None, kinds=None):
         """chunk_sizes (round 6): rows per chunk of a slot, UNEQUAL chunks allowed (sum >= the longest range) -- the chunk-major layout is
         then [chunk k][rank][chunk_sizes[k]]; `kinds` labels the chunks (the mixed layer-1 exchange: "W" = exchanged as the layer's wide
@@ -47,6 +49,9 @@ class RowShards:
         longest = max(1, max(b - a for a, b in zip(self.bounds[:-1], self.bounds[1:])))
         if chunk_sizes is None:
             self.cr = (longest + self.chunks - 1) // self.chunks      # rows per chunk
+            if self.chunks > 1:                                       # ... a whole number of the fused kernel's 32-row tiles, so that ONE launch
+                q = self.CHUNK_QUANTUM                                # can cover all chunks of a rank (no tile straddles two chunks)
+                self.cr = (self.cr + q - 1) // q * q
             self.csize = [self.cr] * self.chunks
         else:
             self.csize = [int(c) for c in chunk_sizes]
@@ -125,6 +130,7 @@ class RowShards:
         return self.position(v, "cm")
 
 
+ONE_LAUNCH = __import__("os").environ.get("GLNN_ONE_LAUNCH", "1") != "0"      # the chunks of the fused layer as tile ranges of ONE launch with completion signals (ShardedTeacher)
 CHUNK_STREAMS = int(__import__("os").environ.get("GLNN_CHUNK_STREAMS", "1"))      # producer chunk launches alternate between this many streams (ShardedTeacher)
 EXCHANGE_STATS = {"collectives": 0, "floats_received": 0}      # per process; tests and bench read / reset it
 FORCE_COLLECTIVES = False      # tests: issue the collectives even for world == 1 (a 1-rank RCCL group exercises the transport calls)
@@ -394,6 +400,7 @@ class ShardedTeacher:
         self.widening_exchange, self.mixed_fraction = widening_exchange, mixed_fraction
         self._bufs = {}
         self._col_cache = {}
+        self.chunk_ready = None      # set to a list: (chunk, launch-start event, ready event) of every one-launch layer ((-1, ..) = the launch's end)
 
     # buffers a later layer GATHERS from, and the row order their columns are addressed in (the others feed a GEMM or are outputs)
     _GATHERED = {"ycm": "cm", "hwcm": "cm", "y": "own", "hw": "own"}
@@ -517,6 +524,72 @@ class ShardedTeacher:
             for st in self._streams:
                 cur.wait_stream(st)
 
+    # ---- the chunks of a fused layer as tile ranges of ONE launch, each with a completion signal (round 6, ONE_LAUNCH) ----------------------
+    def _one_launch_ok(self, x, c0, c1, d_in, d_mid, d_out2=0):
+        be, sh = self.be, self.sh
+        return (ONE_LAUNCH and x.is_cuda and hasattr(be, "ChunkSignals") and hasattr(be, "sage_fused") and 1 <= c1 - c0 <= be.ChunkSignals.MAX
+                and d_in <= 256 and d_mid <= 256 and d_out2 <= 256 and all(o % 32 == 0 for o in sh.coff[:-1]) and sh.chunk_rows(c0)[1] > 0)
+
+    def _launch_chunks(self, c0, c1, x, layout, w, tail, out=None, w_next=None, out_next=None):
+        """ONE fused launch over the own rows of chunks [c0, c1): self rows read from `x` (in `layout`), outputs written to the chunks' slots of
+        the chunk-major buffers `out` / `out_next`; tile order = the chunks' heaviest-first orders one after the other (completion follows
+        it).  Returns (signals, exchange stream, launch stream): `_after_signal` issues a chunk's exchange behind its signal."""
+        be, g, sh, dev = self.be, self.g, self.sh, x.device
+        off0 = sh.coff[c0]
+        nr = max(0, min(sh.rows, sh.coff[c1]) - off0)
+        key = ("signals", c0, c1)
+        if key not in self._col_cache:
+            parts = []
+            for c in range(c0, c1):
+                off, n_c = sh.chunk_rows(c)
+                if n_c > 0:
+                    o = self._tile_order(off, n_c)
+                    o = torch.arange((n_c + 31) // 32, dtype=torch.int32, device=dev) if o is None else o
+                    parts.append(o + (off - off0) // 32)
+            self._col_cache[key] = (be.ChunkSignals([sh.coff[c] - off0 for c in range(c0, c1 + 1)], dev), torch.cat(parts).to(torch.int32).contiguous())
+        sig, order = self._col_cache[key]
+        base = {"cm": None, "nat": sh.lo, "own": sh.slot}[layout]
+        self_rows = [sh.chunk_slot(c) if base is None else base + sh.coff[c] for c in range(c0, c1)]
+        desc = sig.launch(self_rows, [sh.chunk_slot(c) for c in range(c0, c1)], nr)
+        cur = torch.cuda.current_stream(dev)
+        side = self.__dict__.setdefault("_exchange_stream", torch.cuda.Stream(device=dev))
+        side.wait_stream(cur)
+        kw = {"tile_order": order}
+        if w.shape[1] > 128:                               # (the hub plan where it was measured to pay: see _kw)
+            hub = self._hub(off0, nr)
+            if hub is not None:
+                kw["hub"] = hub
+        if self.chunk_ready is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(cur)
+        es, eh, rl = tail
+        be.sage_fused(g.indptr[off0:off0 + nr + 1], self._cols(layout), x, nr, w, ep_scale=es, ep_shift=eh, relu=rl, x_self=x, out=out, w_next=w_next,
+                      out_next=out_next, want_out=out is not None, chunks=desc, **kw)
+        if self.chunk_ready is not None:
+            self._t1 = torch.cuda.Event(enable_timing=True)
+            self._t1.record(cur)
+        return sig, side, cur
+
+    def _after_signal(self, sig, k, side, issue):
+        """Issue chunk k's exchange (`issue()` -> waiter) behind the chunk's completion signal: the exchange stream is held by the signal, the
+        collective is enqueued from it.  (Emulated peers: the fills stay on the launch's own stream -- the model's kernel times are taken
+        without them -- but the signal is still waited for, and `chunk_ready` records when it fired.)"""
+        if not sig.empty(k):
+            sig.wait(side, k)
+        if self.chunk_ready is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(side)
+            self.chunk_ready.append((k, self._t0, e))
+        if _emu(self.group) is not None:
+            return issue()
+        with torch.cuda.stream(side):
+            return issue()
+
+    def _launch_done(self, side, cur):
+        if self.chunk_ready is not None:
+            self.chunk_ready.append((-1, self._t0, self._t1))      # (the launch's own end)
+        cur.wait_stream(side)
+
     def _widening_layer_overlapped(self, l, x, layout, w, tail):
         """2*d_in <= d_out, world > 1: per chunk, by its kind (RowShards.kinds):
              "N" / None   aggregate the own rows -> async all-gather of the d_in-wide aggregate -> REPLICATED GEMM of every rank's rows
@@ -538,7 +611,19 @@ class ShardedTeacher:
             abase = _storage_rows(agg)
         idx = self._cols(layout)
         works = []
-        for c in range(sh.chunks):
+        nw = 0                                                  # leading "W" chunks: ONE launch with a completion signal per chunk
+        while nw < sh.chunks and kinds[nw] == "W":
+            nw += 1
+        if nw and self._one_launch_ok(x, 0, nw, d_in, d_out):
+            sig, side, cur = self._launch_chunks(0, nw, x, layout, w, tail, out=y)
+            for c in range(nw):
+                b0, bn = sh.chunk_block(c)
+                p0, cs = sh.chunk_slot(c), sh.csize[c]
+                works.append(self._after_signal(sig, c, side, lambda: _all_gather_block(ybase[b0:b0 + bn], ybase[p0:p0 + cs], sh, self.group, ("y", l), c)))
+            self._launch_done(side, cur)
+        else:
+            nw = 0
+        for c in range(nw, sh.chunks):
           with self._chunk_stream(c, x.device):
               off, nr = sh.chunk_rows(c)
               b0, bn = sh.chunk_block(c)
@@ -581,7 +666,19 @@ class ShardedTeacher:
         base = _storage_rows(hw)
         idx = self._cols(layout)
         works = []
-        for c in range(sh.chunks):
+        one_launch = self._one_launch_ok(x, 0, sh.chunks, w1.shape[1], d_mid, d_out)
+        if one_launch:
+            # ONE launch over all chunks (round 6): the chunks are tile ranges of the same launch, each signals its completion, and the
+            # exchange stream holds every chunk's all-gather behind the chunk's signal -- the overlap of the chunked form without a short
+            # launch's ramp and tail per chunk (N = 8: 2.53 ms in two launches, 2.74 in four, 2.42 in one).
+            sig, side, cur = self._launch_chunks(0, sh.chunks, x, layout, w1, tail1, w_next=w2, out_next=hw)
+            for c in range(sh.chunks):
+                b0, bn = sh.chunk_block(c)
+                p0 = sh.chunk_slot(c)
+                works.append(self._after_signal(sig, c, side, lambda: _all_gather_block(base[b0:b0 + bn], base[p0:p0 + sh.csize[c]], sh, self.group,
+                                                                                        ("hw", l + 1), c)))
+            self._launch_done(side, cur)
+        for c in (() if one_launch else range(sh.chunks)):
           with self._chunk_stream(c, x.device):
               off, nr = sh.chunk_rows(c)
               b0, bn = sh.chunk_block(c)

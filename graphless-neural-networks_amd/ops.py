@@ -291,12 +291,76 @@ def fused_tile_order(indptr, n_dst):
     return torch.argsort(deg.view(tiles, 32).amax(1), descending=True, stable=True).to(torch.int32)
 
 
+class ChunkSignals:
+    """Completion signals of ONE fused launch over the chunks of a row range (glnn_sage_fused_chunks_f32, round 6): per chunk a signal
+    word a stream can wait on and an arrival counter.  `row_start`: first row of every chunk inside the launch's row range + the end
+    (multiples of 32).  Per launch: sage_fused(..., chunks=sig.launch(self_rows, out_rows)) stamps a new epoch; then
+    sig.wait(stream, c) holds `stream`'s next operation until chunk c's rows are stored and written back -- while the launch still runs.
+    Chunks without rows are never signalled (`sig.empty(c)`: do not wait for them)."""
+    MAX = _lib.MAX_CHUNKS
+
+    def __init__(self, row_start, device):
+        n = len(row_start) - 1
+        if not 1 <= n <= self.MAX or row_start[0] != 0 or any(r % 32 for r in row_start[:-1]) or any(a > b for a, b in zip(row_start[:-1], row_start[1:])):
+            raise ValueError(f"ChunkSignals: 1..{self.MAX} chunks whose first rows are ascending multiples of 32, starting at 0")
+        self.row_start, self.n, self.device, self.epoch = [int(r) for r in row_start], n, device, 0
+        self.arrivals = torch.zeros(n, dtype=torch.int32, device=device)
+        self._signals = []
+        for _ in range(n):
+            p = ctypes.c_void_p()
+            _lib.check(_lib.lib().glnn_signal_alloc(ctypes.byref(p)), "glnn_signal_alloc")
+            self._signals.append(p.value)
+        self._n_dst = None
+
+    def empty(self, c, n_dst=None):
+        n_dst = self._n_dst if n_dst is None else n_dst
+        return min(self.row_start[c + 1], n_dst) <= self.row_start[c]
+
+    def launch(self, self_rows, out_rows, n_dst):
+        """The descriptor of the next launch (a new epoch): self_rows[c] / out_rows[c] = the rows of x_self / of the outputs that hold the
+        chunk's first row."""
+        if len(self_rows) != self.n or len(out_rows) != self.n or self.row_start[-1] < n_dst:
+            raise ValueError("ChunkSignals.launch: one self row and one output row per chunk, chunks covering the launch's rows")
+        self.epoch += 1
+        self._n_dst = int(n_dst)
+        d = _lib.ChunkSignalsDesc()
+        d.n_chunks = self.n
+        for c in range(self.n + 1):
+            d.row_start[c] = self.row_start[c]
+        for c in range(self.n):
+            d.self_row[c], d.out_row[c], d.signal[c] = int(self_rows[c]), int(out_rows[c]), self._signals[c]
+        d.arrivals = self.arrivals.data_ptr()
+        d.epoch = self.epoch
+        return d
+
+    def wait(self, stream, c):
+        """`stream` (torch.cuda.Stream) runs nothing further until chunk c of the LAST launch is complete."""
+        _lib.check(_lib.lib().glnn_stream_wait_value32(ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(self._signals[c]), self.epoch),
+                   "glnn_stream_wait_value32")
+
+    def value(self, c):
+        v = ctypes.c_uint32()
+        _lib.check(_lib.lib().glnn_signal_read(ctypes.c_void_p(self._signals[c]), ctypes.byref(v)), "glnn_signal_read")
+        return v.value
+
+    def __del__(self):
+        try:
+            for p in self._signals:
+                _lib.lib().glnn_signal_free(ctypes.c_void_p(p))
+        except Exception:
+            pass
+
+
 def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=False, out=None, x_self=None, w_packed=None,
-               w_next=None, out_next=None, want_out=True, tile_order=None, hub=None):
+               w_next=None, out_next=None, want_out=True, tile_order=None, hub=None, chunks=None):
     """K1F glnn_sage_fused_f32: epi(((A x + x_self)/(deg+1)) @ w.T) in one launch (d_in, d_out <= 256).
     w_next [d_out2, d_out]: also returns (.. , out @ w_next.T) -- the projection of the NEXT layer when it projects first;
-    with want_out=False the hidden rows themselves are not written at all (returns (None, projected))."""
+    with want_out=False the hidden rows themselves are not written at all (returns (None, projected)).
+    chunks (ChunkSignals.launch(...)): the launch covers the chunks of a row range -- x_self / out / out_next are then WHOLE buffers
+    addressed through the descriptor's per-chunk rows (they must be given), and every chunk signals its completion."""
     _need_cuda(indptr, indices, x, w, ep_scale, ep_shift, out, x_self, w_next, out_next)
+    if chunks is not None and (x_self is None or (out is None and want_out) or (w_next is not None and out_next is None)):
+        raise ValueError("sage_fused(chunks=...): x_self and the output buffers must be given (they are addressed by the chunks' rows)")
     x = as_feat(x)
     x_self = x if x_self is None else as_feat(x_self)
     n_src, d_in = x.shape
@@ -322,7 +386,9 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
                 _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0, _p(out), _ld(out) if out is not None else 0,
                 _p(w2p), d_out2, _p(out_next), _ld(out_next) if out_next is not None else 0, _p(tile_order))
         plan = hub.desc_for(d_in, x.device) if hub is not None else None
-        if plan is not None:
+        if chunks is not None:
+            rc = _lib.lib().glnn_sage_fused_chunks_f32(*args, plan, ctypes.byref(chunks), _stream())
+        elif plan is not None:
             rc = _lib.lib().glnn_sage_fused_plan_f32(*args, plan, _stream())
         else:
             rc = _lib.lib().glnn_sage_fused_f32(*args, _stream())

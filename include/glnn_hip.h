@@ -142,6 +142,46 @@ GLNN_API int glnn_sage_fused_plan_f32(const int64_t* indptr, const int32_t* indi
                                       float* out2, int64_t ldo2, const int32_t* tile_order,
                                       const glnn_hub_plan* plan, void* stream);
 
+/* ABI 12 (round 6): ONE fused launch over the CHUNKS of a row shard, with a completion signal per chunk.  A rank of the sharded forward
+ * (no reference counterpart: the reference is single-device, train_teacher.py:162-165) produces its rows chunk by chunk so that each
+ * chunk's rows can leave over the links while the next is computed; launched one by one the chunks pay a short launch's ramp and tail
+ * each (two launches of a rank's layer 2 at N = 8: 2.55 ms, one launch over the same rows: see DESIGN.md section 6).  Here the chunks
+ * are tile ranges of ONE launch:
+ *   row_start  [n_chunks + 1] first row (relative to `indptr`) of every chunk, multiples of 32 (row_start[0] = 0); row_start[n_chunks]
+ *              >= n_dst (a chunk may be short or empty: an EMPTY chunk is never signalled)
+ *   self_row   row of `x_self` holding the self row of row_start[c] (the chunk's self rows are consecutive from there)
+ *   out_row    row of `out` / `out2` that receives row_start[c]
+ *   arrivals   n_chunks device counters, zero before the first launch (the launch leaves them zero)
+ *   signal     n_chunks words from glnn_signal_alloc(); when every row of chunk c is stored (acknowledged by the L2) the kernel
+ *              stores `epoch` there -- glnn_stream_wait_value32(other_stream, signal[c], epoch) then holds that stream's next
+ *              operation (the chunk's all-gather) until the chunk is complete AND written back to device memory, while the launch
+ *              is still running.  Use a new, larger epoch per launch (the wait is "value >= epoch", unsigned 32-bit).
+ * `tile_order` may permute the tiles freely; completion order follows it (the caller concatenates the chunks' orders). */
+#define GLNN_MAX_CHUNKS 8
+typedef struct glnn_chunk_signals {
+  int32_t n_chunks;
+  int64_t row_start[GLNN_MAX_CHUNKS + 1];
+  int64_t self_row[GLNN_MAX_CHUNKS];
+  int64_t out_row[GLNN_MAX_CHUNKS];
+  int32_t* arrivals;
+  uint32_t* signal[GLNN_MAX_CHUNKS];
+  uint32_t epoch;
+} glnn_chunk_signals;
+GLNN_API int glnn_sage_fused_chunks_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                                        int64_t n_src, const float* x, int64_t ldx, int d_in,
+                                        const float* x_self, int64_t ld_self, const float* w_packed,
+                                        int d_out, const float* ep_scale, const float* ep_shift, int relu,
+                                        float* out, int64_t ldo, const float* w2_packed, int d_out2,
+                                        float* out2, int64_t ldo2, const int32_t* tile_order,
+                                        const glnn_hub_plan* plan, const glnn_chunk_signals* chunks, void* stream);
+/* A 32-bit signal word a stream can wait on (hipExtMallocWithFlags(hipMallocSignalMemory)), initialised to 0; its current value;
+ * "the next operation of `stream` starts when *signal >= value" (hipStreamWaitValue32, GTE) -- followed by an empty kernel on `stream`,
+ * whose end-of-kernel release writes back the L2s in which the signalled rows may still sit. */
+GLNN_API int glnn_signal_alloc(uint32_t** signal);
+GLNN_API int glnn_signal_free(uint32_t* signal);
+GLNN_API int glnn_signal_read(const uint32_t* signal, uint32_t* value);
+GLNN_API int glnn_stream_wait_value32(void* stream, uint32_t* signal, uint32_t value);
+
 /* in_deg[v] = t(indptr[v+1]-indptr[v]); out_deg[u] = t(#edges with source u), as floats, t = `transform`:
  *   GLNN_DEG_RAW          the degree itself            g.in_degrees() / g.out_degrees()
  *   GLNN_DEG_RSQRT_CLAMP1 deg.clamp(min=1) ** -0.5     the norm of dgl GraphConv(norm="both") and utils.py:178-179

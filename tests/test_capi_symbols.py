@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in fns:
         assert hasattr(h, name), f"{name} declared in include/glnn_hip.h but not exported"
     h.glnn_abi_version.restype = ctypes.c_int
-    assert h.glnn_abi_version() == 11
+    assert h.glnn_abi_version() == 12
     h.glnn_last_error.restype = ctypes.c_char_p
     assert h.glnn_last_error() is not None
 

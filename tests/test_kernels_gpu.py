@@ -161,6 +161,69 @@ def test_sage_fused_heaviest_tile_first_order_changes_nothing_but_the_schedule()
         ops.sage_fused(ip, ix, x, n, w, tile_order=order[:-1].contiguous())
 
 
+@pytest.mark.parametrize("chain", [True, False])
+def test_sage_fused_one_launch_over_chunks_equals_the_chunk_launches_and_signals_every_chunk(chain):
+    """glnn_sage_fused_chunks_f32 (round 6): the chunks of a row range as tile ranges of ONE launch -- self rows and outputs of chunk c at
+    the chunk's own rows of whole buffers (the chunk-major slots of the sharded forward), heaviest-first tile order per chunk -- gives
+    the bits of one launch per chunk; and every chunk SIGNALS: a second stream held by glnn_stream_wait_value32 copies chunk c's rows out
+    while the launch may still be running, and the copy already holds the final rows (stores written back before the signal).  Two
+    launches in a row (epochs 1, 2: the arrival counters come back to zero); an empty chunk is never signalled; bad descriptors are
+    refused."""
+    from glnn_amd import ops
+    n, d_in, d_out, d2 = 21003, 256, 256, 47
+    indptr, indices = random_graph(n, 14, seed=9, power=0.8, isolated=7, hub=6000)
+    rs = np.random.RandomState(9)
+    ip, ix = g2d(indptr, indices)
+    x = dev(rs.standard_normal((n, d_in)).astype(np.float32))
+    w = dev((rs.standard_normal((d_out, d_in)) / 16).astype(np.float32))
+    w2 = dev((rs.standard_normal((d2, d_out)) / 16).astype(np.float32)) if chain else None
+    b = dev(rs.standard_normal(d_out).astype(np.float32))
+    row_start = [0, 6400, 6400 + 7168, 6400 + 7168 + 8000, 6400 + 7168 + 8000 + 64]      # 4 chunks, the last one EMPTY (behind n)
+    assert row_start[3] >= n
+    slots = [40000, 10016, 25000, 60000]                      # where the chunks' rows live in the whole buffers (out of order, apart)
+    d_o = d2 if chain else d_out
+    xs = torch.zeros(70000, d_in, device="cuda")             # self rows: chunk c's rows at slots[c]
+    want = torch.zeros(70000, d_o, device="cuda")
+    orders = []
+    for c in range(3):
+        r0, r1 = row_start[c], min(row_start[c + 1], n)
+        xs[slots[c]:slots[c] + r1 - r0] = x[r0:r1]
+        o = ops.fused_tile_order(ip[r0:r1 + 1], r1 - r0)
+        orders.append(o + r0 // 32)
+        kw = dict(ep_shift=b, relu=True, x_self=x[r0:r1], tile_order=o)
+        if chain:
+            ops.sage_fused(ip[r0:r1 + 1], ix, x, r1 - r0, w, w_next=w2, out_next=want[slots[c]:slots[c] + r1 - r0], want_out=False, **kw)
+        else:
+            ops.sage_fused(ip[r0:r1 + 1], ix, x, r1 - r0, w, out=want[slots[c]:slots[c] + r1 - r0], **kw)
+    order = torch.cat(orders).to(torch.int32).contiguous()
+    sig = ops.ChunkSignals(row_start, x.device)
+    side = torch.cuda.Stream()
+    for epoch in (1, 2):
+        got = torch.zeros(70000, d_o, device="cuda")
+        early = torch.zeros(70000, d_o, device="cuda")
+        torch.cuda.synchronize()
+        desc = sig.launch(slots, slots, n)
+        assert sig.epoch == epoch and sig.empty(3) and not sig.empty(2)
+        if chain:
+            ops.sage_fused(ip, ix, x, n, w, ep_shift=b, relu=True, x_self=xs, w_next=w2, out_next=got, want_out=False, tile_order=order, chunks=desc)
+        else:
+            ops.sage_fused(ip, ix, x, n, w, ep_shift=b, relu=True, x_self=xs, out=got, tile_order=order, chunks=desc)
+        for c in range(3):
+            sig.wait(side, c)
+            with torch.cuda.stream(side):
+                nr = min(row_start[c + 1], n) - row_start[c]
+                early[slots[c]:slots[c] + nr].copy_(got[slots[c]:slots[c] + nr])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(early, want)
+        assert [sig.value(c) for c in range(4)] == [epoch, epoch, epoch, 0]
+        assert int(sig.arrivals.abs().sum()) == 0
+    with pytest.raises(ValueError):
+        ops.ChunkSignals([0, 100, 200], x.device)            # not a multiple of the 32-row tile
+    with pytest.raises(ValueError):
+        ops.sage_fused(ip, ix, x, n, w, chunks=sig.launch(slots, slots, n))      # the whole buffers must be given
+
+
 def test_degrees():
     from glnn_amd import ops
     n = 1000
