@@ -1137,7 +1137,7 @@ def test_full_size_xl_teacher_forward_properties():
     assert cfg["rows_per_gpu"] == 12_500_000 and cfg["nnz_per_gpu"] == 250_000_000 and cfg["nodes_total"] == 100_000_000 and cfg["rank_timed"] == 4
     assert out["verified"] is True and out["verify"]["repeat_forward_bit_equal"] and out["verify"]["finite"]
     launches = out["verify"]["launches"]
-    assert len(launches) == 13                       # 4 chunks x (aggregate, replicated projection, fused + chained) + ONE layer-3 aggregate over all own rows
+    assert len(launches) == 10                       # 4 chunks x (aggregate, replicated projection) + ONE fused + chained launch over the chunks (signals) + ONE layer-3 aggregate
     for l in launches:
         assert l["max_abs_diff_vs_fp64"] <= 1e-4, l
         if l["launch"].startswith("spmm"):
