@@ -116,9 +116,9 @@ def run_products(args, rank, world, dev, barrier):
                                                            for w_, d_ in (("narrow", C.SAGE_DIMS[0]), ("wide", C.SAGE_DIMS[1]))})
         base_bounds = shards.bounds
 
-        def time_candidate(form, ch):
+        def time_candidate(form, ch, frac=None):
             sh_c = RowShards(n, world, rank, chunks=ch, bounds=base_bounds)
-            cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form, mixed_fraction=args.mixed_fraction)
+            cand = ShardedTeacher(teacher.encoder, shard_graph, sh_c, ops, widening_exchange=form, mixed_fraction=frac or args.mixed_fraction)
             with torch.no_grad():
                 cand.forward(feats)
                 barrier()
@@ -140,18 +140,26 @@ def run_products(args, rank, world, dev, barrier):
                 # forms themselves (what layer 1 puts on the wire x how many chunks the overlapped exchange is cut into), on this
                 # transport, outside the timed region (max over ranks; identical decision on every rank).  A candidate that fails on any
                 # rank is recorded as an error string and skipped on every rank.
-                autotune, best = {}, None
-                for form in ("narrow", "wide", "mixed"):
+                autotune, best, fracs = {}, None, {}
+                # ("mixed0.75": three quarters of the chunks travel wide -- a stop of the dial that exists from 4 chunks on; with the fused layers
+                #  as ONE launch over the chunks the chunk count costs them nothing, and the emulated model has it fastest: 4.66 ms per rank at N = 8)
+                for form, frac in (("narrow", None), ("wide", None), ("mixed", None), ("mixed0.75", 0.75)):
                     for ch in ([args.chunks] if args.chunks else [2, 4, 8]):
+                        if frac is not None and ch < 4:
+                            continue
                         key = f"{form}/{ch}"
-                        ok, ms = lad.attempt(f"autotune {key}", lambda: time_candidate(form, ch))
+                        fracs[key] = frac
+                        ok, ms = lad.attempt(f"autotune {key}", lambda: time_candidate("mixed" if frac else form, ch, frac))
                         autotune[key] = ms if ok else "error: " + lad.errors[f"autotune {key}"]
                         if ok and (best is None or ms < autotune[best]):
                             best = key
                         torch.cuda.empty_cache()
                 if best is None:
                     raise RuntimeError("every overlapped all-gather form failed")
-                args.layer1_exchange, ch = best.split("/")
+                form, ch = best.split("/")
+                if fracs[best]:
+                    form, args.mixed_fraction = "mixed", fracs[best]
+                args.layer1_exchange = form
                 shards = RowShards(n, world, rank, chunks=int(ch), bounds=base_bounds)
             return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange=args.layer1_exchange, mixed_fraction=args.mixed_fraction)
 
@@ -397,7 +405,7 @@ def run_products(args, rank, world, dev, barrier):
                       "with the aggregation; the projection is replicated and consumes chunks in arrival order)" if args.layer1_exchange == "narrow" else
                       "all-gathers: 256-wide fused output of layer 1 (chunked, overlapped with the aggregation; no replicated projection)"
                       if args.layer1_exchange == "wide" else
-                      f"all-gathers: layer 1 mixed -- {args.mixed_fraction:g} of every chunk's rows as 256-wide fused output, the rest as 100-wide "
+                      f"all-gathers: layer 1 mixed -- {args.mixed_fraction:g} of a rank's chunks as 256-wide fused output, the rest as 100-wide "
                       "aggregate with a replicated projection (chunked, overlapped)")
                      + ", 47-wide projection of layer 3 (chunked, overlapped with layer 2); layer 2 needs none")
                     if args.exchange == "allgather" else
