@@ -41,6 +41,7 @@ static void load_options(Options& o) {
   o.spmm_short = (int)env_ll("GLNN_SPMM_SHORT", 1);
   o.sage_fuse_bn_dy = (int)env_ll("GLNN_SAGE_FUSE_BN_DY", 1);
   o.cls_fused = (int)env_ll("GLNN_STUDENT_CLS_FUSED", 1);
+  o.signal_fence = env_ll("GLNN_SIGNAL_NO_FENCE", 0) ? 0 : 1;
   o.bn0_in_gemm = (int)env_ll("GLNN_STUDENT_BN0_IN_GEMM", 1);
   o.bn0_consts_in_gemm = (int)env_ll("GLNN_STUDENT_BN0_CONSTS_IN_GEMM", 1);
 }

@@ -43,6 +43,7 @@ struct Options {
   int sage_fuse_bn_apply;   // GLNN_SAGE_FUSE_BN_APPLY=0: teacher training writes layer 0's dz (BatchNorm-backward apply as its own launch)
   int bn0_consts_in_gemm;   // GLNN_STUDENT_BN0_CONSTS_IN_GEMM=0: the constants of the deferred apply come from a launch of their own (bn_bwd_parts_finish)
   int bn0_in_gemm;          // GLNN_STUDENT_BN0_IN_GEMM=0: the first hidden layer's BatchNorm backward stays partial + apply launches behind a plain input-gradient GEMM
+  int signal_fence;         // GLNN_SIGNAL_NO_FENCE=1: glnn_stream_wait_value32 without the empty kernel behind the wait (tests: the negative control)
   int cls_fused;            // GLNN_STUDENT_CLS_FUSED=0: the large-batch classifier stays a split-K GEMM launch + a loss launch (cls_block.hip off)
 };
 const Options& opts();

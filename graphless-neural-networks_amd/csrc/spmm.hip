@@ -1456,8 +1456,7 @@ extern "C" int glnn_stream_wait_value32(void* stream, uint32_t* signal, uint32_t
     return glnn::fail(GLNN_ERR_HIP, "glnn_stream_wait_value32: hipStreamWaitValue32 failed (not supported on this device?)");
   }
   // the signalled rows sit in the producing XCDs' L2s (see store_out): an empty kernel, whose end-of-kernel release writes the L2s back
-  static const bool no_fence = getenv("GLNN_SIGNAL_NO_FENCE") != nullptr;      // (tests: the negative control)
-  if (!no_fence) {
+  if (glnn::opts().signal_fence) {                                             // (GLNN_SIGNAL_NO_FENCE=1: the negative control of the tests)
     hipLaunchKernelGGL(signal_fence_kernel, dim3(1), dim3(64), 0, st);
     return glnn::check_launch("glnn_stream_wait_value32(fence)");
   }
