@@ -143,6 +143,16 @@ def _rccl_worker(port, q):
                 yw = gdist.ShardedTeacher(model.encoder, g, sh, ops, widening_exchange="wide").forward(x)
             torch.cuda.synchronize()
             errs[(tuple(dims), "wide")] = (float((yw - want).abs().max()), gdist.EXCHANGE_STATS["collectives"])
+            if chunks > 1 and dims[1] == 256:
+                # round 6: the fused layers as ONE launch over the chunks, every chunk's all-gather held behind its completion signal
+                # (hipStreamWaitValue32 on the exchange stream) -- the same bits as one launch per chunk, narrow and wide
+                for form, got in (("narrow", y), ("wide", yw)):
+                    gdist.ONE_LAUNCH = False
+                    with torch.no_grad():
+                        per_chunk = gdist.ShardedTeacher(model.encoder, g, sh, ops, widening_exchange=form).forward(x)
+                    gdist.ONE_LAUNCH = True
+                    torch.cuda.synchronize()
+                    errs[(tuple(dims), "one-launch == per-chunk launches, " + form)] = (0.0 if torch.equal(got, per_chunk) else 1.0, 1)
         # the gradient all-reduce started from inside the backward (grad_ready hook -> async RCCL all-reduce on the communicator's
         # stream -> wait before Adam): with one rank every reduce is the identity, so the steps must equal the plain engine's
         import copy
