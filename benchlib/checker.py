@@ -129,6 +129,22 @@ class CheckedBackend:
         # (kw: the hub plan of the HIP backend.  The row-range relaunch below runs WITHOUT one: plan and no plan must agree bit for bit)
         out = self.be.spmm(indptr, indices, x, n_dst, mode, row_scale=row_scale, col_scale=col_scale, ep_scale=ep_scale, ep_shift=ep_shift,
                            relu=relu, out=out, x_self=x_self, self_rows=self_rows, **kw)
+        chunks = kw.pop("chunks", None)
+        if n_dst and chunks is not None:
+            # ONE launch over chunks: self rows and output rows of row v sit at the chunk's rows of the whole buffers -- checked through
+            # index vectors (the row-range relaunch and the conservation identity below then see ordinary tensors)
+            v = torch.arange(n_dst, device=x.device)
+            starts = torch.tensor([chunks.row_start[c] for c in range(chunks.n_chunks)], device=x.device)
+            c_ = torch.searchsorted(starts, v, right=True) - 1
+            if self_rows is None:
+                self_rows = torch.tensor([chunks.self_row[i] for i in range(chunks.n_chunks)], device=x.device)[c_] + v - starts[c_]
+            out_view = out[torch.tensor([chunks.out_row[i] for i in range(chunks.n_chunks)], device=x.device)[c_] + v - starts[c_]]
+            self._check_spmm(indptr, indices, x, n_dst, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out_view, x_self, self_rows, kw)
+            return out
+        self._check_spmm(indptr, indices, x, n_dst, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self, self_rows, kw)
+        return out
+
+    def _check_spmm(self, indptr, indices, x, n_dst, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self, self_rows, kw):
         if n_dst:
             xs = x if x_self is None else x_self
             r0, k = self._range(n_dst)

@@ -30,6 +30,8 @@ SIGNATURES = {
                                  c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
     "glnn_sage_fused_chunks_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_vp, c_i64, c_vp, c_int, c_vp, c_vp, c_int, c_vp,
                                    c_i64, c_vp, c_int, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "glnn_spmm_csr_chunks_f32": [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                 c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
     "glnn_signal_alloc": [c_vp],
     "glnn_signal_free": [c_vp],
     "glnn_signal_read": [c_vp, c_vp],

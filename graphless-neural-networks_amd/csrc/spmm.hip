@@ -68,6 +68,51 @@ struct HubPlan {
   int64_t ld_slab;
 };
 
+// Round 6: ONE launch over the CHUNKS of a rank's rows (glnn_sage_fused_chunks_f32).  The rows of chunk c -- tiles [tile_start[c],
+// tile_start[c + 1]) -- read their self rows and write their outputs at a per-chunk row shift (the chunk-major buffers of the sharded
+// forward keep a rank's chunks in separate slots), and every workgroup ARRIVES on its chunk's counter when its waves' stores are done: stores ->
+// (acknowledged by the L2) -> atomic add; the wave that completes the count stores the launch's epoch to the chunk's
+// signal word, on which the host's exchange stream waits (hipStreamWaitValue32) before it sends the chunk -- while the same launch is
+// still working on the next chunk.
+struct ChunkMap {
+  int n;
+  int tile_start[GLNN_MAX_CHUNKS + 1];
+  int64_t self_shift[GLNN_MAX_CHUNKS];                  // self row of own row v = x_self + (v + self_shift[c]) * ld_self
+  int64_t out_shift[GLNN_MAX_CHUNKS];                   // output row of own row v = v + out_shift[c] (out and out2)
+  int* arrivals;                                        // [n] counters, zero between launches (the completing wave resets its counter)
+  uint32_t* signal[GLNN_MAX_CHUNKS];
+  uint32_t epoch;
+};
+
+// constant-index selects over the by-value arrays of a ChunkMap (a dynamic index would send the kernel arguments through scratch)
+__device__ __forceinline__ int64_t cm_pick(const int64_t (&a)[GLNN_MAX_CHUNKS], int c) {
+  int64_t r = a[0];
+#pragma unroll
+  for (int i = 1; i < GLNN_MAX_CHUNKS; ++i) r = (c == i) ? a[i] : r;
+  return r;
+}
+__device__ __forceinline__ int cm_tile_start(const ChunkMap& cm, int c) {       // c in [0, GLNN_MAX_CHUNKS]
+  int r = cm.tile_start[0];
+#pragma unroll
+  for (int i = 1; i <= GLNN_MAX_CHUNKS; ++i) r = (c == i) ? cm.tile_start[i] : r;
+  return r;
+}
+__device__ __forceinline__ uint32_t* cm_signal(const ChunkMap& cm, int c) {
+  uint32_t* r = cm.signal[0];
+#pragma unroll
+  for (int i = 1; i < GLNN_MAX_CHUNKS; ++i) r = (c == i) ? cm.signal[i] : r;
+  return r;
+}
+// one arrival on chunk c's counter (a single thread); the arrival that completes `expected` resets the counter and stores the epoch
+__device__ __forceinline__ void cm_arrive(const ChunkMap& cm, int c, int expected) {
+  int* cnt = cm.arrivals + c;
+  const int prev = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (prev == expected - 1) {
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(cm_signal(cm, c), cm.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 struct SpmmArgs {
   const int64_t* indptr;
   const int32_t* indices;
@@ -92,6 +137,7 @@ struct SpmmArgs {
   // being written by a pass of its own (glnn_act_fwd_f32's arithmetic, element for element)
   int xf_on; const float* xf_scale; const float* xf_shift; uint32_t xf_thr; uint32_t xf_seed; float xf_dscale;
   HubPlan hub;                  // n_hub == 0: hub rows are summed by the row's own workgroup (same order, same bits)
+  ChunkMap cm;                  // n == 0: off (glnn_spmm_csr_chunks_f32: the chunks of a row range in ONE launch, a completion signal per chunk)
 };
 
 // per-lane constants of the source transform: the lane's four columns
@@ -249,7 +295,8 @@ __device__ __forceinline__ EpCols load_ep_cols(const SpmmArgs& a, int col4) {
 
 // finish_row with the self row (SAGE_GCN; behind the source transform) already in hand: `s`
 template <int MODE>
-__device__ __forceinline__ void finish_row_s(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, float4 s, int col4, const EpCols& ep) {
+__device__ __forceinline__ void finish_row_s(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, float4 s, int col4, const EpCols& ep,
+                                             int64_t out_shift = 0) {
   float4 y;
   if (MODE == GLNN_AGG_SAGE_GCN) {
     const float dp1 = (float)deg + 1.0f;
@@ -270,18 +317,18 @@ __device__ __forceinline__ void finish_row_s(const SpmmArgs& a, int64_t v, int64
       yy[t] = 0.f;  // padding columns are written as zero
     }
   }
-  st4_stream(a.out + v * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
+  st4_stream(a.out + (v + out_shift) * a.ldo + col4, make_float4(yy[0], yy[1], yy[2], yy[3]));
 }
 template <int MODE, bool XF = false>
 __device__ __forceinline__ void finish_row(const SpmmArgs& a, int64_t v, int64_t deg, float4 acc, int col4, const EpCols& ep,
-                                           const XfCols& xf) {
+                                           const XfCols& xf, int64_t out_shift = 0, int64_t self_shift = 0) {
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == GLNN_AGG_SAGE_GCN) {
-    const int64_t sr = a.self_rows ? a.self_rows[v] : v;
+    const int64_t sr = a.self_rows ? a.self_rows[v] : v + self_shift;
     s = ld4(a.x_self + sr * a.ld_self + col4);
     if (XF) s = xf_apply(xf, s, (uint32_t)sr);
   }
-  finish_row_s<MODE>(a, v, deg, acc, s, col4, ep);
+  finish_row_s<MODE>(a, v, deg, acc, s, col4, ep, out_shift);
 }
 
 // ---- hub rows ---------------------------------------------------------------------------------------------------------
@@ -384,7 +431,66 @@ __device__ __forceinline__ void long_rows_role(const SpmmArgs& a, int lane, int 
   }
 }
 
-template <int LPR, int U, int MODE, bool CS, bool XF = false>
+// The long-row role of a CHUNKED launch (a.cm.n > 0): the same scan and the same per-row sums, walked chunk by chunk -- inside chunk c (rows
+// [rs, re)) workgroup b takes the sub-ranges b, b + n_long_blocks, .. of ceil((re - rs) / 512), dealt round-robin over the rows as above --
+// and when its share of a chunk is stored the workgroup arrives on the chunk's counter (every long-role workgroup arrives once per non-empty
+// chunk: expected = row workgroups of the chunk + n_long_blocks).
+template <int LPR, int U, int MODE, bool CS, bool XF>
+__device__ __forceinline__ void long_rows_role_chunks(const SpmmArgs& a, const ChunkMap& cm, int lane, int wave, int col4, bool col_ok,
+                                                      const EpCols& ep, const XfCols& xf) {
+  __shared__ int64_t s_rows[kBlock];
+  __shared__ int s_count;
+  __shared__ float4 s_part[kWavesPerBlock][64];
+#pragma unroll 1
+  for (int c = 0; c < cm.n; ++c) {
+    const int64_t rs = (int64_t)cm_tile_start(cm, c) * 32;
+    int64_t re = (int64_t)cm_tile_start(cm, c + 1) * 32;
+    if (re > a.n_dst) re = a.n_dst;
+    if (re <= rs) continue;                               // an empty chunk is never signalled
+    const int64_t out_shift = cm_pick(cm.out_shift, c), self_shift = cm_pick(cm.self_shift, c);
+    const int64_t n_sub = (re - rs + kBlock - 1) / kBlock;
+#pragma unroll 1
+    for (int64_t sub = blockIdx.x; sub < n_sub; sub += a.n_long_blocks) {
+      if (threadIdx.x == 0) s_count = 0;
+      __syncthreads();
+      const int64_t r = rs + (int64_t)threadIdx.x * n_sub + sub;
+      if (r < re && (a.indptr[r + 1] - a.indptr[r]) > kLongRow) {
+        const int slot = atomicAdd(&s_count, 1);
+        s_rows[slot] = r;
+      }
+      __syncthreads();
+      const int n_found = s_count;
+      for (int i = 0; i < n_found; ++i) {
+        const int64_t v = s_rows[i];
+        const int64_t e0 = a.indptr[v], e1 = a.indptr[v + 1];
+        float4 acc;
+        if (e1 - e0 > kHubRow)
+          acc = hub_wave_share<LPR, U, CS, XF>(a.hub, a.indices, v, e0, e1, a.x, a.ldx, col4, col_ok, a.col_scale, wave, lane, xf);
+        else
+          acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, wave, kWavesPerBlock, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
+        if (lane < LPR) s_part[wave][lane] = acc;
+        __syncthreads();
+        if (wave == 0 && lane < LPR && col_ok) {
+          float4 t = s_part[0][lane];
+#pragma unroll
+          for (int w = 1; w < kWavesPerBlock; ++w) t = add4(t, s_part[w][lane]);
+          finish_row<MODE, XF>(a, v, e1 - e0, t, col4, ep, xf, out_shift, self_shift);
+        }
+        __syncthreads();
+      }
+    }
+    // this workgroup's share of chunk c is stored (only wave 0 stores): acknowledged, then one arrival
+    if (wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        const int64_t rpb = a.rows_per_block;
+        cm_arrive(cm, c, (int)((re - rs + rpb - 1) / rpb) + a.n_long_blocks);
+      }
+    }
+  }
+}
+
+template <int LPR, int U, int MODE, bool CS, bool XF = false, bool CM = false>
 __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
   // rows wider than 256 floats (raw cora / citeseer features): blockIdx.y = the 256-column tile of this workgroup -- one launch instead
   // of one per tile (14 for citeseer's 3703 features)
@@ -406,17 +512,28 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
   if (XF) xf = load_xf_cols(a, col_ok ? col4 : 0);
 
   if ((int)blockIdx.x < a.n_long_blocks) {
-    long_rows_role<LPR, U, MODE, CS, XF>(a, lane, wave, col4, col_ok, ep, xf);
+    if constexpr (CM) long_rows_role_chunks<LPR, U, MODE, CS, XF>(a, a0.cm, lane, wave, col4, col_ok, ep, xf);
+    else long_rows_role<LPR, U, MODE, CS, XF>(a, lane, wave, col4, col_ok, ep, xf);
     return;
   }
 
   // ---- row role: one wave per row; the 8 waves of the workgroup pull its 8*kRowsPerWave rows from an LDS ticket
   //      (degrees vary by 100x: a static split leaves waves idle behind the heaviest one; measured -8 % at D=256) ----
   __shared__ int s_ticket;
-  if (threadIdx.x == 0) s_ticket = 0;
+  __shared__ int s_arrived;                            // (CM: waves of this workgroup that are done)
+  if (threadIdx.x == 0) { s_ticket = 0; if (CM) s_arrived = 0; }
   __syncthreads();
   const int64_t blk = (int64_t)blockIdx.x - a.n_long_blocks;
   const int64_t row_base = blk * a.rows_per_block;
+  int chunk = 0;
+  int64_t out_shift = 0, self_shift = 0;
+  if constexpr (CM) {                                  // (chunk boundaries are multiples of rows_per_block: the workgroup lies inside one chunk)
+#pragma unroll
+    for (int c = 1; c < GLNN_MAX_CHUNKS; ++c)
+      if (c < a0.cm.n && row_base >= (int64_t)a0.cm.tile_start[c] * 32) chunk = c;
+    out_shift = cm_pick(a0.cm.out_shift, chunk);
+    self_shift = cm_pick(a0.cm.self_shift, chunk);
+  }
 #pragma unroll 1
   while (true) {
     int lr = 0;
@@ -429,7 +546,18 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_kernel(const SpmmArgs a0) {
     const int64_t deg = e1 - e0;
     if (deg > kLongRow) continue;
     float4 acc = wave_gather_sum<LPR, U, CS, XF>(a.indices, e0, e1, 0, 1, a.x, a.ldx, col4, col_ok, a.col_scale, lane, xf);
-    if (lane < LPR && col_ok) finish_row<MODE, XF>(a, v, deg, acc, col4, ep, xf);
+    if (lane < LPR && col_ok) finish_row<MODE, XF>(a, v, deg, acc, col4, ep, xf, out_shift, self_shift);
+  }
+  if constexpr (CM) {
+    // stores acknowledged -> the eight waves count themselves in LDS -> the last one arrives for the workgroup (see chunk_arrive)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && atomicAdd(&s_arrived, 1) == kWavesPerBlock - 1) {
+      const int64_t rs = (int64_t)cm_tile_start(a0.cm, chunk) * 32;
+      int64_t re = (int64_t)cm_tile_start(a0.cm, chunk + 1) * 32;
+      if (re > a.n_dst) re = a.n_dst;
+      const int64_t rpb = a.rows_per_block;
+      cm_arrive(a0.cm, chunk, (int)((re - rs + rpb - 1) / rpb) + a.n_long_blocks);
+    }
   }
 }
 
@@ -765,22 +893,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kFusedWaves = 8;                      // one wave per 32-column panel of W (d_out <= 256)
 constexpr int kFusedBlock = 64 * kFusedWaves;       // 16-wave workgroups measured 1.5x slower (they drain badly)
 
-// Round 6: ONE launch over the CHUNKS of a rank's rows (glnn_sage_fused_chunks_f32).  The rows of chunk c -- tiles [tile_start[c],
-// tile_start[c + 1]) -- read their self rows and write their outputs at a per-chunk row shift (the chunk-major buffers of the sharded
-// forward keep a rank's chunks in separate slots), and every workgroup ARRIVES on its chunk's counter when its waves' stores are done: stores ->
-// (acknowledged by the L2) -> atomic add; the wave that completes the count stores the launch's epoch to the chunk's
-// signal word, on which the host's exchange stream waits (hipStreamWaitValue32) before it sends the chunk -- while the same launch is
-// still working on the next chunk.
-struct ChunkMap {
-  int n;
-  int tile_start[GLNN_MAX_CHUNKS + 1];
-  int64_t self_shift[GLNN_MAX_CHUNKS];                  // self row of own row v = x_self + (v + self_shift[c]) * ld_self
-  int64_t out_shift[GLNN_MAX_CHUNKS];                   // output row of own row v = v + out_shift[c] (out and out2)
-  int* arrivals;                                        // [n] counters, zero between launches (the completing wave resets its counter)
-  uint32_t* signal[GLNN_MAX_CHUNKS];
-  uint32_t epoch;
-};
-
 // How a chunk's rows become visible to the stream that waits for its signal (three forms were measured, N = 8 emulated, the 256 -> 256 -> 47
 // layer of a rank, profiles/r06_one_launch_ab.txt): a release per storing wave (buffer_wbl2 sc0 sc1 = a write-back of the XCD's whole L2,
 // 19 k of them per launch) took 3.45 ms instead of 2.55; write-through stores (sc0 sc1) + s_waitcnt cost nothing on the 47-wide rows (2.42 ms)
@@ -1053,10 +1165,16 @@ int launch_lpr(const SpmmArgs& a, int mode, hipStream_t st, int grid, int col_ti
     // measured on the products training configuration (profiles/r05_spmm_short.txt): the plain SAGE aggregation of the outermost block (5
     // in-edges per row, 400-byte rows) 365 -> 294 us; the transposed blocks (1-2 in-edges, 1 KB rows written: bandwidth-bound already) equal;
     // the tail-in-gather launches (10-15 in-edges, most of a row's edges behind the batch) slower -- those two keep the row kernel
-    if (short_rows && col_tiles == 1 && mode == GLNN_AGG_SAGE_GCN && !a.xf_on) {
+    if (short_rows && col_tiles == 1 && mode == GLNN_AGG_SAGE_GCN && !a.xf_on && a.cm.n == 0) {
       hipLaunchKernelGGL((spmm_csr_short_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false>), g, dim3(kBlock), 0, st, a);
       return glnn::check_launch("glnn_spmm_csr_f32(short rows)");
     }
+  }
+  if (a.cm.n > 0) {                      // the chunks of a row range in ONE launch (glnn_spmm_csr_chunks_f32): the plain SAGE aggregation only
+    if (mode != GLNN_AGG_SAGE_GCN || a.xf_on || col_tiles != 1)
+      return glnn::fail(GLNN_ERR_UNSUPPORTED, "glnn_spmm_csr_chunks_f32: SAGE_GCN rows of <= 256 floats without a source transform only");
+    hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false, false, true>), g, dim3(kBlock), 0, st, a);
+    return glnn::check_launch("glnn_spmm_csr_chunks_f32");
   }
   if (mode == GLNN_AGG_SAGE_GCN && a.xf_on) {
     hipLaunchKernelGGL((spmm_csr_kernel<LPR, U, GLNN_AGG_SAGE_GCN, false, true>), g, dim3(kBlock), 0, st, a);
@@ -1109,11 +1227,35 @@ static int hub_plan_of(const glnn_hub_plan* plan, int d, HubPlan* h, int* n_seg,
   return GLNN_OK;
 }
 
+// glnn_chunk_signals -> the kernels' ChunkMap (tile = 32 rows); chunks == NULL: off
+static int fill_chunk_map(const glnn_chunk_signals* chunks, int64_t n_dst, ChunkMap* cm, const char* who) {
+  *cm = ChunkMap{};
+  if (!chunks) return GLNN_OK;
+  const int nc = chunks->n_chunks;
+  GLNN_REQUIRE(nc >= 1 && nc <= GLNN_MAX_CHUNKS && chunks->arrivals && chunks->row_start[0] == 0 && chunks->row_start[nc] >= n_dst,
+               "%s: 1..%d chunks covering rows [0, n_dst), arrival counters", who, GLNN_MAX_CHUNKS);
+  const int64_t tiles = (n_dst + 31) / 32;
+  GLNN_REQUIRE(tiles < ((int64_t)1 << 31), "%s: n_dst too large for one launch", who);
+  cm->n = nc; cm->arrivals = chunks->arrivals; cm->epoch = chunks->epoch;
+  for (int c = 0; c < nc; ++c) {
+    const int64_t r0 = chunks->row_start[c], r1 = chunks->row_start[c + 1];
+    GLNN_REQUIRE(r0 % 32 == 0 && r1 >= r0 && chunks->signal[c] && chunks->self_row[c] >= 0 && chunks->out_row[c] >= 0,
+                 "%s: chunk %d: row_start must be an ascending multiple of 32, signal / rows set", who, c);
+    cm->tile_start[c] = (int)(r0 / 32 < tiles ? r0 / 32 : tiles);
+    cm->self_shift[c] = chunks->self_row[c] - r0;
+    cm->out_shift[c] = chunks->out_row[c] - r0;
+    cm->signal[c] = chunks->signal[c];
+  }
+  for (int c = nc; c <= GLNN_MAX_CHUNKS; ++c) cm->tile_start[c] = (int)tiles;
+  return GLNN_OK;
+}
+
 static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
                      const float* x, int64_t ldx, int d, int mode, const float* row_scale,
                      const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
                      const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
-                     void* stream, const glnn::SourceTail* tail, const glnn_hub_plan* plan = nullptr, int64_t nnz_hint = -1) {
+                     void* stream, const glnn::SourceTail* tail, const glnn_hub_plan* plan = nullptr, int64_t nnz_hint = -1,
+                     const glnn_chunk_signals* chunks = nullptr) {
   if (n_dst == 0) return GLNN_OK;                       // nothing to do (empty tensors carry null pointers)
   GLNN_REQUIRE(indptr && x && out, "glnn_spmm_csr_f32: null pointer");   // indices may be NULL iff the graph has no edges
   GLNN_REQUIRE(n_dst >= 0 && n_src >= 0 && n_src < (int64_t)1 << 31, "glnn_spmm_csr_f32: bad n_dst/n_src");
@@ -1153,6 +1295,11 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
     a.xf_scale = tail ? tail->scale : nullptr; a.xf_shift = tail ? tail->shift : nullptr;
     a.xf_thr = tail ? glnn::drop_threshold(tail->drop_p) : 0u; a.xf_seed = tail ? tail->drop_seed : 0u;
     a.xf_dscale = tail ? 1.0f / (1.0f - tail->drop_p) : 1.f;
+    {
+      GLNN_REQUIRE(!chunks || (d <= 256 && mode == GLNN_AGG_SAGE_GCN && !tail), "glnn_spmm_csr_chunks_f32: SAGE_GCN rows of <= 256 floats only");
+      const int rcm = fill_chunk_map(chunks, n_dst, &a.cm, "glnn_spmm_csr_chunks_f32");
+      if (rcm != GLNN_OK) return rcm;
+    }
     int hub_segs = 0;
     {
       const int rch = hub_plan_of(d <= 256 ? plan : nullptr, d, &a.hub, &hub_segs, "glnn_spmm_csr_f32");      // (column-tiled rows: no plan)
@@ -1172,6 +1319,15 @@ static int spmm_impl(const int64_t* indptr, const int32_t* indices, int64_t n_ds
     int64_t rpw = n_dst / (2048 * kWavesPerBlock);
     if (rpw < 1) rpw = 1;
     if (rpw > kRowsPerWave) rpw = kRowsPerWave;
+    if (a.cm.n > 0) {
+      // no row workgroup may straddle two chunks: rows per workgroup = the largest power of two <= the usual count that divides every
+      // chunk's first row (chunks start at multiples of 32: 4 rows per wave always does)
+      int64_t p = 1;
+      while (p * 2 <= rpw) p *= 2;
+      for (int c = 1; c < a.cm.n; ++c)
+        while (p > 1 && ((int64_t)a.cm.tile_start[c] * 32) % (kWavesPerBlock * p) != 0) p /= 2;
+      rpw = p;
+    }
     const int64_t rows_per_block = kWavesPerBlock * rpw;
     a.rows_per_block = (int)rows_per_block;
     const int64_t row_blocks = (n_dst + rows_per_block - 1) / rows_per_block;
@@ -1208,6 +1364,16 @@ extern "C" int glnn_spmm_csr_plan_f32(const int64_t* indptr, const int32_t* indi
                                       const glnn_hub_plan* plan, void* stream) {
   return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, row_scale, col_scale, x_self, ld_self, self_rows, ep_scale, ep_shift, relu,
                    out, ldo, stream, nullptr, plan);
+}
+
+extern "C" int glnn_spmm_csr_chunks_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst, int64_t n_src,
+                                        const float* x, int64_t ldx, int d, int mode, const float* row_scale,
+                                        const float* col_scale, const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                                        const float* ep_scale, const float* ep_shift, int relu, float* out, int64_t ldo,
+                                        const glnn_hub_plan* plan, const glnn_chunk_signals* chunks, void* stream) {
+  GLNN_REQUIRE(chunks, "glnn_spmm_csr_chunks_f32: chunks is NULL (use glnn_spmm_csr_plan_f32)");
+  return spmm_impl(indptr, indices, n_dst, n_src, x, ldx, d, mode, row_scale, col_scale, x_self, ld_self, self_rows, ep_scale, ep_shift, relu,
+                   out, ldo, stream, nullptr, plan, -1, chunks);
 }
 
 extern "C" int glnn_hub_row_threshold(void) { return kHubRow; }
@@ -1340,23 +1506,9 @@ static int sage_fused_impl(const int64_t* indptr, const int32_t* indices, int64_
   a.ep_shift = ep_shift; a.relu = relu; a.out = out; a.ldo = ldo;
   a.w2_packed = w2_packed; a.d_out2 = w2_packed ? d_out2 : 0; a.kgroups2 = w2_packed ? (d_out + 7) / 8 : 0; a.out2 = out2; a.ldo2 = ldo2;
   a.tile_order = tile_order;
-  a.cm = ChunkMap{};
-  if (chunks) {
-    const int nc = chunks->n_chunks;
-    GLNN_REQUIRE(nc >= 1 && nc <= GLNN_MAX_CHUNKS && chunks->arrivals && chunks->row_start[0] == 0 && chunks->row_start[nc] >= n_dst,
-                 "glnn_sage_fused_chunks_f32: 1..%d chunks covering rows [0, n_dst), arrival counters", GLNN_MAX_CHUNKS);
-    const int64_t tiles = (n_dst + 31) / 32;
-    a.cm.n = nc; a.cm.arrivals = chunks->arrivals; a.cm.epoch = chunks->epoch;
-    for (int c = 0; c < nc; ++c) {
-      const int64_t r0 = chunks->row_start[c], r1 = chunks->row_start[c + 1];
-      GLNN_REQUIRE(r0 % 32 == 0 && r1 >= r0 && chunks->signal[c] && chunks->self_row[c] >= 0 && chunks->out_row[c] >= 0,
-                   "glnn_sage_fused_chunks_f32: chunk %d: row_start must be an ascending multiple of 32, signal / rows set", c);
-      a.cm.tile_start[c] = (int)(r0 / 32 < tiles ? r0 / 32 : tiles);
-      a.cm.self_shift[c] = chunks->self_row[c] - r0;
-      a.cm.out_shift[c] = chunks->out_row[c] - r0;
-      a.cm.signal[c] = chunks->signal[c];
-    }
-    for (int c = nc; c <= GLNN_MAX_CHUNKS; ++c) a.cm.tile_start[c] = (int)tiles;
+  {
+    const int rcm = fill_chunk_map(chunks, n_dst, &a.cm, "glnn_sage_fused_chunks_f32");
+    if (rcm != GLNN_OK) return rcm;
   }
   // one 32-row sub-tile per workgroup (RT = 1).  RT = 2 (64-row tiles, every W fragment load feeding two MFMA chains) was measured
   // 1.5x slower in round 1 -- big workgroups drain badly -- and its instantiations were removed in round 3

@@ -32,7 +32,7 @@ class RowShards:
         layout "cm"   chunk-major slots     [chunk][rank][cr]: what the chunked, overlapped exchange produces
     Column indices are relabelled ONCE per layout (ShardedTeacher._cols); activations are never re-packed."""
 
-    CHUNK_QUANTUM = 32
+    CHUNK_QUANTUM = 128      # chunk sizes are whole 32-row tiles of the fused kernel AND whole 128-row workgroups of the stand-alone aggregation
 
     def __init__(self, n, world, rank, chunks=1, bounds=None, chunk_sizes=None, kinds=None):
         """chunk_sizes (round 6): rows per chunk of a slot, UNEQUAL chunks allowed (sum >= the longest range) -- the chunk-major layout is
@@ -530,14 +530,17 @@ class ShardedTeacher:
         return (ONE_LAUNCH and x.is_cuda and hasattr(be, "ChunkSignals") and hasattr(be, "sage_fused") and 1 <= c1 - c0 <= be.ChunkSignals.MAX
                 and d_in <= 256 and d_mid <= 256 and d_out2 <= 256 and all(o % 32 == 0 for o in sh.coff[:-1]) and sh.chunk_rows(c0)[1] > 0)
 
-    def _launch_chunks(self, c0, c1, x, layout, w, tail, out=None, w_next=None, out_next=None):
-        """ONE fused launch over the own rows of chunks [c0, c1): self rows read from `x` (in `layout`), outputs written to the chunks' slots of
-        the chunk-major buffers `out` / `out_next`; tile order = the chunks' heaviest-first orders one after the other (completion follows
-        it).  Returns (signals, exchange stream, launch stream): `_after_signal` issues a chunk's exchange behind its signal."""
+    def _launch_chunks(self, c0, c1, x, layout, w, tail, out=None, w_next=None, out_next=None, agg_out=None):
+        """ONE launch over the own rows of chunks [c0, c1): self rows read from `x` (in `layout`), outputs written to the chunks' slots of
+        the chunk-major buffers -- the fused aggregate + project kernel into `out` / `out_next` (tile order = the chunks' heaviest-first
+        orders one after the other; completion follows it), or, with `agg_out`, the stand-alone aggregation into that buffer (w, tail
+        unused).  Returns (signals, exchange stream, launch stream): `_after_signal` issues a chunk's exchange behind its signal."""
         be, g, sh, dev = self.be, self.g, self.sh, x.device
         off0 = sh.coff[c0]
         nr = max(0, min(sh.rows, sh.coff[c1]) - off0)
-        key = ("signals", c0, c1)
+        key = ("signals", c0, c1, agg_out is not None)
+        if key not in self._col_cache and agg_out is not None:
+            self._col_cache[key] = (be.ChunkSignals([sh.coff[c] - off0 for c in range(c0, c1 + 1)], dev), None)
         if key not in self._col_cache:
             parts = []
             for c in range(c0, c1):
@@ -554,17 +557,20 @@ class ShardedTeacher:
         cur = torch.cuda.current_stream(dev)
         side = self.__dict__.setdefault("_exchange_stream", torch.cuda.Stream(device=dev))
         side.wait_stream(cur)
-        kw = {"tile_order": order}
-        if w.shape[1] > 128:                               # (the hub plan where it was measured to pay: see _kw)
+        kw = {} if agg_out is not None else {"tile_order": order}
+        if agg_out is not None or w.shape[1] > 128:        # (the hub plan where it was measured to pay: see _kw)
             hub = self._hub(off0, nr)
             if hub is not None:
                 kw["hub"] = hub
         if self.chunk_ready is not None:
             self._t0 = torch.cuda.Event(enable_timing=True)
             self._t0.record(cur)
-        es, eh, rl = tail
-        be.sage_fused(g.indptr[off0:off0 + nr + 1], self._cols(layout), x, nr, w, ep_scale=es, ep_shift=eh, relu=rl, x_self=x, out=out, w_next=w_next,
-                      out_next=out_next, want_out=out is not None, chunks=desc, **kw)
+        if agg_out is not None:
+            be.spmm(g.indptr[off0:off0 + nr + 1], self._cols(layout), x, nr, be.AGG_SAGE_GCN, out=agg_out, x_self=x, chunks=desc, **kw)
+        else:
+            es, eh, rl = tail
+            be.sage_fused(g.indptr[off0:off0 + nr + 1], self._cols(layout), x, nr, w, ep_scale=es, ep_shift=eh, relu=rl, x_self=x, out=out,
+                          w_next=w_next, out_next=out_next, want_out=out is not None, chunks=desc, **kw)
         if self.chunk_ready is not None:
             self._t1 = torch.cuda.Event(enable_timing=True)
             self._t1.record(cur)
@@ -623,7 +629,18 @@ class ShardedTeacher:
             self._launch_done(side, cur)
         else:
             nw = 0
-        for c in range(nw, sh.chunks):
+        n_first = nw                                            # the "N" chunks behind them: ONE launch of the stand-alone aggregation, likewise
+        if (nw < sh.chunks and all(k == "N" for k in kinds[nw:]) and x.shape[1] <= 256 and getattr(be, "SELF_ROWS", False)
+                and self._one_launch_ok(x, nw, sh.chunks, d_in, d_out)):
+            sig, side, cur = self._launch_chunks(nw, sh.chunks, x, layout, w, tail, agg_out=agg)
+            for c in range(nw, sh.chunks):
+                b0, bn = sh.chunk_block(c)
+                p0, cs = sh.chunk_slot(c), sh.csize[c]
+                works.append(self._after_signal(sig, c - nw, side, lambda: _all_gather_block(abase[b0:b0 + bn], abase[p0:p0 + cs], sh, self.group,
+                                                                                             ("agg", l), c)))
+            self._launch_done(side, cur)
+            n_first = sh.chunks
+        for c in range(n_first, sh.chunks):
           with self._chunk_stream(c, x.device):
               off, nr = sh.chunk_rows(c)
               b0, bn = sh.chunk_block(c)

@@ -199,8 +199,10 @@ def hub_plan(indptr, n_dst):
 
 
 def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_scale=None, ep_shift=None,
-         relu=False, out=None, x_self=None, self_rows=None, hub=None):
+         relu=False, out=None, x_self=None, self_rows=None, hub=None, chunks=None):
     """K1/K2 glnn_spmm_csr_f32.  x: [n_src, d] feature tensor (see as_feat); returns [n_dst, d].
+    chunks (ChunkSignals.launch(...), SAGE_GCN, d <= 256): ONE launch over the chunks of the row range -- `out` (and `x_self`, unless
+    self_rows is given) are then WHOLE buffers addressed through the descriptor's per-chunk rows, and every chunk signals its completion.
     x_self (SAGE_GCN only): the destination rows' own features, default x[:n_dst] (a row shard passes its slice).
     self_rows (SAGE_GCN only, int64 [n_dst]): destination v's own row is x_self[self_rows[v]] (global-id blocks).
     hub (optional HubPlan of (indptr, n_dst)): the hub rows' segments are gathered by one workgroup each first (same result bit for bit)."""
@@ -210,8 +212,10 @@ def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_sca
         raise ValueError("spmm: self_rows must be a contiguous int64 vector of n_dst row ids")
     if x_self is None:
         x_self = x
-    elif (self_rows is None and x_self.shape[0] < n_dst) or x_self.shape[1] != x.shape[1]:
+    elif (self_rows is None and chunks is None and x_self.shape[0] < n_dst) or x_self.shape[1] != x.shape[1]:
         raise ValueError("spmm: x_self must hold n_dst rows of the same width as x")
+    if chunks is not None and (out is None or mode != AGG_SAGE_GCN):
+        raise ValueError("spmm(chunks=...): SAGE_GCN with the whole output buffer given (it is addressed by the chunks' rows)")
     n_src, d = x.shape
     if indptr.dtype != torch.int64 or indices.dtype != torch.int32:
         raise ValueError("spmm: indptr must be int64 and indices int32")
@@ -220,19 +224,21 @@ def spmm(indptr, indices, x, n_dst, mode, row_scale=None, col_scale=None, ep_sca
     _mat(out, "spmm out")
     with _Timed("spmm", d=d, n_dst=n_dst, mode=mode):
         rc = _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out,
-                        as_feat(x_self), self_rows, hub)
+                        as_feat(x_self), self_rows, hub, chunks)
     _lib.check(rc, "glnn_spmm_csr_f32")
     return out
 
 
 def _spmm_call(indptr, indices, n_dst, n_src, x, d, mode, row_scale, col_scale, ep_scale, ep_shift, relu, out, x_self,
-               self_rows=None, hub=None):
+               self_rows=None, hub=None, chunks=None):
     args = (_p(indptr), _p(indices), n_dst, n_src, _p(x), _ld(x), d, mode,
             _p(_vec(row_scale, n_dst, "row_scale")), _p(_vec(col_scale, n_src, "col_scale")),
             _p(x_self) if mode == AGG_SAGE_GCN else None, _ld(x_self), _p(self_rows),
             _p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0,
             _p(out), _ld(out))
     plan = hub.desc_for(d, x.device) if hub is not None else None
+    if chunks is not None:
+        return _lib.lib().glnn_spmm_csr_chunks_f32(*args, plan, ctypes.byref(chunks), _stream())
     if plan is not None:
         return _lib.lib().glnn_spmm_csr_plan_f32(*args, plan, _stream())
     return _lib.lib().glnn_spmm_csr_f32(*args, _stream())

@@ -174,6 +174,17 @@ GLNN_API int glnn_sage_fused_chunks_f32(const int64_t* indptr, const int32_t* in
                                         float* out, int64_t ldo, const float* w2_packed, int d_out2,
                                         float* out2, int64_t ldo2, const int32_t* tile_order,
                                         const glnn_hub_plan* plan, const glnn_chunk_signals* chunks, void* stream);
+/* The stand-alone SAGE-"gcn" aggregation in the same form (glnn_spmm_csr_plan_f32 + chunks; mode = GLNN_AGG_SAGE_GCN, d <= 256): the self
+ * row of row v of chunk c is x_self[self_rows ? self_rows[v] : self_row[c] + v - row_start[c]], its output row out_row[c] + v - row_start[c].
+ * Rows of more than the long-row threshold are summed by the launch's long-row workgroups chunk by chunk; a chunk signals when its row
+ * workgroups AND every long-row workgroup's share of it are stored. */
+GLNN_API int glnn_spmm_csr_chunks_f32(const int64_t* indptr, const int32_t* indices, int64_t n_dst,
+                                      int64_t n_src, const float* x, int64_t ldx, int d, int mode,
+                                      const float* row_scale, const float* col_scale,
+                                      const float* x_self, int64_t ld_self, const int64_t* self_rows,
+                                      const float* ep_scale, const float* ep_shift, int relu, float* out,
+                                      int64_t ldo, const glnn_hub_plan* plan, const glnn_chunk_signals* chunks,
+                                      void* stream);
 /* A 32-bit signal word a stream can wait on (hipExtMallocWithFlags(hipMallocSignalMemory)), initialised to 0; its current value;
  * "the next operation of `stream` starts when *signal >= value" (hipStreamWaitValue32, GTE) -- followed by an empty kernel on `stream`,
  * whose end-of-kernel release writes back the L2s in which the signalled rows may still sit. */

@@ -182,12 +182,12 @@ def test_bench_xl_is_a_three_layer_forward_with_emulated_peers(l1):
     hbm = [l for l in out["layers"] if l.get("bound") == "hbm"]
     assert len(hbm) == 3 and all(l["ms"] > 0 and l["achieved"] > 0 for l in hbm)
     v = out["verify"]
-    # (narrow: 4 chunks x (aggregate, replicated projection) + one fused launch over the chunks + layer 3; wide: one launch per layer)
-    assert v["repeat_forward_bit_equal"] and all(l["max_abs_diff_vs_fp64"] <= 1e-4 for l in v["launches"]) and len(v["launches"]) >= (3 if l1 == "wide" else 8)
+    # (narrow: one aggregation launch over the 4 chunks + 4 replicated projections + one fused launch over the chunks + layer 3; wide: one launch per layer)
+    assert v["repeat_forward_bit_equal"] and all(l["max_abs_diff_vs_fp64"] <= 1e-4 for l in v["launches"]) and len(v["launches"]) == (3 if l1 == "wide" else 7)
     assert all(l.get("row_range_relaunch_bit_equal", True) for l in v["launches"])
     pf = out["per_forward"]
     r4 = lambda d: (d + 3) // 4 * 4
-    n_pad = 8 * 4 * (-(-(-(-cfg["rows_per_gpu"] // 4)) // 32) * 32)          # 4 chunks per slot, each a whole number of 32-row tiles
+    n_pad = 8 * 4 * (-(-(-(-cfg["rows_per_gpu"] // 4)) // 128) * 128)        # 4 chunks per slot, each a whole number of 128-row workgroups (RowShards.CHUNK_QUANTUM)
     want = 4e-9 * n_pad * ((256 if l1 == "wide" else 128) + r4(47))
     assert abs(pf["GB_received_per_rank"] - want) < 1e-6 * max(1.0, want) + 1e-9, (pf, want)
     assert len(out["_compact"]["layers"]) == len(out["layers"])

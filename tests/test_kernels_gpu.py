@@ -224,6 +224,53 @@ def test_sage_fused_one_launch_over_chunks_equals_the_chunk_launches_and_signals
         ops.sage_fused(ip, ix, x, n, w, chunks=sig.launch(slots, slots, n))      # the whole buffers must be given
 
 
+@pytest.mark.parametrize("d,with_plan", [(100, False), (100, True), (47, False), (256, True)])
+def test_spmm_one_launch_over_chunks_equals_the_chunk_launches_and_signals_every_chunk(d, with_plan):
+    """glnn_spmm_csr_chunks_f32 (round 6): the stand-alone SAGE aggregation over the chunks of a row range in ONE launch -- row workgroups
+    that never straddle a chunk, the long-row role walking the chunks in order, outputs (and self rows) at the chunks' rows of whole
+    buffers -- gives the bits of one launch per chunk, with and without a hub plan; a second stream held by the chunk's signal copies the
+    chunk out while the launch may still run.  Two epochs; an empty chunk is never signalled."""
+    from glnn_amd import ops
+    n = 30011
+    indptr, indices = random_graph(n, 16, seed=d, power=0.9, isolated=9, hub=7000)
+    assert (np.diff(indptr) > 128).sum() > 20                      # long rows in every chunk, one hub row
+    rs = np.random.RandomState(d)
+    ip, ix = g2d(indptr, indices)
+    x = dev(rs.standard_normal((n, d)).astype(np.float32))
+    row_start = [0, 9600, 9600 + 10112, 9600 + 10112 + 12000, 9600 + 10112 + 12000 + 32]     # the last chunk is empty (behind n)
+    assert row_start[3] >= n
+    out_slots, self_slots = [50000, 1024, 20000, 70000], [30016, 64, 50048, 90000]
+    xs = ops.feat_empty(100000, d, x.device, zero=True)
+    want = ops.feat_empty(100000, d, x.device, zero=True)
+    for c in range(3):
+        r0, r1 = row_start[c], min(row_start[c + 1], n)
+        xs[self_slots[c]:self_slots[c] + r1 - r0] = x[r0:r1]
+        hub = ops.hub_plan(ip[r0:r1 + 1], r1 - r0) if with_plan else None
+        ops.spmm(ip[r0:r1 + 1], ix, x, r1 - r0, ops.AGG_SAGE_GCN, out=want[out_slots[c]:out_slots[c] + r1 - r0], x_self=x[r0:r1],
+                 **({"hub": hub} if hub is not None else {}))
+    hub = ops.hub_plan(ip, n) if with_plan else None
+    assert not with_plan or hub is not None
+    sig = ops.ChunkSignals(row_start, x.device)
+    side = torch.cuda.Stream()
+    for epoch in (1, 2):
+        got = ops.feat_empty(100000, d, x.device, zero=True)
+        early = ops.feat_empty(100000, d, x.device, zero=True)
+        torch.cuda.synchronize()
+        ops.spmm(ip, ix, x, n, ops.AGG_SAGE_GCN, out=got, x_self=xs, chunks=sig.launch(self_slots, out_slots, n), **({"hub": hub} if hub is not None else {}))
+        for c in range(3):
+            sig.wait(side, c)
+            with torch.cuda.stream(side):
+                nr = min(row_start[c + 1], n) - row_start[c]
+                early[out_slots[c]:out_slots[c] + nr].copy_(got[out_slots[c]:out_slots[c] + nr])
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(early, want)
+        assert [sig.value(c) for c in range(4)] == [epoch, epoch, epoch, 0]
+        assert int(sig.arrivals.abs().sum()) == 0
+    with pytest.raises(ValueError):
+        ops.spmm(ip, ix, x, n, ops.AGG_SUM, out=got, chunks=sig.launch(self_slots, out_slots, n))
+
+
 def test_degrees():
     from glnn_amd import ops
     n = 1000
