@@ -441,6 +441,7 @@ __device__ __forceinline__ void long_rows_role_chunks(const SpmmArgs& a, const C
   __shared__ int64_t s_rows[kBlock];
   __shared__ int s_count;
   __shared__ float4 s_part[kWavesPerBlock][64];
+  int64_t dealt = 0;
 #pragma unroll 1
   for (int c = 0; c < cm.n; ++c) {
     const int64_t rs = (int64_t)cm_tile_start(cm, c) * 32;
@@ -449,8 +450,12 @@ __device__ __forceinline__ void long_rows_role_chunks(const SpmmArgs& a, const C
     if (re <= rs) continue;                               // an empty chunk is never signalled
     const int64_t out_shift = cm_pick(cm.out_shift, c), self_shift = cm_pick(cm.self_shift, c);
     const int64_t n_sub = (re - rs + kBlock - 1) / kBlock;
+    // the sub-ranges are dealt on round-robin ACROSS the chunks (a chunk of fewer sub-ranges than long-role workgroups would otherwise keep
+    // the same low-numbered workgroups busy chunk after chunk)
+    const int64_t first = ((int64_t)blockIdx.x - dealt % a.n_long_blocks + a.n_long_blocks) % a.n_long_blocks;
+    dealt += n_sub;
 #pragma unroll 1
-    for (int64_t sub = blockIdx.x; sub < n_sub; sub += a.n_long_blocks) {
+    for (int64_t sub = first; sub < n_sub; sub += a.n_long_blocks) {
       if (threadIdx.x == 0) s_count = 0;
       __syncthreads();
       const int64_t r = rs + (int64_t)threadIdx.x * n_sub + sub;
