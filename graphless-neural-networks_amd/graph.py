@@ -193,11 +193,14 @@ class FullNeighborLoader:
             raise RuntimeError("FullNeighborLoader: blocks are built on the GPU (move the graph with g.to(device))")
         n = g.n_dst
         bounds = list(range(0, n, self.batch_size)) + [n]
-        offs = g.indptr[torch.tensor(bounds, device=g.device)].tolist()          # ONE read-back for the whole sweep
+        key = ("loader_offs", self.batch_size)
+        if key not in g._cache:                                                   # ONE read-back per (graph, batch size): a sweep per layer re-uses it
+            g._cache[key] = g.indptr[torch.tensor(bounds, device=g.device)].tolist()
+        offs = g._cache[key]
         for b in range(len(bounds) - 1):
             s, e = bounds[b], bounds[b + 1]
-            output_nodes = torch.arange(s, e, device=g.device)
             if getattr(self, "global_blocks", False):
+                output_nodes = None             # (= arange(s, e) = block.dst_range: not materialised -- one launch and one allocation per chunk saved)
                 # engine mode (round 6, set by SAGE.inference for its sweep): the chunk's block IS rows [s, e) of the resident CSR -- absolute
                 # row offsets into the one indices array, GLOBAL source ids -- so nothing is built, relabelled or gathered: the consumer's
                 # aggregation reads its source rows straight from the layer's input matrix (input_nodes = None)
@@ -207,6 +210,7 @@ class FullNeighborLoader:
                 block._cache["tile_order"] = None      # (a 4096-row launch: the order would cost six small launches per chunk)
                 yield None, output_nodes, [block]
                 continue
+            output_nodes = torch.arange(s, e, device=g.device)
             indptr, indices, _, input_nodes, nnz, n_src = ops.block_build(output_nodes, g.indptr, g.indices, nnz_cap=offs[b + 1] - offs[b],
                                                                           n_nodes=g.n_src)
             block = CSRGraph(indptr, indices, e - s, n_src)
