@@ -36,7 +36,7 @@ def compact(r, detail_path):
     c = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                 "dtype", "data", "verified", "rccl_ranks", "backend")}
     cfg = r.get("config", {})
-    c["config"] = {k: _short(v, 200) for k, v in cfg.items() if k in ("workload", "nodes", "nnz", "edges_aggregated_per_step", "scale", "exchange",
+    c["config"] = {k: _short(v, 200) for k, v in cfg.items() if k in ("workload", "nodes", "nnz", "graph_fingerprint", "edges_aggregated_per_step", "scale", "exchange",
                                                                        "layer1_exchange", "partition", "parallelism", "rows_per_gpu", "nnz_per_gpu",
                                                                        "nodes_total", "shards", "rank_timed", "link_GBps_assumed")}
     v = r.get("verify")

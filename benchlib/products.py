@@ -79,6 +79,8 @@ def run_products(args, rank, world, dev, barrier):
     else:
         g = data.make_graph(C.GRAPH, seed=0, device=dev, scale=args.scale)
     n, nnz = g.n_dst, g.num_edges()
+    # which graph this is (the seeded generator changed once, in round 5: numbers of different rounds are comparable only under one fingerprint)
+    fingerprint = f"{n}-{nnz}-{int(g.indices[::max(1, nnz // 65536)].long().sum().item()):x}-{int(g.indptr[::max(1, n // 65536)].sum().item()):x}"
     feats, labels, out_t, _ = data.make_node_data(C.GRAPH, seed=0, device=dev, n=n)
     partition_s = None
     if world > 1 and args.partition == "lp":      # one-time preparation, outside every timed region (identical on every rank)
@@ -379,7 +381,7 @@ def run_products(args, rank, world, dev, barrier):
         "devices": placement,
         "config": {"workload": f"{C.GRAPH}-shaped SAGE teacher forward (3 layers {'-'.join(map(str, C.SAGE_DIMS))}, BN, layer-wise "
                                f"full-neighbour inference, reference models.py:121-148) + {C.STUDENT['name']} student KL distillation step",
-                   "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward,
+                   "nodes": n, "nnz": nnz, "edges_aggregated_per_step": edges_per_forward, "graph_fingerprint": fingerprint,
                    "graph": "seeded power-law multigraph, random node order" if args.locality == 0 else
                             f"community-structured random graph (64 communities, {args.locality:.2f} of the edges inside), "
                             + ("node ids shuffled" if args.shuffle_ids else "community node order"),

@@ -285,15 +285,18 @@ class NodeDataLoader:
             block.gindices, block.dst_nodes = gidx, seeds       # the same edges with global source ids (TeacherEngine, layer 0)
         return input_nodes, block
 
-    def _batch(self, b, idx, fanouts, epoch=None):
+    def _batch(self, b, idx, fanouts, epoch=None, global_first=None):
+        """global_first: the value of `global_first_block` the ITERATOR was created under (snapshotted by __iter__, like `epoch`): a worker
+        thread that is still building batches when the consumer flips the flag back keeps building the shape its consumer expects."""
         dev = self.g.device
         epoch = self._epoch if epoch is None else epoch
+        gfb = self.global_first_block if global_first is None else global_first
         output_nodes = self.nids[idx].to(dev) if self.nids.device != dev else self.nids[idx.to(dev)]
         seeds, blocks = output_nodes, []
         for l in reversed(range(len(fanouts))):          # last layer's block is sampled first
             rng = (self._seed * 1000003 + epoch * 7919 + b * 31 + l) & 0xFFFFFFFF
-            seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0), global_only=(l == 0 and self.global_first_block))
-            if l > 0 and self.global_first_block and blk.indptr.is_cuda:
+            seeds, blk = self._block(seeds, fanouts[l], rng, want_global=(l == 0), global_only=(l == 0 and gfb))
+            if l > 0 and gfb and blk.indptr.is_cuda:
                 # the consumer is TeacherEngine (train_sage): what its backward needs of an inner block -- the block transposed with a self
                 # entry per destination, 1 / (in-degree + 1) -- depends on the block alone, so it is built HERE, beside the previous step,
                 # instead of by ten launches on the step's own stream (the same two library calls: the same bits)
@@ -310,6 +313,7 @@ class NodeDataLoader:
         the previous batch -- instead of draining it at every read-back (what the CPU workers of dgl's NodeDataLoader do
         for the reference, here as stream-level concurrency on the GPU)."""
         self._epoch += 1
+        gfb = bool(self.global_first_block)      # snapshot: this iterator's batches keep the shape its consumer asked for (see _batch)
         n = self.nids.numel()
         from . import ops
         order = ops.randperm_cpu(n) if self.shuffle else torch.arange(n)
@@ -319,7 +323,7 @@ class NodeDataLoader:
             chunks.pop()
         if not self.g.indptr.is_cuda or not self.prefetch:
             for b, idx in enumerate(chunks):
-                yield self._batch(b, idx, fanouts)
+                yield self._batch(b, idx, fanouts, global_first=gfb)
             return
         main = torch.cuda.current_stream(self.g.device)
         if self._side is None:
@@ -339,7 +343,7 @@ class NodeDataLoader:
 
         def build(b):
             with torch.cuda.stream(side):
-                batch = self._batch(b, chunks[b], fanouts, epoch)
+                batch = self._batch(b, chunks[b], fanouts, epoch, gfb)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return batch, ev

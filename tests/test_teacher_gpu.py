@@ -199,11 +199,11 @@ def test_loader_worker_thread_stops_on_early_exit_and_hands_over_exceptions():
     assert not alive()
     real, calls = ld._batch, []
 
-    def failing(b, idx, fanouts, epoch=None):
+    def failing(b, idx, fanouts, *rest):
         calls.append(b)
         if b == 2:
             raise RuntimeError("boom in batch 2")
-        return real(b, idx, fanouts, epoch)
+        return real(b, idx, fanouts, *rest)
 
     ld._batch = failing
     seen = 0
