@@ -172,7 +172,16 @@ def run_products(args, rank, world, dev, barrier):
             shards = RowShards(n, world, rank, chunks=1, bounds=base_bounds)
             return ShardedTeacher(teacher.encoder, shard_graph, shards, ops, widening_exchange="narrow")
 
+        as_asked = (args.layer1_exchange, args.exchange, args.mixed_fraction)
+
+        def build_per_chunk():
+            """rung 1: the same forms with ONE LAUNCH PER CHUNK (no completion signals, no hipStreamWaitValue32): what rounds 4-5 shipped"""
+            gdist.ONE_LAUNCH = False
+            args.layer1_exchange, args.exchange, args.mixed_fraction = as_asked
+            return build_first()
+
         rungs = [("as configured", build_first),
+                 ("as configured, one launch per chunk (no completion signals)", build_per_chunk),
                  ("synchronous un-chunked in-place all-gather", lambda: build_sync(False)),
                  ("synchronous out-of-place (list form) all-gather", lambda: build_sync(True))]
         shard_rows, shard_nnz = shards.rows, int(shard_graph.num_edges())

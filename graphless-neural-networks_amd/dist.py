@@ -259,7 +259,7 @@ def record_truth(encoder, graph, x, be):
 # The bench's fail-safe ladder (benchlib/products.py): SAFE_LIST_FORM = True makes every RCCL all-gather take the out-of-place list
 # form (what the gloo tests run) instead of the in-place all_gather_into_tensor on a slab of the receive buffer; INJECT_FAIL[kind] = n
 # makes the next n collectives of that kind raise (tests only: "async" = the chunked overlapped all-gathers, "sync" = all_gather_rows,
-# "grad_overlap" / "grad" = the student's gradient all-reduces, "probe" = the link probe).
+# "grad_overlap" / "grad" = the student's gradient all-reduces, "probe" = the link probe, "signal" = the wait for a chunk's completion signal).
 SAFE_LIST_FORM = False
 INJECT_FAIL = {}
 
@@ -580,6 +580,7 @@ class ShardedTeacher:
         """Issue chunk k's exchange (`issue()` -> waiter) behind the chunk's completion signal: the exchange stream is held by the signal, the
         collective is enqueued from it.  (Emulated peers: the fills stay on the launch's own stream -- the model's kernel times are taken
         without them -- but the signal is still waited for, and `chunk_ready` records when it fired.)"""
+        _inject("signal")
         if not sig.empty(k):
             sig.wait(side, k)
         if self.chunk_ready is not None:

@@ -132,6 +132,19 @@ def test_bench_two_ranks_survive_failing_collectives():
     assert c["teacher_rung"] == lad["teacher_rung"] and c["student_rung"] == lad["student_rung"] and c["errors"]
 
 
+def test_bench_two_ranks_fall_back_to_one_launch_per_chunk_when_the_signals_fail():
+    """Round 6: the chunked layers are ONE launch with a completion signal per chunk (hipStreamWaitValue32 on the exchange stream).  If that
+    fails on a node (injected: every wait raises), the ladder's next rung runs the same autotuned forms with one launch per chunk."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port), "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
+               env={"GLNN_SINGLE_DEVICE": "1", "GLNN_DIST_BACKEND": "gloo", "GLNN_BENCH_INJECT": "signal:1000000"})
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["verified"] is True
+    lad = out["exchange"]["ladder"]
+    assert lad["teacher_rung"] == "as configured, one launch per chunk (no completion signals)" and any("signal" in e for e in lad["errors"].values())
+    assert all(isinstance(v, float) for v in out["exchange"]["layer1_autotune_ms"].values())      # (the second autotune, without signals: every form timed)
+
+
 def test_bench_two_ranks_print_a_null_line_when_no_all_gather_works():
     """... and when every rung fails (every all-gather of the forward raises), the line carries value null and the errors instead of a number."""
     out = _run([sys.executable, "bench.py", "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1"],
