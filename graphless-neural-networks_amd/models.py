@@ -326,6 +326,15 @@ class SAGE(nn.Module):
                     pool = _sweep_streams(x.device) if engine else []
                     for st in pool:
                         st.wait_stream(cur)
+                    # ... and launched through ONE prepared call per layer (ops.RowRangeLaunch: the per-chunk ops call's checks and argument
+                    # list done once; a chunk offsets three pointers) where the layer is a single launch
+                    launch = None
+                    if engine and getattr(dataloader, "graph", None) is not None and (xp is not None or layer.fused_eligible()):
+                        tailed = ep_scale is not None or ep_shift is not None or relu
+                        g_ = dataloader.graph
+                        launch = (ops.RowRangeLaunch(g_.indptr, g_.indices, xp, y, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu) if xp is not None else
+                                  ops.RowRangeLaunch(g_.indptr, g_.indices, x, y, w=layer.fc_neigh.weight, ep_scale=ep_scale,
+                                                     ep_shift=ep_shift if tailed else layer.fc_neigh.bias, relu=relu, w_packed=wp))
                     try:
                         it = iter(dataloader)
                         k = 0
@@ -335,7 +344,9 @@ class SAGE(nn.Module):
                             block = blocks[0]
                             s_, e_ = block.dst_range
                             with torch.cuda.stream(pool[k % len(pool)]) if pool else contextlib.nullcontext():
-                                if xp is not None:
+                                if launch is not None:
+                                    launch(s_, e_)
+                                elif xp is not None:
                                     ops.spmm(block.indptr, block.indices, xp, e_ - s_, ops.AGG_SAGE_GCN, ep_scale=ep_scale, ep_shift=ep_shift, relu=relu,
                                              out=y[s_:e_], x_self=xp[s_:e_])
                                 else:

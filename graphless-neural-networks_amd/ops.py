@@ -402,6 +402,61 @@ def sage_fused(indptr, indices, x, n_dst, w, ep_scale=None, ep_shift=None, relu=
     return out if w_next is None else (out, out_next)
 
 
+class RowRangeLaunch:
+    """A PREPARED SAGE-"gcn" launch over row ranges [s, e) of one resident CSR whose column ids are rows of `x` (the engine-mode chunked
+    sweep of SAGE.inference, reference models.py:133-145): everything that does not change from chunk to chunk -- the checks of sage_fused /
+    spmm, the packed weight, the C argument list -- is done ONCE here; a call only offsets three pointers (indptr + s, the self rows
+    x[s:], the output rows out[s:]) and launches.  Same library entries, same arguments, same bits as the per-chunk ops calls (~8 us of
+    host time per chunk instead of ~25).  w = None: the stand-alone aggregation (a layer that projected first), else the fused kernel."""
+
+    def __init__(self, indptr, indices, x, out, w=None, ep_scale=None, ep_shift=None, relu=False, w_packed=None):
+        _need_cuda(indptr, indices, x, out, w, ep_scale, ep_shift)
+        x = as_feat(x)
+        _mat(out, "RowRangeLaunch out")
+        if indptr.dtype != torch.int64 or indices.dtype != torch.int32 or out.shape[0] < indptr.numel() - 1:
+            raise ValueError("RowRangeLaunch: indptr int64, indices int32, one output row per CSR row")
+        n_src, d_in = x.shape
+        self.keep = (indptr, indices, x, out, w, ep_scale, ep_shift)          # (the pointers below stay valid while this object lives)
+        self.n = indptr.numel() - 1
+        self.ip0, self.x0, self.ldx, self.o0, self.ldo = indptr.data_ptr(), x.data_ptr(), _ld(x), out.data_ptr(), _ld(out)
+        if w is None:
+            d = d_in
+            if out.shape[1] != d:
+                raise ValueError("RowRangeLaunch: out must be as wide as x")
+            self.fused, self.info = False, dict(d=d, mode=AGG_SAGE_GCN)
+            self.tail = (_p(_vec(ep_scale, d, "ep_scale")), _p(_vec(ep_shift, d, "ep_shift")), 1 if relu else 0)
+            self.head = (_p(indices),)
+            self.mid = (n_src, self.x0, self.ldx, d, AGG_SAGE_GCN, None, None)
+        else:
+            d_out = w.shape[0]
+            if w.shape[1] != d_in or d_in > 256 or d_out > 256 or out.shape[1] != d_out:
+                raise ValueError("RowRangeLaunch: weight [d_out, d_in] with d_in, d_out <= 256, out [n, d_out]")
+            wp = pack_weight(w) if w_packed is None else w_packed
+            self.keep += (wp,)
+            self.fused, self.info = True, dict(d=d_in, d_out=d_out, d_chain=0, d_written=d_out)
+            self.head = (_p(indices),)
+            self.mid = (n_src, self.x0, self.ldx, d_in)
+            self.tail = (_p(wp), d_out, _p(_vec(ep_scale, d_out, "ep_scale")), _p(_vec(ep_shift, d_out, "ep_shift")), 1 if relu else 0)
+        self.fn = _lib.lib().glnn_sage_fused_f32 if self.fused else _lib.lib().glnn_spmm_csr_f32
+
+    def __call__(self, s, e):
+        if not 0 <= s <= e <= self.n:
+            raise ValueError("RowRangeLaunch: row range outside the CSR")
+        n_dst = e - s
+        ip, xs, o = self.ip0 + 8 * s, self.x0 + 4 * self.ldx * s, self.o0 + 4 * self.ldo * s
+        if self.fused:
+            args = (ip,) + self.head + (n_dst,) + self.mid + (xs, self.ldx) + self.tail + (o, self.ldo, None, 0, None, 0, None, _stream())
+        else:
+            args = (ip,) + self.head + (n_dst,) + self.mid + (xs, self.ldx, None) + self.tail + (o, self.ldo, _stream())
+        if _TIMING is not None:
+            with _Timed("sage_fused" if self.fused else "spmm", n_dst=n_dst, **self.info):
+                rc = self.fn(*args)
+        else:
+            rc = self.fn(*args)
+        if rc != 0:
+            _lib.check(rc, "glnn_sage_fused_f32" if self.fused else "glnn_spmm_csr_f32")
+
+
 # ---- placement of gathered matrices (round 5) ------------------------------------------------------------------------------------
 # The same aggregation launch over the same graph runs 18.1 ... 19.4 ms (fused D=256, products shape) depending on WHICH allocation
 # holds the matrix it gathers from -- stable per buffer, different from one buffer to the next inside one process, unaffected by the
